@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON in this container.
+
+Runs only where /root/reference exists (the build container).  Nothing from the reference is copied
+into the repo: this script imports the reference's L3 functions (scripts/utils/{general,metrics,nms}.py,
+scripts/loss/losses.py, scripts/tensor_decomposition/decomposition.py) with `sys.modules` stubs for the
+third-party packages that are not installed here, feeds them seeded synthetic inputs, and stores
+inputs + outputs as small .npz fixtures (data only).
+
+Third-party leaves are bound to the oracle's restatements so the fixtures pin the reference's WRAPPER
+logic (filtering, offsets, caps, ordering):
+  torchvision.ops.nms / ops.boxes.batched_nms -> oracle.ops_ref.tv_nms / tv_batched_nms
+  tensorly.base.unfold / decomposition.partial_tucker -> oracle.tucker_ref
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from oracle import ops_ref, tucker_ref  # noqa: E402
+
+
+def _install_stubs():
+    for name in ["cv2", "kindle", "kindle.modules", "kindle.model", "kindle.utils", "kindle.utils.torch_utils",
+                 "wandb", "seaborn", "albumentations", "p_tqdm", "orjson", "pycocotools", "pycocotools.coco",
+                 "pycocotools.cocoeval", "optuna", "onnx", "onnxsim", "tensorly", "tensorly.base",
+                 "tensorly.decomposition", "torchvision", "torchvision.ops", "torchvision.ops.boxes",
+                 "torchvision.transforms", "matplotlib.pyplot"]:
+        if name not in sys.modules:
+            sys.modules[name] = MagicMock(name=name)
+    tv = sys.modules["torchvision"]
+    ops = sys.modules["torchvision.ops"]
+    boxes = sys.modules["torchvision.ops.boxes"]
+    tv.ops = ops
+    ops.boxes = boxes
+
+    def nms(b, s, thr):
+        return torch.from_numpy(ops_ref.tv_nms(b.detach().numpy(), s.detach().numpy(), thr))
+
+    def batched_nms(b, s, idx, thr):
+        return torch.from_numpy(ops_ref.tv_batched_nms(b.detach().numpy(), s.detach().numpy(),
+                                                       idx.detach().numpy(), thr))
+
+    ops.nms = nms
+    boxes.batched_nms = batched_nms
+    ops.batched_nms = batched_nms
+
+    tl = sys.modules["tensorly"]
+    tl.base = sys.modules["tensorly.base"]
+    tl.decomposition = sys.modules["tensorly.decomposition"]
+    tl.base.unfold = lambda t, m: torch.from_numpy(tucker_ref.unfold(t.detach().numpy(), m))
+
+    def partial_tucker(t, modes, rank, init="svd"):
+        core, factors = tucker_ref.partial_tucker(t.detach().numpy(), modes, rank)
+        return torch.from_numpy(core), [torch.from_numpy(f) for f in factors]
+
+    tl.decomposition.partial_tucker = partial_tucker
+
+
+def synth_pred(B, N, nc, img, mu_obj, seed):
+    """SURVEY.md 8d 'NMS synthetic' distribution (sized so the reference never trips its 10 s limit)."""
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(B, N, 2, generator=g) * img
+    wh = torch.rand(B, N, 2, generator=g) ** 3 * img / 2 + 2
+    obj = torch.sigmoid(torch.randn(B, N, 1, generator=g) * 2 + mu_obj)
+    cls = torch.sigmoid(torch.randn(B, N, nc, generator=g) * 2 - 4)
+    return torch.cat((xy, wh, obj, cls), 2).float()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    _install_stubs()
+    sys.path.insert(0, REF)
+    from scripts.utils import general as rg
+    from scripts.utils import metrics as rm
+    from scripts.utils import nms as rn
+
+    rng = np.random.default_rng(0)
+
+    # ---- G1 box_iou (incl. degenerate / identical / zero-area boxes)
+    a = rng.uniform(0, 600, (64, 2)).astype(np.float32)
+    a = np.concatenate([a, a + rng.uniform(0, 200, (64, 2)).astype(np.float32)], 1)
+    b = rng.uniform(0, 600, (48, 2)).astype(np.float32)
+    b = np.concatenate([b, b + rng.uniform(0, 200, (48, 2)).astype(np.float32)], 1)
+    b[:8] = a[:8]                       # identical boxes
+    a[60] = [10, 10, 10, 50]            # zero-area
+    b[40] = [10, 10, 10, 50]            # zero-area vs zero-area -> 0/0 = nan
+    b[41] = [300, 300, 250, 250]        # inverted
+    np.savez_compressed(os.path.join(OUT, "g1_box_iou.npz"), box1=a, box2=b,
+                        iou=rm.box_iou(torch.from_numpy(a), torch.from_numpy(b)).numpy())
+
+    # ---- G2 bbox_iou CIoU values and grads
+    p = torch.from_numpy(rng.uniform(0.1, 8, (200, 4)).astype(np.float32)).requires_grad_(True)
+    t = torch.from_numpy(rng.uniform(0.1, 8, (200, 4)).astype(np.float32))
+    out = {}
+    for tag, kw in {"iou": {}, "giou": {"g_iou": True}, "diou": {"d_iou": True}, "ciou": {"c_iou": True}}.items():
+        for fmt in (False, True):
+            pp = p.detach().clone().requires_grad_(True)
+            if fmt:  # make valid xyxy
+                q = torch.cat((pp[:, :2], pp[:, :2] + pp[:, 2:]), 1)
+                tt = torch.cat((t[:, :2], t[:, :2] + t[:, 2:]), 1)
+            else:
+                q, tt = pp, t
+            v = rm.bbox_iou(q.T, tt, x1y1x2y2=fmt, **kw)
+            v.sum().backward()
+            out[f"{tag}_{int(fmt)}"] = v.detach().numpy()
+            out[f"{tag}_{int(fmt)}_grad"] = pp.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g2_bbox_iou.npz"), pred=p.detach().numpy(), target=t.numpy(), **out)
+
+    # ---- G3 general.py helpers
+    x = rng.uniform(0, 640, (100, 4)).astype(np.float32)
+    xyxy = np.concatenate([x[:, :2], x[:, :2] + x[:, 2:]], 1).astype(np.float32) - 100
+    g3 = dict(x=x, xywh2xyxy=rg.xywh2xyxy(torch.from_numpy(x)).numpy(),
+              xywh2xyxy_r=rg.xywh2xyxy(torch.from_numpy(x / 640), ratio=(0.5, 0.75), wh=(640, 480), pad=(3.0, 7.0)).numpy(),
+              xyxy=xyxy,
+              clip=rg.clip_coords(torch.from_numpy(xyxy.copy()), (640, 480)).numpy(),
+              scale_a=rg.scale_coords((640, 640), torch.from_numpy(xyxy.copy()), (480, 600)).numpy(),
+              scale_b=rg.scale_coords((640, 640), torch.from_numpy(xyxy.copy()), (720, 1280),
+                                      ratio_pad=((0.5, 0.5), (0.0, 140.0))).numpy())
+    np.savez_compressed(os.path.join(OUT, "g3_general.npz"), **g3)
+
+    # ---- G4 non_max_suppression: 5 nms types x agnostic x multi_label on (2, 3000, 85)
+    pred = synth_pred(2, 1000, 80, 640, -7.0, seed=1)
+    # float32 and tie-free: equal objectness/conf values would expose torch's unstable argsort tie order
+    assert len(np.unique(pred[..., 4].numpy())) == pred[..., 4].numel()
+    g4 = {"pred": pred.numpy()}
+    for nms_type in ["nms", "batched_nms", "fast_nms", "matrix_nms", "merge_nms"]:
+        for agn in (False, True):
+            for ml in (False, True):
+                res = rm.non_max_suppression(pred.clone(), conf_thres=0.001, iou_thres=0.65, multi_label=ml,
+                                             agnostic=agn, nms_type=nms_type)
+                for bi, r in enumerate(res):
+                    g4[f"{nms_type}_a{int(agn)}_m{int(ml)}_{bi}"] = r.numpy()
+    # a conf/iou variation + classes filter + hybrid labels
+    res = rm.non_max_suppression(pred.clone(), conf_thres=0.25, iou_thres=0.45, classes=[0, 3, 17])
+    for bi, r in enumerate(res):
+        g4[f"cls_filter_{bi}"] = r.numpy()
+    lab = [torch.tensor([[3, 100., 120., 40., 60.], [7, 300., 320., 80., 30.]]), torch.zeros((0, 5))]
+    res = rm.non_max_suppression(pred.clone(), conf_thres=0.1, iou_thres=0.6, labels=lab, multi_label=True)
+    g4["hybrid_labels_0"] = lab[0].numpy()
+    for bi, r in enumerate(res):
+        g4[f"hybrid_{bi}"] = r.numpy()
+    np.savez_compressed(os.path.join(OUT, "g4_nms.npz"), **g4)
+
+    # ---- G5 nms.py::batched_nms
+    g5 = {}   # input = g4_nms.npz["pred"]
+    for nms_type in ["nms", "batched_nms", "fast_nms", "matrix_nms", "merge_nms"]:
+        for agn in (False, True):
+            for nb in (500, 1000):
+                res = rn.batched_nms(pred.clone(), conf_thres=0.001, iou_thres=0.65, nms_box=nb, agnostic=agn,
+                                     nms_type=nms_type)
+                for bi, r in enumerate(res):
+                    g5[f"{nms_type}_a{int(agn)}_n{nb}_{bi}"] = r.numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_batched_nms.npz"), **g5)
+
+    # ---- G6 ComputeLoss on a fake model (hyp after set_model_params scaling, model_manager.py:252-258)
+    from scripts.loss import losses as rl
+    import yaml
+    hyp = yaml.safe_load(open(os.path.join(REF, "res/configs/cfg/train_config.yaml")))["hyper_params"]
+    nl, nc, imgsz = 3, 80, 640
+    hyp["box"] *= 3.0 / nl
+    hyp["cls"] *= nc / 80.0 * 3.0 / nl
+    hyp["obj"] *= (imgsz / 640) ** 2 * 3.0 / nl
+    mcfg = yaml.safe_load(open(os.path.join(REF, "res/configs/model/yolov5s.yaml")))
+    strides = torch.tensor([8., 16., 32.])
+    anchors = torch.tensor(mcfg["anchors"]).float().view(3, 3, 2) / strides.view(-1, 1, 1)
+
+    class Head(torch.nn.Module):
+        pass
+
+    head = Head()
+    head.nl, head.na, head.nc, head.anchors, head.stride = 3, 3, 80, anchors, strides
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.model = torch.nn.ModuleList([torch.nn.Identity(), head])
+            self.hyp = hyp
+
+    rl.is_parallel = lambda m: False
+    fake = Fake()
+    g = torch.Generator().manual_seed(3)
+    preds = [torch.randn(2, 3, s, s, 85, generator=g).requires_grad_(True) for s in (80, 40, 20)]
+    # targets from the reference's own test labels (class x y w h normalised)
+    lab_dir = os.path.join(REF, "tests/res/datasets/coco/labels/train2017")
+    files = sorted(os.listdir(lab_dir))[:2]
+    tg = []
+    for bi, f in enumerate(files):
+        arr = np.loadtxt(os.path.join(lab_dir, f), ndmin=2).astype(np.float32)[:, :5]
+        tg.append(np.concatenate([np.full((arr.shape[0], 1), bi, np.float32), arr], 1))
+    targets = torch.from_numpy(np.concatenate(tg, 0))
+    # torch-1.9 -> 2.x compat shim (the reference pins torch 1.9.1, environment.yml:27): losses.py:385 clamps a
+    # LongTensor in place with 0-dim FLOAT tensor bounds, which torch 1.9 accepted (bound cast to the self
+    # dtype) and torch 2.x rejects.  Reproduce the 1.9 behaviour without touching the reference.
+    _orig_clamp_ = torch.Tensor.clamp_
+
+    def _clamp_compat(self, min=None, max=None):
+        if not self.is_floating_point():
+            min = int(min) if torch.is_tensor(min) else min
+            max = int(max) if torch.is_tensor(max) else max
+        return _orig_clamp_(self, min, max)
+
+    torch.Tensor.clamp_ = _clamp_compat
+    cl = rl.ComputeLoss(fake)
+    loss, items = cl(preds, targets)
+    loss.backward()
+    tcls, tbox, indices, anch = cl.build_targets(preds, targets)
+    g6 = dict(targets=targets.numpy(), loss=loss.detach().numpy(), items=items.numpy(),
+              hyp_box=hyp["box"], hyp_cls=hyp["cls"], hyp_obj=hyp["obj"], anchors=anchors.numpy())
+    for i in range(3):
+        g6[f"pred{i}"] = preds[i].detach().numpy().astype(np.float32)
+        g6[f"grad{i}_sum"] = preds[i].grad.sum((2, 3)).numpy()
+        nz = preds[i].grad.abs().sum(-1) > 1e-3 * preds[i].grad.abs().max()
+        g6[f"grad{i}_abs_total"] = preds[i].grad.abs().sum().numpy()
+        g6[f"tcls{i}"] = tcls[i].numpy()
+        g6[f"tbox{i}"] = tbox[i].numpy()
+        g6[f"idx{i}"] = torch.stack(indices[i]).numpy()
+        g6[f"anch{i}"] = anch[i].numpy()
+    # predictions are regenerated from the seed in the test (too large to store): keep only a checksum
+    for i in range(3):
+        del g6[f"pred{i}"]
+    g6["pred_seed"] = 3
+    np.savez_compressed(os.path.join(OUT, "g6_loss.npz"), **g6)
+
+    # ---- G7 EVBMF ranks + Tucker layer loss through the reference driver
+    from scripts.tensor_decomposition import decomposition as rd
+    g7 = {}
+    for name, (L, M, r) in {"a": (64, 576, 12), "b": (128, 1152, 30), "c": (256, 2304, 40)}.items():
+        rs = np.random.default_rng(7)
+        Y = (rs.standard_normal((L, r)) @ rs.standard_normal((r, M)) / np.sqrt(r) + 0.05 * rs.standard_normal((L, M))).astype(np.float32)
+        _, d, _, _ = rd.EVBMF(torch.from_numpy(Y))
+        g7[f"Y_{name}_seed"] = 7
+        g7[f"rank_{name}"] = d.shape[0]
+        g7[f"shape_{name}"] = np.array([L, M, r])
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(64, 96, 3, padding=1, bias=False)
+    rs = np.random.default_rng(11)
+    core = rs.standard_normal((20, 16, 3, 3)).astype(np.float32)
+    U0 = rs.standard_normal((96, 20)).astype(np.float32)
+    U1 = rs.standard_normal((64, 16)).astype(np.float32)
+    W = np.einsum("abhw,oa,ib->oihw", core, U0, U1) / 10 + 0.01 * rs.standard_normal((96, 64, 3, 3))
+    conv.weight.data = torch.from_numpy(W.astype(np.float32))
+    ranks = rd.estimate_ranks(conv)
+    xin = torch.rand((64, 64, 3, 3), generator=torch.Generator().manual_seed(5))
+    seq, loss = rd.decompose_layer_evaluation(conv, xin, conv(xin))
+    g7["conv_w"] = conv.weight.data.numpy().astype(np.float32)
+    g7["conv_ranks"] = np.array(ranks)
+    g7["conv_loss"] = float(loss)
+    g7["conv_shapes"] = np.array([list(m.weight.shape) for m in seq])
+    np.savez_compressed(os.path.join(OUT, "g7_tucker.npz"), **g7)
+
+    print("golden fixtures written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
