@@ -1,0 +1,94 @@
+"""ctypes binding of libayolo_hip.so (the C ABI declared in include/ayolo.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libayolo_hip.so")
+
+F16, F32 = 0, 1
+EPI_NONE, EPI_AFFINE, EPI_AFFINE_SILU, EPI_HEAD = 0, 1, 2, 3
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("dtype", "B", "H", "W", "Cin", "ldx", "Cout", "ldy", "kh", "kw", "sh", "sw",
+                                     "ph", "pw", "Ho", "Wo")]
+
+
+class AyoloError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+
+# name -> argtypes (restype is int unless noted).  Mirrors include/ayolo.h one to one.
+_SIGNATURES = {
+    "ayolo_conv_fwd": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, c_int, _P],
+    "ayolo_conv_dgrad": [POINTER(ConvDesc), _P, _P, _P, c_int, _P],
+    "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P],
+    "ayolo_cast_weight": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
+    "ayolo_bn_finalize": [_P, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
+    "ayolo_affine_act": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int, _P],
+    "ayolo_bn_act_bwd_reduce": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P],
+    "ayolo_bn_act_bwd_apply": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P,
+                               _P, c_float, _P],
+    "ayolo_maxpool_fwd": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "ayolo_maxpool_bwd": [c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ayolo_upsample2x_fwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "ayolo_upsample2x_bwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ayolo_pack_input": [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    "ayolo_head_grad_pack": [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
+    "ayolo_copy2d": [c_int, _P, c_int, _P, c_int, c_int64, c_int, c_int, _P],
+    "ayolo_head_decode": [_P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int64, c_int64, _P],
+    "ayolo_nms_candidates": [_P, c_int, c_int, c_int, c_float, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_uint32, c_int,
+                             _P],
+    "ayolo_nms_key_bits": [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)],
+    "ayolo_iota_u32": [_P, c_uint32, _P],
+    "ayolo_seg_max_coord": [_P, _P, _P, c_int, _P, _P],
+    "ayolo_sort_pairs_u64": [_P, _P, _P, _P, c_uint32, c_int, c_int, _P, POINTER(c_size_t), _P],
+    "ayolo_nms_obj_keys": [_P, c_int, c_int, c_int, _P, _P, _P],
+    "ayolo_gather_rows": [_P, _P, _P, c_uint32, c_int, _P],
+    "ayolo_nms_mask": [_P, _P, _P, _P, c_int, c_uint32, c_float, c_float, _P, c_int, _P, _P],
+    "ayolo_nms_reduce": [_P, _P, _P, _P, _P, c_int, c_uint32, _P, _P, _P, c_uint32, _P],
+    "ayolo_box_iou": [_P, c_int64, _P, c_int64, _P, _P],
+    "ayolo_iou_colmax": [_P, _P, c_float, c_uint32, _P, _P],
+    "ayolo_matrix_nms_decay": [_P, _P, c_float, c_uint32, _P, _P, _P],
+    "ayolo_merge_boxes": [_P, c_uint32, c_float, _P, c_uint32, c_float, _P, _P, _P],
+}
+
+EXPORTED = sorted(list(_SIGNATURES) + ["ayolo_version", "ayolo_last_error"])
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AyoloError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(or `make -C ayolov2_amd/csrc`). There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = c_int
+        l.ayolo_version.restype = c_int
+        l.ayolo_last_error.restype = c_char_p
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ayolo_last_error()
+        raise AyoloError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,673 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores (no im2col materialisation).
+//
+//   gconv  : y[pixel][n] = sum_{tap,c} x[pixel @ tap][c] * w[n][tap][c]     (forward AND dgrad)
+//   wgrad  : dw[n][tap][c] += sum_{pixel} dy[pixel][n] * x[pixel @ tap][c]
+//
+// Layout: activations NHWC (channel stride = ld*), weights [N][taps][C] with C contiguous.  MFMA roles are
+// "swapped" (A = weights, rows = output channel; B = gathered pixels), so each lane of the 32x32 accumulator
+// holds ONE pixel and 4-channel runs: the epilogue stores 8 B (fp16) / 16 B (fp32) channel vectors straight to
+// NHWC without an LDS transpose.
+//   fp16 : v_mfma_f32_32x32x16_f16  (fp32 accumulate)
+//   fp32 : v_mfma_f32_32x32x2_f32   (exact fp32 -- the 1e-4 parity mode)
+// Tiles: TM in {32,64,128} output channels x 128 pixels x BK=32, 4 wavefronts, register-staged global->LDS
+// double buffer with padded rows (80 B / 144 B) so ds_read_b128 fragments are bank-conflict free.
+//
+// Replaces kindle Conv/YOLOHead.conv forward (yolov5s.yaml:21-57) and the autograd backward torch/cuDNN ran
+// (scripts/train/yolo_trainer.py:329).
+#include "common.h"
+
+#define MAX_TAPS 36
+#define BK 32
+#define TP 128   // pixels per block tile
+
+struct GConvP {
+    const void* x; const void* w; void* y;
+    int B, XH, XW, ldx;
+    int OH, OW, ish, isw;
+    int YH, YW, ldy, osh, osw, oah, oaw;
+    int C, ntaps, K, ldw, Nout;
+    int epi; const float* scale; const float* shift; float* stats;
+    int head_no; int accumulate;
+    long long Mtotal;
+    signed char dh[MAX_TAPS], dw[MAX_TAPS], wt[MAX_TAPS];
+};
+
+template <typename T> struct Tr;
+template <> struct Tr<half_t> {
+    static constexpr int CE = 8;            // elements per 16-byte chunk
+    static constexpr int PADE = 8;          // row padding (elements)
+    typedef half8 frag;                     // 8 k-values per lane per k16 step
+    typedef uint4 chunk;
+};
+template <> struct Tr<float> {
+    static constexpr int CE = 4;
+    static constexpr int PADE = 4;
+    struct frag { float v[8]; };
+    typedef uint4 chunk;
+};
+
+__device__ __forceinline__ void mma_step(const half8& a, const half8& b, float16v& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(const Tr<float>::frag& a, const Tr<float>::frag& b, float16v& acc) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b.v[s], acc, 0, 0, 0);
+}
+__device__ __forceinline__ half8 lds_frag(const half_t* p) { return *reinterpret_cast<const half8*>(p); }
+__device__ __forceinline__ Tr<float>::frag lds_frag(const float* p) {
+    Tr<float>::frag f;
+    float4v a = *reinterpret_cast<const float4v*>(p), b = *reinterpret_cast<const float4v*>(p + 4);
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+    return f;
+}
+
+__device__ __forceinline__ float cvt_round(float v, half_t*) { return (float)(half_t)v; }
+__device__ __forceinline__ float cvt_round(float v, float*) { return v; }
+
+template <typename T, int TM>
+__global__ __launch_bounds__(256) void k_gconv(GConvP p) {
+    constexpr int CE = Tr<T>::CE;
+    constexpr int CPR = BK / CE;             // chunks per tile row
+    constexpr int LDR = BK + Tr<T>::PADE;    // LDS row stride (elements)
+    constexpr int WM = TM / 32;              // waves along channels
+    constexpr int WP = 4 / WM;               // waves along pixels
+    constexpr int NI = TP / (32 * WP);       // 32-pixel MFMA tiles per wave
+    constexpr int XR = (TP * CPR) / 256;     // x chunks per thread
+    constexpr int WCH = TM * CPR;            // w chunks per tile
+    constexpr int WR = (WCH + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sW = reinterpret_cast<T*>(smem_raw);                 // [2][TM][LDR]
+    T* sX = sW + 2 * TM * LDR;                              // [2][TP][LDR]
+    float* sStat = reinterpret_cast<float*>(sX + 2 * TP * LDR);   // [2][TM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wp = wave / WM;
+    const long long m0 = (long long)blockIdx.x * TP;
+    const int n0 = blockIdx.y * TM;
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ Wg = reinterpret_cast<const T*>(p.w);
+
+    // ---- per-thread loader state
+    const int kc = tid % CPR;                // chunk column inside the k-tile (same for all of this thread's rows)
+    int tap = (kc * CE) / p.C, cch = (kc * CE) % p.C;
+    long long xbase[XR];                     // element offset of (n, 0, 0, 0); -1 when the pixel row is out of range
+    int xh0[XR], xw0[XR];
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+        int row = (tid + 256 * r) / CPR;
+        long long m = m0 + row;
+        if (m < p.Mtotal) {
+            int ow = (int)(m % p.OW);
+            long long t = m / p.OW;
+            int oh = (int)(t % p.OH);
+            int n = (int)(t / p.OH);
+            xbase[r] = (long long)n * p.XH * p.XW;
+            xh0[r] = oh * p.ish; xw0[r] = ow * p.isw;
+        } else { xbase[r] = -1; xh0[r] = 0; xw0[r] = 0; }
+    }
+    typename Tr<T>::chunk xreg[XR], wreg[WR];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    // tap tables are read straight from the kernarg segment (a dynamically indexed by-value struct member
+    // would be copied to scratch)
+    typedef __attribute__((address_space(4))) const signed char* kptr_t;
+    const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh);
+
+    float16v acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    // kt = -1 is the prologue (load + stage tile 0); iteration kt prefetches tile kt+1 into registers while the
+    // MFMAs consume LDS buffer kt&1, then stages it into the other buffer.
+    for (int kt = -1; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            if (kt >= 0) {
+                cch += BK;
+                while (cch >= p.C) { cch -= p.C; ++tap; }
+            }
+            const bool tap_ok = tap < p.ntaps;
+            const int tq = tap_ok ? tap : 0;
+            const int dh = ktab[tq], dw = ktab[MAX_TAPS + tq];
+#pragma unroll
+            for (int r = 0; r < XR; ++r) {
+                int ih = xh0[r] + dh, iw = xw0[r] + dw;
+                bool ok = tap_ok && xbase[r] >= 0 && ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW;
+                xreg[r] = zero4;
+                if (ok) xreg[r] = *reinterpret_cast<const uint4*>(X + (xbase[r] + (long long)ih * p.XW + iw) * p.ldx + cch);
+            }
+            const int wcol = tap_ok ? ktab[2 * MAX_TAPS + tq] * p.C + cch : 0;
+#pragma unroll
+            for (int r = 0; r < WR; ++r) {
+                int q = tid + 256 * r;
+                int row = q / CPR;
+                wreg[r] = zero4;
+                if (q < WCH && tap_ok && (n0 + row) < p.Nout)
+                    wreg[r] = *reinterpret_cast<const uint4*>(Wg + (long long)(n0 + row) * p.ldw + wcol);
+            }
+        }
+        if (kt >= 0) {
+            const int buf = kt & 1;
+            const T* cW = sW + buf * TM * LDR + (wm * 32 + (lane & 31)) * LDR + (lane >> 5) * 8;
+            const T* cX = sX + buf * TP * LDR + (wp * NI * 32 + (lane & 31)) * LDR + (lane >> 5) * 8;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                auto a = lds_frag(cW + kk * 16);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    auto b = lds_frag(cX + ni * 32 * LDR + kk * 16);
+                    mma_step(a, b, acc[ni]);
+                }
+            }
+        }
+        if (more) {
+            const int nb = (kt + 1) & 1;
+            T* dX = sX + nb * TP * LDR;
+            T* dW = sW + nb * TM * LDR;
+#pragma unroll
+            for (int r = 0; r < XR; ++r) {
+                int row = (tid + 256 * r) / CPR;
+                *reinterpret_cast<uint4*>(dX + row * LDR + kc * CE) = xreg[r];
+            }
+#pragma unroll
+            for (int r = 0; r < WR; ++r) {
+                int q = tid + 256 * r;
+                if (q < WCH) *reinterpret_cast<uint4*>(dW + (q / CPR) * LDR + kc * CE) = wreg[r];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[ni][r]: channel = n0 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3), pixel = .. + (lane&31)
+    const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
+    const bool want_stats = (p.stats != nullptr);
+    if (want_stats) {
+        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+        __syncthreads();
+    }
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        long long m = m0 + wp * NI * 32 + ni * 32 + (lane & 31);
+        bool pv = m < p.Mtotal;
+        long long yo = 0;
+        int n = 0, oh = 0, ow = 0;
+        if (pv) {
+            ow = (int)(m % p.OW);
+            long long t = m / p.OW;
+            oh = (int)(t % p.OH);
+            n = (int)(t / p.OH);
+            yo = (((long long)n * p.YH + (oh * p.osh + p.oah)) * p.YW + (ow * p.osw + p.oaw)) * p.ldy;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = cbase + 8 * g;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[ni][g * 4 + e];
+            if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (c + e < p.Nout) {
+                        float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
+                        float u = v[e] * sc + sh;
+                        v[e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
+                    }
+                }
+            }
+            if (p.epi == AYOLO_EPI_HEAD) {
+                if (pv) {
+                    float* Y = reinterpret_cast<float*>(p.y);
+                    const int na = p.Nout / p.head_no;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int cc = c + e;
+                        if (cc < p.Nout) {
+                            int a = cc / p.head_no, o = cc - a * p.head_no;
+                            float u = v[e] + (p.shift ? p.shift[cc] : 0.0f);
+                            Y[((((long long)n * na + a) * p.OH + oh) * p.OW + ow) * p.head_no + o] = u;
+                        }
+                    }
+                }
+                continue;
+            }
+            if (want_stats) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
+                    ssum[g * 4 + e] += q;
+                    ssq[g * 4 + e] += q * q;
+                }
+            }
+            if (pv) {
+                T* Y = reinterpret_cast<T*>(p.y) + yo + c;
+                if (c + 3 < p.Nout && (p.ldy & 3) == 0) {
+                    if (p.accumulate) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)Y[e];
+                    }
+                    if constexpr (sizeof(T) == 2) {
+                        half4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+                        *reinterpret_cast<half4*>(Y) = h;
+                    } else {
+                        float4v f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = v[e];
+                        *reinterpret_cast<float4v*>(Y) = f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < p.Nout) Y[e] = (T)(p.accumulate ? v[e] + (float)Y[e] : v[e]);
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        // reduce over the 32 pixel lanes of each half-wave, then one LDS add per (wave, channel)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = ssum[r], b = ssq[r];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                a += __shfl_xor(a, off);
+                b += __shfl_xor(b, off);
+            }
+            if ((lane & 31) == 0) {
+                int cl = wm * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);
+                atomicAdd(&sStat[cl], a);
+                atomicAdd(&sStat[TM + cl], b);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < TM; i += 256) {
+            if (n0 + i < p.Nout) {
+                atomicAdd(&p.stats[n0 + i], sStat[i]);
+                atomicAdd(&p.stats[p.Nout + n0 + i], sStat[TM + i]);
+            }
+        }
+    }
+}
+
+template <typename T, int TM>
+static int launch_gconv(const GConvP& p, hipStream_t s) {
+    constexpr int LDR = BK + Tr<T>::PADE;
+    size_t lds = (size_t)2 * (TM + TP) * LDR * sizeof(T) + 2 * TM * sizeof(float);
+    dim3 grid((unsigned)((p.Mtotal + TP - 1) / TP), (unsigned)((p.Nout + TM - 1) / TM));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gconv<T, TM>), grid, dim3(256), lds, s, p);
+    AY_CHECK_LAUNCH("k_gconv");
+    return AYOLO_OK;
+}
+
+static int dispatch_gconv(int dtype, const GConvP& p, hipStream_t s) {
+    int tm = p.Nout <= 32 ? 32 : (p.Nout <= 64 ? 64 : 128);
+    if (dtype == AYOLO_F16) {
+        if (tm == 32) return launch_gconv<half_t, 32>(p, s);
+        if (tm == 64) return launch_gconv<half_t, 64>(p, s);
+        return launch_gconv<half_t, 128>(p, s);
+    } else {
+        if (tm == 32) return launch_gconv<float, 32>(p, s);
+        if (tm == 64) return launch_gconv<float, 64>(p, s);
+        return launch_gconv<float, 128>(p, s);
+    }
+}
+
+static int check_desc(const ayolo_conv_desc* d, const char* who) {
+    AY_CHECK_ARG(d, "%s: null desc", who);
+    AY_CHECK_ARG(d->dtype == AYOLO_F16 || d->dtype == AYOLO_F32, "%s: dtype %d", who, d->dtype);
+    const int ce = d->dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(d->Cin % ce == 0 && d->ldx % ce == 0, "%s: Cin=%d ldx=%d must be multiples of %d", who, d->Cin,
+                 d->ldx, ce);
+    AY_CHECK_ARG(d->kh * d->kw <= MAX_TAPS && d->kh > 0 && d->kw > 0, "%s: kernel %dx%d unsupported", who, d->kh, d->kw);
+    AY_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "%s: bad dims", who);
+    AY_CHECK_ARG(d->ph < 64 && d->pw < 64, "%s: padding too large", who);
+    return AYOLO_OK;
+}
+
+extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void* y, int epilogue,
+                              const float* scale, const float* shift, float* stats, int head_no, ayolo_stream s) {
+    int rc = check_desc(d, "conv_fwd");
+    if (rc) return rc;
+    AY_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
+    AY_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "conv_fwd: epilogue %d", epilogue);
+    AY_CHECK_ARG(epilogue != AYOLO_EPI_HEAD || (head_no > 0 && d->Cout % head_no == 0), "conv_fwd: head_no=%d", head_no);
+    AY_CHECK_ARG(stats == nullptr || epilogue == AYOLO_EPI_NONE, "conv_fwd: stats need EPI_NONE");
+    GConvP p{};
+    p.x = x; p.w = w; p.y = y;
+    p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = d->ldx;
+    p.OH = d->Ho; p.OW = d->Wo; p.ish = d->sh; p.isw = d->sw;
+    p.YH = d->Ho; p.YW = d->Wo; p.ldy = d->ldy; p.osh = 1; p.osw = 1; p.oah = 0; p.oaw = 0;
+    p.C = d->Cin; p.ntaps = d->kh * d->kw; p.K = p.ntaps * p.C; p.ldw = p.K; p.Nout = d->Cout;
+    p.epi = epilogue; p.scale = scale; p.shift = shift; p.stats = stats; p.head_no = head_no; p.accumulate = 0;
+    p.Mtotal = (long long)d->B * d->Ho * d->Wo;
+    for (int i = 0; i < d->kh; ++i)
+        for (int j = 0; j < d->kw; ++j) {
+            int t = i * d->kw + j;
+            p.dh[t] = (signed char)(i - d->ph); p.dw[t] = (signed char)(j - d->pw); p.wt[t] = (signed char)t;
+        }
+    return dispatch_gconv(d->dtype, p, (hipStream_t)s);
+}
+
+// dgrad: dx[n,h,w,ci] = sum_{kh,kw,co} dy[n,(h+ph-kh)/sh,(w+pw-kw)/sw,co] * w[co,kh,kw,ci] over exact divisions.
+// Each (h mod sh, w mod sw) residue class is a stride-1 gather conv over dy with its own tap subset, so no
+// MFMA work is spent on structural zeros.
+extern "C" int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
+                                ayolo_stream s) {
+    int rc = check_desc(d, "conv_dgrad");
+    if (rc) return rc;
+    AY_CHECK_ARG(dy && wt && dx, "conv_dgrad: null pointer");
+    const int ce = d->dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(d->Cout % ce == 0 && d->ldy % ce == 0, "conv_dgrad: Cout=%d ldy=%d must be multiples of %d", d->Cout,
+                 d->ldy, ce);
+    for (int a = 0; a < d->sh; ++a)
+        for (int b = 0; b < d->sw; ++b) {
+            GConvP p{};
+            p.x = dy; p.w = wt; p.y = dx;
+            p.B = d->B; p.XH = d->Ho; p.XW = d->Wo; p.ldx = d->ldy;
+            p.OH = (d->H - a + d->sh - 1) / d->sh; p.OW = (d->W - b + d->sw - 1) / d->sw;
+            if (p.OH <= 0 || p.OW <= 0) continue;
+            p.ish = 1; p.isw = 1;
+            p.YH = d->H; p.YW = d->W; p.ldy = d->ldx; p.osh = d->sh; p.osw = d->sw; p.oah = a; p.oaw = b;
+            p.C = d->Cout; p.ldw = d->kh * d->kw * d->Cout; p.Nout = d->Cin;
+            p.epi = AYOLO_EPI_NONE; p.accumulate = accumulate;
+            p.Mtotal = (long long)d->B * p.OH * p.OW;
+            int nt = 0;
+            for (int i = 0; i < d->kh; ++i) {
+                if ((a + d->ph - i) % d->sh != 0) continue;
+                for (int j = 0; j < d->kw; ++j) {
+                    if ((b + d->pw - j) % d->sw != 0) continue;
+                    // floor division for negative numerators is not needed: exact multiples only
+                    p.dh[nt] = (signed char)((a + d->ph - i) / d->sh);
+                    p.dw[nt] = (signed char)((b + d->pw - j) / d->sw);
+                    p.wt[nt] = (signed char)(i * d->kw + j);
+                    ++nt;
+                }
+            }
+            p.ntaps = nt; p.K = nt * p.C;   // nt == 0: no tap reaches this residue class -> the kernel writes zeros
+            rc = dispatch_gconv(d->dtype, p, (hipStream_t)s);
+            if (rc) return rc;
+        }
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad
+// ---------------------------------------------------------------------------------------------------
+struct WGradP {
+    const void* x; const void* dy; float* dw;
+    int B, XH, XW, ldx, C;         // x: input activations
+    int OH, OW, ldy, N;            // dy: output gradient, N = Cout
+    int sh, sw, ntaps, K;          // K = ntaps*C (row length of dw)
+    float alpha;
+    long long P;                   // B*OH*OW
+    long long chunk;               // pixels per split (multiple of 32)
+    signed char dh[MAX_TAPS], dw_[MAX_TAPS];
+};
+
+#define BP 32   // pixels per reduction step
+#define TNW 128 // dw columns per block tile
+
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// A/B fragments for v_mfma_f32_32x32x16_f16 out of a pixel-major LDS tile t[pixel][channel] via the gfx950
+// transposing LDS read: each 16-lane group reads a 4(pixel) x 16(channel) block, lane q supplies the address of
+// row q/4, channels (q%4)*4.. and receives channel q of all 4 rows.
+__device__ __forceinline__ half8 tr_frag(const half_t* tile, int ldt, int k0, int c0, int lane) {
+    const int q = lane & 15;
+    const half_t* p0 = tile + (k0 + (q >> 2)) * ldt + c0 + (q & 3) * 4;
+    fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0));
+    fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0 + 4 * ldt));
+    half8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <typename T, int TM>
+__global__ __launch_bounds__(256) void k_wgrad(WGradP p) {
+    constexpr int CE = Tr<T>::CE;
+    constexpr int LDY = TM + Tr<T>::PADE;     // dy tile row stride
+    constexpr int LDX = TNW + Tr<T>::PADE;    // x tile row stride
+    constexpr int WM = TM / 32, WN = 4 / WM, NI = TNW / (32 * WN);
+    constexpr int XCPR = TNW / CE, YCPR = TM / CE;
+    constexpr int XR = (BP * XCPR) / 256;             // x chunks / thread (2 for f16, 4 for f32)
+    constexpr int YCH = BP * YCPR;
+    constexpr int YR = (YCH + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sY = reinterpret_cast<T*>(smem_raw);           // [2][BP][LDY]
+    T* sX = sY + 2 * BP * LDY;                        // [2][BP][LDX]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int n0 = blockIdx.y * TM;                   // output-channel tile
+    const int j0 = blockIdx.x * TNW;                  // dw column tile (tap*C + c)
+    const long long pbeg = (long long)blockIdx.z * p.chunk;
+    const long long pend = min(p.P, pbeg + p.chunk);
+    if (pbeg >= pend) return;
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+
+    // x loader: this thread always loads the same dw column chunk, for XR different pixel rows
+    const int xcc = tid % XCPR;
+    const int xcol = j0 + xcc * CE;
+    const bool xcol_ok = xcol < p.K;
+    const int xtap = xcol_ok ? xcol / p.C : 0;
+    const int xc = xcol_ok ? xcol % p.C : 0;
+    const int xdh = p.dh[xtap], xdw = p.dw_[xtap];
+    const int ycc = tid % YCPR;
+    const bool ycol_ok = (n0 + ycc * CE) < p.N;
+
+    uint4 xreg[XR], yreg[YR];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    // pixel coordinates of this thread's x rows, advanced incrementally (no divisions in the loop)
+    int pn[XR], poh[XR], pow_[XR];
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+        long long pp = pbeg + (tid + 256 * r) / XCPR;
+        pow_[r] = (int)(pp % p.OW);
+        long long t = pp / p.OW;
+        poh[r] = (int)(t % p.OH);
+        pn[r] = (int)(t / p.OH);
+    }
+
+    float16v acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int nk = (int)((pend - pbeg + BP - 1) / BP);
+    for (int kt = -1; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const long long pt = pbeg + (long long)(kt + 1) * BP;
+#pragma unroll
+            for (int r = 0; r < XR; ++r) {
+                int prow = (tid + 256 * r) / XCPR;
+                long long pp = pt + prow;
+                xreg[r] = zero4;
+                if (pp < pend && xcol_ok) {
+                    int ih = poh[r] * p.sh + xdh, iw = pow_[r] * p.sw + xdw;
+                    if (ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW)
+                        xreg[r] = *reinterpret_cast<const uint4*>(X + (((long long)pn[r] * p.XH + ih) * p.XW + iw) * p.ldx + xc);
+                }
+                pow_[r] += BP;
+                while (pow_[r] >= p.OW) { pow_[r] -= p.OW; ++poh[r]; }
+                while (poh[r] >= p.OH) { poh[r] -= p.OH; ++pn[r]; }
+            }
+#pragma unroll
+            for (int r = 0; r < YR; ++r) {
+                int q = tid + 256 * r;
+                int prow = q / YCPR;
+                long long pp = pt + prow;
+                yreg[r] = zero4;
+                if (q < YCH && pp < pend && ycol_ok)
+                    yreg[r] = *reinterpret_cast<const uint4*>(DY + pp * p.ldy + n0 + ycc * CE);
+            }
+        }
+        if (kt >= 0) {
+            const int buf = kt & 1;
+            const T* cY = sY + buf * BP * LDY;
+            const T* cX = sX + buf * BP * LDX;
+#pragma unroll
+            for (int kk = 0; kk < BP / 16; ++kk) {
+                const int k0 = kk * 16 + (lane >> 5) * 8;
+                if constexpr (sizeof(T) == 2) {
+                    const int csub = ((lane >> 4) & 1) * 16;
+                    half8 a = tr_frag(cY, LDY, k0, wm * 32 + csub, lane);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        half8 b = tr_frag(cX, LDX, k0, wn * NI * 32 + ni * 32 + csub, lane);
+                        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ni], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        float a = cY[(k0 + s8) * LDY + wm * 32 + (lane & 31)];
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            float b = cX[(k0 + s8) * LDX + wn * NI * 32 + ni * 32 + (lane & 31)];
+                            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ni], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (more) {
+            const int nb = (kt + 1) & 1;
+            T* dX = sX + nb * BP * LDX;
+            T* dY = sY + nb * BP * LDY;
+#pragma unroll
+            for (int r = 0; r < XR; ++r) {
+                int prow = (tid + 256 * r) / XCPR;
+                *reinterpret_cast<uint4*>(dX + prow * LDX + xcc * CE) = xreg[r];
+            }
+#pragma unroll
+            for (int r = 0; r < YR; ++r) {
+                int q = tid + 256 * r;
+                if (q < YCH) *reinterpret_cast<uint4*>(dY + (q / YCPR) * LDY + ycc * CE) = yreg[r];
+            }
+        }
+        __syncthreads();
+    }
+    // acc[ni][r]: row (out channel) = n0 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); col = j0 + wn*NI*32 + ni*32 + (lane&31)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        int col = j0 + wn * NI * 32 + ni * 32 + (lane & 31);
+        if (col >= p.K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = n0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (row < p.N) unsafeAtomicAdd(&p.dw[(long long)row * p.K + col], acc[ni][r] * p.alpha);
+        }
+    }
+}
+
+template <typename T, int TM>
+static int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
+    constexpr int LDY = TM + Tr<T>::PADE, LDX = TNW + Tr<T>::PADE;
+    size_t lds = (size_t)2 * BP * (LDY + LDX) * sizeof(T);
+    dim3 grid((unsigned)((p.K + TNW - 1) / TNW), (unsigned)((p.N + TM - 1) / TM), (unsigned)splits);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_wgrad<T, TM>), grid, dim3(256), lds, s, p);
+    AY_CHECK_LAUNCH("k_wgrad");
+    return AYOLO_OK;
+}
+
+extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha,
+                                ayolo_stream s) {
+    int rc = check_desc(d, "conv_wgrad");
+    if (rc) return rc;
+    AY_CHECK_ARG(x && dy && dw, "conv_wgrad: null pointer");
+    const int ce = d->dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(d->ldy % ce == 0, "conv_wgrad: ldy=%d must be a multiple of %d", d->ldy, ce);
+    WGradP p{};
+    p.x = x; p.dy = dy; p.dw = dw;
+    p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = d->ldx; p.C = d->Cin;
+    p.OH = d->Ho; p.OW = d->Wo; p.ldy = d->ldy; p.N = d->Cout;
+    p.sh = d->sh; p.sw = d->sw; p.ntaps = d->kh * d->kw; p.K = p.ntaps * p.C; p.alpha = alpha;
+    p.P = (long long)d->B * d->Ho * d->Wo;
+    for (int i = 0; i < d->kh; ++i)
+        for (int j = 0; j < d->kw; ++j) {
+            p.dh[i * d->kw + j] = (signed char)(i - d->ph);
+            p.dw_[i * d->kw + j] = (signed char)(j - d->pw);
+        }
+    const int tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
+    const long long tiles = (long long)((p.K + TNW - 1) / TNW) * ((p.N + tm - 1) / tm);
+    // split the pixel reduction so that ~4 blocks per CU are in flight, each with >= 8 reduction steps
+    long long want = (1024 + tiles - 1) / tiles;
+    long long max_splits = (p.P + 8 * BP - 1) / (8 * BP);
+    long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    long long chunk = (p.P + splits - 1) / splits;
+    chunk = (chunk + BP - 1) / BP * BP;
+    splits = (p.P + chunk - 1) / chunk;
+    p.chunk = chunk;
+    hipStream_t st = (hipStream_t)s;
+    if (d->dtype == AYOLO_F16) {
+        if (tm == 32) return launch_wgrad<half_t, 32>(p, (int)splits, st);
+        if (tm == 64) return launch_wgrad<half_t, 64>(p, (int)splits, st);
+        return launch_wgrad<half_t, 128>(p, (int)splits, st);
+    } else {
+        if (tm == 32) return launch_wgrad<float, 32>(p, (int)splits, st);
+        if (tm == 64) return launch_wgrad<float, 64>(p, (int)splits, st);
+        return launch_wgrad<float, 128>(p, (int)splits, st);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight cast: fp32 [Cout][taps][Cin] -> T [Cout_pad][taps][Cin_pad] and transposed T [Cin_pad][taps][Cout_pad]
+// (padding rows / channels are zero)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_cast_weight(const float* w32, int Cout, int taps, int Cin, int Cout_pad, int Cin_pad, T* w, T* wt) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long tot = (long long)Cout_pad * taps * Cin_pad;
+    if (t >= tot) return;
+    int c = (int)(t % Cin_pad);
+    long long r = t / Cin_pad;
+    int tap = (int)(r % taps);
+    int co = (int)(r / taps);
+    float v = (c < Cin && co < Cout) ? w32[((long long)co * taps + tap) * Cin + c] : 0.0f;
+    if (w) w[t] = (T)v;
+    if (wt) wt[((long long)c * taps + tap) * Cout_pad + co] = (T)v;
+}
+
+extern "C" int ayolo_cast_weight(const float* w32, int Cout, int kh, int kw, int Cin, int Cout_pad, int Cin_pad, int dtype,
+                                 void* w, void* wt, ayolo_stream s) {
+    AY_CHECK_ARG(w32 && (w || wt), "cast_weight: null pointer");
+    AY_CHECK_ARG(Cin_pad >= Cin && Cout_pad >= Cout, "cast_weight: pad < size");
+    long long tot = (long long)Cout_pad * kh * kw * Cin_pad;
+    dim3 grid((unsigned)cdiv64(tot, 256));
+    if (dtype == AYOLO_F16)
+        hipLaunchKernelGGL(k_cast_weight<half_t>, grid, dim3(256), 0, (hipStream_t)s, w32, Cout, kh * kw, Cin, Cout_pad,
+                           Cin_pad, (half_t*)w, (half_t*)wt);
+    else
+        hipLaunchKernelGGL(k_cast_weight<float>, grid, dim3(256), 0, (hipStream_t)s, w32, Cout, kh * kw, Cin, Cout_pad,
+                           Cin_pad, (float*)w, (float*)wt);
+    AY_CHECK_LAUNCH("k_cast_weight");
+    return AYOLO_OK;
+}

@@ -1,0 +1,570 @@
+// HBM-bound NHWC kernels around the conv stack: training-mode BatchNorm + SiLU (forward / backward), SPPF
+// max-pool, nearest 2x upsample, input packing, strided slice copy (concat / residual), YOLOHead decode and the
+// head-gradient repack.  All activations move as 16-byte channel vectors (8 x fp16 / 4 x fp32 per lane).
+//
+// Replaces the BatchNorm2d / SiLU / MaxPool2d / Upsample / cat / sigmoid kernels torch launched for kindle's
+// Conv, SPPF, UpSample, Concat and YOLOHead modules.
+#include "common.h"
+
+template <typename T> struct VecT;
+template <> struct VecT<half_t> { static constexpr int VE = 8; };
+template <> struct VecT<float> { static constexpr int VE = 4; };
+
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, float (&v)[VecT<T>::VE]) {
+    uint4 raw = *reinterpret_cast<const uint4*>(p);
+    const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < VecT<T>::VE; ++i) v[i] = (float)e[i];
+}
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float (&v)[VecT<T>::VE]) {
+    uint4 raw;
+    T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < VecT<T>::VE; ++i) e[i] = (T)v[i];
+    *reinterpret_cast<uint4*>(p) = raw;
+}
+
+static unsigned grid_for(long long work_items, int per_block) {
+    long long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 8192) b = 8192;   // grid-stride beyond 32 blocks/CU
+    return (unsigned)b;
+}
+
+#define DISPATCH_T(dtype, ...)                                 \
+    if ((dtype) == AYOLO_F16) { typedef half_t T; __VA_ARGS__ } \
+    else { typedef float T; __VA_ARGS__ }
+
+// ---------------------------------------------------------------------------------------------------
+// BN finalize
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_bn_finalize(const float* stats, int C, double count, const float* gamma, const float* beta, float eps,
+                              float momentum, float* rmean, float* rvar, float* smean, float* sinv, float* scale,
+                              float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean = (double)stats[c] / count;
+    double var = (double)stats[C + c] / count - mean * mean;
+    if (var < 0) var = 0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    if (smean) smean[c] = (float)mean;
+    if (sinv) sinv[c] = invstd;
+    float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
+    if (rvar) {
+        double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+extern "C" int ayolo_bn_finalize(const float* stats, int C, double count, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                                 float* save_invstd, float* scale, float* shift, ayolo_stream s) {
+    AY_CHECK_ARG(stats && scale && shift && C > 0 && count > 0, "bn_finalize: bad args");
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s, stats, C, count, gamma, beta, eps,
+                       momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
+    AY_CHECK_LAUNCH("k_bn_finalize");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a = act(z*scale + shift)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_affine_act(const T* z, int ldz, T* a, int lda, long long npix, int C,
+                                                    const float* scale, const float* shift, int act) {
+    constexpr int VE = VecT<T>::VE;
+    extern __shared__ float sh[];   // [2][C]
+    for (int i = threadIdx.x; i < C; i += 256) {
+        sh[i] = scale ? scale[i] : 1.0f;
+        sh[C + i] = shift ? shift[i] : 0.0f;
+    }
+    __syncthreads();
+    const int CG = C / VE;
+    const long long total = npix * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        long long pix = t / CG;
+        int cg = (int)(t - pix * CG);
+        float v[VE];
+        load_vec<T>(z + pix * ldz + cg * VE, v);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            float u = v[i] * sh[cg * VE + i] + sh[C + cg * VE + i];
+            v[i] = act ? silu_f(u) : u;
+        }
+        store_vec<T>(a + pix * lda + cg * VE, v);
+    }
+}
+
+extern "C" int ayolo_affine_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C,
+                                const float* scale, const float* shift, int act, ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(z && a && C > 0 && C % ve == 0 && ldz % ve == 0 && lda % ve == 0, "affine_act: C=%d ldz=%d lda=%d", C, ldz, lda);
+    AY_CHECK_ARG(C <= 8192, "affine_act: C too large");
+    if (npix == 0) return AYOLO_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_affine_act<T>, dim3(grid_for(npix * (C / ve), 256 * 4)), dim3(256),
+                                         2 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (T*)a, lda,
+                                         (long long)npix, C, scale, shift, act);)
+    AY_CHECK_LAUNCH("k_affine_act");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward of a = act(bn(z)):  u = xhat*gamma + beta, xhat = (z-mean)*invstd, du = da * act'(u)
+//   pass 1: sums[c] = sum du, sums[C+c] = sum du*xhat
+//   pass 2: dz = gamma*invstd * (du - sums[c]/n - xhat*sums[C+c]/n)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float u, int act) {
+    if (!act) return 1.0f;
+    float sg = 1.0f / (1.0f + expf(-u));
+    return sg * (1.0f + u * (1.0f - sg));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, const T* da, int ldda, long long npix, int C,
+                                                       const float* mean, const float* invstd, const float* gamma,
+                                                       const float* beta, int act, float* sums) {
+    constexpr int VE = VecT<T>::VE;
+    extern __shared__ float sh[];   // [4][C] mean, invstd, gamma, beta ; then [2][C] block sums
+    float* bs = sh + 4 * C;
+    for (int i = threadIdx.x; i < C; i += 256) {
+        sh[i] = mean[i]; sh[C + i] = invstd[i];
+        sh[2 * C + i] = gamma ? gamma[i] : 1.0f; sh[3 * C + i] = beta ? beta[i] : 0.0f;
+        bs[i] = 0.0f; bs[C + i] = 0.0f;
+    }
+    __syncthreads();
+    const int CG = C / VE;
+    const int CGT = CG < 256 ? CG : 256;       // channel groups handled per pass
+    const int RPB = 256 / CGT;                 // pixel rows per block iteration
+    const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
+    const bool active = prow < RPB;
+    for (int cg0 = 0; cg0 < CG; cg0 += CGT) {
+        const int cg = cg0 + cgl;
+        if (!(active && cg < CG)) continue;
+        float s1[VE], s2[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) { s1[i] = 0.0f; s2[i] = 0.0f; }
+        for (long long pix = (long long)blockIdx.x * RPB + prow; pix < npix; pix += (long long)gridDim.x * RPB) {
+            float zv[VE], dv[VE];
+            load_vec<T>(z + pix * ldz + cg * VE, zv);
+            load_vec<T>(da + pix * ldda + cg * VE, dv);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                int c = cg * VE + i;
+                float xh = (zv[i] - sh[c]) * sh[C + c];
+                float u = xh * sh[2 * C + c] + sh[3 * C + c];
+                float du = dv[i] * act_grad(u, act);
+                s1[i] += du;
+                s2[i] += du * xh;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            atomicAdd(&bs[cg * VE + i], s1[i]);
+            atomicAdd(&bs[C + cg * VE + i], s2[i]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], bs[i]);
+}
+
+extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const void* da, int ldda, int64_t npix, int C,
+                                       const float* save_mean, const float* save_invstd, const float* gamma,
+                                       const float* beta, int act, float* sums, ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(z && da && sums && save_mean && save_invstd, "bn_bwd_reduce: null pointer");
+    AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && C <= 2048, "bn_bwd_reduce: C=%d", C);
+    if (npix == 0) return AYOLO_OK;
+    int cg = C / ve, cgt = cg < 256 ? cg : 256, rpb = 256 / cgt;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_reduce<T>, dim3(grid_for(npix, rpb * 16)), dim3(256),
+                                         6 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
+                                         (long long)npix, C, save_mean, save_invstd, gamma, beta, act, sums);)
+    AY_CHECK_LAUNCH("k_bn_bwd_reduce");
+    return AYOLO_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const T* da, int ldda, T* dz, int lddz,
+                                                      long long npix, int C, const float* mean, const float* invstd,
+                                                      const float* gamma, const float* beta, int act, const float* sums,
+                                                      float* dgamma, float* dbeta, float grad_scale) {
+    constexpr int VE = VecT<T>::VE;
+    extern __shared__ float sh[];   // [6][C]: mean, invstd, gamma, beta, sum_du/n, sum_dux/n
+    const float invn = 1.0f / (float)npix;
+    for (int i = threadIdx.x; i < C; i += 256) {
+        sh[i] = mean[i]; sh[C + i] = invstd[i];
+        sh[2 * C + i] = gamma ? gamma[i] : 1.0f; sh[3 * C + i] = beta ? beta[i] : 0.0f;
+        sh[4 * C + i] = sums[i] * invn; sh[5 * C + i] = sums[C + i] * invn;
+        if (blockIdx.x == 0) {
+            if (dbeta) dbeta[i] = sums[i] * grad_scale;
+            if (dgamma) dgamma[i] = sums[C + i] * grad_scale;
+        }
+    }
+    __syncthreads();
+    const int CG = C / VE;
+    const long long total = npix * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        long long pix = t / CG;
+        int cg = (int)(t - pix * CG);
+        float zv[VE], dv[VE];
+        load_vec<T>(z + pix * ldz + cg * VE, zv);
+        load_vec<T>(da + pix * ldda + cg * VE, dv);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            int c = cg * VE + i;
+            float xh = (zv[i] - sh[c]) * sh[C + c];
+            float u = xh * sh[2 * C + c] + sh[3 * C + c];
+            float du = dv[i] * act_grad(u, act);
+            dv[i] = sh[2 * C + c] * sh[C + c] * (du - sh[4 * C + c] - xh * sh[5 * C + c]);
+        }
+        store_vec<T>(dz + pix * lddz + cg * VE, dv);
+    }
+}
+
+extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
+                                      int64_t npix, int C, const float* save_mean, const float* save_invstd,
+                                      const float* gamma, const float* beta, int act, const float* sums, float* dgamma,
+                                      float* dbeta, float grad_scale, ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(z && da && dz && sums, "bn_bwd_apply: null pointer");
+    AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && lddz % ve == 0 && C <= 2048, "bn_bwd_apply: C=%d", C);
+    if (npix == 0) return AYOLO_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(grid_for(npix * (C / ve), 256 * 4)), dim3(256),
+                                         6 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
+                                         (T*)dz, lddz, (long long)npix, C, save_mean, save_invstd, gamma, beta, act,
+                                         sums, dgamma, dbeta, grad_scale);)
+    AY_CHECK_LAUNCH("k_bn_bwd_apply");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// max-pool k x k, stride 1, pad k/2 (SPPF).  Forward records the window position of the first maximum
+// (row-major scan, `val > max || isnan(val)` as torch) so backward is a 25-tap gather without atomics.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const T* x, int ldx, T* y, int ldy, unsigned char* idx, int B, int H,
+                                                     int W, int C, int k) {
+    constexpr int VE = VecT<T>::VE;
+    const int CG = C / VE, pad = k / 2;
+    const long long total = (long long)B * H * W * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int cg = (int)(t % CG);
+        long long pix = t / CG;
+        int w = (int)(pix % W);
+        long long r = pix / W;
+        int h = (int)(r % H);
+        long long n = r / H;
+        float best[VE];
+        int bi[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+        for (int dy = 0; dy < k; ++dy) {
+            int hh = h + dy - pad;
+            if (hh < 0 || hh >= H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                int ww = w + dx - pad;
+                if (ww < 0 || ww >= W) continue;
+                float v[VE];
+                load_vec<T>(x + ((n * H + hh) * W + ww) * ldx + cg * VE, v);
+#pragma unroll
+                for (int i = 0; i < VE; ++i)
+                    if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bi[i] = dy * k + dx; }
+            }
+        }
+        store_vec<T>(y + pix * ldy + cg * VE, best);
+        if (idx) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) idx[pix * C + cg * VE + i] = (unsigned char)bi[i];
+        }
+    }
+}
+
+extern "C" int ayolo_maxpool_fwd(int dtype, const void* x, int ldx, void* y, int ldy, unsigned char* argmax, int B, int H,
+                                 int W, int C, int k, ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(x && y && C % ve == 0 && ldx % ve == 0 && ldy % ve == 0 && k > 0 && k <= 15 && (k & 1), "maxpool_fwd: bad args");
+    long long total = (long long)B * H * W * (C / ve);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_fwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
+                                         (const T*)x, ldx, (T*)y, ldy, argmax, B, H, W, C, k);)
+    AY_CHECK_LAUNCH("k_maxpool_fwd");
+    return AYOLO_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const unsigned char* idx, const T* dy, int lddy, T* dx, int lddx, int B,
+                                                     int H, int W, int C, int k, int accumulate) {
+    constexpr int VE = VecT<T>::VE;
+    const int CG = C / VE, pad = k / 2;
+    const long long total = (long long)B * H * W * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int cg = (int)(t % CG);
+        long long pix = t / CG;
+        int w = (int)(pix % W);
+        long long r = pix / W;
+        int h = (int)(r % H);
+        long long n = r / H;
+        float g[VE];
+        if (accumulate) load_vec<T>(dx + pix * lddx + cg * VE, g);
+        else {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) g[i] = 0.0f;
+        }
+        // output (oh, ow) looks at input (oh + dyy - pad, ow + dxx - pad): this input is tap (dyy,dxx) of
+        // output (h - dyy + pad, w - dxx + pad)
+        for (int dyy = 0; dyy < k; ++dyy) {
+            int oh = h - dyy + pad;
+            if (oh < 0 || oh >= H) continue;
+            for (int dxx = 0; dxx < k; ++dxx) {
+                int ow = w - dxx + pad;
+                if (ow < 0 || ow >= W) continue;
+                long long op = (n * H + oh) * W + ow;
+                const unsigned char* ip = idx + op * C + cg * VE;
+                float dv[VE];
+                load_vec<T>(dy + op * lddy + cg * VE, dv);
+                const int me = dyy * k + dxx;
+#pragma unroll
+                for (int i = 0; i < VE; ++i)
+                    if (ip[i] == me) g[i] += dv[i];
+            }
+        }
+        store_vec<T>(dx + pix * lddx + cg * VE, g);
+    }
+}
+
+extern "C" int ayolo_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, int lddy, void* dx, int lddx, int B,
+                                 int H, int W, int C, int k, int accumulate, ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(argmax && dy && dx && C % ve == 0 && lddy % ve == 0 && lddx % ve == 0, "maxpool_bwd: bad args");
+    long long total = (long long)B * H * W * (C / ve);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, argmax,
+                                         (const T*)dy, lddy, (T*)dx, lddx, B, H, W, C, k, accumulate);)
+    AY_CHECK_LAUNCH("k_maxpool_bwd");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// nearest 2x upsample
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample_fwd(const T* x, int ldx, T* y, int ldy, int B, int H, int W, int C) {
+    constexpr int VE = VecT<T>::VE;
+    const int CG = C / VE, OW = 2 * W, OH = 2 * H;
+    const long long total = (long long)B * OH * OW * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int cg = (int)(t % CG);
+        long long pix = t / CG;
+        int ow = (int)(pix % OW);
+        long long r = pix / OW;
+        int oh = (int)(r % OH);
+        long long n = r / OH;
+        uint4 v = *reinterpret_cast<const uint4*>(x + ((n * H + (oh >> 1)) * W + (ow >> 1)) * ldx + cg * VE);
+        *reinterpret_cast<uint4*>(y + pix * ldy + cg * VE) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample_bwd(const T* dy, int lddy, T* dx, int lddx, int B, int H, int W, int C,
+                                                      int accumulate) {
+    constexpr int VE = VecT<T>::VE;
+    const int CG = C / VE, OW = 2 * W;
+    const long long total = (long long)B * H * W * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int cg = (int)(t % CG);
+        long long pix = t / CG;
+        int w = (int)(pix % W);
+        long long r = pix / W;
+        int h = (int)(r % H);
+        long long n = r / H;
+        float g[VE];
+        if (accumulate) load_vec<T>(dx + pix * lddx + cg * VE, g);
+        else {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) g[i] = 0.0f;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float v[VE];
+                load_vec<T>(dy + ((n * 2 * H + 2 * h + a) * OW + 2 * w + b) * lddy + cg * VE, v);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) g[i] += v[i];
+            }
+        store_vec<T>(dx + pix * lddx + cg * VE, g);
+    }
+}
+
+extern "C" int ayolo_upsample2x_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C,
+                                    ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(x && y && C % ve == 0 && ldx % ve == 0 && ldy % ve == 0, "upsample_fwd: bad args");
+    long long total = (long long)B * 4 * H * W * (C / ve);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_upsample_fwd<T>, dim3(grid_for(total, 256 * 2)), dim3(256), 0, (hipStream_t)s,
+                                         (const T*)x, ldx, (T*)y, ldy, B, H, W, C);)
+    AY_CHECK_LAUNCH("k_upsample_fwd");
+    return AYOLO_OK;
+}
+
+extern "C" int ayolo_upsample2x_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C,
+                                    int accumulate, ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(dy && dx && C % ve == 0 && lddy % ve == 0 && lddx % ve == 0, "upsample_bwd: bad args");
+    long long total = (long long)B * H * W * (C / ve);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_upsample_bwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
+                                         (const T*)dy, lddy, (T*)dx, lddx, B, H, W, C, accumulate);)
+    AY_CHECK_LAUNCH("k_upsample_bwd");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// input packing: NCHW fp32 -> NHWC (Cpad channels, zero filled)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_input(const float* x, int B, int C, int H, int W, T* y, int Cpad) {
+    const long long hw = (long long)H * W, total = (long long)B * hw;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        long long n = t / hw, p = t - n * hw;
+        T* o = y + t * Cpad;
+        for (int c = 0; c < Cpad; ++c) o[c] = c < C ? (T)x[(n * C + c) * hw + p] : (T)0.0f;
+    }
+}
+
+extern "C" int ayolo_pack_input(const float* x, int B, int C, int H, int W, int dtype, void* y, int Cpad, ayolo_stream s) {
+    AY_CHECK_ARG(x && y && Cpad >= C && Cpad <= 16, "pack_input: bad args");
+    long long total = (long long)B * H * W;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_pack_input<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, x, B, C,
+                                         H, W, (T*)y, Cpad);)
+    AY_CHECK_LAUNCH("k_pack_input");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// strided slice copy / add
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy2d(const T* x, int ldx, T* y, int ldy, long long npix, int C, int accumulate) {
+    constexpr int VE = VecT<T>::VE;
+    const int CG = C / VE;
+    const long long total = npix * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        long long pix = t / CG;
+        int cg = (int)(t - pix * CG);
+        if (accumulate) {
+            float a[VE], b[VE];
+            load_vec<T>(x + pix * ldx + cg * VE, a);
+            load_vec<T>(y + pix * ldy + cg * VE, b);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) b[i] += a[i];
+            store_vec<T>(y + pix * ldy + cg * VE, b);
+        } else {
+            *reinterpret_cast<uint4*>(y + pix * ldy + cg * VE) = *reinterpret_cast<const uint4*>(x + pix * ldx + cg * VE);
+        }
+    }
+}
+
+extern "C" int ayolo_copy2d(int dtype, const void* x, int ldx, void* y, int ldy, int64_t npix, int C, int accumulate,
+                            ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(x && y && C % ve == 0 && ldx % ve == 0 && ldy % ve == 0, "copy2d: bad args");
+    if (npix == 0) return AYOLO_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_copy2d<T>, dim3(grid_for(npix * (C / ve), 256 * 4)), dim3(256), 0,
+                                         (hipStream_t)s, (const T*)x, ldx, (T*)y, ldy, (long long)npix, C, accumulate);)
+    AY_CHECK_LAUNCH("k_copy2d");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// YOLOHead: eval decode and gradient repack
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_head_decode(const float* raw, int B, int na, int ny, int nx, int no,
+                                                     const float* anchors_px, float stride, float* out,
+                                                     long long rows_total, long long row_off) {
+    const long long per_img = (long long)na * ny * nx;
+    const long long total = (long long)B * per_img * no;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int o = (int)(t % no);
+        long long cell = t / no;                     // ((b*na + a)*ny + y)*nx + x
+        int x = (int)(cell % nx);
+        long long r = cell / nx;
+        int y = (int)(r % ny);
+        r /= ny;
+        int a = (int)(r % na);
+        long long b = r / na;
+        float sg = 1.0f / (1.0f + expf(-raw[t]));
+        float v = sg;
+        if (o == 0) v = (sg * 2.0f - 0.5f + (float)x) * stride;
+        else if (o == 1) v = (sg * 2.0f - 0.5f + (float)y) * stride;
+        else if (o == 2 || o == 3) { float q = sg * 2.0f; v = q * q * anchors_px[a * 2 + (o - 2)]; }
+        long long row = row_off + ((long long)a * ny + y) * nx + x;
+        out[(b * rows_total + row) * no + o] = v;
+    }
+}
+
+extern "C" int ayolo_head_decode(const float* raw, int B, int na, int ny, int nx, int no, const float* anchors_px,
+                                 float stride, float* out, int64_t rows_total, int64_t row_off, ayolo_stream s) {
+    AY_CHECK_ARG(raw && out && anchors_px && no > 4, "head_decode: bad args");
+    long long total = (long long)B * na * ny * nx * no;
+    hipLaunchKernelGGL(k_head_decode, dim3(grid_for(total, 256 * 4)), dim3(256), 0, (hipStream_t)s, raw, B, na, ny, nx, no,
+                       anchors_px, stride, out, (long long)rows_total, (long long)row_off);
+    AY_CHECK_LAUNCH("k_head_decode");
+    return AYOLO_OK;
+}
+
+// d(raw) (B,na,ny,nx,no) fp32 -> NHWC gradient dz[pix][ldz] (channel c = a*no + o; channels >= na*no zero) and
+// dbias[c] += sum over pixels (fp32, zeroed by the caller).
+template <typename T>
+__global__ __launch_bounds__(256) void k_head_grad_pack(const float* draw, int B, int na, int ny, int nx, int no, T* dz,
+                                                        int ldz, float* dbias) {
+    extern __shared__ float bs[];   // [ldz]
+    for (int i = threadIdx.x; i < ldz; i += 256) bs[i] = 0.0f;
+    __syncthreads();
+    const long long hw = (long long)ny * nx, npix = (long long)B * hw;
+    const int Cc = na * no;
+    // one thread per (pixel, channel), channel fastest: coalesced dz writes, strided-but-cached draw reads
+    const long long total = npix * ldz;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int c = (int)(t % ldz);
+        long long pix = t / ldz;
+        float v = 0.0f;
+        if (c < Cc) {
+            int a = c / no, o = c - a * no;
+            long long b = pix / hw, p = pix - b * hw;
+            v = draw[((b * na + a) * hw + p) * no + o];
+            atomicAdd(&bs[c], v);
+        }
+        dz[t] = (T)v;
+    }
+    __syncthreads();
+    if (dbias)
+        for (int i = threadIdx.x; i < Cc; i += 256) atomicAdd(&dbias[i], bs[i]);
+}
+
+extern "C" int ayolo_head_grad_pack(const float* draw, int B, int na, int ny, int nx, int no, int dtype, void* dz, int ldz,
+                                    float* dbias, ayolo_stream s) {
+    AY_CHECK_ARG(draw && dz && ldz >= na * no && ldz <= 4096, "head_grad_pack: bad args");
+    long long total = (long long)B * ny * nx * ldz;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_grad_pack<T>, dim3(grid_for(total, 256 * 8)), dim3(256),
+                                         ldz * sizeof(float), (hipStream_t)s, draw, B, na, ny, nx, no, (T*)dz, ldz, dbias);)
+    AY_CHECK_LAUNCH("k_head_grad_pack");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void ayolo_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ayolo_last_error(void) { return g_err; }
+extern "C" int ayolo_version(void) { return 1; }

@@ -1,0 +1,215 @@
+"""Tensor-level wrappers over the C ABI.  PyTorch is used here only for device memory and streams.
+
+Activation convention: a logical (B, C, H, W) torch tensor whose memory is NHWC (``channels_last`` strides),
+possibly a channel slice of a wider buffer (then ``ld`` = channel count of the parent).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import F16, F32, ConvDesc, call
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float16:
+        return F16
+    if dt == torch.float32:
+        return F32
+    raise _lib.AyoloError(f"unsupported dtype {dt}")
+
+
+def require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _lib.AyoloError(f"{what}: the HIP path needs a tensor on the GPU (got {t.device}); there is no CPU fallback")
+
+
+def nhwc_info(t: torch.Tensor) -> Tuple[int, int, int, int, int]:
+    """(B, C, H, W, ld) of an NHWC-in-memory tensor (possibly a channel slice of a wider buffer: ld > C)."""
+    if t.dim() != 4:
+        raise _lib.AyoloError(f"expected a 4-D activation, got shape {tuple(t.shape)}")
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if W > 1:
+        ld = sw
+    elif H > 1:
+        ld = sh
+    elif B > 1:
+        ld = sb
+    else:
+        ld = C
+    ok = (C == 1 or sc == 1) and ld >= C
+    if W > 1 and H > 1:
+        ok = ok and sh == W * ld
+    if B > 1:
+        ok = ok and sb == H * W * ld
+    if not ok:
+        raise _lib.AyoloError(f"tensor is not NHWC in memory: shape {tuple(t.shape)} strides {t.stride()}")
+    return B, C, H, W, ld
+
+
+def is_nhwc(t: torch.Tensor) -> bool:
+    try:
+        nhwc_info(t)
+        return True
+    except _lib.AyoloError:
+        return False
+
+
+def to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return t itself if it already is NHWC in memory (16-byte aligned), else a channels_last copy."""
+    if is_nhwc(t) and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def new_act(B: int, C: int, H: int, W: int, dtype: torch.dtype, device) -> torch.Tensor:
+    return torch.empty((B, C, H, W), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def make_desc(dt: torch.dtype, B, H, W, Cin, ldx, Cout, ldy, k, s, p, Ho, Wo) -> ConvDesc:
+    return ConvDesc(dtype_code(dt), B, H, W, Cin, ldx, Cout, ldy, k[0], k[1], s[0], s[1], p[0], p[1], Ho, Wo)
+
+
+# --------------------------------------------------------------------------------------------------
+def conv_fwd(desc: ConvDesc, x, w, y, epilogue=_lib.EPI_NONE, scale=None, shift=None, stats=None, head_no=0):
+    call("ayolo_conv_fwd", desc, _ptr(x), _ptr(w), _ptr(y), epilogue, _ptr(scale), _ptr(shift), _ptr(stats), head_no,
+         _stream())
+
+
+def conv_dgrad(desc: ConvDesc, dy, wt, dx, accumulate=False):
+    call("ayolo_conv_dgrad", desc, _ptr(dy), _ptr(wt), _ptr(dx), int(accumulate), _stream())
+
+
+def conv_wgrad(desc: ConvDesc, x, dy, dw, alpha=1.0):
+    call("ayolo_conv_wgrad", desc, _ptr(x), _ptr(dy), _ptr(dw), float(alpha), _stream())
+
+
+def cast_weight(w32_krsc: torch.Tensor, Cout, kh, kw, Cin, Cout_pad, Cin_pad, dtype: torch.dtype, want_w=True,
+                want_wt=True):
+    """fp32 [Cout][kh][kw][Cin] -> (w [Cout_pad][kh][kw][Cin_pad], wt [Cin_pad][kh][kw][Cout_pad]) of `dtype`."""
+    dev = w32_krsc.device
+    w = torch.empty((Cout_pad, kh, kw, Cin_pad), dtype=dtype, device=dev) if want_w else None
+    wt = torch.empty((Cin_pad, kh, kw, Cout_pad), dtype=dtype, device=dev) if want_wt else None
+    call("ayolo_cast_weight", _ptr(w32_krsc), Cout, kh, kw, Cin, Cout_pad, Cin_pad, dtype_code(dtype), _ptr(w), _ptr(wt),
+         _stream())
+    return w, wt
+
+
+def bn_finalize(stats, C, count, gamma, beta, eps, momentum, running_mean, running_var):
+    dev = stats.device
+    save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+    save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    shift = torch.empty(C, dtype=torch.float32, device=dev)
+    call("ayolo_bn_finalize", _ptr(stats), C, float(count), _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+         _ptr(running_mean), _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), _ptr(scale), _ptr(shift), _stream())
+    return save_mean, save_invstd, scale, shift
+
+
+def affine_act(z, a, scale, shift, act: int):
+    B, C, H, W, ldz = nhwc_info(z)
+    _, _, _, _, lda = nhwc_info(a)
+    call("ayolo_affine_act", dtype_code(z.dtype), _ptr(z), ldz, _ptr(a), lda, B * H * W, C, _ptr(scale), _ptr(shift), act,
+         _stream())
+
+
+def bn_act_bwd(z, da, save_mean, save_invstd, gamma, beta, act: int, want_param_grads=True):
+    """Returns (dz, dgamma, dbeta) for a = act(bn(z)) with batch statistics."""
+    B, C, H, W, ldz = nhwc_info(z)
+    _, _, _, _, ldda = nhwc_info(da)
+    npix = B * H * W
+    dev = z.device
+    sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)
+    dz = new_act(B, C, H, W, z.dtype, dev)
+    dt = dtype_code(z.dtype)
+    call("ayolo_bn_act_bwd_reduce", dt, _ptr(z), ldz, _ptr(da), ldda, npix, C, _ptr(save_mean), _ptr(save_invstd),
+         _ptr(gamma), _ptr(beta), act, _ptr(sums), _stream())
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev) if want_param_grads else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev) if want_param_grads else None
+    call("ayolo_bn_act_bwd_apply", dt, _ptr(z), ldz, _ptr(da), ldda, _ptr(dz), C, npix, C, _ptr(save_mean),
+         _ptr(save_invstd), _ptr(gamma), _ptr(beta), act, _ptr(sums), _ptr(dgamma), _ptr(dbeta), 1.0, _stream())
+    return dz, dgamma, dbeta
+
+
+def maxpool_fwd(x, k: int, y=None, want_argmax=True):
+    B, C, H, W, ldx = nhwc_info(x)
+    if y is None:
+        y = new_act(B, C, H, W, x.dtype, x.device)
+    _, _, _, _, ldy = nhwc_info(y)
+    arg = torch.empty((B, H, W, C), dtype=torch.uint8, device=x.device) if want_argmax else None
+    call("ayolo_maxpool_fwd", dtype_code(x.dtype), _ptr(x), ldx, _ptr(y), ldy, _ptr(arg), B, H, W, C, k, _stream())
+    return y, arg
+
+
+def maxpool_bwd(argmax, dy, k: int, dx=None, accumulate=False):
+    B, C, H, W, lddy = nhwc_info(dy)
+    if dx is None:
+        dx = new_act(B, C, H, W, dy.dtype, dy.device)
+    _, _, _, _, lddx = nhwc_info(dx)
+    call("ayolo_maxpool_bwd", dtype_code(dy.dtype), _ptr(argmax), _ptr(dy), lddy, _ptr(dx), lddx, B, H, W, C, k,
+         int(accumulate), _stream())
+    return dx
+
+
+def upsample2x_fwd(x, y=None):
+    B, C, H, W, ldx = nhwc_info(x)
+    if y is None:
+        y = new_act(B, C, 2 * H, 2 * W, x.dtype, x.device)
+    _, _, _, _, ldy = nhwc_info(y)
+    call("ayolo_upsample2x_fwd", dtype_code(x.dtype), _ptr(x), ldx, _ptr(y), ldy, B, H, W, C, _stream())
+    return y
+
+
+def upsample2x_bwd(dy, dx=None, accumulate=False):
+    B, C, H2, W2, lddy = nhwc_info(dy)
+    H, W = H2 // 2, W2 // 2
+    if dx is None:
+        dx = new_act(B, C, H, W, dy.dtype, dy.device)
+    _, _, _, _, lddx = nhwc_info(dx)
+    call("ayolo_upsample2x_bwd", dtype_code(dy.dtype), _ptr(dy), lddy, _ptr(dx), lddx, B, H, W, C, int(accumulate),
+         _stream())
+    return dx
+
+
+def pack_input(img: torch.Tensor, dtype: torch.dtype, Cpad: int) -> torch.Tensor:
+    """(B, C, H, W) fp32 NCHW -> (B, Cpad, H, W) logical, NHWC in memory, channels >= C zero."""
+    B, C, H, W = img.shape
+    img = img.contiguous()
+    if img.dtype != torch.float32:
+        img = img.float()
+    y = new_act(B, Cpad, H, W, dtype, img.device)
+    call("ayolo_pack_input", _ptr(img), B, C, H, W, dtype_code(dtype), _ptr(y), Cpad, _stream())
+    return y
+
+
+def copy2d(x, y, accumulate=False):
+    B, C, H, W, ldx = nhwc_info(x)
+    _, _, _, _, ldy = nhwc_info(y)
+    call("ayolo_copy2d", dtype_code(x.dtype), _ptr(x), ldx, _ptr(y), ldy, B * H * W, C, int(accumulate), _stream())
+    return y
+
+
+def head_decode(raw, anchors_px, stride: float, out, row_off: int):
+    B, na, ny, nx, no = raw.shape
+    call("ayolo_head_decode", _ptr(raw), B, na, ny, nx, no, _ptr(anchors_px), float(stride), _ptr(out), out.shape[1],
+         row_off, _stream())
+
+
+def head_grad_pack(draw, dtype: torch.dtype, ldz: int, want_bias=True):
+    B, na, ny, nx, no = draw.shape
+    draw = draw.contiguous().float()
+    dz = new_act(B, ldz, ny, nx, dtype, draw.device)
+    dbias = torch.zeros(na * no, dtype=torch.float32, device=draw.device) if want_bias else None
+    call("ayolo_head_grad_pack", _ptr(draw), B, na, ny, nx, no, dtype_code(dtype), _ptr(dz), ldz, _ptr(dbias), _stream())
+    return dz, dbias

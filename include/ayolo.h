@@ -1,0 +1,201 @@
+/*
+ * ayolo.h -- C ABI of libayolo_hip.so: the MI355X (gfx950) hot path of AYolov2's detection pipeline.
+ *
+ * The reference (j-marple-dev/AYolov2) has NO FFI/plugin interface for this path: its operator boundary is
+ * Python objects whose arithmetic is delegated to torch/cuDNN, torchvision and the
+ * un-vendored `kindle` model builder.  Every entry point below therefore cites the reference call site(s)
+ * whose delegated op it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - plain C, no torch types; every tensor is a raw DEVICE pointer + explicit dims; the caller owns every
+ *     buffer (including workspaces whose size is queried first);
+ *   - every function takes a hipStream_t (passed as void*) and is asynchronous on it;
+ *   - returns 0 on success, a negative AYOLO_E* code otherwise; ayolo_last_error() gives the message
+ *     (thread-local);
+ *   - activations are NHWC ("channels last"), dtype AYOLO_F16 (fp16 storage, fp32 MFMA accumulate) or
+ *     AYOLO_F32 (exact fp32 MFMA, used for the 1e-4 parity mode);
+ *   - conv weights are KRSC = [Cout][kh][kw][Cin] (a torch OIHW tensor in channels_last memory format).
+ */
+#ifndef AYOLO_H
+#define AYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AYOLO_OK 0
+#define AYOLO_EINVAL (-1)   /* bad argument / unsupported shape */
+#define AYOLO_ELAUNCH (-2)  /* HIP launch or runtime error      */
+#define AYOLO_ENOSPC (-3)   /* caller-supplied buffer too small */
+
+#define AYOLO_F16 0
+#define AYOLO_F32 1
+
+typedef void* ayolo_stream; /* hipStream_t */
+
+int ayolo_version(void);
+const char* ayolo_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution (kindle `Conv.forward` / `YOLOHead.conv[i]`: yolov5s.yaml:21-57; autograd backward of the
+ * same: scripts/train/yolo_trainer.py:329).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ayolo_conv_desc {
+    int dtype;            /* AYOLO_F16 | AYOLO_F32 (x, w, y element type)                            */
+    int B, H, W;          /* input spatial dims                                                      */
+    int Cin, ldx;         /* channels read, channel stride (elements) of the x buffer (>= Cin)       */
+    int Cout, ldy;        /* channels written, channel stride of the y buffer                        */
+    int kh, kw, sh, sw, ph, pw;
+    int Ho, Wo;           /* output spatial dims                                                     */
+} ayolo_conv_desc;
+
+/* epilogue selectors for ayolo_conv_fwd */
+#define AYOLO_EPI_NONE 0      /* y = conv                        (+ optional per-channel sum/sumsq)   */
+#define AYOLO_EPI_AFFINE 1    /* y = conv*scale[c] + shift[c]                                          */
+#define AYOLO_EPI_AFFINE_SILU 2 /* y = silu(conv*scale[c] + shift[c])  (eval / fused-BN inference)     */
+#define AYOLO_EPI_HEAD 3      /* y(fp32)[b][a][h][w][o] = conv + shift[c], c = a*no + o (YOLOHead)     */
+
+/* y = conv(x, w).  `stats` (nullable, EPI_NONE only): float[2*Cout] zero-initialised by the caller; receives
+ * per-channel sum and sum of squares of the fp32 accumulators rounded to the output dtype (training-mode BN).
+ * scale/shift: float[Cout] (nullable where unused).  head_no: `no` for AYOLO_EPI_HEAD (y is fp32). */
+int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void* y, int epilogue,
+                   const float* scale, const float* shift, float* stats, int head_no, ayolo_stream s);
+
+/* dx (+)= conv_transpose(dy, w).  wt is the transposed weight [Cin][kh][kw][Cout] (see ayolo_cast_weight).
+ * accumulate != 0 adds into the existing dx. d describes the FORWARD conv (x:B,H,W,Cin  y:B,Ho,Wo,Cout);
+ * dy uses d->ldy, dx uses d->ldx. */
+int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
+                     ayolo_stream s);
+
+/* dw[Cout][kh][kw][Cin] (fp32, must be zeroed by the caller) += sum_pixels dy (x) x ; alpha scales the result. */
+int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha,
+                     ayolo_stream s);
+
+/* fp32 KRSC master weight [Cout][kh][kw][Cin] -> compute-dtype copy `w` [Cout_pad][kh][kw][Cin_pad] and
+ * transposed copy `wt` [Cin_pad][kh][kw][Cout_pad] (either nullable); padding rows/channels are zero
+ * (stem: Cin 3 -> 4, see ayolo_pack_input; head: Cout 255 -> 256). */
+int ayolo_cast_weight(const float* w32, int Cout, int kh, int kw, int Cin, int Cout_pad, int Cin_pad, int dtype,
+                      void* w, void* wt, ayolo_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm (training statistics) + SiLU, NHWC.  kindle Conv = Conv2d -> BatchNorm2d -> SiLU.
+ * ---------------------------------------------------------------------------------------------- */
+/* From stats (sum,sumsq over `count` elements per channel): mean/invstd, running-stat update
+ * (momentum, unbiased var), scale = gamma*invstd, shift = beta - mean*scale.  save_mean/save_invstd/scale/
+ * shift: float[C].  running_* nullable. */
+int ayolo_bn_finalize(const float* stats, int C, double count, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                      float* save_invstd, float* scale, float* shift, ayolo_stream s);
+/* a = act(z*scale[c] + shift[c]); act: 0 identity, 1 SiLU.  z: npix x C (ldz), a: npix x C (lda). */
+int ayolo_affine_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* scale,
+                     const float* shift, int act, ayolo_stream s);
+/* Backward of a = silu(bn(z)): pass 1 accumulates sums[0:C] = sum(du), sums[C:2C] = sum(du * xhat)
+ * (zeroed by caller); pass 2 writes dz and (from sums) dgamma/dbeta. */
+int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const void* da, int ldda, int64_t npix, int C,
+                            const float* save_mean, const float* save_invstd, const float* gamma,
+                            const float* beta, int act, float* sums, ayolo_stream s);
+int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
+                           int64_t npix, int C, const float* save_mean, const float* save_invstd,
+                           const float* gamma, const float* beta, int act, const float* sums, float* dgamma,
+                           float* dbeta, float grad_scale, ayolo_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small NHWC ops: kindle SPPF's MaxPool2d(5,1,2), UpSample(None,2) nearest, input packing, bias grad.
+ * ---------------------------------------------------------------------------------------------- */
+/* k x k / stride 1 / pad k/2 max-pool.  argmax (nullable): uint8[B*H*W*C] window position (dy*k+dx) of the first
+ * maximum in row-major scan order (torch tie rule), consumed by the backward. */
+int ayolo_maxpool_fwd(int dtype, const void* x, int ldx, void* y, int ldy, unsigned char* argmax, int B, int H,
+                      int W, int C, int k, ayolo_stream s);
+/* dx (+)= gather of dy through argmax */
+int ayolo_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, int lddy, void* dx, int lddx, int B,
+                      int H, int W, int C, int k, int accumulate, ayolo_stream s);
+int ayolo_upsample2x_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C,
+                         ayolo_stream s);
+int ayolo_upsample2x_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C,
+                         int accumulate, ayolo_stream s);
+/* NCHW fp32 image batch (B,3,H,W) -> NHWC with 4 channels (4th = 0) of `dtype`: the stem's 6x6/s2 conv then
+ * runs as a 6x3 / stride (2,1) conv over the (B, H, W/2, 8) view of the same memory. */
+int ayolo_pack_input(const float* x, int B, int C, int H, int W, int dtype, void* y, int Cpad, ayolo_stream s);
+/* YOLOHead backward entry: d(raw) (B,na,ny,nx,no) fp32 -> NHWC dz[pix][ldz] of `dtype` (channel = a*no+o, channels
+ * >= na*no zero) and dbias[c] += sum over pixels (fp32[na*no], zeroed by the caller, nullable). */
+int ayolo_head_grad_pack(const float* draw, int B, int na, int ny, int nx, int no, int dtype, void* dz, int ldz,
+                         float* dbias, ayolo_stream s);
+/* strided 2-D copy / add (concat slices, residual):  y[p][0:C] (+)= x[p][0:C] */
+int ayolo_copy2d(int dtype, const void* x, int ldx, void* y, int ldy, int64_t npix, int C, int accumulate,
+                 ayolo_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * YOLOHead eval decode (layout: scripts/loss/losses.py:245-256,350; scripts/utils/tta_utils.py:52-58):
+ * raw (B,na,ny,nx,no) fp32 logits -> out[b][row_off + (a*ny+y)*nx+x][0:no]:
+ *   xy = (sig*2-0.5+grid)*stride, wh = (sig*2)^2*anchor_px, rest = sig.
+ * ---------------------------------------------------------------------------------------------- */
+int ayolo_head_decode(const float* raw, int B, int na, int ny, int nx, int no, const float* anchors_px,
+                      float stride, float* out, int64_t rows_total, int64_t row_off, ayolo_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * NMS (scripts/utils/metrics.py:285-443 `non_max_suppression`, scripts/utils/nms.py:15-116 `batched_nms`,
+ * torchvision.ops.nms / ops.boxes.batched_nms call sites metrics.py:385,394,421 nms.py:66,71,102,
+ * scripts/utils/metrics.py:138-164 `box_iou`).
+ * ---------------------------------------------------------------------------------------------- */
+/* Stage A: stream pred (B,N,no) fp32 once; emit one candidate per (proposal, class) with
+ * obj > conf (if require_obj) and obj*cls > conf [multi_label] or the best class [otherwise], optionally
+ * restricted to classes whose bit is set in class_mask (uint64[(nc+63)/64], nullable).
+ * rows: nullable int32 [B][rows_per_img] proposal indices to visit instead of 0..N-1 (batched_nms top-k).
+ * Outputs: det[slot][6] = x1,y1,x2,y2,conf,cls ; keys[slot] = img | ~conf | seq (unique, sort ascending =
+ * image, conf descending, candidate order ascending); counters[0] = total, counters[1+b] = per image.
+ * Candidates beyond `capacity` are counted but not stored (caller re-runs with a larger buffer). */
+int ayolo_nms_candidates(const float* pred, int B, int N, int no, float conf_thres, int multi_label,
+                         int require_obj, const uint64_t* class_mask, const int32_t* rows, int rows_per_img,
+                         float* det, uint64_t* keys, uint32_t* counters, uint32_t capacity, int order_by_seq,
+                         ayolo_stream s);
+/* layout of the candidate key: seq occupies the low seq_bits, then (unless order_by_seq) 32 bits of ~conf, then
+ * the image index; returns AYOLO_EINVAL when more than 64 bits would be needed. */
+int ayolo_nms_key_bits(int B, int rows_per_img, int nc_eff, int order_by_seq, int* seq_bits, int* total_bits);
+int ayolo_iota_u32(uint32_t* v, uint32_t n, ayolo_stream s);
+/* torchvision batched_nms coordinate trick: out[b] = max over the segment's box coordinates + 1 */
+int ayolo_seg_max_coord(const float* sdet, const uint32_t* seg_off, const uint32_t* seg_n, int B, float* out,
+                        ayolo_stream s);
+/* 64-bit key / 32-bit value radix sort (rocPRIM); ws_bytes queried with ws == NULL. */
+int ayolo_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                         uint32_t* vals_out, uint32_t n, int begin_bit, int end_bit, void* ws, size_t* ws_bytes,
+                         ayolo_stream s);
+/* objectness keys for batched_nms' per-image top-k: keys[b*N+i] = b | ~obj | i, vals = i */
+int ayolo_nms_obj_keys(const float* pred, int B, int N, int no, uint64_t* keys, uint32_t* vals, ayolo_stream s);
+/* gather det rows into sorted order: sdet[t] = det[order[t]] */
+int ayolo_gather_rows(const float* src, const uint32_t* order, float* dst, uint32_t n, int width, ayolo_stream s);
+/* Stage C: suppression bit matrix for image segments.  sdet: sorted candidates; seg_off[B+1] (device):
+ * segment b = [seg_off[b], seg_off[b]+seg_n[b]).  mask[b]: rows of `words` uint64 at mask + mask_off[b].
+ * bit j of row i set iff j > i and IoU(i,j) > thr (mode 0), with boxes offset by cls*offset_scale;
+ * class_aware != 0 restricts to cls_i == cls_j (per-class NMS).  thr_f is the float threshold such that
+ * (ovr > thr_f) == ((double)ovr > thr_d). */
+int ayolo_nms_mask(const float* sdet, const uint32_t* seg_off, const uint32_t* seg_n, const uint64_t* mask_off,
+                   int B, uint32_t max_n, float thr_f, float offset_scale, const float* per_img_offset,
+                   int class_aware, uint64_t* mask, ayolo_stream s);
+/* Stage D: greedy scan (one wavefront per image) + output gather.
+ * out[b][k][0:6] = sdet row of the k-th kept candidate (k < max_out), out_idx[b][k] = its index in the
+ * segment, out_count[b] = number kept (capped at max_out). */
+int ayolo_nms_reduce(const float* sdet, const uint32_t* seg_off, const uint32_t* seg_n, const uint64_t* mask_off,
+                     const uint64_t* mask, int B, uint32_t max_out, float* out, int32_t* out_idx,
+                     uint32_t* out_count, uint32_t max_n, ayolo_stream s);
+/* Dense IoU (metrics.py:138-164): out[N][M]. */
+int ayolo_box_iou(const float* a, int64_t N, const float* b, int64_t M, float* out, ayolo_stream s);
+/* fast_nms / matrix_nms column reductions over the upper-triangular IoU of n boxes (never materialised):
+ * colmax[j] = max_{i<j} iou(i,j) (0 for j = 0; NaN propagates); decay (nullable) [j] =
+ * min_i exp(-(iou(i,j)^2 - colmax[i]^2)/0.5) with iou(i,j)=0 for i>=j. */
+int ayolo_iou_colmax(const float* boxes, const float* cls, float offset_scale, uint32_t n, float* colmax,
+                     ayolo_stream s);
+int ayolo_matrix_nms_decay(const float* boxes, const float* cls, float offset_scale, uint32_t n,
+                           const float* colmax, float* decay, ayolo_stream s);
+/* merge_nms (metrics.py:418-435): for kept row k, weights = (iou(off_box[kept[k]], off_box[:]) > thr) * conf;
+ * merged[k][0:4] = (weights @ box) / sum(weights); redundant[k] = (#iou > thr) > 1.  det: n x 6 rows. */
+int ayolo_merge_boxes(const float* det, uint32_t n, float offset_scale, const int32_t* kept, uint32_t nk,
+                      float thr_f32, float* merged, int32_t* redundant, ayolo_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AYOLO_H */
