@@ -27,6 +27,10 @@ def _ce(dt: torch.dtype) -> int:
     return 8 if dt == torch.float16 else 4
 
 
+def _pair_(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
 def _round_up(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 

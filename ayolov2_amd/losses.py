@@ -1,0 +1,139 @@
+"""YOLO loss with the reference's interface (scripts/loss/losses.py:168-391 ``ComputeLoss``).
+
+It sits between the forward and backward of a train step and is < 1 % of its FLOPs, so
+it is written with device-agnostic torch ops; the tensors it consumes/produces stay on the GPU and its backward
+feeds ``HeadConvFn.backward`` (the HIP path).  Semantics follow the reference:
+
+* ``build_targets``: anchor matching ``max(r, 1/r) < anchor_t`` and the 3-neighbour 0.5-cell offsets
+  (losses.py:303-391);
+* box loss ``1 - CIoU`` on ``(sigmoid*2-0.5, (sigmoid*2)^2*anchor)`` (losses.py:254-260), objectness BCE against
+  the detached IoU with ``balance = [4, 1, 0.4]`` (losses.py:204-206, 285-286), class BCE with label smoothing
+  (losses.py:277-279); returns ``(loss * batch_size, cat(lbox, lobj, lcls, loss).detach())`` (losses.py:297-300).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Tuple
+
+import torch
+from torch import nn
+
+from .metrics import bbox_iou
+
+
+def smooth_bce(eps: float = 0.1) -> Tuple[float, float]:
+    return 1.0 - 0.5 * eps, 0.5 * eps
+
+
+def _unwrap(model: nn.Module) -> nn.Module:
+    return model.module if isinstance(model, (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel)) else model
+
+
+class FocalLoss(nn.Module):
+    def __init__(self, loss_fcn: nn.BCEWithLogitsLoss, gamma: float = 1.5, alpha: float = 0.25) -> None:
+        super().__init__()
+        self.loss_fcn, self.gamma, self.alpha = loss_fcn, gamma, alpha
+        self.reduction = loss_fcn.reduction
+        self.loss_fcn.reduction = "none"
+
+    def forward(self, pred, true):
+        loss = self.loss_fcn(pred, true)
+        p = torch.sigmoid(pred)
+        p_t = true * p + (1 - true) * (1 - p)
+        loss = loss * (true * self.alpha + (1 - true) * (1 - self.alpha)) * (1.0 - p_t) ** self.gamma
+        return loss.mean() if self.reduction == "mean" else loss.sum() if self.reduction == "sum" else loss
+
+
+class ComputeLoss:
+    def __init__(self, model: nn.Module, autobalance: bool = False) -> None:
+        self.sort_obj_iou = False
+        m = _unwrap(model)
+        device = next(m.parameters()).device
+        hyp: Dict[str, Any] = m.hyp
+        bce_cls: nn.Module = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([hyp["cls_pw"]], device=device))
+        bce_obj: nn.Module = nn.BCEWithLogitsLoss(pos_weight=torch.tensor([hyp["obj_pw"]], device=device))
+        self.cp, self.cn = smooth_bce(eps=hyp.get("label_smoothing", 0.0))
+        if hyp["fl_gamma"] > 0:
+            bce_cls, bce_obj = FocalLoss(bce_cls, hyp["fl_gamma"]), FocalLoss(bce_obj, hyp["fl_gamma"])
+        head = m.model[-1]
+        self.balance = {3: [4.0, 1.0, 0.4]}.get(head.nl, [4.0, 1.0, 0.25, 0.06, 0.02])
+        self.ssi = list(head.stride).index(16) if autobalance else 0
+        self.BCEcls, self.BCEobj, self.gr, self.hyp, self.autobalance = bce_cls, bce_obj, 1.0, hyp, autobalance
+        self.na, self.nc, self.nl, self.anchors = head.na, head.nc, head.nl, head.anchors
+
+    def __call__(self, preds: List[torch.Tensor], targets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        device = targets.device
+        lcls = torch.zeros(1, device=device)
+        lbox = torch.zeros(1, device=device)
+        lobj = torch.zeros(1, device=device)
+        tcls, tbox, indices, anchors = self.build_targets(preds, targets)
+        for i, pi in enumerate(preds):
+            b, a, gj, gi = indices[i]
+            tobj = torch.zeros_like(pi[..., 0], device=device)
+            n = b.shape[0]
+            if n:
+                ps = pi[b, a, gj, gi]
+                pxy = ps[:, :2].sigmoid() * 2.0 - 0.5
+                pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * anchors[i]
+                iou = bbox_iou(torch.cat((pxy, pwh), 1).T, tbox[i], x1y1x2y2=False, c_iou=True)
+                lbox = lbox + (1.0 - iou).mean()
+                score = iou.detach().clamp(0).type(tobj.dtype)
+                if self.sort_obj_iou:
+                    order = torch.argsort(score)
+                    b, a, gj, gi, score = b[order], a[order], gj[order], gi[order], score[order]
+                tobj[b, a, gj, gi] = (1.0 - self.gr) + self.gr * score
+                if self.nc > 1:
+                    t = torch.full_like(ps[:, 5:], self.cn, device=device)
+                    t[range(n), tcls[i]] = self.cp
+                    lcls = lcls + self.BCEcls(ps[:, 5:], t)
+            obji = self.BCEobj(pi[..., 4], tobj)
+            lobj = lobj + obji * self.balance[i]
+            if self.autobalance:
+                self.balance[i] = self.balance[i] * 0.9999 + 0.0001 / obji.detach().item()
+        if self.autobalance:
+            self.balance = [x / self.balance[self.ssi] for x in self.balance]
+        lbox = lbox * self.hyp["box"]
+        lobj = lobj * self.hyp["obj"]
+        lcls = lcls * self.hyp["cls"]
+        bs = preds[0].shape[0]
+        loss = lbox + lobj + lcls
+        return loss * bs, torch.cat((lbox, lobj, lcls, loss)).detach()
+
+    def build_targets(self, preds: List[torch.Tensor], targets: torch.Tensor):
+        """targets: (nt, 6) [image, class, x, y, w, h] normalised -> per level (classes, boxes, indices, anchors)."""
+        na, nt = self.na, targets.shape[0]
+        dev = targets.device
+        tcls, tbox, indices, anch = [], [], [], []
+        gain = torch.ones(7, device=dev)
+        ai = torch.arange(na, device=dev).float().view(na, 1).repeat(1, nt)
+        targets = torch.cat((targets.repeat(na, 1, 1), ai[:, :, None]), 2)      # (na, nt, 7)
+        g = 0.5
+        off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=dev).float() * g
+        for i in range(self.nl):
+            anchors = self.anchors[i].to(dev)
+            shape = preds[i].shape
+            gain[2:6] = torch.tensor([shape[3], shape[2], shape[3], shape[2]], device=dev, dtype=gain.dtype)
+            t = targets * gain
+            if nt:
+                r = t[:, :, 4:6] / anchors[:, None]
+                keep = torch.max(r, 1.0 / r).max(2)[0] < self.hyp["anchor_t"]
+                t = t[keep]
+                gxy = t[:, 2:4]
+                gxi = gain[[2, 3]] - gxy
+                j, k = ((gxy % 1.0 < g) & (gxy > 1.0)).T
+                l, m = ((gxi % 1.0 < g) & (gxi > 1.0)).T
+                sel = torch.stack((torch.ones_like(j), j, k, l, m))
+                t = t.repeat((5, 1, 1))[sel]
+                offsets = (torch.zeros_like(gxy)[None] + off[:, None])[sel]
+            else:
+                t = targets[0]
+                offsets = 0
+            b, c = t[:, :2].long().T
+            gxy, gwh = t[:, 2:4], t[:, 4:6]
+            gij = (gxy - offsets).long()
+            gi, gj = gij.T
+            a = t[:, 6].long()
+            indices.append((b, a, gj.clamp_(0, int(shape[2]) - 1), gi.clamp_(0, int(shape[3]) - 1)))
+            tbox.append(torch.cat((gxy - gij, gwh), 1))
+            anch.append(anchors[a])
+            tcls.append(c)
+        return tcls, tbox, indices, anch

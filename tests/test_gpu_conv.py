@@ -1,0 +1,186 @@
+"""HIP conv / BN / pool kernels (fp32 exact-MFMA mode and fp16 mode) against plain PyTorch fp32 on the CPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (B, Cin, Cout, k, s, p, H, W)
+SHAPES = [
+    (2, 32, 64, 3, 2, 1, 40, 40),
+    (2, 64, 32, 1, 1, 0, 20, 24),
+    (3, 32, 32, 3, 1, 1, 13, 17),      # odd sizes: ragged pixel tiles
+    (1, 128, 256, 3, 2, 1, 16, 16),
+    (2, 256, 128, 1, 1, 0, 8, 8),
+    (1, 64, 64, 3, 1, 1, 33, 9),
+    (2, 16, 48, 3, 1, 1, 12, 12),      # Cout not a multiple of 32
+]
+
+
+def _tol(dt):
+    return (1e-4, 1e-4) if dt == torch.float32 else (2e-2, 2e-2)
+
+
+def _rel_err(got, want):
+    got, want = got.detach(), want.detach()
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_fwd_dgrad_wgrad(shape, dt):
+    from ayolov2_amd import functional as F_
+    B, Cin, Cout, k, s, p, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    if dt == torch.float16:
+        x, w = x.half().float(), w.half().float()       # same rounded operands on both sides
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, p)
+    gy = torch.randn(yr.shape, generator=g)
+    if dt == torch.float16:
+        gy = gy.half().float()
+    yr.backward(gy)
+
+    xg = x.cuda().to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    if dt == torch.float16:
+        with torch.autocast("cuda", dtype=torch.float16):
+            yg = F_.ConvFn.apply(xg, wg, (s, s), (p, p), F_._WeightCache())
+    else:
+        yg = F_.ConvFn.apply(xg, wg, (s, s), (p, p), F_._WeightCache())
+    assert yg.dtype == dt
+    yg.backward(gy.cuda().to(dt))
+    rt = _tol(dt)[0]
+    e = _rel_err(yg.float().cpu(), yr.detach())
+    assert e < rt, f"fwd rel err {e}"
+    e = _rel_err(xg.grad.float().cpu(), xr.grad)
+    assert e < rt, f"dgrad rel err {e}"
+    e = _rel_err(wg.grad.float().cpu(), wr.grad)
+    assert e < rt, f"wgrad rel err {e}"
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_stem_conv(dt):
+    """6x6/s2/p2 on a 3-channel NCHW image (fp16: pixel-pair packed 6x3 conv; fp32: channel-padded)."""
+    from ayolov2_amd.modules import Conv
+    from oracle.model_ref import RConv
+    torch.manual_seed(0)
+    ref = RConv(3, 32, 6, 2, 2)
+    m = Conv(3, 32, 6, 2, 2)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda()
+    x = torch.rand(2, 3, 64, 96)
+    ref.train(); m.train()
+    yr = ref(x)
+    gy = torch.randn(yr.shape)
+    yr.backward(gy)
+    if dt == torch.float16:
+        with torch.autocast("cuda", dtype=torch.float16):
+            yg = m(x.cuda())
+    else:
+        yg = m(x.cuda())
+    yg.backward(gy.cuda().to(yg.dtype))
+    rt = 2e-4 if dt == torch.float32 else 3e-2
+    assert _rel_err(yg.float().cpu(), yr.detach()) < rt
+    assert _rel_err(m.conv.weight.grad.float().cpu(), ref.conv.weight.grad) < rt * 2
+    assert _rel_err(m.batch_norm.weight.grad.cpu(), ref.batch_norm.weight.grad) < rt * 2
+    assert _rel_err(m.batch_norm.bias.grad.cpu(), ref.batch_norm.bias.grad) < rt * 2
+    if dt == torch.float32:
+        np.testing.assert_allclose(m.batch_norm.running_mean.cpu(), ref.batch_norm.running_mean, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(m.batch_norm.running_var.cpu(), ref.batch_norm.running_var, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cfg", [(64, 64, 3, 1), (64, 128, 3, 2), (128, 64, 1, 1)])
+def test_conv_bn_silu_block_train(cfg, dt):
+    """Conv -> BatchNorm(batch stats) -> SiLU forward + backward vs torch.nn on the CPU."""
+    from ayolov2_amd.modules import Conv
+    from oracle.model_ref import RConv
+    cin, cout, k, s = cfg
+    torch.manual_seed(1)
+    ref = RConv(cin, cout, k, s)
+    with torch.no_grad():
+        ref.batch_norm.weight.uniform_(0.5, 1.5)
+        ref.batch_norm.bias.uniform_(-0.5, 0.5)
+    m = Conv(cin, cout, k, s)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda()
+    x = torch.randn(4, cin, 20, 20)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    gy = torch.randn(yr.shape)
+    yr.backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    if dt == torch.float16:
+        with torch.autocast("cuda", dtype=torch.float16):
+            yg = m(xg)
+    else:
+        yg = m(xg)
+    yg.backward(gy.cuda().to(yg.dtype))
+    rt = 2e-4 if dt == torch.float32 else 3e-2
+    assert _rel_err(yg.float().cpu(), yr.detach()) < rt
+    assert _rel_err(xg.grad.float().cpu(), xr.grad) < rt * 2
+    assert _rel_err(m.conv.weight.grad.float().cpu(), ref.conv.weight.grad) < rt * 2
+    assert _rel_err(m.batch_norm.weight.grad.cpu(), ref.batch_norm.weight.grad) < rt * 2
+    assert _rel_err(m.batch_norm.bias.grad.cpu(), ref.batch_norm.bias.grad) < rt * 2
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_conv_eval_and_fuse(dt):
+    from ayolov2_amd.modules import Conv
+    from oracle.model_ref import RConv
+    torch.manual_seed(2)
+    ref = RConv(32, 64, 3, 1)
+    with torch.no_grad():
+        ref.batch_norm.running_mean.uniform_(-0.3, 0.3)
+        ref.batch_norm.running_var.uniform_(0.5, 2.0)
+        ref.batch_norm.weight.uniform_(0.5, 1.5)
+        ref.batch_norm.bias.uniform_(-0.5, 0.5)
+    ref.eval()
+    m = Conv(32, 64, 3, 1)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda().eval()
+    x = torch.randn(2, 32, 24, 24)
+    with torch.no_grad():
+        yr = ref(x)
+        xg = x.cuda()
+        if dt == torch.float16:
+            m = m.half()
+            xg = xg.half()
+        y1 = m(xg)
+        y2 = m.fuse()(xg)
+    rt = 2e-4 if dt == torch.float32 else 3e-2
+    assert _rel_err(y1.float().cpu(), yr) < rt
+    assert _rel_err(y2.float().cpu(), yr) < rt
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_maxpool_upsample(dt):
+    from ayolov2_amd import functional as F_
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 20, 20, generator=g)
+    if dt == torch.float16:
+        x = x.half().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 5, 1, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = x.cuda().to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yg = F_.MaxPoolFn.apply(xg, 5)
+    yg.backward(gy.cuda().to(dt))
+    np.testing.assert_array_equal(yg.detach().float().cpu().numpy(), yr.detach().numpy())
+    rt = 1e-6 if dt == torch.float32 else 5e-3
+    assert _rel_err(xg.grad.float().cpu(), xr.grad) <= rt
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = x.cuda().to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yg = F_.Upsample2xFn.apply(xg)
+    yg.backward(gy.cuda().to(dt))
+    np.testing.assert_array_equal(yg.detach().float().cpu().numpy(), yr.detach().numpy())
+    assert _rel_err(xg.grad.float().cpu(), xr.grad) <= rt

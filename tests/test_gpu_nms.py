@@ -1,0 +1,141 @@
+"""HIP NMS path vs the CPU oracle and the golden vectors.  Indices / rows must be bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_ref
+
+pytestmark = pytest.mark.gpu
+
+NMS_TYPES = ["nms", "batched_nms", "fast_nms", "matrix_nms", "merge_nms"]
+
+
+def synth_pred(B, N, nc, img, mu_obj, seed):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(B, N, 2, generator=g) * img
+    wh = torch.rand(B, N, 2, generator=g) ** 3 * img / 2 + 2
+    obj = torch.sigmoid(torch.randn(B, N, 1, generator=g) * 2 + mu_obj)
+    cls = torch.sigmoid(torch.randn(B, N, nc, generator=g) * 2 - 4)
+    return torch.cat((xy, wh, obj, cls), 2).float()
+
+
+def _cmp(got, want, exact=True, what=""):
+    got = [g.cpu().numpy() for g in got]
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape, f"{what} image {i}: shape {g.shape} vs {w.shape}"
+        if exact:
+            np.testing.assert_array_equal(g, w, err_msg=f"{what} image {i}")
+        else:
+            np.testing.assert_allclose(g, w, rtol=1e-5, atol=1e-4, err_msg=f"{what} image {i}")
+
+
+def test_box_iou_golden(golden_dir):
+    from ayolov2_amd.metrics import box_iou
+    g = np.load(os.path.join(golden_dir, "g1_box_iou.npz"))
+    got = box_iou(torch.from_numpy(g["box1"]).cuda(), torch.from_numpy(g["box2"]).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, g["iou"])
+
+
+@pytest.mark.parametrize("nms_type", NMS_TYPES)
+def test_nms_golden(golden_dir, nms_type):
+    from ayolov2_amd.metrics import non_max_suppression
+    g = np.load(os.path.join(golden_dir, "g4_nms.npz"))
+    pred = torch.from_numpy(g["pred"]).cuda()
+    exact = nms_type not in ("matrix_nms", "merge_nms")
+    for agn in (0, 1):
+        for ml in (0, 1):
+            got = non_max_suppression(pred, conf_thres=0.001, iou_thres=0.65, multi_label=bool(ml), agnostic=bool(agn),
+                                      nms_type=nms_type)
+            want = [g[f"{nms_type}_a{agn}_m{ml}_{bi}"] for bi in range(pred.shape[0])]
+            _cmp(got, want, exact, f"{nms_type} a{agn} m{ml}")
+
+
+def test_nms_golden_variants(golden_dir):
+    from ayolov2_amd.metrics import non_max_suppression
+    g = np.load(os.path.join(golden_dir, "g4_nms.npz"))
+    pred = torch.from_numpy(g["pred"]).cuda()
+    got = non_max_suppression(pred, conf_thres=0.25, iou_thres=0.45, classes=[0, 3, 17])
+    _cmp(got, [g[f"cls_filter_{bi}"] for bi in range(2)], True, "classes")
+    lab = [torch.from_numpy(g["hybrid_labels_0"]).cuda(), torch.zeros((0, 5)).cuda()]
+    got = non_max_suppression(pred, conf_thres=0.1, iou_thres=0.6, labels=lab, multi_label=True)
+    _cmp(got, [g[f"hybrid_{bi}"] for bi in range(2)], True, "hybrid labels")
+
+
+@pytest.mark.parametrize("nms_type", NMS_TYPES)
+def test_batched_nms_golden(golden_dir, nms_type):
+    from ayolov2_amd.nms import batched_nms
+    g = np.load(os.path.join(golden_dir, "g5_batched_nms.npz"))
+    pred = torch.from_numpy(np.load(os.path.join(golden_dir, "g4_nms.npz"))["pred"]).cuda()
+    exact = nms_type not in ("matrix_nms", "merge_nms")
+    for agn in (0, 1):
+        for nb in (500, 1000):
+            got = batched_nms(pred, conf_thres=0.001, iou_thres=0.65, nms_box=nb, agnostic=bool(agn), nms_type=nms_type)
+            want = [g[f"{nms_type}_a{agn}_n{nb}_{bi}"] for bi in range(pred.shape[0])]
+            _cmp(got, want, exact, f"{nms_type} a{agn} n{nb}")
+
+
+@pytest.mark.parametrize("B,N,mu,ml", [(2, 25200, -9.5, True), (1, 25200, -6.0, True), (3, 6000, -7.0, False)])
+def test_nms_vs_oracle_large(B, N, mu, ml):
+    """COCO-shape proposal counts (BASELINE.json config 1 shape), compared with the CPU oracle row for row."""
+    from ayolov2_amd.metrics import non_max_suppression
+    pred = synth_pred(B, N, 80, 640, mu, seed=11)
+    want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.65, multi_label=ml)
+    got = non_max_suppression(pred.cuda(), conf_thres=0.001, iou_thres=0.65, multi_label=ml)
+    _cmp(got, want, True, "large")
+
+
+def test_nms_edge_cases():
+    from ayolov2_amd.metrics import non_max_suppression
+    # nothing passes the threshold -> empty (0, 6) outputs
+    pred = synth_pred(2, 500, 80, 640, -30.0, seed=2).cuda()
+    out = non_max_suppression(pred, conf_thres=0.5)
+    assert all(o.shape == (0, 6) for o in out)
+    # single proposal, identical boxes, ties
+    p = torch.zeros((1, 4, 7))
+    p[0, :, :4] = torch.tensor([100., 100., 50., 50.])
+    p[0, :, 4] = 0.9
+    p[0, :, 5] = 0.8
+    got = non_max_suppression(p.cuda(), conf_thres=0.1, iou_thres=0.5)
+    want = ops_ref.non_max_suppression(p.numpy(), conf_thres=0.1, iou_thres=0.5)
+    _cmp(got, want, True, "ties")
+    assert got[0].shape[0] == 1
+    # ragged: one image empty, one full
+    pred = synth_pred(2, 3000, 80, 640, -6.0, seed=3)
+    pred[0, :, 4] = 0
+    want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.65, multi_label=True)
+    got = non_max_suppression(pred.cuda(), conf_thres=0.001, iou_thres=0.65, multi_label=True)
+    _cmp(got, want, True, "ragged")
+
+
+def test_nms_idempotent_and_sorted():
+    """Size-independent properties at a large size: outputs are conf-sorted, and NMS of the kept boxes keeps all."""
+    from ayolov2_amd.metrics import non_max_suppression
+    pred = synth_pred(4, 100800, 80, 1280, -9.5, seed=5).cuda()
+    out = non_max_suppression(pred, conf_thres=0.001, iou_thres=0.65, multi_label=True)
+    for o in out:
+        assert o.shape[0] <= 300
+        c = o[:, 4].cpu().numpy()
+        assert (np.diff(c) <= 0).all()
+        if o.shape[0]:
+            boxes = o[:, :4] + o[:, 5:6] * 4096
+            keep = ops_ref.tv_nms(boxes.cpu().numpy(), c, 0.65)
+            assert len(keep) == o.shape[0]
+
+
+def test_head_decode_vs_oracle():
+    from ayolov2_amd import ops
+    g = torch.Generator().manual_seed(0)
+    anchors = np.array([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]], np.float32)
+    strides = [8., 16., 32.]
+    raws = [torch.randn(2, 3, s, s, 85, generator=g) * 3 for s in (16, 8, 4)]
+    want = ops_ref.head_decode([r.numpy() for r in raws], anchors.reshape(3, 3, 2), strides)
+    total = sum(3 * s * s for s in (16, 8, 4))
+    out = torch.empty((2, total, 85), dtype=torch.float32, device="cuda")
+    off = 0
+    for i, r in enumerate(raws):
+        ops.head_decode(r.cuda(), torch.from_numpy(anchors[i].reshape(3, 2)).cuda(), strides[i], out, off)
+        off += 3 * r.shape[2] * r.shape[3]
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-4)

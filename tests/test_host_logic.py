@@ -1,0 +1,136 @@
+"""CPU-only checks of the host side: model construction KATs, state-dict naming, loss vs golden, C-ABI exports."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_DIR = os.path.join(ROOT, "ayolov2_amd", "configs")
+
+
+@pytest.mark.parametrize("name,want", [("n", 1872157), ("s", 7235389), ("m", 21190557), ("l", 46563709), ("x", 86749405)])
+def test_param_count_kat(name, want):
+    """K1: README.md:206-211 parameter counts (architecture known-answer test)."""
+    from ayolov2_amd import YOLOModel
+    m = YOLOModel(os.path.join(CFG_DIR, f"yolov5{name}.yaml"))
+    assert sum(p.numel() for p in m.parameters()) == want
+    assert m.stride.tolist() == [8.0, 16.0, 32.0]
+    head = m.model[-1]
+    assert (head.nl, head.na, head.nc) == (3, 3, 80)
+    assert all(k.startswith("model.") for k in m.state_dict())
+    # 640 -> 25200 proposals, 1280 -> 100800
+    assert sum(3 * (640 // int(s)) ** 2 for s in m.stride) == 25200
+    assert sum(3 * (1280 // int(s)) ** 2 for s in m.stride) == 100800
+
+
+def test_oracle_model_shares_state_dict():
+    from ayolov2_amd import YOLOModel
+    from oracle.model_ref import RefYOLO
+    cfg = os.path.join(CFG_DIR, "yolov5s.yaml")
+    m, r = YOLOModel(cfg), RefYOLO(cfg)
+    assert set(m.state_dict()) == set(r.state_dict())
+    r.load_state_dict(m.state_dict())
+
+
+def test_model_is_picklable_and_decomposable_surface():
+    import copy
+    import pickle
+    from torch import nn
+    from ayolov2_amd import YOLOModel
+    from ayolov2_amd.modules import Conv
+    m = YOLOModel(os.path.join(CFG_DIR, "yolov5n.yaml"))
+    m2 = pickle.loads(pickle.dumps(m))
+    assert sum(p.numel() for p in m2.parameters()) == 1872157
+    copy.deepcopy(m).half().float()
+    # every Conv block exposes `.conv: nn.Conv2d` as a direct child (decomposition.py:262-272)
+    convs = [mod for mod in m.modules() if isinstance(mod, Conv)]
+    assert len(convs) == 57 and all(isinstance(c.conv, nn.Conv2d) for c in convs)
+    assert isinstance(m.model[-1].conv, nn.ModuleList) and len(m.model[-1].conv) == 3
+
+
+def test_product_raises_without_gpu_tensor():
+    from ayolov2_amd import YOLOModel, _lib
+    from ayolov2_amd.metrics import non_max_suppression
+    m = YOLOModel(os.path.join(CFG_DIR, "yolov5n.yaml"))
+    with pytest.raises(_lib.AyoloError):
+        m(torch.rand(1, 3, 64, 64))
+    with pytest.raises(_lib.AyoloError):
+        non_max_suppression(torch.rand(1, 10, 85))
+
+
+def test_loss_vs_golden(golden_dir):
+    """G6: ComputeLoss value, items, build_targets indices and d loss / d preds vs the reference's own run."""
+    from ayolov2_amd.losses import ComputeLoss
+    g = np.load(os.path.join(golden_dir, "g6_loss.npz"))
+    hyp = dict(box=float(g["hyp_box"]), cls=float(g["hyp_cls"]), obj=float(g["hyp_obj"]), cls_pw=1.0, obj_pw=1.0,
+               anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+
+    class Head(torch.nn.Module):
+        pass
+
+    head = Head()
+    head.nl, head.na, head.nc = 3, 3, 80
+    head.anchors, head.stride = torch.from_numpy(g["anchors"]), torch.tensor([8., 16., 32.])
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.model = torch.nn.ModuleList([torch.nn.Identity(), head])
+            self.hyp = hyp
+
+    gen = torch.Generator().manual_seed(int(g["pred_seed"]))
+    preds = [torch.randn(2, 3, s, s, 85, generator=gen).requires_grad_(True) for s in (80, 40, 20)]
+    targets = torch.from_numpy(g["targets"])
+    cl = ComputeLoss(Fake())
+    loss, items = cl(preds, targets)
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().numpy(), g["loss"], rtol=1e-5)
+    np.testing.assert_allclose(items.numpy(), g["items"], rtol=1e-5)
+    tcls, tbox, indices, anch = cl.build_targets(preds, targets)
+    for i in range(3):
+        np.testing.assert_array_equal(tcls[i].numpy(), g[f"tcls{i}"])
+        np.testing.assert_allclose(tbox[i].numpy(), g[f"tbox{i}"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(torch.stack(indices[i]).numpy(), g[f"idx{i}"])
+        np.testing.assert_allclose(anch[i].numpy(), g[f"anch{i}"])
+        np.testing.assert_allclose(preds[i].grad.sum((2, 3)).numpy(), g[f"grad{i}_sum"], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(preds[i].grad.abs().sum().numpy(), g[f"grad{i}_abs_total"], rtol=1e-4)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libayolo_hip.so loads (no GPU needed) and exports exactly the entry points include/ayolo.h declares."""
+    from ayolov2_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ayolo.h")).read()
+    declared = sorted(set(re.findall(r"\b(ayolo_[a-z0-9_]+)\s*\(", hdr)))
+    assert os.path.exists(_lib.LIB_PATH), "build the library first (__graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in ayolo.h but not exported"
+    assert sorted(_lib.EXPORTED) == declared
+    assert lib.ayolo_version() >= 1
+
+
+def test_general_helpers_vs_golden(golden_dir):
+    from ayolov2_amd import general
+    g = np.load(os.path.join(golden_dir, "g3_general.npz"))
+    t = torch.from_numpy
+    np.testing.assert_array_equal(general.xywh2xyxy(t(g["x"])).numpy(), g["xywh2xyxy"])
+    np.testing.assert_array_equal(general.clip_coords(t(g["xyxy"].copy()), (640, 480)).numpy(), g["clip"])
+    np.testing.assert_array_equal(general.scale_coords((640, 640), t(g["xyxy"].copy()), (480, 600)).numpy(), g["scale_a"])
+    np.testing.assert_array_equal(
+        general.scale_coords((640, 640), t(g["xyxy"].copy()), (720, 1280), ratio_pad=((0.5, 0.5), (0.0, 140.0))).numpy(),
+        g["scale_b"])
+
+
+def test_bbox_iou_vs_golden(golden_dir):
+    from ayolov2_amd.metrics import bbox_iou
+    g = np.load(os.path.join(golden_dir, "g2_bbox_iou.npz"))
+    p = torch.from_numpy(g["pred"]).requires_grad_(True)
+    t = torch.from_numpy(g["target"])
+    v = bbox_iou(p.T, t, x1y1x2y2=False, c_iou=True)
+    v.sum().backward()
+    np.testing.assert_allclose(v.detach().numpy(), g["ciou_0"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(p.grad.numpy(), g["ciou_0_grad"], rtol=1e-4, atol=1e-5)
