@@ -28,15 +28,15 @@ _P = c_void_p
 
 # name -> argtypes (restype is int unless noted).  Mirrors include/ayolo.h one to one.
 _SIGNATURES = {
-    "ayolo_conv_fwd": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, c_int, _P],
+    "ayolo_conv_fwd": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, _P],
     "ayolo_conv_dgrad": [POINTER(ConvDesc), _P, _P, _P, c_int, _P],
     "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P],
     "ayolo_cast_weight": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
-    "ayolo_bn_finalize": [_P, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
+    "ayolo_bn_finalize": [_P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
     "ayolo_affine_act": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int, _P],
-    "ayolo_bn_act_bwd_reduce": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P],
-    "ayolo_bn_act_bwd_apply": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P,
-                               _P, c_float, _P],
+    "ayolo_bn_act_bwd_reduce": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P],
+    "ayolo_bn_act_bwd_apply": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, c_int,
+                               _P, _P, c_float, _P],
     "ayolo_maxpool_fwd": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "ayolo_maxpool_bwd": [c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ayolo_upsample2x_fwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],

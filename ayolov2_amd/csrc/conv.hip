@@ -27,7 +27,8 @@ struct GConvP {
     int YH, YW, ldy, osh, osw, oah, oaw;
     int C, ntaps, K, ldw, Nout;
     int epi; const float* scale; const float* shift; float* stats;
-    int head_no; int accumulate;
+    int head_no; int accumulate; int stat_reps;
+    int x_linear, y_linear, ntn, nslots;
     long long Mtotal;
     signed char dh[MAX_TAPS], dw[MAX_TAPS], wt[MAX_TAPS];
 };
@@ -65,8 +66,15 @@ __device__ __forceinline__ Tr<float>::frag lds_frag(const float* p) {
 __device__ __forceinline__ float cvt_round(float v, half_t*) { return (float)(half_t)v; }
 __device__ __forceinline__ float cvt_round(float v, float*) { return v; }
 
-template <typename T, int TM>
+// EM (epilogue mode, compile time so that unused paths cost no registers):
+//   0 plain store (+ optional BN statistics)   1 accumulate into y (dgrad)   2 affine / affine+SiLU   3 YOLOHead fp32
+template <typename T, int TM, int EM>
 __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
+    // Persistent, tile-pipelined implicit GEMM.  A workgroup owns output-channel tile `nt` and walks pixel tiles
+    // tile0, tile0+stride, ...; the global loads of step (tile, kt)+1 are in flight while the MFMAs consume
+    // step (tile, kt) from LDS, across tile boundaries, so short-K layers (1x1 convs, K = 32..128) stream
+    // instead of paying a load->use latency per 128-pixel tile.  BN statistics are accumulated in registers
+    // across all tiles of the workgroup and reduced once at the end.
     constexpr int CE = Tr<T>::CE;
     constexpr int CPR = BK / CE;             // chunks per tile row
     constexpr int LDR = BK + Tr<T>::PADE;    // LDS row stride (elements)
@@ -85,61 +93,105 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wp = wave / WM;
-    const long long m0 = (long long)blockIdx.x * TP;
-    const int n0 = blockIdx.y * TM;
     const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ Wg = reinterpret_cast<const T*>(p.w);
 
-    // ---- per-thread loader state
-    const int kc = tid % CPR;                // chunk column inside the k-tile (same for all of this thread's rows)
-    int tap = (kc * CE) / p.C, cch = (kc * CE) % p.C;
-    long long xbase[XR];                     // element offset of (n, 0, 0, 0); -1 when the pixel row is out of range
-    int xh0[XR], xw0[XR];
-#pragma unroll
-    for (int r = 0; r < XR; ++r) {
-        int row = (tid + 256 * r) / CPR;
-        long long m = m0 + row;
-        if (m < p.Mtotal) {
-            int ow = (int)(m % p.OW);
-            long long t = m / p.OW;
-            int oh = (int)(t % p.OH);
-            int n = (int)(t / p.OH);
-            xbase[r] = (long long)n * p.XH * p.XW;
-            xh0[r] = oh * p.ish; xw0[r] = ow * p.isw;
-        } else { xbase[r] = -1; xh0[r] = 0; xw0[r] = 0; }
-    }
-    typename Tr<T>::chunk xreg[XR], wreg[WR];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    // tap tables are read straight from the kernarg segment (a dynamically indexed by-value struct member
-    // would be copied to scratch)
+    // ---- block -> (channel tile, first pixel tile, tile stride).  Workgroups are dealt round-robin to the 8 XCDs;
+    // all channel tiles of one pixel tile are given to the SAME XCD, back to back, so the gathered input tile is
+    // fetched into that XCD's L2 once.
+    const unsigned L = blockIdx.x;
+    const unsigned xcd = L & 7u, idx = L >> 3;
+    const unsigned nt = idx % (unsigned)p.ntn;
+    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;     // pixel-tile slot of this workgroup
+    const unsigned nslots = (unsigned)p.nslots;                   // = gridDim.x / ntn
+    const int n0 = (int)nt * TM;
+    const long long ntiles = (p.Mtotal + TP - 1) / TP;
+
     typedef __attribute__((address_space(4))) const signed char* kptr_t;
     const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh);
+
+    // ---- per-thread loader state (for the tile being LOADED)
+    const int kc = tid % CPR;
+    int tap = 0, cch = 0;
+    long long xbase[XR];
+    int xh0[XR], xw0[XR];
+    uint4 xreg[XR], wreg[WR];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto setup_rows = [&](long long tile) {
+        tap = (kc * CE) / p.C;
+        cch = (kc * CE) % p.C;
+        const long long m0 = tile * TP;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            const int row = (tid + 256 * r) / CPR;
+            const long long m = m0 + row;
+            if (m < p.Mtotal) {
+                if (p.x_linear) {                     // 1x1 / stride 1: input pixel == output pixel
+                    xbase[r] = m; xh0[r] = 0; xw0[r] = 0;
+                } else {
+                    const unsigned mu = (unsigned)m;
+                    unsigned t = mu / (unsigned)p.OW;
+                    int ow = (int)(mu - t * (unsigned)p.OW);
+                    unsigned n = t / (unsigned)p.OH;
+                    int oh = (int)(t - n * (unsigned)p.OH);
+                    xbase[r] = (long long)n * p.XH * p.XW;
+                    xh0[r] = oh * p.ish; xw0[r] = ow * p.isw;
+                }
+            } else { xbase[r] = -1; xh0[r] = 0; xw0[r] = 0; }
+        }
+    };
 
     float16v acc[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const bool want_stats = (EM == 0) && (p.stats != nullptr);
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+    const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
 
-    const int nk = (p.K + BK - 1) / BK;
-    // kt = -1 is the prologue (load + stage tile 0); iteration kt prefetches tile kt+1 into registers while the
-    // MFMAs consume LDS buffer kt&1, then stages it into the other buffer.
-    for (int kt = -1; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) {
-            if (kt >= 0) {
-                cch += BK;
-                while (cch >= p.C) { cch -= p.C; ++tap; }
+    int nk = (p.K + BK - 1) / BK;
+    if (nk < 1) nk = 1;                      // K == 0 (tap-less dgrad residue class): one all-zero step
+    long long cur_tile = slot;
+    if (cur_tile >= ntiles) return;
+    long long ld_tile = cur_tile;
+    int ld_kt = 0, cur_kt = 0, buf = 0;
+    bool first = true;
+    while (true) {
+        // ---------------- issue the loads of the NEXT step (or of the very first one)
+        bool more;
+        if (first) {
+            more = true;
+            setup_rows(ld_tile);
+        } else {
+            ++ld_kt;
+            if (ld_kt == nk) { ld_kt = 0; ld_tile += nslots; }
+            more = ld_tile < ntiles;
+            if (more) {
+                if (ld_kt == 0) setup_rows(ld_tile);
+                else {
+                    cch += BK;
+                    while (cch >= p.C) { cch -= p.C; ++tap; }
+                }
             }
+        }
+        if (more) {
             const bool tap_ok = tap < p.ntaps;
             const int tq = tap_ok ? tap : 0;
             const int dh = ktab[tq], dw = ktab[MAX_TAPS + tq];
 #pragma unroll
             for (int r = 0; r < XR; ++r) {
-                int ih = xh0[r] + dh, iw = xw0[r] + dw;
-                bool ok = tap_ok && xbase[r] >= 0 && ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW;
                 xreg[r] = zero4;
-                if (ok) xreg[r] = *reinterpret_cast<const uint4*>(X + (xbase[r] + (long long)ih * p.XW + iw) * p.ldx + cch);
+                if (p.x_linear) {
+                    if (tap_ok && xbase[r] >= 0) xreg[r] = *reinterpret_cast<const uint4*>(X + xbase[r] * p.ldx + cch);
+                } else {
+                    int ih = xh0[r] + dh, iw = xw0[r] + dw;
+                    bool ok = tap_ok && xbase[r] >= 0 && ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW;
+                    if (ok) xreg[r] = *reinterpret_cast<const uint4*>(X + (xbase[r] + (long long)ih * p.XW + iw) * p.ldx + cch);
+                }
             }
             const int wcol = tap_ok ? ktab[2 * MAX_TAPS + tq] * p.C + cch : 0;
 #pragma unroll
@@ -151,8 +203,8 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
                     wreg[r] = *reinterpret_cast<const uint4*>(Wg + (long long)(n0 + row) * p.ldw + wcol);
             }
         }
-        if (kt >= 0) {
-            const int buf = kt & 1;
+        // ---------------- MFMAs of the current step
+        if (!first) {
             const T* cW = sW + buf * TM * LDR + (wm * 32 + (lane & 31)) * LDR + (lane >> 5) * 8;
             const T* cX = sX + buf * TP * LDR + (wp * NI * 32 + (lane & 31)) * LDR + (lane >> 5) * 8;
 #pragma unroll
@@ -164,9 +216,103 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
                     mma_step(a, b, acc[ni]);
                 }
             }
+            // ------------ tile finished: epilogue.  acc[ni][r]: channel = cbase + 8*(r>>2) + (r&3), pixel = .. + (lane&31)
+            if (cur_kt == nk - 1) {
+                const long long m0 = cur_tile * TP;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const long long m = m0 + wp * NI * 32 + ni * 32 + (lane & 31);
+                    const bool pv = m < p.Mtotal;
+                    long long yo = 0;
+                    int n = 0, oh = 0, ow = 0;
+                    if (pv) {
+                        if (p.y_linear) yo = m * p.ldy;
+                        else {
+                            const unsigned mu = (unsigned)m;
+                            unsigned t = mu / (unsigned)p.OW;
+                            ow = (int)(mu - t * (unsigned)p.OW);
+                            unsigned nn = t / (unsigned)p.OH;
+                            oh = (int)(t - nn * (unsigned)p.OH);
+                            n = (int)nn;
+                            yo = (((long long)n * p.YH + (oh * p.osh + p.oah)) * p.YW + (ow * p.osw + p.oaw)) * p.ldy;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = cbase + 8 * g;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
+                        if constexpr (EM == 2) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (c + e < p.Nout) {
+                                    float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
+                                    float u = v[e] * sc + sh;
+                                    v[e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
+                                }
+                            }
+                        }
+                        if constexpr (EM == 3) {
+                            if (pv) {
+                                float* Y = reinterpret_cast<float*>(p.y);
+                                const int na = p.Nout / p.head_no;
+                                const unsigned mu = (unsigned)m;        // head: y_linear is set, decode here
+                                unsigned t = mu / (unsigned)p.OW;
+                                int hw_ow = (int)(mu - t * (unsigned)p.OW);
+                                unsigned hn = t / (unsigned)p.OH;
+                                int hw_oh = (int)(t - hn * (unsigned)p.OH);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    int cc = c + e;
+                                    if (cc < p.Nout) {
+                                        int a = cc / p.head_no, o = cc - a * p.head_no;
+                                        float u = v[e] + (p.shift ? p.shift[cc] : 0.0f);
+                                        Y[((((long long)hn * na + a) * p.OH + hw_oh) * p.OW + hw_ow) * p.head_no + o] = u;
+                                    }
+                                }
+                            }
+                            continue;
+                        }
+                        if (want_stats) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
+                                ssum[g * 4 + e] += q;
+                                ssq[g * 4 + e] += q * q;
+                            }
+                        }
+                        if (pv) {
+                            T* Y = reinterpret_cast<T*>(p.y) + yo + c;
+                            if (c + 3 < p.Nout && (p.ldy & 3) == 0) {
+                                if constexpr (EM == 1) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] += (float)Y[e];
+                                }
+                                if constexpr (sizeof(T) == 2) {
+                                    half4 h;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+                                    *reinterpret_cast<half4*>(Y) = h;
+                                } else {
+                                    float4v f;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) f[e] = v[e];
+                                    *reinterpret_cast<float4v*>(Y) = f;
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (c + e < p.Nout) Y[e] = (T)(EM == 1 ? v[e] + (float)Y[e] : v[e]);
+                            }
+                        }
+                    }
+                }
+            }
         }
+        // ---------------- stage the prefetched step into the other LDS buffer
+        const int nb = first ? 0 : (buf ^ 1);
         if (more) {
-            const int nb = (kt + 1) & 1;
             T* dX = sX + nb * TP * LDR;
             T* dW = sW + nb * TM * LDR;
 #pragma unroll
@@ -181,100 +327,19 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
             }
         }
         __syncthreads();
+        if (!more) break;
+        if (first) { first = false; cur_tile = ld_tile; cur_kt = 0; buf = 0; }
+        else {
+            ++cur_kt;
+            if (cur_kt == nk) { cur_kt = 0; cur_tile += nslots; }
+            buf ^= 1;
+        }
     }
 
-    // ---- epilogue.  acc[ni][r]: channel = n0 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3), pixel = .. + (lane&31)
-    const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
-    const bool want_stats = (p.stats != nullptr);
     if (want_stats) {
         for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
         __syncthreads();
-    }
-    float ssum[16], ssq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
-
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        long long m = m0 + wp * NI * 32 + ni * 32 + (lane & 31);
-        bool pv = m < p.Mtotal;
-        long long yo = 0;
-        int n = 0, oh = 0, ow = 0;
-        if (pv) {
-            ow = (int)(m % p.OW);
-            long long t = m / p.OW;
-            oh = (int)(t % p.OH);
-            n = (int)(t / p.OH);
-            yo = (((long long)n * p.YH + (oh * p.osh + p.oah)) * p.YW + (ow * p.osw + p.oaw)) * p.ldy;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = cbase + 8 * g;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[ni][g * 4 + e];
-            if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (c + e < p.Nout) {
-                        float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
-                        float u = v[e] * sc + sh;
-                        v[e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
-                    }
-                }
-            }
-            if (p.epi == AYOLO_EPI_HEAD) {
-                if (pv) {
-                    float* Y = reinterpret_cast<float*>(p.y);
-                    const int na = p.Nout / p.head_no;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int cc = c + e;
-                        if (cc < p.Nout) {
-                            int a = cc / p.head_no, o = cc - a * p.head_no;
-                            float u = v[e] + (p.shift ? p.shift[cc] : 0.0f);
-                            Y[((((long long)n * na + a) * p.OH + oh) * p.OW + ow) * p.head_no + o] = u;
-                        }
-                    }
-                }
-                continue;
-            }
-            if (want_stats) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
-                    ssum[g * 4 + e] += q;
-                    ssq[g * 4 + e] += q * q;
-                }
-            }
-            if (pv) {
-                T* Y = reinterpret_cast<T*>(p.y) + yo + c;
-                if (c + 3 < p.Nout && (p.ldy & 3) == 0) {
-                    if (p.accumulate) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)Y[e];
-                    }
-                    if constexpr (sizeof(T) == 2) {
-                        half4 h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
-                        *reinterpret_cast<half4*>(Y) = h;
-                    } else {
-                        float4v f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) f[e] = v[e];
-                        *reinterpret_cast<float4v*>(Y) = f;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c + e < p.Nout) Y[e] = (T)(p.accumulate ? v[e] + (float)Y[e] : v[e]);
-                }
-            }
-        }
-    }
-    if (want_stats) {
-        // reduce over the 32 pixel lanes of each half-wave, then one LDS add per (wave, channel)
+        // one reduction per workgroup: over the 32 pixel lanes of each half-wave, then LDS, then one replica
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float a = ssum[r], b = ssq[r];
@@ -290,29 +355,57 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
             }
         }
         __syncthreads();
+        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
         for (int i = tid; i < TM; i += 256) {
             if (n0 + i < p.Nout) {
-                atomicAdd(&p.stats[n0 + i], sStat[i]);
-                atomicAdd(&p.stats[p.Nout + n0 + i], sStat[TM + i]);
+                atomicAdd(&st[n0 + i], sStat[i]);
+                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
             }
         }
     }
 }
 
-template <typename T, int TM>
-static int launch_gconv(const GConvP& p, hipStream_t s) {
+static int g_num_cu = 0;
+static int num_cus() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+template <typename T, int TM, int EM>
+static int launch_gconv_em(GConvP p, hipStream_t s) {
     constexpr int LDR = BK + Tr<T>::PADE;
     size_t lds = (size_t)2 * (TM + TP) * LDR * sizeof(T) + 2 * TM * sizeof(float);
-    dim3 grid((unsigned)((p.Mtotal + TP - 1) / TP), (unsigned)((p.Nout + TM - 1) / TM));
+    const long long ntiles = (p.Mtotal + TP - 1) / TP;
+    p.ntn = (p.Nout + TM - 1) / TM;
+    // persistent grid: ~4 workgroups per CU in total, pixel-tile slots a multiple of the 8 XCDs
+    long long want_slots = (long long)num_cus() * 4 / p.ntn;
+    if (want_slots < 8) want_slots = 8;
+    long long slots = ntiles < want_slots ? ntiles : want_slots;
+    slots = (slots + 7) / 8 * 8;
+    p.nslots = (int)slots;
+    dim3 grid((unsigned)(slots * p.ntn));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gconv<T, TM>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_gconv<T, TM, EM>), grid, dim3(256), lds, s, p);
     AY_CHECK_LAUNCH("k_gconv");
     return AYOLO_OK;
+}
+
+template <typename T, int TM>
+static int launch_gconv(const GConvP& p, hipStream_t s) {
+    if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
+    if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_gconv_em<T, TM, 2>(p, s);
+    if (p.accumulate) return launch_gconv_em<T, TM, 1>(p, s);
+    return launch_gconv_em<T, TM, 0>(p, s);
 }
 
 static int dispatch_gconv(int dtype, const GConvP& p, hipStream_t s) {
@@ -337,11 +430,14 @@ static int check_desc(const ayolo_conv_desc* d, const char* who) {
     AY_CHECK_ARG(d->kh * d->kw <= MAX_TAPS && d->kh > 0 && d->kw > 0, "%s: kernel %dx%d unsupported", who, d->kh, d->kw);
     AY_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "%s: bad dims", who);
     AY_CHECK_ARG(d->ph < 64 && d->pw < 64, "%s: padding too large", who);
+    AY_CHECK_ARG((long long)d->B * d->H * d->W < (1ll << 31) && (long long)d->B * d->Ho * d->Wo < (1ll << 31),
+                 "%s: more than 2^31 pixels", who);
     return AYOLO_OK;
 }
 
 extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void* y, int epilogue,
-                              const float* scale, const float* shift, float* stats, int head_no, ayolo_stream s) {
+                              const float* scale, const float* shift, float* stats, int stat_reps, int head_no,
+                              ayolo_stream s) {
     int rc = check_desc(d, "conv_fwd");
     if (rc) return rc;
     AY_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
@@ -355,6 +451,9 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
     p.YH = d->Ho; p.YW = d->Wo; p.ldy = d->ldy; p.osh = 1; p.osw = 1; p.oah = 0; p.oaw = 0;
     p.C = d->Cin; p.ntaps = d->kh * d->kw; p.K = p.ntaps * p.C; p.ldw = p.K; p.Nout = d->Cout;
     p.epi = epilogue; p.scale = scale; p.shift = shift; p.stats = stats; p.head_no = head_no; p.accumulate = 0;
+    p.stat_reps = stat_reps > 0 ? stat_reps : 1;
+    p.y_linear = 1;
+    p.x_linear = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0) ? 1 : 0;
     p.Mtotal = (long long)d->B * d->Ho * d->Wo;
     for (int i = 0; i < d->kh; ++i)
         for (int j = 0; j < d->kw; ++j) {
@@ -385,7 +484,9 @@ extern "C" int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const 
             p.ish = 1; p.isw = 1;
             p.YH = d->H; p.YW = d->W; p.ldy = d->ldx; p.osh = d->sh; p.osw = d->sw; p.oah = a; p.oaw = b;
             p.C = d->Cout; p.ldw = d->kh * d->kw * d->Cout; p.Nout = d->Cin;
-            p.epi = AYOLO_EPI_NONE; p.accumulate = accumulate;
+            p.epi = AYOLO_EPI_NONE; p.accumulate = accumulate; p.stat_reps = 1;
+            p.y_linear = (d->sh == 1 && d->sw == 1) ? 1 : 0;
+            p.x_linear = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0) ? 1 : 0;
             p.Mtotal = (long long)d->B * p.OH * p.OW;
             int nt = 0;
             for (int i = 0; i < d->kh; ++i) {
@@ -420,7 +521,7 @@ struct WGradP {
     signed char dh[MAX_TAPS], dw_[MAX_TAPS];
 };
 
-#define BP 32   // pixels per reduction step
+#define BP_MAX 64   // pixels per reduction step: 64 (fp16) / 32 (fp32)
 #define TNW 128 // dw columns per block tile
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -442,6 +543,7 @@ __device__ __forceinline__ half8 tr_frag(const half_t* tile, int ldt, int k0, in
 template <typename T, int TM>
 __global__ __launch_bounds__(256) void k_wgrad(WGradP p) {
     constexpr int CE = Tr<T>::CE;
+    constexpr int BP = sizeof(T) == 2 ? 64 : 32;
     constexpr int LDY = TM + Tr<T>::PADE;     // dy tile row stride
     constexpr int LDX = TNW + Tr<T>::PADE;    // x tile row stride
     constexpr int WM = TM / 32, WN = 4 / WM, NI = TNW / (32 * WN);
@@ -583,6 +685,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WGradP p) {
 template <typename T, int TM>
 static int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
     constexpr int LDY = TM + Tr<T>::PADE, LDX = TNW + Tr<T>::PADE;
+    constexpr int BP = sizeof(T) == 2 ? 64 : 32;
     size_t lds = (size_t)2 * BP * (LDY + LDX) * sizeof(T);
     dim3 grid((unsigned)((p.K + TNW - 1) / TNW), (unsigned)((p.N + TM - 1) / TM), (unsigned)splits);
     static bool attr_set = false;
@@ -618,12 +721,12 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
     const long long tiles = (long long)((p.K + TNW - 1) / TNW) * ((p.N + tm - 1) / tm);
     // split the pixel reduction so that ~4 blocks per CU are in flight, each with >= 8 reduction steps
     long long want = (1024 + tiles - 1) / tiles;
-    long long max_splits = (p.P + 8 * BP - 1) / (8 * BP);
+    long long max_splits = (p.P + 8 * BP_MAX - 1) / (8 * BP_MAX);
     long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     long long chunk = (p.P + splits - 1) / splits;
-    chunk = (chunk + BP - 1) / BP * BP;
+    chunk = (chunk + BP_MAX - 1) / BP_MAX * BP_MAX;
     splits = (p.P + chunk - 1) / chunk;
     p.chunk = chunk;
     hipStream_t st = (hipStream_t)s;

@@ -40,13 +40,18 @@ static unsigned grid_for(long long work_items, int per_block) {
 // ---------------------------------------------------------------------------------------------------
 // BN finalize
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_bn_finalize(const float* stats, int C, double count, const float* gamma, const float* beta, float eps,
-                              float momentum, float* rmean, float* rvar, float* smean, float* sinv, float* scale,
-                              float* shift) {
+__global__ void k_bn_finalize(const float* stats, int reps, int C, double count, const float* gamma, const float* beta,
+                              float eps, float momentum, float* rmean, float* rvar, float* smean, float* sinv,
+                              float* scale, float* shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double mean = (double)stats[c] / count;
-    double var = (double)stats[C + c] / count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        s1 += (double)stats[(size_t)r * 2 * C + c];
+        s2 += (double)stats[(size_t)r * 2 * C + C + c];
+    }
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
     float invstd = (float)(1.0 / sqrt(var + (double)eps));
     float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
@@ -62,11 +67,11 @@ __global__ void k_bn_finalize(const float* stats, int C, double count, const flo
     }
 }
 
-extern "C" int ayolo_bn_finalize(const float* stats, int C, double count, const float* gamma, const float* beta,
+extern "C" int ayolo_bn_finalize(const float* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
                                  float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                                  float* save_invstd, float* scale, float* shift, ayolo_stream s) {
     AY_CHECK_ARG(stats && scale && shift && C > 0 && count > 0, "bn_finalize: bad args");
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s, stats, C, count, gamma, beta, eps,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s, stats, stat_reps > 0 ? stat_reps : 1, C, count, gamma, beta, eps,
                        momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
     AY_CHECK_LAUNCH("k_bn_finalize");
     return AYOLO_OK;
@@ -128,7 +133,7 @@ __device__ __forceinline__ float act_grad(float u, int act) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, const T* da, int ldda, long long npix, int C,
                                                        const float* mean, const float* invstd, const float* gamma,
-                                                       const float* beta, int act, float* sums) {
+                                                       const float* beta, int act, float* sums, int reps) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sh[];   // [4][C] mean, invstd, gamma, beta ; then [2][C] block sums
     float* bs = sh + 4 * C;
@@ -170,20 +175,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], bs[i]);
+    float* dst = sums + (size_t)(blockIdx.x % (unsigned)reps) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&dst[i], bs[i]);
 }
 
 extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const void* da, int ldda, int64_t npix, int C,
                                        const float* save_mean, const float* save_invstd, const float* gamma,
-                                       const float* beta, int act, float* sums, ayolo_stream s) {
+                                       const float* beta, int act, float* sums, int sum_reps, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    if (sum_reps < 1) sum_reps = 1;
     AY_CHECK_ARG(z && da && sums && save_mean && save_invstd, "bn_bwd_reduce: null pointer");
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && C <= 2048, "bn_bwd_reduce: C=%d", C);
     if (npix == 0) return AYOLO_OK;
     int cg = C / ve, cgt = cg < 256 ? cg : 256, rpb = 256 / cgt;
     DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_reduce<T>, dim3(grid_for(npix, rpb * 16)), dim3(256),
                                          6 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
-                                         (long long)npix, C, save_mean, save_invstd, gamma, beta, act, sums);)
+                                         (long long)npix, C, save_mean, save_invstd, gamma, beta, act, sums, sum_reps);)
     AY_CHECK_LAUNCH("k_bn_bwd_reduce");
     return AYOLO_OK;
 }
@@ -192,17 +199,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const T* da, int ldda, T* dz, int lddz,
                                                       long long npix, int C, const float* mean, const float* invstd,
                                                       const float* gamma, const float* beta, int act, const float* sums,
-                                                      float* dgamma, float* dbeta, float grad_scale) {
+                                                      int reps, float* dgamma, float* dbeta, float grad_scale) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sh[];   // [6][C]: mean, invstd, gamma, beta, sum_du/n, sum_dux/n
     const float invn = 1.0f / (float)npix;
     for (int i = threadIdx.x; i < C; i += 256) {
         sh[i] = mean[i]; sh[C + i] = invstd[i];
         sh[2 * C + i] = gamma ? gamma[i] : 1.0f; sh[3 * C + i] = beta ? beta[i] : 0.0f;
-        sh[4 * C + i] = sums[i] * invn; sh[5 * C + i] = sums[C + i] * invn;
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int r = 0; r < reps; ++r) { s1 += sums[(size_t)r * 2 * C + i]; s2 += sums[(size_t)r * 2 * C + C + i]; }
+        sh[4 * C + i] = s1 * invn; sh[5 * C + i] = s2 * invn;
         if (blockIdx.x == 0) {
-            if (dbeta) dbeta[i] = sums[i] * grad_scale;
-            if (dgamma) dgamma[i] = sums[C + i] * grad_scale;
+            if (dbeta) dbeta[i] = s1 * grad_scale;
+            if (dgamma) dgamma[i] = s2 * grad_scale;
         }
     }
     __syncthreads();
@@ -228,16 +237,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
 
 extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
                                       int64_t npix, int C, const float* save_mean, const float* save_invstd,
-                                      const float* gamma, const float* beta, int act, const float* sums, float* dgamma,
-                                      float* dbeta, float grad_scale, ayolo_stream s) {
+                                      const float* gamma, const float* beta, int act, const float* sums, int sum_reps,
+                                      float* dgamma, float* dbeta, float grad_scale, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    if (sum_reps < 1) sum_reps = 1;
     AY_CHECK_ARG(z && da && dz && sums, "bn_bwd_apply: null pointer");
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && lddz % ve == 0 && C <= 2048, "bn_bwd_apply: C=%d", C);
     if (npix == 0) return AYOLO_OK;
     DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(grid_for(npix * (C / ve), 256 * 4)), dim3(256),
                                          6 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
                                          (T*)dz, lddz, (long long)npix, C, save_mean, save_invstd, gamma, beta, act,
-                                         sums, dgamma, dbeta, grad_scale);)
+                                         sums, sum_reps, dgamma, dbeta, grad_scale);)
     AY_CHECK_LAUNCH("k_bn_bwd_apply");
     return AYOLO_OK;
 }
@@ -520,36 +530,34 @@ extern "C" int ayolo_head_decode(const float* raw, int B, int na, int ny, int nx
 template <typename T>
 __global__ __launch_bounds__(256) void k_head_grad_pack(const float* draw, int B, int na, int ny, int nx, int no, T* dz,
                                                         int ldz, float* dbias) {
-    extern __shared__ float bs[];   // [ldz]
-    for (int i = threadIdx.x; i < ldz; i += 256) bs[i] = 0.0f;
-    __syncthreads();
+    // thread = channel (coalesced in o for reads, in c for writes); pixels strided over the grid; the bias
+    // partial lives in a register, one global atomic per (block, channel)
     const long long hw = (long long)ny * nx, npix = (long long)B * hw;
     const int Cc = na * no;
-    // one thread per (pixel, channel), channel fastest: coalesced dz writes, strided-but-cached draw reads
-    const long long total = npix * ldz;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-        int c = (int)(t % ldz);
-        long long pix = t / ldz;
-        float v = 0.0f;
-        if (c < Cc) {
-            int a = c / no, o = c - a * no;
-            long long b = pix / hw, p = pix - b * hw;
-            v = draw[((b * na + a) * hw + p) * no + o];
-            atomicAdd(&bs[c], v);
+    for (int c = threadIdx.x; c < ldz; c += 256) {
+        const int a = c < Cc ? c / no : 0, o = c < Cc ? c - a * no : 0;
+        float acc = 0.0f;
+        for (long long pix = blockIdx.x; pix < npix; pix += gridDim.x) {
+            float v = 0.0f;
+            if (c < Cc) {
+                long long b = pix / hw, p = pix - b * hw;
+                v = draw[((b * na + a) * hw + p) * no + o];
+            }
+            acc += v;
+            dz[pix * ldz + c] = (T)v;
         }
-        dz[t] = (T)v;
+        if (dbias && c < Cc) atomicAdd(&dbias[c], acc);
     }
-    __syncthreads();
-    if (dbias)
-        for (int i = threadIdx.x; i < Cc; i += 256) atomicAdd(&dbias[i], bs[i]);
 }
 
 extern "C" int ayolo_head_grad_pack(const float* draw, int B, int na, int ny, int nx, int no, int dtype, void* dz, int ldz,
                                     float* dbias, ayolo_stream s) {
     AY_CHECK_ARG(draw && dz && ldz >= na * no && ldz <= 4096, "head_grad_pack: bad args");
     long long total = (long long)B * ny * nx * ldz;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_grad_pack<T>, dim3(grid_for(total, 256 * 8)), dim3(256),
-                                         ldz * sizeof(float), (hipStream_t)s, draw, B, na, ny, nx, no, (T*)dz, ldz, dbias);)
+    long long npix = (long long)B * ny * nx;
+    (void)total;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_head_grad_pack<T>, dim3((unsigned)(npix < 2048 ? npix : 2048)), dim3(256), 0,
+                                         (hipStream_t)s, draw, B, na, ny, nx, no, (T*)dz, ldz, dbias);)
     AY_CHECK_LAUNCH("k_head_grad_pack");
     return AYOLO_OK;
 }

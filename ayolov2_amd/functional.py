@@ -114,7 +114,7 @@ class ConvBnActFn(torch.autograd.Function):
         w, wt = cache.get(weight, dt, Cout, geo.cin_pad)
         dev = xk.device
         z = ops.new_act(geo.B, Cout, geo.Ho, geo.Wo, dt, dev)
-        stats = torch.zeros(2 * Cout, dtype=torch.float32, device=dev)
+        stats = torch.zeros((ops.STAT_REPS, 2 * Cout), dtype=torch.float32, device=dev)
         d = geo.desc(dt, ldx, Cout)
         ops.conv_fwd(d, xk, w, z, EPI_NONE, stats=stats)
         count = geo.B * geo.Ho * geo.Wo

@@ -82,8 +82,12 @@ def make_desc(dt: torch.dtype, B, H, W, Cin, ldx, Cout, ldy, k, s, p, Ho, Wo) ->
 
 
 # --------------------------------------------------------------------------------------------------
+STAT_REPS = 32   # replicas of the per-channel BN accumulators (see ayolo.h)
+
+
 def conv_fwd(desc: ConvDesc, x, w, y, epilogue=_lib.EPI_NONE, scale=None, shift=None, stats=None, head_no=0):
-    call("ayolo_conv_fwd", desc, _ptr(x), _ptr(w), _ptr(y), epilogue, _ptr(scale), _ptr(shift), _ptr(stats), head_no,
+    reps = stats.shape[0] if (stats is not None and stats.dim() == 2) else 1
+    call("ayolo_conv_fwd", desc, _ptr(x), _ptr(w), _ptr(y), epilogue, _ptr(scale), _ptr(shift), _ptr(stats), reps, head_no,
          _stream())
 
 
@@ -112,7 +116,8 @@ def bn_finalize(stats, C, count, gamma, beta, eps, momentum, running_mean, runni
     save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
     scale = torch.empty(C, dtype=torch.float32, device=dev)
     shift = torch.empty(C, dtype=torch.float32, device=dev)
-    call("ayolo_bn_finalize", _ptr(stats), C, float(count), _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+    reps = stats.shape[0] if stats.dim() == 2 else 1
+    call("ayolo_bn_finalize", _ptr(stats), reps, C, float(count), _ptr(gamma), _ptr(beta), float(eps), float(momentum),
          _ptr(running_mean), _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), _ptr(scale), _ptr(shift), _stream())
     return save_mean, save_invstd, scale, shift
 
@@ -130,15 +135,15 @@ def bn_act_bwd(z, da, save_mean, save_invstd, gamma, beta, act: int, want_param_
     _, _, _, _, ldda = nhwc_info(da)
     npix = B * H * W
     dev = z.device
-    sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)
+    sums = torch.zeros((STAT_REPS, 2 * C), dtype=torch.float32, device=dev)
     dz = new_act(B, C, H, W, z.dtype, dev)
     dt = dtype_code(z.dtype)
     call("ayolo_bn_act_bwd_reduce", dt, _ptr(z), ldz, _ptr(da), ldda, npix, C, _ptr(save_mean), _ptr(save_invstd),
-         _ptr(gamma), _ptr(beta), act, _ptr(sums), _stream())
+         _ptr(gamma), _ptr(beta), act, _ptr(sums), STAT_REPS, _stream())
     dgamma = torch.empty(C, dtype=torch.float32, device=dev) if want_param_grads else None
     dbeta = torch.empty(C, dtype=torch.float32, device=dev) if want_param_grads else None
     call("ayolo_bn_act_bwd_apply", dt, _ptr(z), ldz, _ptr(da), ldda, _ptr(dz), C, npix, C, _ptr(save_mean),
-         _ptr(save_invstd), _ptr(gamma), _ptr(beta), act, _ptr(sums), _ptr(dgamma), _ptr(dbeta), 1.0, _stream())
+         _ptr(save_invstd), _ptr(gamma), _ptr(beta), act, _ptr(sums), STAT_REPS, _ptr(dgamma), _ptr(dbeta), 1.0, _stream())
     return dz, dgamma, dbeta
 
 

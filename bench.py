@@ -95,7 +95,7 @@ def conv_kernel_roofline(model, batch, size, device, reps=5):
         cout = conv.weight.shape[0]
         w, _ = mod._cache(0).get(conv.weight, dt, cout, geo.cin_pad)
         y = ops.new_act(batch, cout, geo.Ho, geo.Wo, dt, device)
-        stats = torch.zeros(2 * cout, dtype=torch.float32, device=device)
+        stats = torch.zeros((ops.STAT_REPS, 2 * cout), dtype=torch.float32, device=device)
         d = geo.desc(dt, geo.Cin_k, cout)
         for _ in range(2):
             ops.conv_fwd(d, xk, w, y, 0, stats=stats)

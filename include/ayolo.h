@@ -59,11 +59,13 @@ typedef struct ayolo_conv_desc {
 #define AYOLO_EPI_AFFINE_SILU 2 /* y = silu(conv*scale[c] + shift[c])  (eval / fused-BN inference)     */
 #define AYOLO_EPI_HEAD 3      /* y(fp32)[b][a][h][w][o] = conv + shift[c], c = a*no + o (YOLOHead)     */
 
-/* y = conv(x, w).  `stats` (nullable, EPI_NONE only): float[2*Cout] zero-initialised by the caller; receives
- * per-channel sum and sum of squares of the fp32 accumulators rounded to the output dtype (training-mode BN).
+/* y = conv(x, w).  `stats` (nullable, EPI_NONE only): float[stat_reps][2*Cout] zero-initialised by the caller;
+ * receives per-channel sum and sum of squares of the fp32 accumulators rounded to the output dtype (training-mode
+ * BN), spread over stat_reps replicas (workgroup b adds into replica b % stat_reps) to avoid serialising L2
+ * atomics; ayolo_bn_finalize sums the replicas.
  * scale/shift: float[Cout] (nullable where unused).  head_no: `no` for AYOLO_EPI_HEAD (y is fp32). */
 int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void* y, int epilogue,
-                   const float* scale, const float* shift, float* stats, int head_no, ayolo_stream s);
+                   const float* scale, const float* shift, float* stats, int stat_reps, int head_no, ayolo_stream s);
 
 /* dx (+)= conv_transpose(dy, w).  wt is the transposed weight [Cin][kh][kw][Cout] (see ayolo_cast_weight).
  * accumulate != 0 adds into the existing dx. d describes the FORWARD conv (x:B,H,W,Cin  y:B,Ho,Wo,Cout);
@@ -87,21 +89,21 @@ int ayolo_cast_weight(const float* w32, int Cout, int kh, int kw, int Cin, int C
 /* From stats (sum,sumsq over `count` elements per channel): mean/invstd, running-stat update
  * (momentum, unbiased var), scale = gamma*invstd, shift = beta - mean*scale.  save_mean/save_invstd/scale/
  * shift: float[C].  running_* nullable. */
-int ayolo_bn_finalize(const float* stats, int C, double count, const float* gamma, const float* beta,
+int ayolo_bn_finalize(const float* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                       float* save_invstd, float* scale, float* shift, ayolo_stream s);
 /* a = act(z*scale[c] + shift[c]); act: 0 identity, 1 SiLU.  z: npix x C (ldz), a: npix x C (lda). */
 int ayolo_affine_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* scale,
                      const float* shift, int act, ayolo_stream s);
-/* Backward of a = silu(bn(z)): pass 1 accumulates sums[0:C] = sum(du), sums[C:2C] = sum(du * xhat)
- * (zeroed by caller); pass 2 writes dz and (from sums) dgamma/dbeta. */
+/* Backward of a = silu(bn(z)): pass 1 accumulates sums[r][0:C] = sum(du), sums[r][C:2C] = sum(du * xhat) over
+ * sum_reps replicas (float[sum_reps][2*C], zeroed by caller); pass 2 sums the replicas, writes dz and dgamma/dbeta. */
 int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const void* da, int ldda, int64_t npix, int C,
                             const float* save_mean, const float* save_invstd, const float* gamma,
-                            const float* beta, int act, float* sums, ayolo_stream s);
+                            const float* beta, int act, float* sums, int sum_reps, ayolo_stream s);
 int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
                            int64_t npix, int C, const float* save_mean, const float* save_invstd,
-                           const float* gamma, const float* beta, int act, const float* sums, float* dgamma,
-                           float* dbeta, float grad_scale, ayolo_stream s);
+                           const float* gamma, const float* beta, int act, const float* sums, int sum_reps,
+                           float* dgamma, float* dbeta, float grad_scale, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Small NHWC ops: kindle SPPF's MaxPool2d(5,1,2), UpSample(None,2) nearest, input packing, bias grad.
