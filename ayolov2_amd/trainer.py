@@ -1,0 +1,84 @@
+"""Data-parallel training glue with the reference's interface for this path
+(scripts/train/train_model_builder.py:75-141 ``TrainModelBuilder``, scripts/train/yolo_trainer.py:289-358
+``training_step``).  One process per GPU; gradients are all-reduced by torch DDP, whose "nccl" backend IS RCCL on
+ROCm (over xGMI inside a node), bucketed and overlapped with the HIP backward kernels.
+
+Conventions kept from the reference: the loss is multiplied by WORLD_SIZE under DDP
+(yolo_trainer.py:325-326) on top of ``loss * batch_size`` (losses.py:297-300); BatchNorm statistics stay local
+(``sync_bn`` defaults to false, train_config.yaml:17); the process group falls back to "gloo" when no GPU backend is
+available (train_model_builder.py:112-114).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+LOCAL_RANK = int(os.getenv("LOCAL_RANK", -1))
+RANK = int(os.getenv("RANK", -1))
+WORLD_SIZE = int(os.getenv("WORLD_SIZE", 1))
+
+
+class TrainModelBuilder:
+    def __init__(self, model: nn.Module, cfg: Dict[str, Any], log_dir: str = "exp", full_cfg: Optional[dict] = None) -> None:
+        self.model = model
+        self.cfg = cfg
+        self.log_dir = log_dir
+        self.device = torch.device("cuda", max(LOCAL_RANK, 0)) if torch.cuda.is_available() else torch.device("cpu")
+        self.cuda = self.device.type == "cuda"
+        self.rank = int(os.getenv("RANK", -1))
+        self.local_rank = int(os.getenv("LOCAL_RANK", -1))
+        self.world_size = int(os.getenv("WORLD_SIZE", 1))
+
+    def ddp_init(self) -> None:
+        """One process per GPU: bind the device and join the process group (RCCL when GPUs are present)."""
+        if self.local_rank == -1:
+            return
+        if self.cuda:
+            assert torch.cuda.device_count() > self.local_rank, "insufficient GPUs for DDP"
+            torch.cuda.set_device(self.local_rank)
+            self.device = torch.device("cuda", self.local_rank)
+        train_cfg = self.cfg.get("train", {})
+        assert train_cfg.get("batch_size", self.world_size) % self.world_size == 0, "--batch-size must be multiple of GPU count"
+        assert not train_cfg.get("image_weights", False), "--image-weights argument is not compatible with DDP training"
+        if not dist.is_initialized():
+            backend = "nccl" if (self.cuda and dist.is_nccl_available()) else "gloo"
+            dist.init_process_group(backend=backend)
+
+    def to_ddp(self) -> nn.Module:
+        if self.cuda:
+            return nn.parallel.DistributedDataParallel(self.model, device_ids=[self.local_rank], output_device=self.local_rank,
+                                                       gradient_as_bucket_view=True)
+        return nn.parallel.DistributedDataParallel(self.model)
+
+    def prepare(self) -> Tuple[nn.Module, Optional[Any], torch.device]:
+        torch.manual_seed(1 + max(self.rank, 0))
+        self.model.to(self.device)
+        ema = None
+        if self.cuda and self.rank != -1 and self.cfg.get("train", {}).get("sync_bn", False):
+            raise NotImplementedError("sync_bn: the HIP BatchNorm keeps statistics local (reference default)")
+        if self.rank != -1:
+            self.model = self.to_ddp()
+        return self.model, ema, self.device
+
+
+def training_step(model: nn.Module, loss_fn, optimizer: torch.optim.Optimizer, scaler, imgs: torch.Tensor,
+                  targets: torch.Tensor, world_size: int = 1, amp: bool = True):
+    """autocast forward -> ComputeLoss -> (x world_size under DDP) -> scaled backward -> step (accumulate = 1)."""
+    with torch.autocast(imgs.device.type, dtype=torch.float16, enabled=amp and imgs.is_cuda):
+        pred = model(imgs)
+        loss, items = loss_fn(pred, targets)
+    if world_size > 1:
+        loss = loss * world_size
+    if scaler is not None:
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        loss.backward()
+        optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), items

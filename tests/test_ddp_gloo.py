@@ -1,0 +1,89 @@
+"""N > 1 path on CPU: two gloo ranks run the package's TrainModelBuilder + training_step around a CPU module
+(the oracle network -- the HIP modules refuse CPU tensors by design) and must end with identical parameters that
+equal a single-process run on the concatenated batch (gradient averaging x world_size loss convention)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HYP = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model():
+    from oracle.model_ref import RefYOLO
+    torch.manual_seed(0)
+    m = RefYOLO(os.path.join(ROOT, "ayolov2_amd", "configs", "yolov5n.yaml"))
+    for mod in m.modules():                      # BN in eval mode: the check is about gradient sync, not batch stats
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+    m.hyp, m.gr = dict(HYP), 1.0
+    return m
+
+
+def _data(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    imgs = torch.rand(2, 3, 64, 64, generator=g)
+    t = torch.tensor([[0, 3, 0.5, 0.5, 0.3, 0.4], [1, 7, 0.3, 0.6, 0.2, 0.2]])
+    t[:, 2:] += 0.05 * rank
+    return imgs, t
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from ayolov2_amd.losses import ComputeLoss
+    from ayolov2_amd.trainer import TrainModelBuilder, training_step
+    model = _make_model()
+    b = TrainModelBuilder(model, {"train": {"batch_size": 4}})
+    b.cuda = False
+    b.device = torch.device("cpu")
+    b.ddp_init()
+    ddp, _, _ = b.prepare()
+    loss_fn = ComputeLoss(model)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    imgs, t = _data(rank)
+    for mod in ddp.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eval()
+    training_step(ddp, loss_fn, opt, None, imgs, t, world_size=world, amp=False)
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out, f"rank{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_ddp_two_ranks_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    b = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"ranks diverged at {k}"
+    # single process reference: sum of the per-rank losses (mean-over-ranks gradient x world_size)
+    sys.path.insert(0, ROOT)
+    from ayolov2_amd.losses import ComputeLoss
+    model = _make_model()
+    loss_fn = ComputeLoss(model)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    total = 0
+    for r in range(2):
+        imgs, t = _data(r)
+        l, _ = loss_fn(model(imgs), t)
+        total = total + l
+    total.backward()
+    opt.step()
+    ref = model.state_dict()
+    for k in a:
+        if a[k].dtype.is_floating_point:
+            assert torch.allclose(a[k], ref[k], rtol=1e-4, atol=1e-6), k

@@ -92,7 +92,7 @@ def test_train_step_fp16_autocast():
     for a, b in zip(raws_g, raws_r):
         assert a.dtype == torch.float32
         assert _rel(a.detach().cpu(), b.detach()) < 2e-2
-    scale = 64.0                          # static loss scale, as GradScaler would apply
+    scale = 8192.0                        # static loss scale (GradScaler starts at 65536): keeps fp16 grads normal
     sum((a * w).sum() for a, w in zip(raws_r, gws)).backward()
     (sum((a * w.cuda()).sum() for a, w in zip(raws_g, gws)) * scale).backward()
     pr = dict(r.named_parameters())
@@ -121,3 +121,32 @@ def test_full_val_path_640():
     want = ops_ref.non_max_suppression(out.cpu().numpy(), conf_thres=0.001, iou_thres=0.65, multi_label=True)
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g.cpu().numpy(), w)
+
+
+def test_tucker_decomposed_model_eval():
+    """BASELINE.json config 4 in miniature: decompose_model() on the HIP model and on the CPU oracle (same weights),
+    then eval forward through the 1x1 -> kxk -> 1x1 Sequential path of modules.Conv."""
+    from torch import nn
+    from ayolov2_amd import decomposition as D
+    from ayolov2_amd.modules import Conv
+    m, r = _pair("n", seed=11)
+    m = m.cpu()
+    with torch.no_grad():
+        for blk in (m.model[1], m.model[2].m[0].cv2, m.model[3]):
+            w = blk.conv.weight.data
+            co, ci = w.shape[:2]
+            core = torch.randn(co // 4, ci // 4, 3, 3)
+            w.copy_(torch.einsum("abhw,oa,ib->oihw", core, torch.randn(co, co // 4), torch.randn(ci, ci // 4)) / 8
+                    + 0.002 * torch.randn_like(w))
+    r.load_state_dict(m.state_dict())
+    D.decompose_model(m, loss_thr=0.1, prune_step=0.0)
+    D.decompose_model(r, loss_thr=0.1, prune_step=0.0)
+    n_seq = sum(isinstance(c.conv, nn.Sequential) for c in m.modules() if isinstance(c, Conv))
+    assert n_seq >= 3
+    m = m.cuda().eval()
+    r.eval()
+    x = torch.rand(2, 3, 128, 128)
+    with torch.no_grad():
+        zr, _ = r(x)
+        zg, _ = m(x.cuda())
+    np.testing.assert_allclose(zg.cpu().numpy(), zr.numpy(), rtol=2e-4, atol=2e-3)
