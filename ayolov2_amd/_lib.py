@@ -44,7 +44,7 @@ _SIGNATURES = {
     "ayolo_pack_input": [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "ayolo_head_grad_pack": [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     "ayolo_copy2d": [c_int, _P, c_int, _P, c_int, c_int64, c_int, c_int, _P],
-    "ayolo_head_decode": [_P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int64, c_int64, _P],
+    "ayolo_head_decode": [_P, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int64, c_int64, _P],
     "ayolo_nms_candidates": [_P, c_int, c_int, c_int, c_float, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_uint32, c_int,
                              _P],
     "ayolo_nms_key_bits": [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)],

@@ -254,23 +254,14 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
                             }
                         }
                         if constexpr (EM == 3) {
-                            if (pv) {
-                                float* Y = reinterpret_cast<float*>(p.y);
-                                const int na = p.Nout / p.head_no;
-                                const unsigned mu = (unsigned)m;        // head: y_linear is set, decode here
-                                unsigned t = mu / (unsigned)p.OW;
-                                int hw_ow = (int)(mu - t * (unsigned)p.OW);
-                                unsigned hn = t / (unsigned)p.OH;
-                                int hw_oh = (int)(t - hn * (unsigned)p.OH);
+                            // YOLOHead: fp32 logits + bias, NHWC [pixel][ldy] (ldy = Cout rounded up to 8), 16-byte stores;
+                            // the (B, na, ny, nx, no) tensor the loss / decode see is a strided view of this buffer
+                            if (pv && c < p.ldy) {
+                                float* Y = reinterpret_cast<float*>(p.y) + m * p.ldy + c;
+                                float4v f;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    int cc = c + e;
-                                    if (cc < p.Nout) {
-                                        int a = cc / p.head_no, o = cc - a * p.head_no;
-                                        float u = v[e] + (p.shift ? p.shift[cc] : 0.0f);
-                                        Y[((((long long)hn * na + a) * p.OH + hw_oh) * p.OW + hw_ow) * p.head_no + o] = u;
-                                    }
-                                }
+                                for (int e = 0; e < 4; ++e) f[e] = v[e] + ((p.shift && c + e < p.Nout) ? p.shift[c + e] : 0.0f);
+                                *reinterpret_cast<float4v*>(Y) = f;
                             }
                             continue;
                         }

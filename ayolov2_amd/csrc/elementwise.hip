@@ -26,6 +26,20 @@ __device__ __forceinline__ void store_vec(T* p, const float (&v)[VecT<T>::VE]) {
     *reinterpret_cast<uint4*>(p) = raw;
 }
 
+// SiLU and its derivative.  The fp32 (exact-parity) instantiation uses expf + IEEE division; the fp16-storage
+// instantiation uses v_exp_f32 / v_rcp_f32 (error ~1e-6 relative, far below the fp16 output rounding) so these
+// HBM-bound passes are not VALU-limited.
+template <typename T> __device__ __forceinline__ float sigmoid_t(float u) {
+    if constexpr (sizeof(T) == 2) return __frcp_rn(1.0f + __expf(-u));
+    else return 1.0f / (1.0f + expf(-u));
+}
+template <typename T> __device__ __forceinline__ float silu_t(float u) { return u * sigmoid_t<T>(u); }
+template <typename T> __device__ __forceinline__ float act_grad_t(float u, int act) {
+    if (!act) return 1.0f;
+    float sg = sigmoid_t<T>(u);
+    return sg * (1.0f + u * (1.0f - sg));
+}
+
 static unsigned grid_for(long long work_items, int per_block) {
     long long b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(256) void k_affine_act(const T* z, int ldz, T* a, i
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
             float u = v[i] * sh[cg * VE + i] + sh[C + cg * VE + i];
-            v[i] = act ? silu_f(u) : u;
+            v[i] = act ? silu_t<T>(u) : u;
         }
         store_vec<T>(a + pix * lda + cg * VE, v);
     }
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
                 int c = cg * VE + i;
                 float xh = (zv[i] - sh[c]) * sh[C + c];
                 float u = xh * sh[2 * C + c] + sh[3 * C + c];
-                float du = dv[i] * act_grad(u, act);
+                float du = dv[i] * act_grad_t<T>(u, act);
                 s1[i] += du;
                 s2[i] += du * xh;
             }
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
             int c = cg * VE + i;
             float xh = (zv[i] - sh[c]) * sh[C + c];
             float u = xh * sh[2 * C + c] + sh[3 * C + c];
-            float du = dv[i] * act_grad(u, act);
+            float du = dv[i] * act_grad_t<T>(u, act);
             dv[i] = sh[2 * C + c] * sh[C + c] * (du - sh[4 * C + c] - xh * sh[5 * C + c]);
         }
         store_vec<T>(dz + pix * lddz + cg * VE, dv);
@@ -491,7 +505,8 @@ extern "C" int ayolo_copy2d(int dtype, const void* x, int ldx, void* y, int ldy,
 // ---------------------------------------------------------------------------------------------------
 // YOLOHead: eval decode and gradient repack
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_head_decode(const float* raw, int B, int na, int ny, int nx, int no,
+__global__ __launch_bounds__(256) void k_head_decode(const float* raw, long long sb, long long sa, long long sy, long long sx,
+                                                     int B, int na, int ny, int nx, int no,
                                                      const float* anchors_px, float stride, float* out,
                                                      long long rows_total, long long row_off) {
     const long long per_img = (long long)na * ny * nx;
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(256) void k_head_decode(const float* raw, int B, in
         r /= ny;
         int a = (int)(r % na);
         long long b = r / na;
-        float sg = 1.0f / (1.0f + expf(-raw[t]));
+        float sg = 1.0f / (1.0f + expf(-raw[b * sb + a * sa + y * sy + x * sx + o]));
         float v = sg;
         if (o == 0) v = (sg * 2.0f - 0.5f + (float)x) * stride;
         else if (o == 1) v = (sg * 2.0f - 0.5f + (float)y) * stride;
@@ -515,11 +530,14 @@ __global__ __launch_bounds__(256) void k_head_decode(const float* raw, int B, in
     }
 }
 
-extern "C" int ayolo_head_decode(const float* raw, int B, int na, int ny, int nx, int no, const float* anchors_px,
-                                 float stride, float* out, int64_t rows_total, int64_t row_off, ayolo_stream s) {
+extern "C" int ayolo_head_decode(const float* raw, const int64_t* raw_strides, int B, int na, int ny, int nx, int no,
+                                 const float* anchors_px, float stride, float* out, int64_t rows_total, int64_t row_off,
+                                 ayolo_stream s) {
     AY_CHECK_ARG(raw && out && anchors_px && no > 4, "head_decode: bad args");
     long long total = (long long)B * na * ny * nx * no;
-    hipLaunchKernelGGL(k_head_decode, dim3(grid_for(total, 256 * 4)), dim3(256), 0, (hipStream_t)s, raw, B, na, ny, nx, no,
+    long long sb = (long long)na * ny * nx * no, sa = (long long)ny * nx * no, sy = (long long)nx * no, sx = no;
+    if (raw_strides) { sb = raw_strides[0]; sa = raw_strides[1]; sy = raw_strides[2]; sx = raw_strides[3]; }
+    hipLaunchKernelGGL(k_head_decode, dim3(grid_for(total, 256 * 4)), dim3(256), 0, (hipStream_t)s, raw, sb, sa, sy, sx, B, na, ny, nx, no,
                        anchors_px, stride, out, (long long)rows_total, (long long)row_off);
     AY_CHECK_LAUNCH("k_head_decode");
     return AYOLO_OK;

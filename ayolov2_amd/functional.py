@@ -114,7 +114,7 @@ class ConvBnActFn(torch.autograd.Function):
         w, wt = cache.get(weight, dt, Cout, geo.cin_pad)
         dev = xk.device
         z = ops.new_act(geo.B, Cout, geo.Ho, geo.Wo, dt, dev)
-        stats = torch.zeros((ops.STAT_REPS, 2 * Cout), dtype=torch.float32, device=dev)
+        stats = ops.zero_stats(Cout, dev)
         d = geo.desc(dt, ldx, Cout)
         ops.conv_fwd(d, xk, w, z, EPI_NONE, stats=stats)
         count = geo.B * geo.Ho * geo.Wo
@@ -234,9 +234,10 @@ class HeadConvFn(torch.autograd.Function):
         Cout = weight.shape[0]
         cout_pad = _round_up(Cout, 8)
         w, wt = cache.get(weight, dt, cout_pad, geo.cin_pad)
-        raw = torch.empty((B, na, H, W, no), dtype=torch.float32, device=xk.device)
-        ops.conv_fwd(geo.desc(dt, ldx, Cout), xk, w, raw, EPI_HEAD, shift=bias.float().contiguous() if bias is not None else None,
-                     head_no=no)
+        buf = torch.empty((B, H, W, cout_pad), dtype=torch.float32, device=xk.device)       # NHWC logits
+        ops.conv_fwd(geo.desc(dt, ldx, cout_pad), xk, w, buf, EPI_HEAD,
+                     shift=bias.float().contiguous() if bias is not None else None, head_no=no)
+        raw = buf.as_strided((B, na, H, W, no), (H * W * cout_pad, no, W * cout_pad, cout_pad, 1))
         ctx.save_for_backward(xk, wt)
         ctx.geo, ctx.dt, ctx.ldx, ctx.cout_pad, ctx.na, ctx.no = geo, dt, ldx, cout_pad, na, no
         ctx.weight_shape = tuple(weight.shape)

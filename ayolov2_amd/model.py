@@ -109,6 +109,9 @@ class YOLOModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
+        if self.training:
+            from . import ops
+            ops.ARENA.reset()          # one fill for all BN accumulators of this step
         outs: List[Any] = []
         for i, m in enumerate(self.model):
             frm = self.routes[i]

@@ -85,6 +85,37 @@ def make_desc(dt: torch.dtype, B, H, W, Cin, ldx, Cout, ldy, k, s, p, Ho, Wo) ->
 STAT_REPS = 32   # replicas of the per-channel BN accumulators (see ayolo.h)
 
 
+class _ZeroArena:
+    """Bump allocator of zero-initialised fp32 scratch (BN accumulators).  One fill kernel per training step
+    (``reset`` at the start of the model forward) replaces one ``torch.zeros`` launch per layer per pass.  A slice
+    is only valid inside the call that took it (all work is stream-ordered on the current stream)."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+
+    def reset(self):
+        if self.buf is not None and self.off > 0:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+    def take(self, n: int, device) -> torch.Tensor:
+        n = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            self.buf = torch.zeros(max(1 << 21, 2 * n), dtype=torch.float32, device=device)
+            self.off = 0
+        out = self.buf[self.off:self.off + n]
+        self.off += n
+        return out
+
+
+ARENA = _ZeroArena()
+
+
+def zero_stats(C: int, device) -> torch.Tensor:
+    return ARENA.take(STAT_REPS * 2 * C, device)[:STAT_REPS * 2 * C].view(STAT_REPS, 2 * C)
+
+
 def conv_fwd(desc: ConvDesc, x, w, y, epilogue=_lib.EPI_NONE, scale=None, shift=None, stats=None, head_no=0):
     reps = stats.shape[0] if (stats is not None and stats.dim() == 2) else 1
     call("ayolo_conv_fwd", desc, _ptr(x), _ptr(w), _ptr(y), epilogue, _ptr(scale), _ptr(shift), _ptr(stats), reps, head_no,
@@ -135,7 +166,7 @@ def bn_act_bwd(z, da, save_mean, save_invstd, gamma, beta, act: int, want_param_
     _, _, _, _, ldda = nhwc_info(da)
     npix = B * H * W
     dev = z.device
-    sums = torch.zeros((STAT_REPS, 2 * C), dtype=torch.float32, device=dev)
+    sums = zero_stats(C, dev)
     dz = new_act(B, C, H, W, z.dtype, dev)
     dt = dtype_code(z.dtype)
     call("ayolo_bn_act_bwd_reduce", dt, _ptr(z), ldz, _ptr(da), ldda, npix, C, _ptr(save_mean), _ptr(save_invstd),
@@ -207,8 +238,11 @@ def copy2d(x, y, accumulate=False):
 
 def head_decode(raw, anchors_px, stride: float, out, row_off: int):
     B, na, ny, nx, no = raw.shape
-    call("ayolo_head_decode", _ptr(raw), B, na, ny, nx, no, _ptr(anchors_px), float(stride), _ptr(out), out.shape[1],
-         row_off, _stream())
+    if raw.stride(4) != 1:
+        raw = raw.contiguous()
+    strides = (_lib.c_int64 * 4)(*raw.stride()[:4])
+    call("ayolo_head_decode", _ptr(raw), strides, B, na, ny, nx, no, _ptr(anchors_px), float(stride), _ptr(out),
+         out.shape[1], row_off, _stream())
 
 
 def head_grad_pack(draw, dtype: torch.dtype, ldz: int, want_bias=True):

@@ -57,7 +57,8 @@ typedef struct ayolo_conv_desc {
 #define AYOLO_EPI_NONE 0      /* y = conv                        (+ optional per-channel sum/sumsq)   */
 #define AYOLO_EPI_AFFINE 1    /* y = conv*scale[c] + shift[c]                                          */
 #define AYOLO_EPI_AFFINE_SILU 2 /* y = silu(conv*scale[c] + shift[c])  (eval / fused-BN inference)     */
-#define AYOLO_EPI_HEAD 3      /* y(fp32)[b][a][h][w][o] = conv + shift[c], c = a*no + o (YOLOHead)     */
+#define AYOLO_EPI_HEAD 3      /* y(fp32)[pixel][ldy] = conv + shift[c] (YOLOHead logits; ldy = Cout rounded up
+                               * to 8; the (B,na,ny,nx,no) tensor is a strided view: c = a*no + o)           */
 
 /* y = conv(x, w).  `stats` (nullable, EPI_NONE only): float[stat_reps][2*Cout] zero-initialised by the caller;
  * receives per-channel sum and sum of squares of the fp32 accumulators rounded to the output dtype (training-mode
@@ -132,10 +133,11 @@ int ayolo_copy2d(int dtype, const void* x, int ldx, void* y, int ldy, int64_t np
 
 /* ------------------------------------------------------------------------------------------------
  * YOLOHead eval decode (layout: scripts/loss/losses.py:245-256,350; scripts/utils/tta_utils.py:52-58):
- * raw (B,na,ny,nx,no) fp32 logits -> out[b][row_off + (a*ny+y)*nx+x][0:no]:
+ * raw (B,na,ny,nx,no) fp32 logits (any b/a/y/x strides, o contiguous) -> out[b][row_off + (a*ny+y)*nx+x][0:no]:
  *   xy = (sig*2-0.5+grid)*stride, wh = (sig*2)^2*anchor_px, rest = sig.
  * ---------------------------------------------------------------------------------------------- */
-int ayolo_head_decode(const float* raw, int B, int na, int ny, int nx, int no, const float* anchors_px,
+int ayolo_head_decode(const float* raw, const int64_t* raw_strides /* host int64[4] element strides of (b,a,y,x);
+                      NULL = contiguous */, int B, int na, int ny, int nx, int no, const float* anchors_px,
                       float stride, float* out, int64_t rows_total, int64_t row_off, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
