@@ -12,7 +12,7 @@ feeds ``HeadConvFn.backward`` (the HIP path).  Semantics follow the reference:
 """
 from __future__ import annotations
 
-from typing import Any, Dict, List, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 from torch import nn
@@ -59,13 +59,29 @@ class ComputeLoss:
         self.ssi = list(head.stride).index(16) if autobalance else 0
         self.BCEcls, self.BCEobj, self.gr, self.hyp, self.autobalance = bce_cls, bce_obj, 1.0, hyp, autobalance
         self.na, self.nc, self.nl, self.anchors = head.na, head.nc, head.nl, head.anchors
+        self._anchors_cpu = None
 
-    def __call__(self, preds: List[torch.Tensor], targets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        device = targets.device
+    def prepare(self, targets: torch.Tensor, pred_shapes, device=None):
+        """Target assignment done on the HOST (labels come from the CPU data loader) before / while the forward
+        runs, so the loss itself contains no device->host synchronisation: the boolean-mask gathers of
+        ``build_targets`` would otherwise stall the stream between forward and backward.  Returns what
+        ``build_targets`` returns, moved to ``device``; pass it to ``__call__(..., prepared=...)``."""
+        device = device if device is not None else targets.device
+        if self._anchors_cpu is None:
+            self._anchors_cpu = self.anchors.detach().float().cpu()
+        t_cpu = targets.detach().float().cpu()
+        fake = [torch.empty(tuple(s), device="meta") for s in pred_shapes]
+        tcls, tbox, indices, anch = self.build_targets(fake, t_cpu, anchors=self._anchors_cpu)
+        mv = lambda x: x.to(device, non_blocking=True)
+        return ([mv(c) for c in tcls], [mv(b) for b in tbox], [tuple(mv(i) for i in idx) for idx in indices],
+                [mv(a) for a in anch])
+
+    def __call__(self, preds: List[torch.Tensor], targets: torch.Tensor, prepared=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        device = preds[0].device
         lcls = torch.zeros(1, device=device)
         lbox = torch.zeros(1, device=device)
         lobj = torch.zeros(1, device=device)
-        tcls, tbox, indices, anchors = self.build_targets(preds, targets)
+        tcls, tbox, indices, anchors = prepared if prepared is not None else self.build_targets(preds, targets)
         for i, pi in enumerate(preds):
             b, a, gj, gi = indices[i]
             tobj = torch.zeros_like(pi[..., 0], device=device)
@@ -98,8 +114,9 @@ class ComputeLoss:
         loss = lbox + lobj + lcls
         return loss * bs, torch.cat((lbox, lobj, lcls, loss)).detach()
 
-    def build_targets(self, preds: List[torch.Tensor], targets: torch.Tensor):
+    def build_targets(self, preds: List[torch.Tensor], targets: torch.Tensor, anchors: Optional[torch.Tensor] = None):
         """targets: (nt, 6) [image, class, x, y, w, h] normalised -> per level (classes, boxes, indices, anchors)."""
+        all_anchors = self.anchors if anchors is None else anchors
         na, nt = self.na, targets.shape[0]
         dev = targets.device
         tcls, tbox, indices, anch = [], [], [], []
@@ -109,7 +126,7 @@ class ComputeLoss:
         g = 0.5
         off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=dev).float() * g
         for i in range(self.nl):
-            anchors = self.anchors[i].to(dev)
+            anchors = all_anchors[i].to(dev)
             shape = preds[i].shape
             gain[2:6] = torch.tensor([shape[3], shape[2], shape[3], shape[2]], device=dev, dtype=gain.dtype)
             t = targets * gain

@@ -56,7 +56,8 @@ def build_train_objects(model_name, device, world_size):
             pg_bn.append(mod.weight)
         elif hasattr(mod, "weight") and isinstance(mod.weight, nn.Parameter):
             pg_w.append(mod.weight)
-    opt = torch.optim.SGD(pg_bn, lr=HYP["lr"], momentum=HYP["momentum"], nesterov=True)
+    # fused multi-tensor SGD: one launch per parameter group and, with GradScaler, no found-inf host sync
+    opt = torch.optim.SGD(pg_bn, lr=HYP["lr"], momentum=HYP["momentum"], nesterov=True, fused=True)
     opt.add_param_group({"params": pg_w, "weight_decay": HYP["weight_decay"]})
     opt.add_param_group({"params": pg_b})
     loss_fn = ComputeLoss(model)
@@ -191,12 +192,16 @@ def main():
     model, run_model, opt, loss_fn, scaler = build_train_objects(args.model, device, world)
     gen = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, args.size, args.size, generator=gen).to(device)       # resident in HBM
-    targets = synth_targets(args.batch, 8, gen).to(device)
+    targets_cpu = synth_targets(args.batch, 8, gen)              # labels arrive from the CPU loader (data_loader.py:905-908)
+    targets = targets_cpu.to(device)
+    head = model.model[-1]
+    pred_shapes = [(args.batch, head.na, args.size // int(s), args.size // int(s), head.no) for s in head._strides_py]
 
     def step():
+        prep = loss_fn.prepare(targets_cpu, pred_shapes, device)   # host-side target assignment, no stream sync
         with torch.autocast("cuda", dtype=torch.float16):
             pred = run_model(imgs)
-            loss, _ = loss_fn(pred, targets)
+            loss, _ = loss_fn(pred, targets, prepared=prep)
         if world > 1:
             loss = loss * world                       # yolo_trainer.py:325-326
         scaler.scale(loss).backward()
