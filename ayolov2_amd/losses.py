@@ -72,9 +72,39 @@ class ComputeLoss:
         t_cpu = targets.detach().float().cpu()
         fake = [torch.empty(tuple(s), device="meta") for s in pred_shapes]
         tcls, tbox, indices, anch = self.build_targets(fake, t_cpu, anchors=self._anchors_cpu)
-        mv = lambda x: x.to(device, non_blocking=True)
-        return ([mv(c) for c in tcls], [mv(b) for b in tbox], [tuple(mv(i) for i in idx) for idx in indices],
-                [mv(a) for a in anch])
+        if torch.device(device).type != "cuda":
+            return tcls, tbox, indices, anch
+        # two pinned staging buffers -> two asynchronous H2D copies (pageable copies would block on the stream)
+        ints = [c for c in tcls] + [i for idx in indices for i in idx]
+        flts = [b.reshape(-1) for b in tbox] + [a.reshape(-1) for a in anch]
+        ni, nf = sum(t.numel() for t in ints), sum(t.numel() for t in flts)
+        if getattr(self, "_pin_i", None) is None or self._pin_i.numel() < ni:
+            self._pin_i = torch.empty(max(ni, 1) * 2, dtype=torch.int64).pin_memory()
+        if getattr(self, "_pin_f", None) is None or self._pin_f.numel() < nf:
+            self._pin_f = torch.empty(max(nf, 1) * 2, dtype=torch.float32).pin_memory()
+        torch.cat(ints, out=self._pin_i[:ni]) if ni else None
+        torch.cat(flts, out=self._pin_f[:nf]) if nf else None
+        di = self._pin_i[:ni].to(device, non_blocking=True)
+        df = self._pin_f[:nf].to(device, non_blocking=True)
+        oi, of = 0, 0
+
+        def take_i(t):
+            nonlocal oi
+            v = di[oi:oi + t.numel()]
+            oi += t.numel()
+            return v
+
+        def take_f(t):
+            nonlocal of
+            v = df[of:of + t.numel()].view(t.shape)
+            of += t.numel()
+            return v
+
+        d_tcls = [take_i(c) for c in tcls]
+        d_idx = [tuple(take_i(i) for i in idx) for idx in indices]
+        d_tbox = [take_f(b) for b in tbox]
+        d_anch = [take_f(a) for a in anch]
+        return d_tcls, d_tbox, d_idx, d_anch
 
     def __call__(self, preds: List[torch.Tensor], targets: torch.Tensor, prepared=None) -> Tuple[torch.Tensor, torch.Tensor]:
         device = preds[0].device
@@ -99,7 +129,7 @@ class ComputeLoss:
                 tobj[b, a, gj, gi] = (1.0 - self.gr) + self.gr * score
                 if self.nc > 1:
                     t = torch.full_like(ps[:, 5:], self.cn, device=device)
-                    t[range(n), tcls[i]] = self.cp
+                    t[torch.arange(n, device=device), tcls[i]] = self.cp
                     lcls = lcls + self.BCEcls(ps[:, 5:], t)
             obji = self.BCEobj(pi[..., 4], tobj)
             lobj = lobj + obji * self.balance[i]
