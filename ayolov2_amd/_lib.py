@@ -59,6 +59,9 @@ _SIGNATURES = {
     "ayolo_iou_colmax": [_P, _P, c_float, c_uint32, _P, _P],
     "ayolo_matrix_nms_decay": [_P, _P, c_float, c_uint32, _P, _P, _P],
     "ayolo_merge_boxes": [_P, c_uint32, c_float, _P, c_uint32, c_float, _P, _P, _P],
+    "ayolo_affine_act_res": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int, _P, c_int, _P],
+    "ayolo_bn_eval_affine": [_P, _P, _P, _P, _P, c_float, c_int, _P, _P, _P],
+    "ayolo_run_ops": [_P, c_int, _P],
 }
 
 EXPORTED = sorted(list(_SIGNATURES) + ["ayolo_version", "ayolo_last_error"])

@@ -91,12 +91,32 @@ extern "C" int ayolo_bn_finalize(const float* stats, int stat_reps, int C, doubl
     return AYOLO_OK;
 }
 
+__global__ void k_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, const float* cbias,
+                                 float eps, int C, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = (gamma ? gamma[c] : 1.0f) / sqrtf(rv[c] + eps);
+    float sh = (beta ? beta[c] : 0.0f) - rm[c] * sc;
+    if (cbias) sh += cbias[c] * sc;
+    scale[c] = sc;
+    shift[c] = sh;
+}
+
+extern "C" int ayolo_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                    const float* conv_bias, float eps, int C, float* scale, float* shift, ayolo_stream s) {
+    AY_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "bn_eval_affine: bad args");
+    hipLaunchKernelGGL(k_bn_eval_affine, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s, gamma, beta, running_mean, running_var,
+                       conv_bias, eps, C, scale, shift);
+    AY_CHECK_LAUNCH("k_bn_eval_affine");
+    return AYOLO_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
-// a = act(z*scale + shift)
+// a = act(z*scale + shift) (+ residual)
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_affine_act(const T* z, int ldz, T* a, int lda, long long npix, int C,
-                                                    const float* scale, const float* shift, int act) {
+                                                    const float* scale, const float* shift, int act, const T* res, int ldr) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sh[];   // [2][C]
     for (int i = threadIdx.x; i < C; i += 256) {
@@ -116,19 +136,35 @@ __global__ __launch_bounds__(256) void k_affine_act(const T* z, int ldz, T* a, i
             float u = v[i] * sh[cg * VE + i] + sh[C + cg * VE + i];
             v[i] = act ? silu_t<T>(u) : u;
         }
+        if (res) {
+            float r[VE];
+            load_vec<T>(res + pix * ldr + cg * VE, r);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) v[i] += r[i];
+        }
         store_vec<T>(a + pix * lda + cg * VE, v);
     }
 }
 
+extern "C" int ayolo_affine_act_res(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C,
+                                    const float* scale, const float* shift, int act, const void* residual, int ldr,
+                                    ayolo_stream s);
 extern "C" int ayolo_affine_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C,
                                 const float* scale, const float* shift, int act, ayolo_stream s) {
+    return ayolo_affine_act_res(dtype, z, ldz, a, lda, npix, C, scale, shift, act, nullptr, 0, s);
+}
+
+extern "C" int ayolo_affine_act_res(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C,
+                                    const float* scale, const float* shift, int act, const void* residual, int ldr,
+                                    ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(residual == nullptr || ldr % ve == 0, "affine_act: ldr=%d", ldr);
     AY_CHECK_ARG(z && a && C > 0 && C % ve == 0 && ldz % ve == 0 && lda % ve == 0, "affine_act: C=%d ldz=%d lda=%d", C, ldz, lda);
     AY_CHECK_ARG(C <= 8192, "affine_act: C too large");
     if (npix == 0) return AYOLO_OK;
     DISPATCH_T(dtype, hipLaunchKernelGGL(k_affine_act<T>, dim3(grid_for(npix * (C / ve), 256 * 4)), dim3(256),
                                          2 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (T*)a, lda,
-                                         (long long)npix, C, scale, shift, act);)
+                                         (long long)npix, C, scale, shift, act, (const T*)residual, ldr);)
     AY_CHECK_LAUNCH("k_affine_act");
     return AYOLO_OK;
 }

@@ -1,0 +1,86 @@
+// Batched launcher: one C call enqueues a whole pre-compiled list of kernel launches (a model forward or
+// backward) on one stream.  The op list is built once per (model, shape, dtype) by ayolov2_amd/plan.py over
+// static buffers, so a training step costs two host calls instead of ~1600 Python-level launches, and the
+// list is a straight-line HIP stream program (graph-capturable).
+#include "common.h"
+
+extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
+    AY_CHECK_ARG(ops || n == 0, "run_ops: null op list");
+    for (int k = 0; k < n; ++k) {
+        const ayolo_op& o = ops[k];
+        int rc = AYOLO_OK;
+        switch (o.kind) {
+        case AYOLO_OP_CONV_FWD:
+            rc = ayolo_conv_fwd(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const float*)o.p[3], (const float*)o.p[4],
+                                (float*)o.p[5], o.i[1], o.i[2], s);
+            break;
+        case AYOLO_OP_CONV_DGRAD:
+            rc = ayolo_conv_dgrad(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], s);
+            break;
+        case AYOLO_OP_CONV_WGRAD:
+            rc = ayolo_conv_wgrad(&o.conv, o.p[0], o.p[1], (float*)o.p[2], o.f[0], s);
+            break;
+        case AYOLO_OP_CAST_WEIGHT:
+            rc = ayolo_cast_weight((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.p[1], o.p[2], s);
+            break;
+        case AYOLO_OP_BN_FINALIZE:
+            rc = ayolo_bn_finalize((const float*)o.p[0], o.i[0], o.i[1], o.d[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
+                                   o.f[1], (float*)o.p[3], (float*)o.p[4], (float*)o.p[5], (float*)o.p[6], (float*)o.p[7],
+                                   (float*)o.p[8], s);
+            break;
+        case AYOLO_OP_AFFINE_ACT:
+            rc = ayolo_affine_act_res(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], (const float*)o.p[2],
+                                      (const float*)o.p[3], o.i[4], o.p[4], o.i[5], s);
+            break;
+        case AYOLO_OP_BN_BWD_REDUCE:
+            rc = ayolo_bn_act_bwd_reduce(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], (const float*)o.p[2],
+                                         (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5], o.i[4], (float*)o.p[6],
+                                         o.i[5], s);
+            break;
+        case AYOLO_OP_BN_BWD_APPLY:
+            rc = ayolo_bn_act_bwd_apply(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.p[2], o.i[3], o.l[0], o.i[4],
+                                        (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5], (const float*)o.p[6],
+                                        o.i[5], (const float*)o.p[7], o.i[6], (float*)o.p[8], (float*)o.p[9], o.f[0], s);
+            break;
+        case AYOLO_OP_MAXPOOL_FWD:
+            rc = ayolo_maxpool_fwd(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], (unsigned char*)o.p[2], o.i[3], o.i[4], o.i[5], o.i[6],
+                                   o.i[7], s);
+            break;
+        case AYOLO_OP_MAXPOOL_BWD:
+            rc = ayolo_maxpool_bwd(o.i[0], (const unsigned char*)o.p[0], o.p[1], o.i[1], o.p[2], o.i[2], o.i[3], o.i[4], o.i[5],
+                                   o.i[6], o.i[7], o.i[8], s);
+            break;
+        case AYOLO_OP_UPSAMPLE_FWD:
+            rc = ayolo_upsample2x_fwd(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], s);
+            break;
+        case AYOLO_OP_UPSAMPLE_BWD:
+            rc = ayolo_upsample2x_bwd(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], s);
+            break;
+        case AYOLO_OP_PACK_INPUT:
+            rc = ayolo_pack_input((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.p[1], o.i[5], s);
+            break;
+        case AYOLO_OP_HEAD_GRAD_PACK:
+            rc = ayolo_head_grad_pack((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.p[1], o.i[6],
+                                      (float*)o.p[2], s);
+            break;
+        case AYOLO_OP_COPY2D:
+            rc = ayolo_copy2d(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], o.i[4], s);
+            break;
+        case AYOLO_OP_MEMSET:
+            if (o.l[0] > 0 && hipMemsetAsync(o.p[0], 0, (size_t)o.l[0], (hipStream_t)s) != hipSuccess) {
+                ayolo_set_error("run_ops: memset failed");
+                rc = AYOLO_ELAUNCH;
+            }
+            break;
+        case AYOLO_OP_BN_EVAL_AFFINE:
+            rc = ayolo_bn_eval_affine((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2], (const float*)o.p[3],
+                                      (const float*)o.p[4], o.f[0], o.i[0], (float*)o.p[5], (float*)o.p[6], s);
+            break;
+        default:
+            ayolo_set_error("run_ops: unknown op kind %d at index %d", o.kind, k);
+            return AYOLO_EINVAL;
+        }
+        if (rc != AYOLO_OK) return rc;
+    }
+    return AYOLO_OK;
+}

@@ -111,6 +111,11 @@ class YOLOModel(nn.Module):
     def forward(self, x: torch.Tensor):
         if self.training:
             from . import ops
+            if x.is_cuda and x.dim() == 4 and getattr(self, "use_plan", True):
+                from .plan import plan_forward_train
+                raws = plan_forward_train(self, x)     # static-plan fast path (None: unsupported structure)
+                if raws is not None:
+                    return raws
             ops.ARENA.reset()          # one fill for all BN accumulators of this step
         outs: List[Any] = []
         for i, m in enumerate(self.model):

@@ -1,0 +1,519 @@
+"""Static execution plans: the model is compiled ONCE per (input shape, dtype) into two straight-line lists of
+kernel launches over static HBM buffers -- forward and backward -- which ``ayolo_run_ops`` enqueues with a single
+host call each (csrc/plan.hip).
+
+Compared with the per-module autograd path (functional.py) the plan
+  * removes ~1600 Python-level launches / allocations per training step (the step was host-bound);
+  * eliminates the glue kernels torch ran between the HIP kernels: every Concat input is written by its producer
+    directly into a channel slice of the concat buffer, the Bottleneck shortcut is added inside the BN+SiLU pass,
+    gradients of multi-consumer tensors are accumulated by the dgrad epilogue (``accumulate``), BN accumulators and
+    weight gradients are zeroed by one memset each;
+  * keeps the reference's surface: the plan is wrapped in ONE ``torch.autograd.Function`` whose outputs are the
+    YOLOHead raw tensors and whose backward returns ordinary per-parameter gradients (DDP / GradScaler / any torch
+    optimiser work unchanged).
+
+The arithmetic is the same kernels in the same order as the module path (parity-tested against the CPU oracle).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_double, c_float, c_int, c_int64, c_void_p
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, ops
+from . import functional as F_
+from ._lib import EPI_HEAD, EPI_NONE, ConvDesc
+from .modules import C3, SPPF, Bottleneck, Concat, Conv, UpSample, YOLOHead, _act_code, _pair
+
+(OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_CAST_WEIGHT, OP_BN_FINALIZE, OP_AFFINE_ACT, OP_BN_BWD_REDUCE,
+ OP_BN_BWD_APPLY, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_PACK_INPUT, OP_HEAD_GRAD_PACK,
+ OP_COPY2D, OP_MEMSET, OP_BN_EVAL_AFFINE) = range(1, 18)
+
+
+class Op(ctypes.Structure):
+    _fields_ = [("kind", c_int), ("i", c_int * 12), ("f", c_float * 2), ("d", c_double * 1), ("l", c_int64 * 1),
+                ("p", c_void_p * 10), ("conv", ConvDesc)]
+
+
+def _op(kind, i=(), f=(), d=(), l=(), p=(), conv: Optional[ConvDesc] = None) -> Op:
+    o = Op()
+    o.kind = kind
+    for k, v in enumerate(i):
+        o.i[k] = int(v)
+    for k, v in enumerate(f):
+        o.f[k] = float(v)
+    for k, v in enumerate(d):
+        o.d[k] = float(v)
+    for k, v in enumerate(l):
+        o.l[k] = int(v)
+    for k, v in enumerate(p):
+        o.p[k] = None if v is None else (v if isinstance(v, int) else v.data_ptr())
+    if conv is not None:
+        o.conv = conv
+    return o
+
+
+class PlanUnsupported(Exception):
+    pass
+
+
+class Act:
+    """An activation in NHWC memory; possibly a channel slice of a wider root buffer (concat elimination)."""
+
+    def __init__(self, t: torch.Tensor, root: Optional["Act"] = None, c0: int = 0):
+        self.t = t
+        self.root = root if root is not None else self
+        self.c0 = c0
+        if root is None:
+            self.g: Optional[torch.Tensor] = None
+            self.ginit = np.zeros(t.shape[1], dtype=bool)
+
+    @property
+    def C(self) -> int:
+        return self.t.shape[1]
+
+    def slice(self, c0: int, c1: int) -> "Act":
+        return Act(self.t[:, c0:c1], self.root, self.c0 + c0)
+
+    def grad(self) -> torch.Tensor:
+        r = self.root
+        if r.g is None:
+            r.g = torch.empty_like(r.t)
+        return r.g[:, self.c0:self.c0 + self.C]
+
+    def is_init(self) -> bool:
+        return bool(self.root.ginit[self.c0:self.c0 + self.C].all())
+
+    def mark_init(self) -> None:
+        self.root.ginit[self.c0:self.c0 + self.C] = True
+
+
+class _FloatArena:
+    def __init__(self):
+        self.reqs: List[Tuple[int, list]] = []
+        self.total = 0
+        self.buf: Optional[torch.Tensor] = None
+
+    def request(self, n: int) -> int:
+        off = self.total
+        self.total += (n + 63) // 64 * 64
+        return off
+
+    def allocate(self, device):
+        self.buf = torch.zeros(max(self.total, 64), dtype=torch.float32, device=device)
+
+    def view(self, off: int, n: int) -> torch.Tensor:
+        return self.buf[off:off + n]
+
+
+class TrainPlan:
+    def __init__(self, model, x_shape: Sequence[int], dt: torch.dtype, device):
+        self.model = model
+        self.dt = dt
+        self.device = device
+        self.B, self.Cimg, self.H, self.W = x_shape
+        self.keep: List[torch.Tensor] = []          # everything the op lists point to
+        self.fwd: List[Op] = []
+        self.casts: List[Op] = []
+        self.bwd_emitters: List[Callable[[], None]] = []
+        self.bwd: List[Op] = []
+        self.stats = _FloatArena()                  # BN forward accumulators (zeroed at the start of forward)
+        self.sums = _FloatArena()                   # BN backward accumulators (zeroed at the start of backward)
+        self.small = _FloatArena()                  # mean / invstd / scale / shift
+        self.gradarena = _FloatArena()              # every parameter gradient (zeroed at the start of backward)
+        self.param_grad_view: Dict[int, Callable[[], torch.Tensor]] = {}
+        self.params: List[nn.Parameter] = []
+        self.dz_elems = 0
+        self.late: List[Callable[[], None]] = []    # closures run after the arenas exist (pointer binding)
+        self.bn_counters: List[torch.Tensor] = []
+        self.raw_specs = []
+        self.draw_ops: List[Op] = []
+        self.pack_op: Optional[Op] = None
+        self._compile()
+
+    # ------------------------------------------------------------------ helpers
+    def _new_act(self, C, H, W) -> Act:
+        t = ops.new_act(self.B, C, H, W, self.dt, self.device)
+        self.keep.append(t)
+        return Act(t)
+
+    def _register_param(self, p: nn.Parameter, numel_pad: int, view_fn) -> int:
+        off = self.gradarena.request(numel_pad)
+        self.params.append(p)
+        self.param_grad_view[id(p)] = (off, numel_pad, view_fn)
+        return off
+
+    # ------------------------------------------------------------------ conv + BN + act
+    def _conv_block(self, mod: Conv, x: Optional[Act], dst: Optional[Act], residual: Optional[Act] = None,
+                    image: bool = False) -> Act:
+        conv, bn = mod.conv, getattr(mod, "batch_norm", None)
+        if not isinstance(conv, nn.Conv2d) or bn is None or conv.bias is not None or bn.momentum is None:
+            raise PlanUnsupported("non-standard Conv block")
+        if bn.running_mean is None or bn.running_mean.dtype != torch.float32 or conv.weight.dtype != torch.float32:
+            raise PlanUnsupported("needs fp32 master weights / BN buffers")
+        act = _act_code(mod.activation)
+        dt, dev = self.dt, self.device
+        w32 = conv.weight
+        if not w32.detach().permute(0, 2, 3, 1).is_contiguous():
+            w32.data = w32.data.contiguous(memory_format=torch.channels_last)
+        Cout, Cin, kh, kw = w32.shape
+        if image:
+            xshape = (self.B, self.Cimg, self.H, self.W)
+        else:
+            xshape = tuple(x.t.shape)
+        geo = F_._Geometry(xshape, w32.shape, _pair(conv.stride), _pair(conv.padding), dt)
+        if image:
+            packed = ops.new_act(self.B, geo.cin_pad, self.H, self.W, dt, dev)
+            self.keep.append(packed)
+            self.pack_op = _op(OP_PACK_INPUT, i=(self.B, self.Cimg, self.H, self.W, ops.dtype_code(dt), geo.cin_pad), p=(None, packed))
+            self.fwd.append(self.pack_op)
+            xk = packed.as_strided((self.B, 8, self.H, self.W // 2), (self.H * self.W * 4, 1, self.W * 4, 8)) if geo.packed_stem else packed
+        else:
+            if geo.needs_pack:
+                raise PlanUnsupported("channel count not a multiple of the vector width")
+            xk = x.t
+        _, _, _, _, ldx = ops.nhwc_info(xk)
+        # weights: compute-dtype copy and its transpose, refreshed by a cast op at the start of every forward
+        wc = torch.empty((Cout, kh, kw, geo.cin_pad), dtype=dt, device=dev)
+        wt = torch.empty((geo.cin_pad, kh, kw, Cout), dtype=dt, device=dev)
+        self.keep += [wc, wt]
+        self.casts.append(_op(OP_CAST_WEIGHT, i=(Cout, kh, kw, Cin, Cout, geo.cin_pad, ops.dtype_code(dt)), p=(w32, wc, wt)))
+        z = self._new_act(Cout, geo.Ho, geo.Wo)
+        a = dst if dst is not None else self._new_act(Cout, geo.Ho, geo.Wo)
+        assert a.C == Cout and tuple(a.t.shape[2:]) == (geo.Ho, geo.Wo)
+        _, _, _, _, lda = ops.nhwc_info(a.t)
+        R = ops.STAT_REPS
+        st_off = self.stats.request(R * 2 * Cout)
+        sm_off = self.small.request(4 * Cout)
+        npix = self.B * geo.Ho * geo.Wo
+        d_fwd = geo.desc(dt, ldx, Cout)
+        code = ops.dtype_code(dt)
+        op_conv = _op(OP_CONV_FWD, i=(EPI_NONE, R, 0), p=(xk, wc, z.t, None, None, None), conv=d_fwd)
+        op_fin = _op(OP_BN_FINALIZE, i=(R, Cout), d=(float(npix),), f=(bn.eps, bn.momentum),
+                     p=(None, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, None, None, None))
+        res_t = residual.t if residual is not None else None
+        ldr = ops.nhwc_info(res_t)[4] if res_t is not None else 0
+        op_act = _op(OP_AFFINE_ACT, i=(code, Cout, lda, Cout, act, ldr), l=(npix,), p=(z.t, a.t, None, None, res_t))
+        self.fwd += [op_conv, op_fin, op_act]
+
+        def bind_fwd():
+            st = self.stats.view(st_off, R * 2 * Cout)
+            sm = self.small.view(sm_off, 4 * Cout)
+            op_conv.p[5] = st.data_ptr()
+            op_fin.p[0] = st.data_ptr()
+            for k in range(4):     # save_mean, save_invstd, scale, shift
+                op_fin.p[5 + k] = sm[k * Cout:(k + 1) * Cout].data_ptr()
+            op_act.p[2] = sm[2 * Cout:3 * Cout].data_ptr()
+            op_act.p[3] = sm[3 * Cout:4 * Cout].data_ptr()
+
+        self.late.append(bind_fwd)
+        if bn.num_batches_tracked is not None:
+            self.bn_counters.append(bn.num_batches_tracked)
+        # ---- parameters / gradient slots
+        K = geo.kdims[0] * geo.kdims[1] * geo.Cin_k
+
+        def wview(buf, Cout=Cout, kh=kh, kw=kw, cp=geo.cin_pad, Cin=Cin):
+            g = buf.view(Cout, kh, kw, cp)[..., :Cin].permute(0, 3, 1, 2)
+            return g if cp == Cin else g.contiguous(memory_format=torch.channels_last)
+
+        gw_off = self._register_param(conv.weight, Cout * K, wview)
+        gg_off = self._register_param(bn.weight, Cout, lambda b: b) if bn.weight is not None else None
+        gb_off = self._register_param(bn.bias, Cout, lambda b: b) if bn.bias is not None else None
+        su_off = self.sums.request(R * 2 * Cout)
+        self.dz_elems = max(self.dz_elems, npix * Cout)
+        x_act = x
+
+        def emit_bwd():
+            da = a.grad()
+            if not a.is_init():
+                raise RuntimeError("plan: gradient of a conv output was never produced")
+            _, _, _, _, ldda = ops.nhwc_info(da)
+            sm = self.small.view(sm_off, 4 * Cout)
+            su = self.sums.view(su_off, R * 2 * Cout)
+            ga = self.gradarena
+            dgam = ga.view(gg_off, Cout) if gg_off is not None else None
+            dbet = ga.view(gb_off, Cout) if gb_off is not None else None
+            dz = self.dz_buf[:npix * Cout]
+            self.bwd.append(_op(OP_BN_BWD_REDUCE, i=(code, Cout, ldda, Cout, act, R), l=(npix,),
+                                p=(z.t, da, sm[0:Cout], sm[Cout:2 * Cout], bn.weight, bn.bias, su)))
+            self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Cout, ldda, Cout, Cout, act, R), l=(npix,), f=(1.0,),
+                                p=(z.t, da, dz, sm[0:Cout], sm[Cout:2 * Cout], bn.weight, bn.bias, su, dgam, dbet)))
+            if residual is not None:      # shortcut: d(residual) += d(a)
+                dr = residual.grad()
+                self.bwd.append(_op(OP_COPY2D, i=(code, ldda, ops.nhwc_info(dr)[4], Cout, int(residual.is_init())), l=(npix,),
+                                    p=(da, dr)))
+                residual.mark_init()
+            if not image:
+                dx = x_act.grad()
+                self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
+                                    conv=geo.desc(dt, ops.nhwc_info(dx)[4], Cout)))
+                x_act.mark_init()
+            self.bwd.append(_op(OP_CONV_WGRAD, f=(1.0,), p=(xk, dz, ga.view(gw_off, Cout * K)), conv=geo.desc(dt, ldx, Cout)))
+
+        self.bwd_emitters.append(emit_bwd)
+        return a
+
+    # ------------------------------------------------------------------ composite blocks
+    def _bottleneck(self, b: Bottleneck, x: Act, dst: Optional[Act]) -> Act:
+        y1 = self._conv_block(b.cv1, x, None)
+        return self._conv_block(b.cv2, y1, dst, residual=x if b.add else None)
+
+    def _c3(self, m: C3, x: Act, dst: Optional[Act]) -> Act:
+        h = m.cv1.conv.out_channels
+        _, _, H, W = x.t.shape
+        cat = self._new_act(2 * h, H, W)
+        n = len(m.m)
+        t = self._conv_block(m.cv1, x, cat.slice(0, h) if n == 0 else None)
+        for bi, b in enumerate(m.m):
+            t = self._bottleneck(b, t, cat.slice(0, h) if bi == n - 1 else None)
+        self._conv_block(m.cv2, x, cat.slice(h, 2 * h))
+        return self._conv_block(m.cv3, cat, dst)
+
+    def _pool(self, k: int, src: Act, dst: Act) -> None:
+        B, C, H, W = src.t.shape
+        arg = torch.empty((B, H, W, C), dtype=torch.uint8, device=self.device)
+        self.keep.append(arg)
+        code = ops.dtype_code(self.dt)
+        lds, ldd = ops.nhwc_info(src.t)[4], ops.nhwc_info(dst.t)[4]
+        self.fwd.append(_op(OP_MAXPOOL_FWD, i=(code, lds, ldd, B, H, W, C, k), p=(src.t, dst.t, arg)))
+
+        def emit():
+            dy, dx = dst.grad(), src.grad()
+            self.bwd.append(_op(OP_MAXPOOL_BWD, i=(code, ops.nhwc_info(dy)[4], ops.nhwc_info(dx)[4], B, H, W, C, k, int(src.is_init())),
+                                p=(arg, dy, dx)))
+            src.mark_init()
+
+        self.bwd_emitters.append(emit)
+
+    def _sppf(self, m: SPPF, x: Act, dst: Optional[Act]) -> Act:
+        h = m.cv1.conv.out_channels
+        _, _, H, W = x.t.shape
+        cat = self._new_act(4 * h, H, W)
+        self._conv_block(m.cv1, x, cat.slice(0, h))
+        k = m.pool.kernel_size
+        for j in range(3):
+            self._pool(k, cat.slice(j * h, (j + 1) * h), cat.slice((j + 1) * h, (j + 2) * h))
+        return self._conv_block(m.cv2, cat, dst)
+
+    def _upsample(self, x: Act, dst: Optional[Act]) -> Act:
+        B, C, H, W = x.t.shape
+        out = dst if dst is not None else self._new_act(C, 2 * H, 2 * W)
+        code = ops.dtype_code(self.dt)
+        self.fwd.append(_op(OP_UPSAMPLE_FWD, i=(code, ops.nhwc_info(x.t)[4], ops.nhwc_info(out.t)[4], B, H, W, C), p=(x.t, out.t)))
+
+        def emit():
+            dy, dx = out.grad(), x.grad()
+            self.bwd.append(_op(OP_UPSAMPLE_BWD, i=(code, ops.nhwc_info(dy)[4], ops.nhwc_info(dx)[4], B, H, W, C, int(x.is_init())),
+                                p=(dy, dx)))
+            x.mark_init()
+
+        self.bwd_emitters.append(emit)
+        return out
+
+    def _head(self, head: YOLOHead, xs: List[Act]) -> None:
+        dt, dev = self.dt, self.device
+        for lvl, x in enumerate(xs):
+            conv = head.conv[lvl]
+            if not isinstance(conv, nn.Conv2d) or conv.weight.dtype != torch.float32:
+                raise PlanUnsupported("non-standard head conv")
+            Cout, Cin = conv.weight.shape[:2]
+            cp = F_._round_up(Cout, 8)
+            B, _, H, W = x.t.shape
+            geo = F_._Geometry(tuple(x.t.shape), conv.weight.shape, (1, 1), (0, 0), dt)
+            wc = torch.empty((cp, 1, 1, Cin), dtype=dt, device=dev)
+            wt = torch.empty((Cin, 1, 1, cp), dtype=dt, device=dev)
+            buf = torch.empty((B, H, W, cp), dtype=torch.float32, device=dev)
+            self.keep += [wc, wt, buf]
+            self.casts.append(_op(OP_CAST_WEIGHT, i=(Cout, 1, 1, Cin, cp, Cin, ops.dtype_code(dt)), p=(conv.weight, wc, wt)))
+            ldx = ops.nhwc_info(x.t)[4]
+            self.fwd.append(_op(OP_CONV_FWD, i=(EPI_HEAD, 1, head.no), p=(x.t, wc, buf, None, conv.bias, None),
+                                conv=geo.desc(dt, ldx, cp)))
+            self.raw_specs.append((buf, (B, head.na, H, W, head.no), (H * W * cp, head.no, W * cp, cp, 1)))
+            gw_off = self._register_param(conv.weight, cp * Cin, lambda b, Cout=Cout, Cin=Cin: b.view(-1, Cin)[:Cout].view(Cout, Cin, 1, 1))
+            gb_off = self._register_param(conv.bias, Cout, lambda b: b) if conv.bias is not None else None
+            npix = B * H * W
+            self.dz_elems = max(self.dz_elems, npix * cp)
+            code = ops.dtype_code(dt)
+
+            def emit(x=x, geo=geo, wt=wt, cp=cp, Cin=Cin, Cout=Cout, B=B, H=H, W=W, gw_off=gw_off, gb_off=gb_off, ldx=ldx, npix=npix):
+                ga = self.gradarena
+                dz = self.dz_buf[:npix * cp]
+                op = _op(OP_HEAD_GRAD_PACK, i=(B, head.na, H, W, head.no, code, cp),
+                         p=(None, dz, ga.view(gb_off, Cout) if gb_off is not None else None))
+                self.draw_ops.append(op)
+                self.bwd.append(op)
+                dx = x.grad()
+                self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x.is_init()),), p=(dz, wt, dx),
+                                    conv=geo.desc(dt, ops.nhwc_info(dx)[4], cp, cout=cp)))
+                x.mark_init()
+                self.bwd.append(_op(OP_CONV_WGRAD, f=(1.0,), p=(x.t, dz, ga.view(gw_off, cp * Cin)), conv=geo.desc(dt, ldx, cp, cout=cp)))
+
+            self.bwd_emitters.append(emit)
+
+    # ------------------------------------------------------------------ whole model
+    def _compile(self) -> None:
+        model = self.model
+        layers = list(model.model)
+        routes = model.routes
+        n = len(layers)
+        # -- shape inference (channels, spatial) per layer output
+        ch: List[int] = []
+        hw: List[Tuple[int, int]] = []
+        for i, m in enumerate(layers):
+            frm = routes[i]
+            fl = frm if isinstance(frm, list) else [frm]
+            srcs = [(i + f) if f < 0 else f for f in fl]
+            cin = [self.Cimg if s < 0 else ch[s] for s in srcs]
+            sin = [(self.H, self.W) if s < 0 else hw[s] for s in srcs]
+            if isinstance(m, Conv):
+                s = _pair(m.conv.stride)
+                k = _pair(m.conv.kernel_size)
+                p = _pair(m.conv.padding)
+                ch.append(m.conv.out_channels)
+                hw.append(((sin[0][0] + 2 * p[0] - k[0]) // s[0] + 1, (sin[0][1] + 2 * p[1] - k[1]) // s[1] + 1))
+            elif isinstance(m, C3):
+                ch.append(m.cv3.conv.out_channels); hw.append(sin[0])
+            elif isinstance(m, SPPF):
+                ch.append(m.cv2.conv.out_channels); hw.append(sin[0])
+            elif isinstance(m, UpSample):
+                ch.append(cin[0]); hw.append((sin[0][0] * 2, sin[0][1] * 2))
+            elif isinstance(m, Concat):
+                if m.dimension != 1:
+                    raise PlanUnsupported("concat on a non-channel dim")
+                ch.append(sum(cin)); hw.append(sin[0])
+            elif isinstance(m, YOLOHead):
+                ch.append(0); hw.append((0, 0))
+            else:
+                raise PlanUnsupported(type(m).__name__)
+        # -- concat destinations: producer layer -> (concat layer, channel offset)
+        dest: Dict[int, Tuple[int, int]] = {}
+        for j, m in enumerate(layers):
+            if isinstance(m, Concat):
+                off = 0
+                fl = routes[j]
+                for f in fl:
+                    s = (j + f) if f < 0 else f
+                    if s in dest or s < 0:
+                        raise PlanUnsupported("layer feeds two concats")
+                    dest[s] = (j, off)
+                    off += ch[s]
+        cat_bufs: Dict[int, Act] = {}
+        outs: List[Optional[Act]] = []
+        for i, m in enumerate(layers):
+            frm = routes[i]
+            fl = frm if isinstance(frm, list) else [frm]
+            srcs = [(i + f) if f < 0 else f for f in fl]
+            xin = [None if s < 0 else outs[s] for s in srcs]
+            dst = None
+            if i in dest:
+                j, off = dest[i]
+                if j not in cat_bufs:
+                    cat_bufs[j] = self._new_act(ch[j], hw[j][0], hw[j][1])
+                dst = cat_bufs[j].slice(off, off + ch[i])
+            if isinstance(m, Conv):
+                out = self._conv_block(m, xin[0], dst, image=(srcs[0] < 0))
+            elif isinstance(m, C3):
+                out = self._c3(m, xin[0], dst)
+            elif isinstance(m, SPPF):
+                out = self._sppf(m, xin[0], dst)
+            elif isinstance(m, UpSample):
+                out = self._upsample(xin[0], dst)
+            elif isinstance(m, Concat):
+                out = cat_bufs[i]
+            elif isinstance(m, YOLOHead):
+                self._head(m, xin)
+                out = None
+            outs.append(out)
+        # -- arenas, late binding, backward emission (reverse order)
+        dev = self.device
+        for ar in (self.stats, self.sums, self.small, self.gradarena):
+            ar.allocate(dev)
+        self.dz_buf = torch.empty(max(self.dz_elems, 8), dtype=self.dt, device=dev)
+        for fn in self.late:
+            fn()
+        head_ops = [_op(OP_MEMSET, l=(self.stats.buf.numel() * 4,), p=(self.stats.buf,))]
+        self.fwd = head_ops + self.casts + self.fwd
+        self.bwd = [_op(OP_MEMSET, l=(self.sums.buf.numel() * 4,), p=(self.sums.buf,)),
+                    _op(OP_MEMSET, l=(self.gradarena.buf.numel() * 4,), p=(self.gradarena.buf,))]
+        for emit in reversed(self.bwd_emitters):
+            emit()
+        self.fwd_arr = (Op * len(self.fwd))(*self.fwd)
+        self.bwd_arr = (Op * len(self.bwd))(*self.bwd)
+        # pointer-patch slots inside the arrays (ctypes copies structs into the array)
+        self.pack_idx = next(k for k, o in enumerate(self.fwd) if o is self.pack_op)
+        self.draw_idx = [next(k for k, o in enumerate(self.bwd) if o is d) for d in self.draw_ops]
+        # draw ops were emitted in reverse level order
+        self.draw_levels = list(reversed(range(len(self.raw_specs))))
+        self.param_ptrs = tuple(p.data_ptr() for p in self.params)
+
+    # ------------------------------------------------------------------ execution
+    def valid_for(self, params_ptrs) -> bool:
+        return params_ptrs == self.param_ptrs
+
+    def run_forward(self, x: torch.Tensor) -> List[torch.Tensor]:
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        self._x_keep = x
+        self.fwd_arr[self.pack_idx].p[0] = x.data_ptr()
+        _lib.check(_lib.lib().ayolo_run_ops(self.fwd_arr, len(self.fwd), torch.cuda.current_stream().cuda_stream), "ayolo_run_ops(forward)")
+        if self.bn_counters:
+            torch._foreach_add_(self.bn_counters, 1)
+        return [buf.as_strided(shape, strides) for buf, shape, strides in self.raw_specs]
+
+    def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
+        keep = []
+        for idx, lvl in zip(self.draw_idx, self.draw_levels):
+            d = draws[lvl]
+            buf, shape, _ = self.raw_specs[lvl]
+            if d is None:
+                d = torch.zeros(shape, dtype=torch.float32, device=self.device)
+            if d.dtype != torch.float32 or not d.is_contiguous():
+                d = d.float().contiguous()
+            keep.append(d)
+            self.bwd_arr[idx].p[0] = d.data_ptr()
+        _lib.check(_lib.lib().ayolo_run_ops(self.bwd_arr, len(self.bwd), torch.cuda.current_stream().cuda_stream), "ayolo_run_ops(backward)")
+        self._d_keep = keep
+        ga = self.gradarena
+        grads = []
+        for p in self.params:
+            off, n, view_fn = self.param_grad_view[id(p)]
+            g = view_fn(ga.view(off, n))
+            grads.append(g.clone() if p.grad is not None else g)     # never alias an accumulating .grad
+        return grads
+
+
+class _PlanTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan: TrainPlan, x: torch.Tensor, *params):
+        ctx.plan = plan
+        return tuple(plan.run_forward(x))
+
+    @staticmethod
+    def backward(ctx, *draws):
+        grads = ctx.plan.run_backward(draws)
+        return (None, None) + tuple(grads)
+
+
+def plan_forward_train(model, x: torch.Tensor):
+    """Training forward through the cached plan; returns the list of raw head tensors (or None if unsupported)."""
+    dt = torch.float16 if torch.is_autocast_enabled() else torch.float32
+    key = (tuple(x.shape), dt, x.device)
+    cache = model.__dict__.setdefault("_plans", {})
+    plan = cache.get(key)
+    if plan is False:
+        return None
+    if plan is not None and not plan.valid_for(tuple(p.data_ptr() for p in plan.params)):
+        plan = None
+    if plan is None:
+        try:
+            plan = TrainPlan(model, tuple(x.shape), dt, x.device)
+        except PlanUnsupported:
+            cache[key] = False
+            return None
+        cache[key] = plan
+    return list(_PlanTrainFn.apply(plan, x, *plan.params))

@@ -199,6 +199,34 @@ int ayolo_matrix_nms_decay(const float* boxes, const float* cls, float offset_sc
 int ayolo_merge_boxes(const float* det, uint32_t n, float offset_scale, const int32_t* kept, uint32_t nk,
                       float thr_f32, float* merged, int32_t* redundant, ayolo_stream s);
 
+/* a = act(z*scale + shift) + residual (residual nullable: Bottleneck shortcut fused into the activation pass) */
+int ayolo_affine_act_res(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* scale,
+                         const float* shift, int act, const void* residual, int ldr, ayolo_stream s);
+/* inference BatchNorm folded to an affine: scale = gamma/sqrt(var+eps), shift = beta - mean*scale (+ bias*scale) */
+int ayolo_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                         const float* conv_bias, float eps, int C, float* scale, float* shift, ayolo_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched launch: a pre-compiled straight-line program of the calls above (one model forward or backward over
+ * static buffers) enqueued by ONE host call.  Field use per kind: see csrc/plan.hip.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    AYOLO_OP_CONV_FWD = 1, AYOLO_OP_CONV_DGRAD, AYOLO_OP_CONV_WGRAD, AYOLO_OP_CAST_WEIGHT, AYOLO_OP_BN_FINALIZE,
+    AYOLO_OP_AFFINE_ACT, AYOLO_OP_BN_BWD_REDUCE, AYOLO_OP_BN_BWD_APPLY, AYOLO_OP_MAXPOOL_FWD, AYOLO_OP_MAXPOOL_BWD,
+    AYOLO_OP_UPSAMPLE_FWD, AYOLO_OP_UPSAMPLE_BWD, AYOLO_OP_PACK_INPUT, AYOLO_OP_HEAD_GRAD_PACK, AYOLO_OP_COPY2D,
+    AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE
+};
+typedef struct ayolo_op {
+    int kind;
+    int i[12];
+    float f[2];
+    double d[1];
+    int64_t l[1];
+    void* p[10];
+    ayolo_conv_desc conv;
+} ayolo_op;
+int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,3 +150,30 @@ def test_tucker_decomposed_model_eval():
         zr, _ = r(x)
         zg, _ = m(x.cuda())
     np.testing.assert_allclose(zg.cpu().numpy(), zr.numpy(), rtol=2e-4, atol=2e-3)
+
+
+def test_plan_equals_module_path():
+    """The static-plan executor and the per-module autograd path launch the same kernels: logits are identical and
+    gradients agree to atomics-order noise (fp32 mode)."""
+    import copy
+    m, _ = _pair("n", seed=13)
+    m2 = copy.deepcopy(m)
+    m2.use_plan = False
+    m.train(); m2.train()
+    x = torch.rand(2, 3, 96, 128).cuda()
+    ra, rb = m(x), m2(x)
+    for a, b in zip(ra, rb):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=0, atol=1e-6)
+    sum(t.square().sum() for t in ra).backward()
+    sum(t.square().sum() for t in rb).backward()
+    pb = dict(m2.named_parameters())
+    for k, p in m.named_parameters():
+        assert _rel(p.grad.float().cpu(), pb[k].grad.float().cpu()) < 1e-4, k
+    # second step through the cached plan (buffers reused) still matches
+    m.zero_grad(set_to_none=True); m2.zero_grad(set_to_none=True)
+    x2 = torch.rand(2, 3, 96, 128).cuda()
+    ra, rb = m(x2), m2(x2)
+    sum(t.abs().sum() for t in ra).backward()
+    sum(t.abs().sum() for t in rb).backward()
+    for k, p in m.named_parameters():
+        assert _rel(p.grad.float().cpu(), pb[k].grad.float().cpu()) < 1e-4, k
