@@ -3,12 +3,27 @@
 // static buffers, so a training step costs two host calls instead of ~1600 Python-level launches, and the
 // list is a straight-line HIP stream program (graph-capturable).
 #include "common.h"
+#include <time.h>
+#include <stdlib.h>
+
+static inline double now_us() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
 
 extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
     AY_CHECK_ARG(ops || n == 0, "run_ops: null op list");
+    static const bool debug_stall = getenv("AYOLO_DEBUG_STALL") != nullptr;
+    double t_prev = debug_stall ? now_us() : 0.0;
     for (int k = 0; k < n; ++k) {
         const ayolo_op& o = ops[k];
         int rc = AYOLO_OK;
+        if (debug_stall) {
+            double t = now_us();
+            if (t - t_prev > 500.0) fprintf(stderr, "[ayolo] run_ops: op %d/%d (kind %d) was blocked %.1f us in the HIP runtime\n", k - 1, n, k ? ops[k - 1].kind : 0, t - t_prev);
+            t_prev = t;
+        }
         switch (o.kind) {
         case AYOLO_OP_CONV_FWD:
             rc = ayolo_conv_fwd(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const float*)o.p[3], (const float*)o.p[4],

@@ -70,8 +70,9 @@ class ComputeLoss:
         if self._anchors_cpu is None:
             self._anchors_cpu = self.anchors.detach().float().cpu()
         t_cpu = targets.detach().float().cpu()
-        fake = [torch.empty(tuple(s), device="meta") for s in pred_shapes]
-        tcls, tbox, indices, anch = self.build_targets(fake, t_cpu, anchors=self._anchors_cpu)
+        # numpy, not torch-CPU: torch's intra-op thread pool (one spinning OpenMP thread per host core) starves the
+        # HIP runtime's helper threads and stalls the GPU for tens of ms every other step
+        tcls, tbox, indices, anch = self._build_targets_np(t_cpu.numpy(), pred_shapes, self._anchors_cpu.numpy())
         if torch.device(device).type != "cuda":
             return tcls, tbox, indices, anch
         # two pinned staging buffers -> two asynchronous H2D copies (pageable copies would block on the stream)
@@ -82,10 +83,26 @@ class ComputeLoss:
             self._pin_i = torch.empty(max(ni, 1) * 2, dtype=torch.int64).pin_memory()
         if getattr(self, "_pin_f", None) is None or self._pin_f.numel() < nf:
             self._pin_f = torch.empty(max(nf, 1) * 2, dtype=torch.float32).pin_memory()
-        torch.cat(ints, out=self._pin_i[:ni]) if ni else None
-        torch.cat(flts, out=self._pin_f[:nf]) if nf else None
-        di = self._pin_i[:ni].to(device, non_blocking=True)
-        df = self._pin_f[:nf].to(device, non_blocking=True)
+        mode = getattr(self, "h2d_mode", "same")
+        if mode == "pageable":
+            di = torch.cat(ints).to(device) if ni else torch.empty(0, dtype=torch.int64, device=device)
+            df = torch.cat(flts).to(device) if nf else torch.empty(0, device=device)
+        else:
+            torch.cat(ints, out=self._pin_i[:ni]) if ni else None
+            torch.cat(flts, out=self._pin_f[:nf]) if nf else None
+            if mode == "side":     # copy engine on its own stream; the compute stream only waits on the event
+                if getattr(self, "_copy_stream", None) is None:
+                    self._copy_stream = torch.cuda.Stream(device=device)
+                cur = torch.cuda.current_stream(device)
+                with torch.cuda.stream(self._copy_stream):
+                    di = self._pin_i[:ni].to(device, non_blocking=True)
+                    df = self._pin_f[:nf].to(device, non_blocking=True)
+                cur.wait_stream(self._copy_stream)
+                di.record_stream(cur)
+                df.record_stream(cur)
+            else:
+                di = self._pin_i[:ni].to(device, non_blocking=True)
+                df = self._pin_f[:nf].to(device, non_blocking=True)
         oi, of = 0, 0
 
         def take_i(t):
@@ -128,8 +145,10 @@ class ComputeLoss:
                     b, a, gj, gi, score = b[order], a[order], gj[order], gi[order], score[order]
                 tobj[b, a, gj, gi] = (1.0 - self.gr) + self.gr * score
                 if self.nc > 1:
+                    # one-hot class targets; scatter_ with a Python scalar launches no host->device copy (an
+                    # index_put of a CPU scalar would block on the stream)
                     t = torch.full_like(ps[:, 5:], self.cn, device=device)
-                    t[torch.arange(n, device=device), tcls[i]] = self.cp
+                    t.scatter_(1, tcls[i].view(-1, 1), self.cp)
                     lcls = lcls + self.BCEcls(ps[:, 5:], t)
             obji = self.BCEobj(pi[..., 4], tobj)
             lobj = lobj + obji * self.balance[i]
@@ -143,6 +162,48 @@ class ComputeLoss:
         bs = preds[0].shape[0]
         loss = lbox + lobj + lcls
         return loss * bs, torch.cat((lbox, lobj, lcls, loss)).detach()
+
+    def _build_targets_np(self, targets, pred_shapes, anchors_all):
+        """float32 numpy twin of ``build_targets`` (same operations in the same order)."""
+        import numpy as np
+        f32 = np.float32
+        na, nt = self.na, targets.shape[0]
+        tcls, tbox, indices, anch = [], [], [], []
+        gain = np.ones(7, f32)
+        ai = np.repeat(np.arange(na, dtype=f32).reshape(na, 1), nt, 1)
+        tg = np.concatenate((np.broadcast_to(targets.astype(f32), (na, nt, 6)), ai[:, :, None]), 2)
+        g = f32(0.5)
+        off = np.array([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], f32) * g
+        for i in range(self.nl):
+            anchors = anchors_all[i].astype(f32)
+            shape = pred_shapes[i]
+            gain[2:6] = np.array([shape[3], shape[2], shape[3], shape[2]], f32)
+            t = tg * gain
+            if nt:
+                r = t[:, :, 4:6] / anchors[:, None]
+                keep = np.maximum(r, f32(1.0) / r).max(2) < f32(self.hyp["anchor_t"])
+                t = t[keep]
+                gxy = t[:, 2:4]
+                gxi = gain[[2, 3]] - gxy
+                jk = (np.mod(gxy, f32(1.0)) < g) & (gxy > f32(1.0))
+                lm = (np.mod(gxi, f32(1.0)) < g) & (gxi > f32(1.0))
+                sel = np.stack((np.ones_like(jk[:, 0]), jk[:, 0], jk[:, 1], lm[:, 0], lm[:, 1]))
+                t = np.broadcast_to(t, (5,) + t.shape)[sel]
+                offsets = (np.zeros_like(gxy)[None] + off[:, None])[sel]
+            else:
+                t = tg[0]
+                offsets = f32(0)
+            b, c = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
+            gxy, gwh = t[:, 2:4], t[:, 4:6]
+            gij = (gxy - offsets).astype(np.int64)
+            gi, gj = gij[:, 0], gij[:, 1]
+            a = t[:, 6].astype(np.int64)
+            indices.append((torch.from_numpy(b), torch.from_numpy(a), torch.from_numpy(np.clip(gj, 0, int(shape[2]) - 1)),
+                            torch.from_numpy(np.clip(gi, 0, int(shape[3]) - 1))))
+            tbox.append(torch.from_numpy(np.concatenate((gxy - gij.astype(f32), gwh), 1).astype(f32)))
+            anch.append(torch.from_numpy(anchors[a]))
+            tcls.append(torch.from_numpy(c))
+        return tcls, tbox, indices, anch
 
     def build_targets(self, preds: List[torch.Tensor], targets: torch.Tensor, anchors: Optional[torch.Tensor] = None):
         """targets: (nt, 6) [image, class, x, y, w, h] normalised -> per level (classes, boxes, indices, anchors)."""

@@ -459,10 +459,19 @@ class TrainPlan:
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
         self._x_keep = x
+        # Bound the host's run-ahead: the ROCm runtime degrades badly (long stalls with the GPU idle) once several
+        # thousand launches are queued, and with one host call per pass the host is ~4 steps ahead within
+        # milliseconds.  Waiting for the PREVIOUS step's forward (long finished when the GPU is the bottleneck)
+        # keeps at most ~1 step in flight and never idles the GPU.
+        prev = getattr(self, "_fwd_done", None)
+        if prev is not None:
+            prev.synchronize()
         self.fwd_arr[self.pack_idx].p[0] = x.data_ptr()
         _lib.check(_lib.lib().ayolo_run_ops(self.fwd_arr, len(self.fwd), torch.cuda.current_stream().cuda_stream), "ayolo_run_ops(forward)")
         if self.bn_counters:
             torch._foreach_add_(self.bn_counters, 1)
+        self._fwd_done = torch.cuda.Event()
+        self._fwd_done.record()
         return [buf.as_strided(shape, strides) for buf, shape, strides in self.raw_specs]
 
     def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:

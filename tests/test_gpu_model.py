@@ -163,7 +163,7 @@ def test_plan_equals_module_path():
     x = torch.rand(2, 3, 96, 128).cuda()
     ra, rb = m(x), m2(x)
     for a, b in zip(ra, rb):
-        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)   # atomics order
     sum(t.square().sum() for t in ra).backward()
     sum(t.square().sum() for t in rb).backward()
     pb = dict(m2.named_parameters())
