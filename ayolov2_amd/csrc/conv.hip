@@ -15,6 +15,7 @@
 // Replaces kindle Conv/YOLOHead.conv forward (yolov5s.yaml:21-57) and the autograd backward torch/cuDNN ran
 // (scripts/train/yolo_trainer.py:329).
 #include "common.h"
+#include <stdlib.h>
 
 #define MAX_TAPS 36
 #define BK 32
@@ -105,7 +106,15 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
     const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;     // pixel-tile slot of this workgroup
     const unsigned nslots = (unsigned)p.nslots;                   // = gridDim.x / ntn
     const int n0 = (int)nt * TM;
-    const long long ntiles = (p.Mtotal + TP - 1) / TP;
+    const long long ntiles_all = (p.Mtotal + TP - 1) / TP;
+    // Each XCD walks a CONTIGUOUS band of pixel tiles (its 32 CUs x resident workgroups cover neighbouring image
+    // rows at the same time), so the 3x3 halo rows that neighbouring tiles re-read are hits in that XCD's own L2
+    // instead of round trips to the die-level cache.
+    const long long tpx = (ntiles_all + 7) / 8;                  // tiles per XCD band
+    const long long band_lo = (long long)xcd * tpx;
+    const long long ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;   // band end (exclusive)
+    const unsigned lslot = idx / (unsigned)p.ntn;                 // slot inside the band
+    const unsigned lstride = nslots / 8u;
 
     typedef __attribute__((address_space(4))) const signed char* kptr_t;
     const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh);
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
 
     int nk = (p.K + BK - 1) / BK;
     if (nk < 1) nk = 1;                      // K == 0 (tap-less dgrad residue class): one all-zero step
-    long long cur_tile = slot;
+    long long cur_tile = band_lo + lslot;
     if (cur_tile >= ntiles) return;
     long long ld_tile = cur_tile;
     int ld_kt = 0, cur_kt = 0, buf = 0;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
             setup_rows(ld_tile);
         } else {
             ++ld_kt;
-            if (ld_kt == nk) { ld_kt = 0; ld_tile += nslots; }
+            if (ld_kt == nk) { ld_kt = 0; ld_tile += lstride; }
             more = ld_tile < ntiles;
             if (more) {
                 if (ld_kt == 0) setup_rows(ld_tile);
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
         if (first) { first = false; cur_tile = ld_tile; cur_kt = 0; buf = 0; }
         else {
             ++cur_kt;
-            if (cur_kt == nk) { cur_kt = 0; cur_tile += nslots; }
+            if (cur_kt == nk) { cur_kt = 0; cur_tile += lstride; }
             buf ^= 1;
         }
     }
@@ -331,6 +340,300 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
         for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
         __syncthreads();
         // one reduction per workgroup: over the 32 pixel lanes of each half-wave, then LDS, then one replica
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = ssum[r], b = ssq[r];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                a += __shfl_xor(a, off);
+                b += __shfl_xor(b, off);
+            }
+            if ((lane & 31) == 0) {
+                int cl = wm * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);
+                atomicAdd(&sStat[cl], a);
+                atomicAdd(&sStat[TM + cl], b);
+            }
+        }
+        __syncthreads();
+        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
+        for (int i = tid; i < TM; i += 256) {
+            if (n0 + i < p.Nout) {
+                atomicAdd(&st[n0 + i], sStat[i]);
+                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Direct (halo-tiled) convolution for k x k > 1x1: the input patch of an 8x16 output tile (with halo) is
+// staged in LDS ONCE per 32-channel chunk and all k*k taps read their MFMA fragments from it at shifted
+// addresses, so global/L2 traffic for the activations drops from k*k x to ~(1 + halo) x.  Weights stream as
+// [TM x 32] tiles per (chunk, tap) step; the next step's weights and a slice of the next patch are
+// prefetched into registers while the MFMAs run (persistent over tiles, same epilogue as k_gconv).
+// ---------------------------------------------------------------------------------------------------
+#define DTH 8
+#define DTW 16
+#define DCK 32          // channels per LDS patch chunk
+#define DSL_MAX 3       // patch chunk loads per thread per step (upper bound)
+
+struct DConvP {
+    GConvP g;            // shared fields (x, w, y, dims, epilogue, taps)
+    int tyn, txn;        // tiles per image in y / x
+    int PH, PW;          // patch extent (pixels)
+    int dh_min, dw_min;  // smallest tap offsets
+    int sl;              // patch chunk loads per thread per step
+};
+
+template <typename T, int TM, int EM>
+__global__ __launch_bounds__(256) void k_dconv(DConvP dp) {
+    const GConvP& p = dp.g;
+    constexpr int CE = Tr<T>::CE;
+    constexpr int CPR = DCK / CE;            // 16-byte chunks per patch pixel
+    constexpr int LDR = DCK + Tr<T>::PADE;   // LDS row stride (elements) for both the patch and the weight tile
+    constexpr int WM = TM / 32, WP = 4 / WM, NI = TP / (32 * WP);
+    constexpr int WCH = TM * CPR;
+    constexpr int WR = (WCH + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int patch_elems = dp.PH * dp.PW * LDR;
+    T* sW = reinterpret_cast<T*>(smem_raw);                        // [2][TM][LDR]
+    T* sP = sW + 2 * TM * LDR;                                     // [2][PH*PW][LDR]
+    float* sStat = reinterpret_cast<float*>(sP + 2 * patch_elems); // [2][TM]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wp = wave / WM;
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ Wg = reinterpret_cast<const T*>(p.w);
+
+    const unsigned L = blockIdx.x;
+    const unsigned xcd = L & 7u, idx = L >> 3;
+    const unsigned nt = idx % (unsigned)p.ntn;
+    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
+    const unsigned nslots = (unsigned)p.nslots;
+    const int n0 = (int)nt * TM;
+    const long long tiles_per_img = (long long)dp.tyn * dp.txn;
+    const long long ntiles_all = (long long)p.B * tiles_per_img;
+    const long long tpx = (ntiles_all + 7) / 8;
+    const long long band_lo = (long long)xcd * tpx;
+    const long long ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
+    const unsigned lslot = idx / (unsigned)p.ntn;
+    const unsigned lstride = nslots / 8u;
+
+    typedef __attribute__((address_space(4))) const signed char* kptr_t;
+    const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh);
+
+    const int nchunks = p.C / DCK;
+    const int nsteps = nchunks * p.ntaps;            // steps per tile: (chunk, tap)
+    const int patch_chunks = dp.PH * dp.PW * CPR;
+    const int kc = tid % CPR;
+
+    float16v acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const bool want_stats = (EM == 0) && (p.stats != nullptr);
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+    const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
+
+    // per-lane fragment geometry: pixel j of the tile -> (oy, ox)
+    int frag_off[NI];     // element offset of the lane's pixel inside the patch for tap offset (dh_min, dw_min)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int j = wp * NI * 32 + ni * 32 + (lane & 31);
+        const int oy = j / DTW, ox = j % DTW;
+        frag_off[ni] = ((oy * p.ish) * dp.PW + ox * p.isw) * LDR + (lane >> 5) * 8;
+    }
+
+    uint4 preg[DSL_MAX], wreg[WR];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    long long cur_tile = band_lo + lslot;
+    if (cur_tile >= ntiles) return;
+    // loader position (one step ahead of the compute position)
+    long long ld_tile = cur_tile;
+    int ld_step = 0;
+    int cur_step = 0;
+    int wbuf = 0, pbuf = 0;      // LDS buffers holding the CURRENT step's weights / CURRENT chunk's patch
+    bool first = true;
+
+    // tile origin of the patch being loaded
+    auto tile_origin = [&](long long tile, int& n, int& ih0, int& iw0) {
+        const unsigned tu = (unsigned)tile;
+        const unsigned nn = tu / (unsigned)tiles_per_img;
+        const unsigned r = tu - nn * (unsigned)tiles_per_img;
+        const unsigned ty = r / (unsigned)dp.txn, tx = r - ty * (unsigned)dp.txn;
+        n = (int)nn;
+        ih0 = (int)ty * DTH * p.ish + dp.dh_min;
+        iw0 = (int)tx * DTW * p.isw + dp.dw_min;
+    };
+    // loads slice `sl_idx` (0..ntaps-1) of the patch for (tile, chunk) into preg
+    auto load_patch_slice = [&](long long tile, int chunk, int slice) {
+        int n, ih0, iw0;
+        tile_origin(tile, n, ih0, iw0);
+#pragma unroll
+        for (int u = 0; u < DSL_MAX; ++u) {
+            preg[u] = zero4;
+            if (u < dp.sl) {
+                const int q = (slice * dp.sl + u) * 256 + tid;
+                if (q < patch_chunks) {
+                    const int pix = q / CPR;
+                    const int py = pix / dp.PW, px = pix - py * dp.PW;
+                    const int ih = ih0 + py, iw = iw0 + px;
+                    if (ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW)
+                        preg[u] = *reinterpret_cast<const uint4*>(X + (((long long)n * p.XH + ih) * p.XW + iw) * p.ldx + chunk * DCK + kc * CE);
+                }
+            }
+        }
+    };
+    auto store_patch_slice = [&](int buf, int slice) {
+        T* dP = sP + buf * patch_elems;
+#pragma unroll
+        for (int u = 0; u < DSL_MAX; ++u) {
+            if (u < dp.sl) {
+                const int q = (slice * dp.sl + u) * 256 + tid;
+                if (q < patch_chunks) *reinterpret_cast<uint4*>(dP + (q / CPR) * LDR + kc * CE) = preg[u];
+            }
+        }
+    };
+    auto load_w = [&](int step) {
+        const int chunk = step / p.ntaps, tap = step - chunk * p.ntaps;
+        const int wcol = ktab[2 * MAX_TAPS + tap] * p.C + chunk * DCK + kc * CE;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+            const int q = tid + 256 * r, row = q / CPR;
+            wreg[r] = zero4;
+            if (q < WCH && (n0 + row) < p.Nout) wreg[r] = *reinterpret_cast<const uint4*>(Wg + (long long)(n0 + row) * p.ldw + wcol);
+        }
+    };
+    auto store_w = [&](int buf) {
+        T* dW = sW + buf * TM * LDR;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) {
+            const int q = tid + 256 * r;
+            if (q < WCH) *reinterpret_cast<uint4*>(dW + (q / CPR) * LDR + kc * CE) = wreg[r];
+        }
+    };
+
+    // ---- prologue: whole first patch (all slices) + first weight tile
+    for (int sidx = 0; sidx < p.ntaps; ++sidx) {
+        load_patch_slice(cur_tile, 0, sidx);
+        store_patch_slice(0, sidx);
+    }
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+
+    while (true) {
+        // ---------------- prefetch for the next step: its weight tile, and one slice of the NEXT chunk's patch
+        int nx_step = cur_step + 1;
+        long long nx_tile = cur_tile;
+        if (nx_step == nsteps) { nx_step = 0; nx_tile += lstride; }
+        const bool more = nx_tile < ntiles;
+        const int cur_chunk = cur_step / p.ntaps, cur_tap = cur_step - cur_chunk * p.ntaps;
+        // the patch that follows the current chunk
+        int pn_chunk = cur_chunk + 1;
+        long long pn_tile = cur_tile;
+        if (pn_chunk == nchunks) { pn_chunk = 0; pn_tile += lstride; }
+        const bool pmore = pn_tile < ntiles;
+        if (more) load_w(nx_step);
+        if (pmore) load_patch_slice(pn_tile, pn_chunk, cur_tap);
+
+        // ---------------- MFMAs of the current step
+        {
+            const int toff = ((ktab[cur_tap] - dp.dh_min) * dp.PW + (ktab[MAX_TAPS + cur_tap] - dp.dw_min)) * LDR;
+            const T* cW = sW + wbuf * TM * LDR + (wm * 32 + (lane & 31)) * LDR + (lane >> 5) * 8;
+            const T* cP = sP + pbuf * patch_elems + toff;
+#pragma unroll
+            for (int kk = 0; kk < DCK / 16; ++kk) {
+                auto a = lds_frag(cW + kk * 16);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    auto b = lds_frag(cP + frag_off[ni] + kk * 16);
+                    mma_step(a, b, acc[ni]);
+                }
+            }
+        }
+        // ---------------- tile finished: epilogue
+        if (cur_step == nsteps - 1) {
+            const unsigned tu = (unsigned)cur_tile;
+            const unsigned nn = tu / (unsigned)tiles_per_img;
+            const unsigned rr = tu - nn * (unsigned)tiles_per_img;
+            const unsigned ty = rr / (unsigned)dp.txn, tx = rr - ty * (unsigned)dp.txn;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int j = wp * NI * 32 + ni * 32 + (lane & 31);
+                const int oh = (int)ty * DTH + j / DTW, ow = (int)tx * DTW + j % DTW;
+                const bool pv = oh < p.OH && ow < p.OW;
+                const long long yo = (((long long)nn * p.YH + (oh * p.osh + p.oah)) * p.YW + (ow * p.osw + p.oaw)) * p.ldy;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = cbase + 8 * g;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
+                    if constexpr (EM == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (c + e < p.Nout) {
+                                float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
+                                float u = v[e] * sc + sh;
+                                v[e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
+                            }
+                        }
+                    }
+                    if (want_stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
+                            ssum[g * 4 + e] += q;
+                            ssq[g * 4 + e] += q * q;
+                        }
+                    }
+                    if (pv) {
+                        T* Y = reinterpret_cast<T*>(p.y) + yo + c;
+                        if (c + 3 < p.Nout && (p.ldy & 3) == 0) {
+                            if constexpr (EM == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)Y[e];
+                            }
+                            if constexpr (sizeof(T) == 2) {
+                                half4 h;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+                                *reinterpret_cast<half4*>(Y) = h;
+                            } else {
+                                float4v f;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) f[e] = v[e];
+                                *reinterpret_cast<float4v*>(Y) = f;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c + e < p.Nout) Y[e] = (T)(EM == 1 ? v[e] + (float)Y[e] : v[e]);
+                        }
+                    }
+                }
+            }
+        }
+        // ---------------- stage the prefetched data
+        if (more) store_w(wbuf ^ 1);
+        if (pmore) store_patch_slice(pbuf ^ 1, cur_tap);
+        __syncthreads();
+        if (!more) break;
+        wbuf ^= 1;
+        if (cur_tap == p.ntaps - 1) pbuf ^= 1;       // next step starts a new chunk: its patch is complete
+        cur_step = nx_step;
+        cur_tile = nx_tile;
+    }
+
+    if (want_stats) {
+        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float a = ssum[r], b = ssq[r];
@@ -391,8 +694,70 @@ static int launch_gconv_em(GConvP p, hipStream_t s) {
     return AYOLO_OK;
 }
 
+template <typename T, int TM, int EM>
+static int launch_dconv_em(DConvP dp, hipStream_t s) {
+    constexpr int LDR = DCK + Tr<T>::PADE;
+    GConvP& p = dp.g;
+    size_t lds = (size_t)2 * (TM + dp.PH * dp.PW) * LDR * sizeof(T) + 2 * TM * sizeof(float);
+    const long long ntiles = (long long)p.B * dp.tyn * dp.txn;
+    p.ntn = (p.Nout + TM - 1) / TM;
+    int blocks_per_cu = (int)(150 * 1024 / lds);
+    if (blocks_per_cu > 4) blocks_per_cu = 4;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    long long want_slots = (long long)num_cus() * blocks_per_cu / p.ntn;
+    if (want_slots < 8) want_slots = 8;
+    long long slots = ntiles < want_slots ? ntiles : want_slots;
+    slots = (slots + 7) / 8 * 8;
+    p.nslots = (int)slots;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dconv<T, TM, EM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((k_dconv<T, TM, EM>), dim3((unsigned)(slots * p.ntn)), dim3(256), lds, s, dp);
+    AY_CHECK_LAUNCH("k_dconv");
+    return AYOLO_OK;
+}
+
+// Halo-tiled direct kernel is used for multi-tap convs on maps large enough to tile (>= 2 tiles per image) whose
+// channel count is a multiple of the 32-channel LDS chunk; everything else goes through k_gconv.
+static bool dconv_applicable(const GConvP& p, DConvP* out, int elem_size) {
+    static const bool disabled = getenv("AYOLO_NO_DCONV") != nullptr;
+    if (disabled || p.ntaps < 2 || p.C % DCK != 0 || p.epi == AYOLO_EPI_HEAD) return false;
+    if (p.ish != 1 || p.isw != 1) return false;   // strided forward: the 17x33 halo patch leaves one workgroup per CU (measured slower)
+    if (p.OH < DTH || p.OW < DTW) return false;
+    int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
+    for (int t = 0; t < p.ntaps; ++t) {
+        dh_min = p.dh[t] < dh_min ? p.dh[t] : dh_min; dh_max = p.dh[t] > dh_max ? p.dh[t] : dh_max;
+        dw_min = p.dw[t] < dw_min ? p.dw[t] : dw_min; dw_max = p.dw[t] > dw_max ? p.dw[t] : dw_max;
+    }
+    DConvP dp;
+    dp.g = p;
+    dp.tyn = (p.OH + DTH - 1) / DTH; dp.txn = (p.OW + DTW - 1) / DTW;
+    dp.PH = (DTH - 1) * p.ish + (dh_max - dh_min) + 1;
+    dp.PW = (DTW - 1) * p.isw + (dw_max - dw_min) + 1;
+    dp.dh_min = dh_min; dp.dw_min = dw_min;
+    const int cpr = DCK * elem_size / 16;
+    const int patch_chunks = dp.PH * dp.PW * cpr;
+    dp.sl = (patch_chunks + 256 * p.ntaps - 1) / (256 * p.ntaps);
+    if (dp.sl > DSL_MAX) return false;
+    const size_t lds_max = (size_t)2 * (128 + dp.PH * dp.PW) * (DCK + 16 / elem_size) * elem_size + 1024;
+    if (lds_max > 150 * 1024) return false;
+    // tile utilisation: skip when padding to 8x16 tiles wastes more than ~35 % of the MFMA work
+    const double util = (double)p.OH * p.OW / ((double)dp.tyn * DTH * dp.txn * DTW);
+    if (util < 0.65) return false;
+    *out = dp;
+    return true;
+}
+
 template <typename T, int TM>
 static int launch_gconv(const GConvP& p, hipStream_t s) {
+    DConvP dp;
+    if (dconv_applicable(p, &dp, (int)sizeof(T))) {
+        if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_dconv_em<T, TM, 2>(dp, s);
+        if (p.accumulate) return launch_dconv_em<T, TM, 1>(dp, s);
+        return launch_dconv_em<T, TM, 0>(dp, s);
+    }
     if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
     if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_gconv_em<T, TM, 2>(p, s);
     if (p.accumulate) return launch_gconv_em<T, TM, 1>(p, s);

@@ -114,36 +114,50 @@ extern "C" int ayolo_bn_eval_affine(const float* gamma, const float* beta, const
 // ---------------------------------------------------------------------------------------------------
 // a = act(z*scale + shift) (+ residual)
 // ---------------------------------------------------------------------------------------------------
+// Thread mapping shared by the three BN/SiLU passes: a thread owns ONE 16-byte channel group (its per-channel
+// constants live in registers) and walks pixels with a grid stride -- no index divisions, no LDS, coalesced
+// 16-byte accesses (a wave covers consecutive channel groups of consecutive pixels).
 template <typename T>
 __global__ __launch_bounds__(256) void k_affine_act(const T* z, int ldz, T* a, int lda, long long npix, int C,
                                                     const float* scale, const float* shift, int act, const T* res, int ldr) {
     constexpr int VE = VecT<T>::VE;
-    extern __shared__ float sh[];   // [2][C]
-    for (int i = threadIdx.x; i < C; i += 256) {
-        sh[i] = scale ? scale[i] : 1.0f;
-        sh[C + i] = shift ? shift[i] : 0.0f;
-    }
-    __syncthreads();
     const int CG = C / VE;
-    const long long total = npix * CG;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-        long long pix = t / CG;
-        int cg = (int)(t - pix * CG);
-        float v[VE];
-        load_vec<T>(z + pix * ldz + cg * VE, v);
+    const int CGT = CG < 256 ? CG : 256;
+    const int RPB = 256 / CGT;
+    const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
+    if (prow >= RPB) return;
+    for (int cg = cgl; cg < CG; cg += CGT) {
+        float sc[VE], sh[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
-            float u = v[i] * sh[cg * VE + i] + sh[C + cg * VE + i];
-            v[i] = act ? silu_t<T>(u) : u;
+            sc[i] = scale ? scale[cg * VE + i] : 1.0f;
+            sh[i] = shift ? shift[cg * VE + i] : 0.0f;
         }
-        if (res) {
-            float r[VE];
-            load_vec<T>(res + pix * ldr + cg * VE, r);
+        for (long long pix = (long long)blockIdx.x * RPB + prow; pix < npix; pix += (long long)gridDim.x * RPB) {
+            float v[VE];
+            load_vec<T>(z + pix * ldz + cg * VE, v);
 #pragma unroll
-            for (int i = 0; i < VE; ++i) v[i] += r[i];
+            for (int i = 0; i < VE; ++i) {
+                float u = v[i] * sc[i] + sh[i];
+                v[i] = act ? silu_t<T>(u) : u;
+            }
+            if (res) {
+                float r[VE];
+                load_vec<T>(res + pix * ldr + cg * VE, r);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] += r[i];
+            }
+            store_vec<T>(a + pix * lda + cg * VE, v);
         }
-        store_vec<T>(a + pix * lda + cg * VE, v);
     }
+}
+
+static unsigned grid_pixels(long long npix, int C, int ve, int min_iters) {
+    int cg = C / ve, cgt = cg < 256 ? cg : 256, rpb = 256 / cgt;
+    long long b = npix / ((long long)rpb * min_iters);
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (unsigned)b;
 }
 
 extern "C" int ayolo_affine_act_res(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C,
@@ -162,8 +176,8 @@ extern "C" int ayolo_affine_act_res(int dtype, const void* z, int ldz, void* a, 
     AY_CHECK_ARG(z && a && C > 0 && C % ve == 0 && ldz % ve == 0 && lda % ve == 0, "affine_act: C=%d ldz=%d lda=%d", C, ldz, lda);
     AY_CHECK_ARG(C <= 8192, "affine_act: C too large");
     if (npix == 0) return AYOLO_OK;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_affine_act<T>, dim3(grid_for(npix * (C / ve), 256 * 4)), dim3(256),
-                                         2 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (T*)a, lda,
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_affine_act<T>, dim3(grid_pixels(npix, C, ve, 4)), dim3(256),
+                                         0, (hipStream_t)s, (const T*)z, ldz, (T*)a, lda,
                                          (long long)npix, C, scale, shift, act, (const T*)residual, ldr);)
     AY_CHECK_LAUNCH("k_affine_act");
     return AYOLO_OK;
@@ -185,43 +199,58 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
                                                        const float* mean, const float* invstd, const float* gamma,
                                                        const float* beta, int act, float* sums, int reps) {
     constexpr int VE = VecT<T>::VE;
-    extern __shared__ float sh[];   // [4][C] mean, invstd, gamma, beta ; then [2][C] block sums
-    float* bs = sh + 4 * C;
-    for (int i = threadIdx.x; i < C; i += 256) {
-        sh[i] = mean[i]; sh[C + i] = invstd[i];
-        sh[2 * C + i] = gamma ? gamma[i] : 1.0f; sh[3 * C + i] = beta ? beta[i] : 0.0f;
-        bs[i] = 0.0f; bs[C + i] = 0.0f;
-    }
+    extern __shared__ float bs[];   // [2][C] block sums
+    for (int i = threadIdx.x; i < 2 * C; i += 256) bs[i] = 0.0f;
     __syncthreads();
     const int CG = C / VE;
-    const int CGT = CG < 256 ? CG : 256;       // channel groups handled per pass
-    const int RPB = 256 / CGT;                 // pixel rows per block iteration
+    const int CGT = CG < 256 ? CG : 256;
+    const int RPB = 256 / CGT;
     const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
-    const bool active = prow < RPB;
-    for (int cg0 = 0; cg0 < CG; cg0 += CGT) {
-        const int cg = cg0 + cgl;
-        if (!(active && cg < CG)) continue;
-        float s1[VE], s2[VE];
-#pragma unroll
-        for (int i = 0; i < VE; ++i) { s1[i] = 0.0f; s2[i] = 0.0f; }
-        for (long long pix = (long long)blockIdx.x * RPB + prow; pix < npix; pix += (long long)gridDim.x * RPB) {
-            float zv[VE], dv[VE];
-            load_vec<T>(z + pix * ldz + cg * VE, zv);
-            load_vec<T>(da + pix * ldda + cg * VE, dv);
+    if (prow < RPB) {
+        for (int cg = cgl; cg < CG; cg += CGT) {
+            float mu[VE], is[VE], ga[VE], be[VE], s1[VE], s2[VE];
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
-                int c = cg * VE + i;
-                float xh = (zv[i] - sh[c]) * sh[C + c];
-                float u = xh * sh[2 * C + c] + sh[3 * C + c];
-                float du = dv[i] * act_grad_t<T>(u, act);
-                s1[i] += du;
-                s2[i] += du * xh;
+                const int c = cg * VE + i;
+                mu[i] = mean[c]; is[i] = invstd[c];
+                ga[i] = gamma ? gamma[c] : 1.0f; be[i] = beta ? beta[c] : 0.0f;
+                s1[i] = 0.0f; s2[i] = 0.0f;
             }
-        }
+            const long long stride = (long long)gridDim.x * RPB;
+            long long pix = (long long)blockIdx.x * RPB + prow;
+            // two pixels per iteration: four independent 16-byte loads in flight per lane
+            for (; pix + stride < npix; pix += 2 * stride) {
+                float z0[VE], d0[VE], z1[VE], d1[VE];
+                load_vec<T>(z + pix * ldz + cg * VE, z0);
+                load_vec<T>(da + pix * ldda + cg * VE, d0);
+                load_vec<T>(z + (pix + stride) * ldz + cg * VE, z1);
+                load_vec<T>(da + (pix + stride) * ldda + cg * VE, d1);
 #pragma unroll
-        for (int i = 0; i < VE; ++i) {
-            atomicAdd(&bs[cg * VE + i], s1[i]);
-            atomicAdd(&bs[C + cg * VE + i], s2[i]);
+                for (int i = 0; i < VE; ++i) {
+                    float xa = (z0[i] - mu[i]) * is[i], xb = (z1[i] - mu[i]) * is[i];
+                    float dua = d0[i] * act_grad_t<T>(xa * ga[i] + be[i], act);
+                    float dub = d1[i] * act_grad_t<T>(xb * ga[i] + be[i], act);
+                    s1[i] += dua + dub;
+                    s2[i] += dua * xa + dub * xb;
+                }
+            }
+            for (; pix < npix; pix += stride) {
+                float z0[VE], d0[VE];
+                load_vec<T>(z + pix * ldz + cg * VE, z0);
+                load_vec<T>(da + pix * ldda + cg * VE, d0);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    float xa = (z0[i] - mu[i]) * is[i];
+                    float dua = d0[i] * act_grad_t<T>(xa * ga[i] + be[i], act);
+                    s1[i] += dua;
+                    s2[i] += dua * xa;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                atomicAdd(&bs[cg * VE + i], s1[i]);
+                atomicAdd(&bs[C + cg * VE + i], s2[i]);
+            }
         }
     }
     __syncthreads();
@@ -237,9 +266,10 @@ extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const 
     AY_CHECK_ARG(z && da && sums && save_mean && save_invstd, "bn_bwd_reduce: null pointer");
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && C <= 2048, "bn_bwd_reduce: C=%d", C);
     if (npix == 0) return AYOLO_OK;
-    int cg = C / ve, cgt = cg < 256 ? cg : 256, rpb = 256 / cgt;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_reduce<T>, dim3(grid_for(npix, rpb * 16)), dim3(256),
-                                         6 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
+    unsigned grid = grid_pixels(npix, C, ve, 8);
+    if (grid > 2048) grid = 2048;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_reduce<T>, dim3(grid), dim3(256),
+                                         2 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
                                          (long long)npix, C, save_mean, save_invstd, gamma, beta, act, sums, sum_reps);)
     AY_CHECK_LAUNCH("k_bn_bwd_reduce");
     return AYOLO_OK;
@@ -294,7 +324,9 @@ extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const v
     AY_CHECK_ARG(z && da && dz && sums, "bn_bwd_apply: null pointer");
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && lddz % ve == 0 && C <= 2048, "bn_bwd_apply: C=%d", C);
     if (npix == 0) return AYOLO_OK;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(grid_for(npix * (C / ve), 256 * 4)), dim3(256),
+    // the per-workgroup prologue stages (6 + 2*reps)*C floats in LDS: scale the elements per workgroup with C
+    const int per_thread = C >= 256 ? 16 : (C >= 128 ? 8 : 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(grid_for(npix * (C / ve), 256 * per_thread)), dim3(256),
                                          6 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
                                          (T*)dz, lddz, (long long)npix, C, save_mean, save_invstd, gamma, beta, act,
                                          sums, sum_reps, dgamma, dbeta, grad_scale);)

@@ -82,7 +82,7 @@ def make_desc(dt: torch.dtype, B, H, W, Cin, ldx, Cout, ldy, k, s, p, Ho, Wo) ->
 
 
 # --------------------------------------------------------------------------------------------------
-STAT_REPS = 32   # replicas of the per-channel BN accumulators (see ayolo.h)
+STAT_REPS = 8    # replicas of the per-channel BN accumulators (see ayolo.h)
 
 
 class _ZeroArena:
