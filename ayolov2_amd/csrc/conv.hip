@@ -69,91 +69,294 @@ __device__ __forceinline__ float cvt_round(float v, float*) { return v; }
 
 // EM (epilogue mode, compile time so that unused paths cost no registers):
 //   0 plain store (+ optional BN statistics)   1 accumulate into y (dgrad)   2 affine / affine+SiLU   3 YOLOHead fp32
-template <typename T, int TM, int EM>
-__global__ __launch_bounds__(256) void k_gconv(GConvP p) {
-    // Persistent, tile-pipelined implicit GEMM.  A workgroup owns output-channel tile `nt` and walks pixel tiles
-    // tile0, tile0+stride, ...; the global loads of step (tile, kt)+1 are in flight while the MFMAs consume
-    // step (tile, kt) from LDS, across tile boundaries, so short-K layers (1x1 convs, K = 32..128) stream
-    // instead of paying a load->use latency per 128-pixel tile.  BN statistics are accumulated in registers
-    // across all tiles of the workgroup and reduced once at the end.
-    constexpr int CE = Tr<T>::CE;
-    constexpr int CPR = BK / CE;             // chunks per tile row
-    constexpr int LDR = BK + Tr<T>::PADE;    // LDS row stride (elements)
-    constexpr int WM = TM / 32;              // waves along channels
-    constexpr int WP = 4 / WM;               // waves along pixels
-    constexpr int NI = TP / (32 * WP);       // 32-pixel MFMA tiles per wave
-    constexpr int XR = (TP * CPR) / 256;     // x chunks per thread
-    constexpr int WCH = TM * CPR;            // w chunks per tile
-    constexpr int WR = (WCH + 255) / 256;
+//
+// Persistent, tile-pipelined implicit GEMM.  A workgroup owns output-channel tile `nt` and walks the pixel tiles of
+// its XCD's band; one "step" = (pixel tile, 32-wide k slice).  The global loads of step s+2 are issued while the
+// MFMAs consume step s from LDS and step s+1 waits in registers (two register stages + two LDS stages), across
+// tile boundaries: the measured load->use latency under load (~3000 cycles) is hidden by ~two compute phases per
+// workgroup times the resident workgroups.  BN statistics are accumulated in registers across all tiles of the
+// workgroup and reduced once at the end.
+template <typename T, int TM>
+struct GTile {
+    static constexpr int CE = Tr<T>::CE;
+    static constexpr int CPR = BK / CE;
+    static constexpr int LDR = BK + Tr<T>::PADE;
+    static constexpr int WM = TM / 32, WP = 4 / WM, NI = TP / (32 * WP);
+    static constexpr int XR = (TP * CPR) / 256;
+    static constexpr int WCH = TM * CPR;
+    static constexpr int WR = (WCH + 255) / 256;
+};
 
+// loader position: which (tile, k-slice) is fetched next, plus the per-row pixel decode of that tile
+template <typename T, int TM>
+struct GLoader {
+    long long tile;
+    int kt, tap, cch;
+    bool valid;
+    long long xbase[GTile<T, TM>::XR];
+    int xh0[GTile<T, TM>::XR], xw0[GTile<T, TM>::XR];
+};
+
+template <typename T, int TM>
+__device__ __forceinline__ void g_setup_rows(const GConvP& p, GLoader<T, TM>& L, int tid, int kc) {
+    using G = GTile<T, TM>;
+    L.tap = (kc * G::CE) / p.C;
+    L.cch = (kc * G::CE) % p.C;
+    const long long m0 = L.tile * TP;
+#pragma unroll
+    for (int r = 0; r < G::XR; ++r) {
+        const int row = (tid + 256 * r) / G::CPR;
+        const long long m = m0 + row;
+        if (m < p.Mtotal) {
+            if (p.x_linear) {
+                L.xbase[r] = m; L.xh0[r] = 0; L.xw0[r] = 0;
+            } else {
+                const unsigned mu = (unsigned)m;
+                unsigned t = mu / (unsigned)p.OW;
+                int ow = (int)(mu - t * (unsigned)p.OW);
+                unsigned n = t / (unsigned)p.OH;
+                int oh = (int)(t - n * (unsigned)p.OH);
+                L.xbase[r] = (long long)n * p.XH * p.XW;
+                L.xh0[r] = oh * p.ish; L.xw0[r] = ow * p.isw;
+            }
+        } else { L.xbase[r] = -1; L.xh0[r] = 0; L.xw0[r] = 0; }
+    }
+}
+
+// advance the loader by one step (possibly into the next tile of the band) and issue its global loads
+template <typename T, int TM, typename KT>
+__device__ __forceinline__ void g_issue(const GConvP& p, GLoader<T, TM>& L, bool first, int nk, long long ntiles, unsigned lstride,
+                                        KT ktab, const T* __restrict__ X, const T* __restrict__ Wg, int tid, int kc, int n0,
+                                        uint4 (&xreg)[GTile<T, TM>::XR], uint4 (&wreg)[GTile<T, TM>::WR]) {
+    using G = GTile<T, TM>;
+    if (first) {
+        L.valid = L.tile < ntiles;
+        if (L.valid) g_setup_rows<T, TM>(p, L, tid, kc);
+    } else if (L.valid) {
+        ++L.kt;
+        if (L.kt == nk) {
+            L.kt = 0;
+            L.tile += lstride;
+            L.valid = L.tile < ntiles;
+            if (L.valid) g_setup_rows<T, TM>(p, L, tid, kc);
+        } else {
+            L.cch += BK;
+            while (L.cch >= p.C) { L.cch -= p.C; ++L.tap; }
+        }
+    }
+    if (!L.valid) return;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const bool tap_ok = L.tap < p.ntaps;
+    const int tq = tap_ok ? L.tap : 0;
+    const int dh = ktab[tq], dw = ktab[MAX_TAPS + tq];
+#pragma unroll
+    for (int r = 0; r < G::XR; ++r) {
+        xreg[r] = zero4;
+        if (p.x_linear) {
+            if (tap_ok && L.xbase[r] >= 0) xreg[r] = *reinterpret_cast<const uint4*>(X + L.xbase[r] * p.ldx + L.cch);
+        } else {
+            int ih = L.xh0[r] + dh, iw = L.xw0[r] + dw;
+            bool ok = tap_ok && L.xbase[r] >= 0 && ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW;
+            if (ok) xreg[r] = *reinterpret_cast<const uint4*>(X + (L.xbase[r] + (long long)ih * p.XW + iw) * p.ldx + L.cch);
+        }
+    }
+    const int wcol = tap_ok ? ktab[2 * MAX_TAPS + tq] * p.C + L.cch : 0;
+#pragma unroll
+    for (int r = 0; r < G::WR; ++r) {
+        int q = tid + 256 * r;
+        int row = q / G::CPR;
+        wreg[r] = zero4;
+        if (q < G::WCH && tap_ok && (n0 + row) < p.Nout)
+            wreg[r] = *reinterpret_cast<const uint4*>(Wg + (long long)(n0 + row) * p.ldw + wcol);
+    }
+}
+
+template <typename T, int TM>
+__device__ __forceinline__ void g_stage(T* sW, T* sX, int buf, int tid, int kc, const uint4 (&xreg)[GTile<T, TM>::XR],
+                                        const uint4 (&wreg)[GTile<T, TM>::WR]) {
+    using G = GTile<T, TM>;
+    T* dX = sX + buf * TP * G::LDR;
+    T* dW = sW + buf * TM * G::LDR;
+#pragma unroll
+    for (int r = 0; r < G::XR; ++r) {
+        int row = (tid + 256 * r) / G::CPR;
+        *reinterpret_cast<uint4*>(dX + row * G::LDR + kc * G::CE) = xreg[r];
+    }
+#pragma unroll
+    for (int r = 0; r < G::WR; ++r) {
+        int q = tid + 256 * r;
+        if (q < G::WCH) *reinterpret_cast<uint4*>(dW + (q / G::CPR) * G::LDR + kc * G::CE) = wreg[r];
+    }
+}
+
+template <typename T, int TM>
+__device__ __forceinline__ void g_mma(const T* sW, const T* sX, int buf, int wm, int wp, int lane,
+                                      float16v (&acc)[GTile<T, TM>::NI]) {
+    using G = GTile<T, TM>;
+    const T* cW = sW + buf * TM * G::LDR + (wm * 32 + (lane & 31)) * G::LDR + (lane >> 5) * 8;
+    const T* cX = sX + buf * TP * G::LDR + (wp * G::NI * 32 + (lane & 31)) * G::LDR + (lane >> 5) * 8;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+        auto a = lds_frag(cW + kk * 16);
+#pragma unroll
+        for (int ni = 0; ni < G::NI; ++ni) {
+            auto b = lds_frag(cX + ni * 32 * G::LDR + kk * 16);
+            mma_step(a, b, acc[ni]);
+        }
+    }
+}
+
+// tile finished: acc[ni][r] holds channel = cbase + 8*(r>>2) + (r&3), pixel = m0 + wp*NI*32 + ni*32 + (lane&31)
+template <typename T, int TM, int EM>
+__device__ __forceinline__ void g_epilogue(const GConvP& p, long long tile, int wp, int lane, int cbase, bool want_stats,
+                                           float16v (&acc)[GTile<T, TM>::NI], float (&ssum)[16], float (&ssq)[16]) {
+    using G = GTile<T, TM>;
+    const long long m0 = tile * TP;
+#pragma unroll
+    for (int ni = 0; ni < G::NI; ++ni) {
+        const long long m = m0 + wp * G::NI * 32 + ni * 32 + (lane & 31);
+        const bool pv = m < p.Mtotal;
+        long long yo = 0;
+        if (pv) {
+            if (p.y_linear) yo = m * p.ldy;
+            else {
+                const unsigned mu = (unsigned)m;
+                unsigned t = mu / (unsigned)p.OW;
+                int ow = (int)(mu - t * (unsigned)p.OW);
+                unsigned nn = t / (unsigned)p.OH;
+                int oh = (int)(t - nn * (unsigned)p.OH);
+                yo = (((long long)nn * p.YH + (oh * p.osh + p.oah)) * p.YW + (ow * p.osw + p.oaw)) * p.ldy;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = cbase + 8 * g;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
+            if constexpr (EM == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (c + e < p.Nout) {
+                        float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
+                        float u = v[e] * sc + sh;
+                        v[e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
+                    }
+                }
+            }
+            if constexpr (EM == 3) {
+                // YOLOHead: fp32 logits + bias, NHWC [pixel][ldy] (ldy = Cout rounded up to 8), 16-byte stores;
+                // the (B, na, ny, nx, no) tensor the loss / decode see is a strided view of this buffer
+                if (pv && c < p.ldy) {
+                    float* Y = reinterpret_cast<float*>(p.y) + m * p.ldy + c;
+                    float4v f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = v[e] + ((p.shift && c + e < p.Nout) ? p.shift[c + e] : 0.0f);
+                    *reinterpret_cast<float4v*>(Y) = f;
+                }
+                continue;
+            }
+            if (want_stats) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
+                    ssum[g * 4 + e] += q;
+                    ssq[g * 4 + e] += q * q;
+                }
+            }
+            if (pv) {
+                T* Y = reinterpret_cast<T*>(p.y) + yo + c;
+                if (c + 3 < p.Nout && (p.ldy & 3) == 0) {
+                    if constexpr (EM == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)Y[e];
+                    }
+                    if constexpr (sizeof(T) == 2) {
+                        half4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+                        *reinterpret_cast<half4*>(Y) = h;
+                    } else {
+                        float4v f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = v[e];
+                        *reinterpret_cast<float4v*>(Y) = f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < p.Nout) Y[e] = (T)(EM == 1 ? v[e] + (float)Y[e] : v[e]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int TM>
+__device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int tid, int lane, int wm, int n0, unsigned slot,
+                                              const float (&ssum)[16], const float (&ssq)[16]) {
+    for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float a = ssum[r], b = ssq[r];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            a += __shfl_xor(a, off);
+            b += __shfl_xor(b, off);
+        }
+        if ((lane & 31) == 0) {
+            int cl = wm * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);
+            atomicAdd(&sStat[cl], a);
+            atomicAdd(&sStat[TM + cl], b);
+        }
+    }
+    __syncthreads();
+    // replicated accumulators: workgroups spread over stat_reps copies so L2 atomics do not serialise
+    float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
+    for (int i = tid; i < TM; i += 256) {
+        if (n0 + i < p.Nout) {
+            atomicAdd(&st[n0 + i], sStat[i]);
+            atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
+        }
+    }
+}
+
+template <typename T, int TM, int EM>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 128 ? 2 : (TM == 64 ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
+    using G = GTile<T, TM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* sW = reinterpret_cast<T*>(smem_raw);                 // [2][TM][LDR]
-    T* sX = sW + 2 * TM * LDR;                              // [2][TP][LDR]
-    float* sStat = reinterpret_cast<float*>(sX + 2 * TP * LDR);   // [2][TM]
+    T* sW = reinterpret_cast<T*>(smem_raw);                          // [2][TM][LDR]
+    T* sX = sW + 2 * TM * G::LDR;                                    // [2][TP][LDR]
+    float* sStat = reinterpret_cast<float*>(sX + 2 * TP * G::LDR);   // [2][TM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wp = wave / WM;
+    const int wm = wave % G::WM, wp = wave / G::WM;
     const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ Wg = reinterpret_cast<const T*>(p.w);
 
-    // ---- block -> (channel tile, first pixel tile, tile stride).  Workgroups are dealt round-robin to the 8 XCDs;
-    // all channel tiles of one pixel tile are given to the SAME XCD, back to back, so the gathered input tile is
-    // fetched into that XCD's L2 once.
-    const unsigned L = blockIdx.x;
-    const unsigned xcd = L & 7u, idx = L >> 3;
+    // ---- block -> (channel tile, XCD band, slot).  Workgroups are dealt round-robin to the 8 XCDs; all channel
+    // tiles of one pixel tile go to the SAME XCD back to back, and each XCD walks a contiguous band of pixel tiles.
+    const unsigned Lb = blockIdx.x;
+    const unsigned xcd = Lb & 7u, idx = Lb >> 3;
     const unsigned nt = idx % (unsigned)p.ntn;
-    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;     // pixel-tile slot of this workgroup
-    const unsigned nslots = (unsigned)p.nslots;                   // = gridDim.x / ntn
+    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
     const int n0 = (int)nt * TM;
     const long long ntiles_all = (p.Mtotal + TP - 1) / TP;
-    // Each XCD walks a CONTIGUOUS band of pixel tiles (its 32 CUs x resident workgroups cover neighbouring image
-    // rows at the same time), so the 3x3 halo rows that neighbouring tiles re-read are hits in that XCD's own L2
-    // instead of round trips to the die-level cache.
-    const long long tpx = (ntiles_all + 7) / 8;                  // tiles per XCD band
+    const long long tpx = (ntiles_all + 7) / 8;
     const long long band_lo = (long long)xcd * tpx;
-    const long long ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;   // band end (exclusive)
-    const unsigned lslot = idx / (unsigned)p.ntn;                 // slot inside the band
-    const unsigned lstride = nslots / 8u;
+    const long long ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
+    const unsigned lslot = idx / (unsigned)p.ntn;
+    const unsigned lstride = (unsigned)p.nslots / 8u;
 
     typedef __attribute__((address_space(4))) const signed char* kptr_t;
     const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh);
+    const int kc = tid % G::CPR;
 
-    // ---- per-thread loader state (for the tile being LOADED)
-    const int kc = tid % CPR;
-    int tap = 0, cch = 0;
-    long long xbase[XR];
-    int xh0[XR], xw0[XR];
-    uint4 xreg[XR], wreg[WR];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    auto setup_rows = [&](long long tile) {
-        tap = (kc * CE) / p.C;
-        cch = (kc * CE) % p.C;
-        const long long m0 = tile * TP;
+    float16v acc[G::NI];
 #pragma unroll
-        for (int r = 0; r < XR; ++r) {
-            const int row = (tid + 256 * r) / CPR;
-            const long long m = m0 + row;
-            if (m < p.Mtotal) {
-                if (p.x_linear) {                     // 1x1 / stride 1: input pixel == output pixel
-                    xbase[r] = m; xh0[r] = 0; xw0[r] = 0;
-                } else {
-                    const unsigned mu = (unsigned)m;
-                    unsigned t = mu / (unsigned)p.OW;
-                    int ow = (int)(mu - t * (unsigned)p.OW);
-                    unsigned n = t / (unsigned)p.OH;
-                    int oh = (int)(t - n * (unsigned)p.OH);
-                    xbase[r] = (long long)n * p.XH * p.XW;
-                    xh0[r] = oh * p.ish; xw0[r] = ow * p.isw;
-                }
-            } else { xbase[r] = -1; xh0[r] = 0; xw0[r] = 0; }
-        }
-    };
-
-    float16v acc[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < G::NI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const bool want_stats = (EM == 0) && (p.stats != nullptr);
@@ -166,203 +369,63 @@ __global__ __launch_bounds__(256) void k_gconv(GConvP p) {
     if (nk < 1) nk = 1;                      // K == 0 (tap-less dgrad residue class): one all-zero step
     long long cur_tile = band_lo + lslot;
     if (cur_tile >= ntiles) return;
-    long long ld_tile = cur_tile;
-    int ld_kt = 0, cur_kt = 0, buf = 0;
-    bool first = true;
-    while (true) {
-        // ---------------- issue the loads of the NEXT step (or of the very first one)
-        bool more;
-        if (first) {
-            more = true;
-            setup_rows(ld_tile);
-        } else {
-            ++ld_kt;
-            if (ld_kt == nk) { ld_kt = 0; ld_tile += lstride; }
-            more = ld_tile < ntiles;
-            if (more) {
-                if (ld_kt == 0) setup_rows(ld_tile);
-                else {
-                    cch += BK;
-                    while (cch >= p.C) { cch -= p.C; ++tap; }
-                }
-            }
-        }
-        if (more) {
-            const bool tap_ok = tap < p.ntaps;
-            const int tq = tap_ok ? tap : 0;
-            const int dh = ktab[tq], dw = ktab[MAX_TAPS + tq];
-#pragma unroll
-            for (int r = 0; r < XR; ++r) {
-                xreg[r] = zero4;
-                if (p.x_linear) {
-                    if (tap_ok && xbase[r] >= 0) xreg[r] = *reinterpret_cast<const uint4*>(X + xbase[r] * p.ldx + cch);
-                } else {
-                    int ih = xh0[r] + dh, iw = xw0[r] + dw;
-                    bool ok = tap_ok && xbase[r] >= 0 && ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW;
-                    if (ok) xreg[r] = *reinterpret_cast<const uint4*>(X + (xbase[r] + (long long)ih * p.XW + iw) * p.ldx + cch);
-                }
-            }
-            const int wcol = tap_ok ? ktab[2 * MAX_TAPS + tq] * p.C + cch : 0;
-#pragma unroll
-            for (int r = 0; r < WR; ++r) {
-                int q = tid + 256 * r;
-                int row = q / CPR;
-                wreg[r] = zero4;
-                if (q < WCH && tap_ok && (n0 + row) < p.Nout)
-                    wreg[r] = *reinterpret_cast<const uint4*>(Wg + (long long)(n0 + row) * p.ldw + wcol);
-            }
-        }
-        // ---------------- MFMAs of the current step
-        if (!first) {
-            const T* cW = sW + buf * TM * LDR + (wm * 32 + (lane & 31)) * LDR + (lane >> 5) * 8;
-            const T* cX = sX + buf * TP * LDR + (wp * NI * 32 + (lane & 31)) * LDR + (lane >> 5) * 8;
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                auto a = lds_frag(cW + kk * 16);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    auto b = lds_frag(cX + ni * 32 * LDR + kk * 16);
-                    mma_step(a, b, acc[ni]);
-                }
-            }
-            // ------------ tile finished: epilogue.  acc[ni][r]: channel = cbase + 8*(r>>2) + (r&3), pixel = .. + (lane&31)
-            if (cur_kt == nk - 1) {
-                const long long m0 = cur_tile * TP;
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const long long m = m0 + wp * NI * 32 + ni * 32 + (lane & 31);
-                    const bool pv = m < p.Mtotal;
-                    long long yo = 0;
-                    int n = 0, oh = 0, ow = 0;
-                    if (pv) {
-                        if (p.y_linear) yo = m * p.ldy;
-                        else {
-                            const unsigned mu = (unsigned)m;
-                            unsigned t = mu / (unsigned)p.OW;
-                            ow = (int)(mu - t * (unsigned)p.OW);
-                            unsigned nn = t / (unsigned)p.OH;
-                            oh = (int)(t - nn * (unsigned)p.OH);
-                            n = (int)nn;
-                            yo = (((long long)n * p.YH + (oh * p.osh + p.oah)) * p.YW + (ow * p.osw + p.oaw)) * p.ldy;
-                        }
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c = cbase + 8 * g;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
-                        if constexpr (EM == 2) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (c + e < p.Nout) {
-                                    float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
-                                    float u = v[e] * sc + sh;
-                                    v[e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
-                                }
-                            }
-                        }
-                        if constexpr (EM == 3) {
-                            // YOLOHead: fp32 logits + bias, NHWC [pixel][ldy] (ldy = Cout rounded up to 8), 16-byte stores;
-                            // the (B, na, ny, nx, no) tensor the loss / decode see is a strided view of this buffer
-                            if (pv && c < p.ldy) {
-                                float* Y = reinterpret_cast<float*>(p.y) + m * p.ldy + c;
-                                float4v f;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) f[e] = v[e] + ((p.shift && c + e < p.Nout) ? p.shift[c + e] : 0.0f);
-                                *reinterpret_cast<float4v*>(Y) = f;
-                            }
-                            continue;
-                        }
-                        if (want_stats) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
-                                ssum[g * 4 + e] += q;
-                                ssq[g * 4 + e] += q * q;
-                            }
-                        }
-                        if (pv) {
-                            T* Y = reinterpret_cast<T*>(p.y) + yo + c;
-                            if (c + 3 < p.Nout && (p.ldy & 3) == 0) {
-                                if constexpr (EM == 1) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] += (float)Y[e];
-                                }
-                                if constexpr (sizeof(T) == 2) {
-                                    half4 h;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
-                                    *reinterpret_cast<half4*>(Y) = h;
-                                } else {
-                                    float4v f;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) f[e] = v[e];
-                                    *reinterpret_cast<float4v*>(Y) = f;
-                                }
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (c + e < p.Nout) Y[e] = (T)(EM == 1 ? v[e] + (float)Y[e] : v[e]);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // ---------------- stage the prefetched step into the other LDS buffer
-        const int nb = first ? 0 : (buf ^ 1);
-        if (more) {
-            T* dX = sX + nb * TP * LDR;
-            T* dW = sW + nb * TM * LDR;
-#pragma unroll
-            for (int r = 0; r < XR; ++r) {
-                int row = (tid + 256 * r) / CPR;
-                *reinterpret_cast<uint4*>(dX + row * LDR + kc * CE) = xreg[r];
-            }
-#pragma unroll
-            for (int r = 0; r < WR; ++r) {
-                int q = tid + 256 * r;
-                if (q < WCH) *reinterpret_cast<uint4*>(dW + (q / CPR) * LDR + kc * CE) = wreg[r];
-            }
-        }
+    int cur_kt = 0;
+
+    GLoader<T, TM> L;
+    L.tile = cur_tile; L.kt = 0; L.tap = 0; L.cch = 0; L.valid = true;
+    // Prefetch depth: two register stages for the wide tiles; the 32-channel tile keeps one (its 4 workgroups
+    // per CU hide latency better than a deeper pipeline at 3 per CU -- measured).
+    constexpr bool DEEP = (TM != 32);
+    uint4 xA[G::XR], wA[G::WR];
+
+    if constexpr (DEEP) {
+        uint4 xB[G::XR], wB[G::WR];
+        // prologue: step 0 -> regs A -> LDS[0]; step 1 -> regs B (in flight)
+        g_issue<T, TM>(p, L, true, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xA, wA);
+        g_stage<T, TM>(sW, sX, 0, tid, kc, xA, wA);
+        g_issue<T, TM>(p, L, false, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xB, wB);
+        bool next_valid = L.valid;               // regs B hold a real step
         __syncthreads();
-        if (!more) break;
-        if (first) { first = false; cur_tile = ld_tile; cur_kt = 0; buf = 0; }
-        else {
+        // One half-iteration: compute the step in LDS[BUF]; regs `xn/wn` hold the following step (staged into
+        // LDS[BUF^1] afterwards); regs `xf/wf` are free and receive the loads of the step after that.
+#define G_HALF(BUF, xf, wf, xn, wn)                                                                              \
+        {                                                                                                        \
+            const bool have_next = next_valid;                                                                   \
+            g_issue<T, TM>(p, L, false, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xf, wf);                  \
+            next_valid = L.valid;                                                                                \
+            g_mma<T, TM>(sW, sX, BUF, wm, wp, lane, acc);                                                        \
+            if (cur_kt == nk - 1) g_epilogue<T, TM, EM>(p, cur_tile, wp, lane, cbase, want_stats, acc, ssum, ssq); \
+            if (have_next) g_stage<T, TM>(sW, sX, (BUF) ^ 1, tid, kc, xn, wn);                                   \
+            __syncthreads();                                                                                     \
+            if (!have_next) break;                                                                               \
+            ++cur_kt;                                                                                            \
+            if (cur_kt == nk) { cur_kt = 0; cur_tile += lstride; }                                               \
+        }
+        while (true) {
+            G_HALF(0, xA, wA, xB, wB)
+            G_HALF(1, xB, wB, xA, wA)
+        }
+#undef G_HALF
+    } else {
+        g_issue<T, TM>(p, L, true, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xA, wA);
+        g_stage<T, TM>(sW, sX, 0, tid, kc, xA, wA);
+        __syncthreads();
+        int buf = 0;
+        while (true) {
+            g_issue<T, TM>(p, L, false, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xA, wA);   // step s+1
+            const bool have_next = L.valid;
+            g_mma<T, TM>(sW, sX, buf, wm, wp, lane, acc);
+            if (cur_kt == nk - 1) g_epilogue<T, TM, EM>(p, cur_tile, wp, lane, cbase, want_stats, acc, ssum, ssq);
+            if (have_next) g_stage<T, TM>(sW, sX, buf ^ 1, tid, kc, xA, wA);
+            __syncthreads();
+            if (!have_next) break;
+            buf ^= 1;
             ++cur_kt;
             if (cur_kt == nk) { cur_kt = 0; cur_tile += lstride; }
-            buf ^= 1;
         }
     }
 
-    if (want_stats) {
-        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
-        __syncthreads();
-        // one reduction per workgroup: over the 32 pixel lanes of each half-wave, then LDS, then one replica
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = ssum[r], b = ssq[r];
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                a += __shfl_xor(a, off);
-                b += __shfl_xor(b, off);
-            }
-            if ((lane & 31) == 0) {
-                int cl = wm * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);
-                atomicAdd(&sStat[cl], a);
-                atomicAdd(&sStat[TM + cl], b);
-            }
-        }
-        __syncthreads();
-        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
-        for (int i = tid; i < TM; i += 256) {
-            if (n0 + i < p.Nout) {
-                atomicAdd(&st[n0 + i], sStat[i]);
-                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
-            }
-        }
-    }
+    if (want_stats) g_stats_flush<T, TM>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -677,7 +740,8 @@ static int launch_gconv_em(GConvP p, hipStream_t s) {
     const long long ntiles = (p.Mtotal + TP - 1) / TP;
     p.ntn = (p.Nout + TM - 1) / TM;
     // persistent grid: ~4 workgroups per CU in total, pixel-tile slots a multiple of the 8 XCDs
-    long long want_slots = (long long)num_cus() * 4 / p.ntn;
+    static const int bpc = getenv("AYOLO_GCONV_BPC") ? atoi(getenv("AYOLO_GCONV_BPC")) : 4;
+    long long want_slots = (long long)num_cus() * bpc / p.ntn;
     if (want_slots < 8) want_slots = 8;
     long long slots = ntiles < want_slots ? ntiles : want_slots;
     slots = (slots + 7) / 8 * 8;
