@@ -1102,6 +1102,166 @@ __global__ __launch_bounds__(256) void k_wgrad(WGradP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Halo-tiled wgrad for multi-tap stride-1 convs (fp16).  The generic k_wgrad re-reads dy once per 128-column tile
+// of dw and x once per tap (PMC: 2.4x the algorithmic HBM bytes over a training step).  Here a workgroup owns
+// (TM output channels) x (one 32-channel chunk of the input) x ALL taps: per 8x16 pixel tile it stages the dy
+// tile and the x patch (with halo) in LDS once and every tap's MFMAs read shifted fragments of the same patch
+// through the transposing LDS read.
+// ---------------------------------------------------------------------------------------------------
+#define WD_MAXT 9
+struct WGradDP {
+    WGradP w;
+    int tyn, txn, PH, PW, dh_min, dw_min;
+    long long tiles_total, tiles_per_split;
+};
+
+template <int TM>
+__global__ __launch_bounds__(256) void k_wgrad_d(WGradDP dp) {
+    typedef half_t T;
+    const WGradP& p = dp.w;
+    constexpr int LDY = TM + 8;
+    constexpr int LDP = DCK + 8;
+    constexpr int WM = TM / 32, WT = 4 / WM;          // waves along channels / along taps
+    constexpr int TPW = (WD_MAXT + WT - 1) / WT;      // taps per wave (upper bound)
+    constexpr int YCH = TP * (TM / 8);                // dy chunks per tile
+    constexpr int YR = YCH / 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sY = reinterpret_cast<T*>(smem_raw);           // [128][LDY]
+    T* sP = sY + TP * LDY;                            // [PH*PW][LDP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wt = wave / WM;
+    const int chunk = blockIdx.x, n0 = blockIdx.y * TM;
+    const long long t_beg = (long long)blockIdx.z * dp.tiles_per_split;
+    const long long t_end = min(dp.tiles_total, t_beg + dp.tiles_per_split);
+    if (t_beg >= t_end) return;
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+    const int tiles_per_img = dp.tyn * dp.txn;
+    const int patch_chunks = dp.PH * dp.PW * 4;
+
+    float16v acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int q = lane & 15;
+    const int csub = ((lane >> 4) & 1) * 16;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    for (long long tile = t_beg; tile < t_end; ++tile) {
+        const int n = (int)(tile / tiles_per_img);
+        const int rr = (int)(tile - (long long)n * tiles_per_img);
+        const int ty = rr / dp.txn, tx = rr - ty * dp.txn;
+        // ---- stage dy tile: pixel j = (oy, ox), TM channels
+#pragma unroll
+        for (int r = 0; r < YR; ++r) {
+            const int qq = tid + 256 * r;
+            const int j = qq / (TM / 8), c8 = qq % (TM / 8);
+            const int oh = ty * DTH + j / DTW, ow = tx * DTW + j % DTW;
+            uint4 v = zero4;
+            if (oh < p.OH && ow < p.OW && (n0 + c8 * 8) < p.N)
+                v = *reinterpret_cast<const uint4*>(DY + (((long long)n * p.OH + oh) * p.OW + ow) * p.ldy + n0 + c8 * 8);
+            *reinterpret_cast<uint4*>(sY + j * LDY + c8 * 8) = v;
+        }
+        // ---- stage x patch (32 channels of this chunk, halo included)
+        const int ih0 = ty * DTH * p.sh + dp.dh_min, iw0 = tx * DTW * p.sw + dp.dw_min;
+        for (int qq = tid; qq < patch_chunks; qq += 256) {
+            const int pix = qq >> 2, kc4 = qq & 3;
+            const int py = pix / dp.PW, px = pix - py * dp.PW;
+            const int ih = ih0 + py, iw = iw0 + px;
+            uint4 v = zero4;
+            if (ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW)
+                v = *reinterpret_cast<const uint4*>(X + (((long long)n * p.XH + ih) * p.XW + iw) * p.ldx + chunk * DCK + kc4 * 8);
+            *reinterpret_cast<uint4*>(sP + pix * LDP + kc4 * 8) = v;
+        }
+        __syncthreads();
+        // ---- MFMAs: k = the 128 pixels of the tile, 16 per step (one tile row oy = kk)
+#pragma unroll
+        for (int kk = 0; kk < TP / 16; ++kk) {
+            const int k0 = kk * 16 + (lane >> 5) * 8;
+            half8 a = tr_frag(sY, LDY, k0, wm * 32 + csub, lane);
+            const int ox0 = (lane >> 5) * 8 + (q >> 2);            // first of this lane's 2 x 4 pixel rows
+#pragma unroll
+            for (int ti = 0; ti < TPW; ++ti) {
+                const int t = wt + ti * WT;
+                if (t < p.ntaps) {
+                    const int dh = p.dh[t] - dp.dh_min, dw = p.dw_[t] - dp.dw_min;
+                    const T* b0 = sP + ((kk * p.sh + dh) * dp.PW + (ox0 * p.sw + dw)) * LDP + csub + (q & 3) * 4;
+                    fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(b0));
+                    fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(b0 + 4 * p.sw * LDP));
+                    half8 b;
+                    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
+                    b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- acc[ti][r]: out channel = n0 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); dw column = t*C + chunk*32 + (lane&31)
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int t = wt + ti * WT;
+        if (t >= p.ntaps) continue;
+        const int col = t * p.C + chunk * DCK + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = n0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (row < p.N) unsafeAtomicAdd(&p.dw[(long long)row * p.K + col], acc[ti][r] * p.alpha);
+        }
+    }
+}
+
+template <int TM>
+static int launch_wgrad_d(const WGradDP& dp, dim3 grid, hipStream_t s) {
+    size_t lds = (size_t)(TP * (TM + 8) + dp.PH * dp.PW * (DCK + 8)) * sizeof(half_t);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_d<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((k_wgrad_d<TM>), grid, dim3(256), lds, s, dp);
+    AY_CHECK_LAUNCH("k_wgrad_d");
+    return AYOLO_OK;
+}
+
+// returns 1 when the halo-tiled kernel was launched, 0 when it does not apply, < 0 on error
+static int try_wgrad_d(const ayolo_conv_desc* d, const WGradP& p, hipStream_t s) {
+    static const bool disabled = getenv("AYOLO_NO_WGRAD_D") != nullptr;
+    // one workgroup per 32-channel chunk re-reads dy C/32 times: only a win for single-chunk layers (measured)
+    if (disabled || d->dtype != AYOLO_F16 || p.ntaps < 2 || p.ntaps > WD_MAXT || p.C != DCK) return 0;
+    if (p.sh != 1 || p.sw != 1 || p.OH < DTH || p.OW < DTW || p.ldy % 8 != 0) return 0;
+    WGradDP dp;
+    dp.w = p;
+    int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
+    for (int t = 0; t < p.ntaps; ++t) {
+        dh_min = p.dh[t] < dh_min ? p.dh[t] : dh_min; dh_max = p.dh[t] > dh_max ? p.dh[t] : dh_max;
+        dw_min = p.dw_[t] < dw_min ? p.dw_[t] : dw_min; dw_max = p.dw_[t] > dw_max ? p.dw_[t] : dw_max;
+    }
+    dp.tyn = (p.OH + DTH - 1) / DTH; dp.txn = (p.OW + DTW - 1) / DTW;
+    const double util = (double)p.OH * p.OW / ((double)dp.tyn * DTH * dp.txn * DTW);
+    if (util < 0.65) return 0;
+    dp.PH = (DTH - 1) * p.sh + (dh_max - dh_min) + 1;
+    dp.PW = (DTW - 1) * p.sw + (dw_max - dw_min) + 1;
+    dp.dh_min = dh_min; dp.dw_min = dw_min;
+    dp.tiles_total = (long long)p.B * dp.tyn * dp.txn;
+    const int tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
+    const long long nxy = (long long)(p.C / DCK) * ((p.N + tm - 1) / tm);
+    long long splits = (2048 + nxy - 1) / nxy;
+    if (splits > dp.tiles_total / 2) splits = dp.tiles_total / 2;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    dp.tiles_per_split = (dp.tiles_total + splits - 1) / splits;
+    splits = (dp.tiles_total + dp.tiles_per_split - 1) / dp.tiles_per_split;
+    dim3 grid((unsigned)(p.C / DCK), (unsigned)((p.N + tm - 1) / tm), (unsigned)splits);
+    int rc = tm == 32 ? launch_wgrad_d<32>(dp, grid, s) : (tm == 64 ? launch_wgrad_d<64>(dp, grid, s) : launch_wgrad_d<128>(dp, grid, s));
+    return rc == AYOLO_OK ? 1 : rc;
+}
+
 template <typename T, int TM>
 static int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
     constexpr int LDY = TM + Tr<T>::PADE, LDX = TNW + Tr<T>::PADE;
@@ -1137,6 +1297,10 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
             p.dh[i * d->kw + j] = (signed char)(i - d->ph);
             p.dw_[i * d->kw + j] = (signed char)(j - d->pw);
         }
+    {
+        int rd = try_wgrad_d(d, p, (hipStream_t)s);
+        if (rd != 0) return rd < 0 ? rd : AYOLO_OK;
+    }
     const int tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
     const long long tiles = (long long)((p.K + TNW - 1) / TNW) * ((p.N + tm - 1) / tm);
     // split the pixel reduction so that ~4 blocks per CU are in flight, each with >= 8 reduction steps

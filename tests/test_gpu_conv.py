@@ -15,6 +15,9 @@ SHAPES = [
     (2, 256, 128, 1, 1, 0, 8, 8),
     (1, 64, 64, 3, 1, 1, 33, 9),
     (2, 16, 48, 3, 1, 1, 12, 12),      # Cout not a multiple of 32
+    (2, 32, 64, 3, 1, 1, 24, 32),      # halo-tiled direct fwd/dgrad + halo-tiled wgrad (8x16 tiles, exact fit)
+    (1, 64, 160, 3, 1, 1, 20, 40),     # halo-tiled, ragged tiles, Cout > 128
+    (2, 128, 32, 3, 1, 1, 8, 16),      # halo-tiled, 4 channel chunks, single tile per image
 ]
 
 
