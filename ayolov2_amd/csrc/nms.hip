@@ -8,7 +8,7 @@
 #include "common.h"
 #include <hipcub/hipcub.hpp>
 
-#define CAND_ROWS 32
+#define CAND_ROWS 64
 
 // ---------------------------------------------------------------------------------------------------
 // Stage A: candidates
@@ -34,14 +34,19 @@ __device__ __forceinline__ bool class_ok(const uint64_t* m, int c) {
 }
 
 __global__ __launch_bounds__(256) void k_candidates(CandParams p) {
+    // Two passes over the chunk held in LDS: (1) count hits, (2) emit them.  Slots are reserved with ONE global
+    // atomic per workgroup (plus one per image the chunk touches) -- a per-hit or per-wave atomic on the 1 + B
+    // counters serialises in L2 and was 95 % of this kernel's time.
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ unsigned s_total, s_base, s_local;
+    __shared__ unsigned s_img_cnt[2];
     const int nc = p.no - 5;
     const int64_t total_rows = (int64_t)p.B * p.rows_per_img;
     const int64_t r0 = (int64_t)blockIdx.x * CAND_ROWS;
     const int nrows = (int)min((int64_t)CAND_ROWS, total_rows - r0);
     const int tid = threadIdx.x;
+    if (tid == 0) { s_total = 0; s_local = 0; s_img_cnt[0] = 0; s_img_cnt[1] = 0; }
 
-    // coalesced stream of the chunk into LDS
     const int nelem = nrows * p.no;
     if (p.rows == nullptr) {
         const float* src = p.pred + r0 * p.no;   // rows_per_img == N: flattened rows are contiguous
@@ -57,16 +62,60 @@ __global__ __launch_bounds__(256) void k_candidates(CandParams p) {
     }
     __syncthreads();
 
-    const int pr = tid >> 3, sub = tid & 7;
+    // a chunk of CAND_ROWS rows spans at most two images (CAND_ROWS <= rows_per_img is checked on the host)
+    const int img0 = (int)(r0 / p.rows_per_img);
+    constexpr int TPR = 256 / CAND_ROWS;         // threads per row
+    const int pr = tid / TPR, sub = tid % TPR;
     const bool row_ok = pr < nrows;
     const int64_t r = r0 + pr;
-    const int img = row_ok ? (int)(r / p.rows_per_img) : 0;
+    const int img = row_ok ? (int)(r / p.rows_per_img) : img0;
     const uint32_t rowpos = row_ok ? (uint32_t)(r - (int64_t)img * p.rows_per_img) : 0u;
     const float* L = lds + pr * p.no;
     const float obj = row_ok ? L[4] : 0.0f;
     const bool pass = row_ok && (!p.require_obj || obj > p.ct);
-    const int lane = tid & 63;
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    float best = -INFINITY;
+    int besti = 0;
+    if (!p.multi_label) {
+        // best class: first maximal index (torch.max semantics), conf = cls*obj computed before the max
+        for (int c = sub; c < nc; c += TPR) {
+            float v = row_ok ? L[5 + c] * obj : -INFINITY;
+            if (v > best) { best = v; besti = c; }
+        }
+        for (int off = 1; off < TPR; off <<= 1) {
+            float ov = __shfl_xor(best, off);
+            int oi = __shfl_xor(besti, off);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+    }
+    const int iters = p.multi_label ? (nc + TPR - 1) / TPR : 1;
+
+    // ---- pass 1: count
+    unsigned mine = 0;
+    for (int it = 0; it < iters; ++it) {
+        bool hit;
+        if (p.multi_label) {
+            int c = sub + it * TPR;
+            float conf = (c < nc && row_ok) ? L[5 + c] * obj : 0.0f;
+            hit = pass && c < nc && conf > p.ct && class_ok(p.class_mask, c);
+        } else {
+            hit = pass && sub == 0 && best > p.ct && class_ok(p.class_mask, besti);
+        }
+        mine += hit ? 1u : 0u;
+    }
+    if (mine) {
+        atomicAdd(&s_total, mine);
+        atomicAdd(&s_img_cnt[img - img0], mine);
+    }
+    __syncthreads();
+    if (tid == 0 && s_total) {
+        s_base = atomicAdd(&p.counters[0], s_total);
+        if (s_img_cnt[0]) atomicAdd(&p.counters[1 + img0], s_img_cnt[0]);
+        if (s_img_cnt[1]) atomicAdd(&p.counters[2 + img0], s_img_cnt[1]);
+    }
+    __syncthreads();
+    if (s_total == 0) return;
+    const unsigned base = s_base;
 
     // box (general.py:297-321 with ratio = wh = 1, pad = 0): c -/+ size/2
     float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
@@ -77,28 +126,14 @@ __global__ __launch_bounds__(256) void k_candidates(CandParams p) {
         x2 = 1.0f * (L[0] + hw) + 0.0f;
         y2 = 1.0f * (L[1] + hh) + 0.0f;
     }
-
-    const int iters = p.multi_label ? (nc + 7) / 8 : 1;
-    float best = -INFINITY;
-    int besti = 0;
-    if (!p.multi_label) {
-        // best class: first maximal index (torch.max semantics), conf = cls*obj computed before the max
-        for (int c = sub; c < nc; c += 8) {
-            float v = row_ok ? L[5 + c] * obj : -INFINITY;
-            if (v > best) { best = v; besti = c; }
-        }
-        for (int off = 1; off < 8; off <<= 1) {
-            float ov = __shfl_xor(best, off);
-            int oi = __shfl_xor(besti, off);
-            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-        }
-    }
+    // ---- pass 2: emit (order inside the workgroup is irrelevant: keys are unique and sorted afterwards)
+    unsigned my_off = mine ? atomicAdd(&s_local, mine) : 0u;
     for (int it = 0; it < iters; ++it) {
         int c;
         float conf;
         bool hit;
         if (p.multi_label) {
-            c = sub + it * 8;
+            c = sub + it * TPR;
             conf = (c < nc && row_ok) ? L[5 + c] * obj : 0.0f;
             hit = pass && c < nc && conf > p.ct && class_ok(p.class_mask, c);
         } else {
@@ -106,28 +141,20 @@ __global__ __launch_bounds__(256) void k_candidates(CandParams p) {
             conf = best;
             hit = pass && sub == 0 && conf > p.ct && class_ok(p.class_mask, c);
         }
-        uint64_t m = __ballot(hit);
-        if (m == 0) continue;
-        uint32_t base = 0;
-        int leader = __ffsll((unsigned long long)m) - 1;
-        if (lane == leader) base = atomicAdd(&p.counters[0], (uint32_t)__popcll(m));
-        base = __shfl(base, leader);
-        if (hit) {
-            atomicAdd(&p.counters[1 + img], 1u);
-            uint32_t slot = base + (uint32_t)__popcll(m & lt_mask);
-            if (slot < p.capacity) {
-                float* d = p.det + (size_t)slot * 6;
-                d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = conf; d[5] = (float)c;
-                uint64_t seq = p.multi_label ? (uint64_t)rowpos * (uint64_t)nc + (uint64_t)c : (uint64_t)rowpos;
-                uint64_t key;
-                if (p.order_by_seq) {
-                    key = ((uint64_t)img << p.seq_bits) | seq;
-                } else {
-                    uint32_t cb = ~__float_as_uint(conf);   // conf > ct >= 0: bits monotonic
-                    key = ((uint64_t)img << (32 + p.seq_bits)) | ((uint64_t)cb << p.seq_bits) | seq;
-                }
-                p.keys[slot] = key;
+        if (!hit) continue;
+        uint32_t slot = base + my_off++;
+        if (slot < p.capacity) {
+            float* d = p.det + (size_t)slot * 6;
+            d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = conf; d[5] = (float)c;
+            uint64_t seq = p.multi_label ? (uint64_t)rowpos * (uint64_t)nc + (uint64_t)c : (uint64_t)rowpos;
+            uint64_t key;
+            if (p.order_by_seq) {
+                key = ((uint64_t)img << p.seq_bits) | seq;
+            } else {
+                uint32_t cb = ~__float_as_uint(conf);   // conf > ct >= 0: bits monotonic
+                key = ((uint64_t)img << (32 + p.seq_bits)) | ((uint64_t)cb << p.seq_bits) | seq;
             }
+            p.keys[slot] = key;
         }
     }
 }
@@ -164,6 +191,7 @@ extern "C" int ayolo_nms_candidates(const float* pred, int B, int N, int no, flo
     }
     CandParams p{pred, B, N, no, conf_thres, multi_label, require_obj, class_mask, rows, rows_per_img,
                  det, keys, counters, capacity, seq_bits, order_by_seq};
+    AY_CHECK_ARG(rows_per_img >= CAND_ROWS || B == 1, "nms_candidates: fewer than %d rows per image with B > 1", CAND_ROWS);
     int64_t total_rows = (int64_t)B * rows_per_img;
     int64_t nblk = cdiv64(total_rows, CAND_ROWS);
     size_t lds = (size_t)CAND_ROWS * no * sizeof(float);
@@ -191,6 +219,12 @@ extern "C" int ayolo_sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out,
                                            end_bit, (hipStream_t)s);
     if (e != hipSuccess) { ayolo_set_error("sort: %s", hipGetErrorString(e)); return AYOLO_ELAUNCH; }
     return AYOLO_OK;
+}
+
+// fills run as kernels on the caller's stream (see csrc/plan.hip: hipMemsetAsync ordering on ROCm 7.2)
+__global__ void k_fill_u32(uint32_t* v, uint32_t n, uint32_t value) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = value;
 }
 
 __global__ void k_iota(uint32_t* v, uint32_t n) {
@@ -501,7 +535,7 @@ __global__ __launch_bounds__(64) void k_iou_colmax(const float* boxes, const flo
 extern "C" int ayolo_iou_colmax(const float* boxes, const float* cls, float offset_scale, uint32_t n, float* colmax,
                                 ayolo_stream s) {
     if (n == 0) return AYOLO_OK;
-    AY_CHECK_HIP(hipMemsetAsync(colmax, 0, (size_t)n * 4, (hipStream_t)s));
+    hipLaunchKernelGGL(k_fill_u32, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, (uint32_t*)colmax, n, 0u);
     hipLaunchKernelGGL(k_iou_colmax, dim3((n + 63) / 64, (n + CM_ROWS - 1) / CM_ROWS), dim3(64), 0, (hipStream_t)s,
                        boxes, cls, offset_scale, n, (int*)colmax);
     AY_CHECK_LAUNCH("k_iou_colmax");
@@ -537,7 +571,7 @@ __global__ __launch_bounds__(64) void k_matrix_decay(const float* boxes, const f
 extern "C" int ayolo_matrix_nms_decay(const float* boxes, const float* cls, float offset_scale, uint32_t n,
                                       const float* colmax, float* decay, ayolo_stream s) {
     if (n == 0) return AYOLO_OK;
-    AY_CHECK_HIP(hipMemsetAsync(decay, 0x7f, (size_t)n * 4, (hipStream_t)s));   // 0x7f7f7f7f: large positive float
+    hipLaunchKernelGGL(k_fill_u32, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, (uint32_t*)decay, n, 0x7f7f7f7fu);   // large positive float
     hipLaunchKernelGGL(k_matrix_decay, dim3((n + 63) / 64, (n + CM_ROWS - 1) / CM_ROWS), dim3(64), 0, (hipStream_t)s,
                        boxes, cls, offset_scale, n, colmax, (int*)decay);
     AY_CHECK_LAUNCH("k_matrix_decay");

@@ -12,6 +12,28 @@ static inline double now_us() {
     return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 
+// Zero fill as an ordinary kernel on the caller's stream.  hipMemsetAsync was observed (ROCm 7.2, null stream) to
+// complete AFTER kernels enqueued behind it when the GPU was idle, wiping partially accumulated BN sums.
+__global__ void k_fill_zero(uint4* p16, size_t n16, unsigned char* tail, size_t ntail) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) p16[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+extern "C" int ayolo_fill_zero(void* ptr, size_t bytes, ayolo_stream s) {
+    if (bytes == 0) return AYOLO_OK;
+    AY_CHECK_ARG(ptr && ((uintptr_t)ptr % 16) == 0, "fill_zero: pointer must be 16-byte aligned");
+    size_t n16 = bytes / 16, ntail = bytes % 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (uint4*)ptr, n16,
+                       (unsigned char*)ptr + n16 * 16, ntail);
+    AY_CHECK_LAUNCH("k_fill_zero");
+    return AYOLO_OK;
+}
+
 extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
     AY_CHECK_ARG(ops || n == 0, "run_ops: null op list");
     static const bool debug_stall = getenv("AYOLO_DEBUG_STALL") != nullptr;
@@ -82,10 +104,7 @@ extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
             rc = ayolo_copy2d(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], o.i[4], s);
             break;
         case AYOLO_OP_MEMSET:
-            if (o.l[0] > 0 && hipMemsetAsync(o.p[0], 0, (size_t)o.l[0], (hipStream_t)s) != hipSuccess) {
-                ayolo_set_error("run_ops: memset failed");
-                rc = AYOLO_ELAUNCH;
-            }
+            rc = ayolo_fill_zero(o.p[0], (size_t)o.l[0], s);
             break;
         case AYOLO_OP_BN_EVAL_AFFINE:
             rc = ayolo_bn_eval_affine((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2], (const float*)o.p[3],

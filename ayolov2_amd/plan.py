@@ -492,6 +492,9 @@ class TrainPlan:
         for p in self.params:
             off, n, view_fn = self.param_grad_view[id(p)]
             g = view_fn(ga.view(off, n))
+            if g.stride() != p.stride() and g.is_contiguous(memory_format=torch.channels_last) and p.dim() == 4 \
+                    and p.shape[2] == 1 and p.shape[3] == 1:
+                g = g.as_strided(p.shape, p.stride())                # 1x1 kernels: same memory, the parameter's strides
             grads.append(g.clone() if p.grad is not None else g)     # never alias an accumulating .grad
         return grads
 

@@ -184,12 +184,16 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_ddp = os.environ.get("AYOLO_FORCE_DDP") == "1"       # exercise the DDP/RCCL path on a single GPU
+    if world > 1 or force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
-    model, run_model, opt, loss_fn, scaler = build_train_objects(args.model, device, world)
+    model, run_model, opt, loss_fn, scaler = build_train_objects(args.model, device, 2 if force_ddp and world == 1 else world)
     gen = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, args.size, args.size, generator=gen).to(device)       # resident in HBM
     targets_cpu = synth_targets(args.batch, 8, gen)              # labels arrive from the CPU loader (data_loader.py:905-908)
@@ -248,7 +252,7 @@ def main():
             out["extra"] = nms_extra(device)
             out["cpu_baseline"] = cpu_baseline(args.model, args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         torch.distributed.destroy_process_group()
 
 

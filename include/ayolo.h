@@ -226,6 +226,8 @@ typedef struct ayolo_op {
     ayolo_conv_desc conv;
 } ayolo_op;
 int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s);
+/* zero `bytes` bytes at a 16-byte aligned device pointer with an ordinary kernel on stream s */
+int ayolo_fill_zero(void* ptr, size_t bytes, ayolo_stream s);
 
 #ifdef __cplusplus
 }
