@@ -86,7 +86,7 @@ def conv_kernel_roofline(model, batch, size, device, reps=5):
         model.train()
     for h in hs:
         h.remove()
-    total_flop, total_s = 0.0, 0.0
+    total_flop, total_s, alg_bytes = 0.0, 0.0, 0.0
     for mod, xs in shapes:
         conv = mod.conv
         _, cin, H, W = xs
@@ -109,10 +109,29 @@ def conv_kernel_roofline(model, batch, size, device, reps=5):
         total_s += e0.elapsed_time(e1) / 1e3 / reps
         kh, kw = conv.kernel_size
         total_flop += 2.0 * batch * geo.Ho * geo.Wo * cout * conv.in_channels * kh * kw
+        # forward reads x,w writes y; the dgrad launch of the same layer (same kernel family) reads dy,w writes dx
+        alg_bytes += 2.0 * (xk.numel() + w.numel() + y.numel()) * (1 if cin == 3 else 2)
     achieved = total_flop / total_s / 1e12
     return {"bound": "mfma", "kernel": "k_gconv<f16> (57 Conv forward launches of one step)", "achieved": round(achieved, 2),
-            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+            "traffic": pmc_traffic(("k_gconv", "k_dconv"), ""), "traffic_unit": "GB per train step over every k_gconv/k_dconv launch "
+            "(forward + dgrad), rocprofv3 --pmc FETCH_SIZE(x2 gfx950)/WRITE_SIZE passes committed under profiles/; algorithmic_gb "
+            "covers the same launches", "algorithmic_gb": round(alg_bytes / 1e9, 3),
             "launch_ms_sum": round(total_s * 1e3, 3)}
+
+
+def pmc_traffic(families, suffix):
+    """HBM bytes of the roofline kernel family from the newest committed PMC summary (tools/profile_round.sh); the
+    counters need their own rocprofv3 passes, so bench.py reports the committed measurement rather than re-collecting."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    tot = 0.0
+    for k, v in json.load(open(files[-1])).items():
+        if any(f in k for f in families) and suffix in k:
+            tot += v["fetch_GB_per_step_corrected"] + v["write_GB_per_step"]
+    return round(tot, 3) if tot else None
 
 
 def cpu_baseline(model_name, size, batch=4, budget_s=25.0):
