@@ -21,6 +21,19 @@
 #define BK 32
 #define TP 128   // pixels per block tile
 
+// exact unsigned division by a runtime constant (Granlund-Montgomery round-up form), all 32-bit numerators
+struct FastDiv { unsigned m, s1, s2; };
+static FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned l = 0;
+    if (d < 1) d = 1;
+    while ((1ull << l) < d) ++l;
+    f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+
 struct GConvP {
     const void* x; const void* w; void* y;
     int B, XH, XW, ldx;
@@ -32,6 +45,8 @@ struct GConvP {
     int x_linear, y_linear, ntn, nslots;
     long long Mtotal;
     signed char dh[MAX_TAPS], dw[MAX_TAPS], wt[MAX_TAPS];
+    unsigned x_bytes, w_bytes, y_bytes;      // extents for the buffer descriptors (k_gconv)
+    FastDiv dOW, dOH, dC;
 };
 
 template <typename T> struct Tr;
@@ -67,165 +82,188 @@ __device__ __forceinline__ Tr<float>::frag lds_frag(const float* p) {
 __device__ __forceinline__ float cvt_round(float v, half_t*) { return (float)(half_t)v; }
 __device__ __forceinline__ float cvt_round(float v, float*) { return v; }
 
+// ---------------------------------------------------------------------------------------------------
+// k_gconv: persistent implicit GEMM, operands staged by LDS-DMA (buffer_load ... lds, 16 B per lane).
+//
 // EM (epilogue mode, compile time so that unused paths cost no registers):
 //   0 plain store (+ optional BN statistics)   1 accumulate into y (dgrad)   2 affine / affine+SiLU   3 YOLOHead fp32
 //
-// Persistent, tile-pipelined implicit GEMM.  A workgroup owns output-channel tile `nt` and walks the pixel tiles of
-// its XCD's band; one "step" = (pixel tile, 32-wide k slice).  The global loads of step s+2 are issued while the
-// MFMAs consume step s from LDS and step s+1 waits in registers (two register stages + two LDS stages), across
-// tile boundaries: the measured load->use latency under load (~3000 cycles) is hidden by ~two compute phases per
-// workgroup times the resident workgroups.  BN statistics are accumulated in registers across all tiles of the
-// workgroup and reduced once at the end.
+// A workgroup owns output-channel tile `nt` and walks the pixel tiles of its XCD's band; one "step" = (pixel tile,
+// 32-wide k slice).  The tiles of step s+2 are in flight (global -> LDS, no VGPR staging, no ds_write pass) while the
+// MFMAs consume step s, across tile boundaries: three LDS stages, ONE raw s_barrier per step and a counted
+// s_waitcnt vmcnt(N) that never drains the queue.  Every load is unconditional: halo / padding / out-of-range rows get
+// the buffer descriptor's out-of-range offset (hardware returns 0), so the instruction stream has no branch around a
+// load and no vmcnt(0) in the loop (the branchy loader this replaces waited for every load it issued).
+// The LDS image is lane-linear (what the DMA writes): row-major [row][BK] with the 16-byte chunk position XOR-swizzled
+// by the row ((row / rows-per-256B) & (chunks-1)), applied on the SOURCE address, which makes the ds_read_b128 MFMA
+// fragment reads bank-conflict free without padding.
+// BN statistics are accumulated in registers across all tiles of the workgroup and reduced once at the end.
+// ---------------------------------------------------------------------------------------------------
+#define GNS 3                      // LDS stages
+#define G_OOB 0x80000000u          // buffer offset beyond any descriptor (tensors are < 2 GiB, checked on the host)
+
+typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <typename T, int TM>
-struct GTile {
-    static constexpr int CE = Tr<T>::CE;
-    static constexpr int CPR = BK / CE;
-    static constexpr int LDR = BK + Tr<T>::PADE;
+struct GT {
+    static constexpr int ES = sizeof(T);
+    static constexpr int CE = 16 / ES;              // elements per 16-byte chunk
+    static constexpr int ROWB = BK * ES;            // bytes per tile row: 64 / 128
+    static constexpr int CPR = ROWB / 16;           // chunks per row: 4 / 8
+    static constexpr int RPB = 256 / ROWB;          // rows per 256-byte bank row: 4 / 2
+    static constexpr int RW = 1024 / ROWB;          // rows written by one wave-instruction: 16 / 8
+    static constexpr int XSTAGE = TP * ROWB;        // 8 KiB / 16 KiB
+    static constexpr int XR = XSTAGE / 4096;        // x DMA instructions per thread per step
+    static constexpr int WSTAGE = TM * ROWB < 4096 ? 4096 : TM * ROWB;
+    static constexpr int WR = WSTAGE / 4096;
+    static constexpr int STAGE = XSTAGE + WSTAGE;
+    static constexpr int LPS = XR + WR;             // DMA instructions per thread per step
     static constexpr int WM = TM / 32, WP = 4 / WM, NI = TP / (32 * WP);
-    static constexpr int XR = (TP * CPR) / 256;
-    static constexpr int WCH = TM * CPR;
-    static constexpr int WR = (WCH + 255) / 256;
+    static constexpr int NST = NI * 4;              // store instructions per thread per epilogue
+    static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 2 * TM * sizeof(float);
 };
 
-// loader position: which (tile, k-slice) is fetched next, plus the per-row pixel decode of that tile
-template <typename T, int TM>
-struct GLoader {
-    long long tile;
-    int kt, tap, cch;
-    bool valid;
-    long long xbase[GTile<T, TM>::XR];
-    int xh0[GTile<T, TM>::XR], xw0[GTile<T, TM>::XR];
-};
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Buffer descriptor (raw, stride 0, `bytes` records) held in 4 SGPRs, and the LDS-DMA load itself.  The DMA is issued
+// from inline asm on purpose: hipcc (ROCm 7.2) orders every LDS read behind ALL LDS-DMA it knows to be in flight with a
+// vmcnt(0), which would drain the two-steps-ahead pipeline at each step; hidden from its scoreboard, completion is
+// tracked by the counted wait_vm<N>() + s_barrier of the step loop alone.  (The compiler's own vmcnt for its loads and
+// stores stays correct: completion is in order, so extra younger operations only make its counts conservative.)
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i32 make_srd(const void* ptr, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    v4i32 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+// 64 lanes x 16 B: global (srd base + voff, zero when voff is beyond the descriptor) -> LDS [lds_addr + lane*16, +16)
+__device__ __forceinline__ void glds16(v4i32 srd, unsigned lds_addr, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd)
+                 : "memory");
+}
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
+    const unsigned t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// pixel decode of the loader's rows for pixel tile `tile` (invalid tile / rows beyond Mtotal -> never in range).
+// Branch-free on purpose (selects only): see the header comment.
 template <typename T, int TM>
-__device__ __forceinline__ void g_setup_rows(const GConvP& p, GLoader<T, TM>& L, int tid, int kc) {
-    using G = GTile<T, TM>;
-    L.tap = (kc * G::CE) / p.C;
-    L.cch = (kc * G::CE) % p.C;
-    const long long m0 = L.tile * TP;
+__device__ __forceinline__ void g_setup_rows(const GConvP& p, unsigned tile, bool valid, int wave, int rowin, int kc,
+                                             int (&xoff)[GT<T, TM>::XR], int (&xh0)[GT<T, TM>::XR], int (&xw0)[GT<T, TM>::XR]) {
+    using G = GT<T, TM>;
 #pragma unroll
     for (int r = 0; r < G::XR; ++r) {
-        const int row = (tid + 256 * r) / G::CPR;
-        const long long m = m0 + row;
-        if (m < p.Mtotal) {
-            if (p.x_linear) {
-                L.xbase[r] = m; L.xh0[r] = 0; L.xw0[r] = 0;
-            } else {
-                const unsigned mu = (unsigned)m;
-                unsigned t = mu / (unsigned)p.OW;
-                int ow = (int)(mu - t * (unsigned)p.OW);
-                unsigned n = t / (unsigned)p.OH;
-                int oh = (int)(t - n * (unsigned)p.OH);
-                L.xbase[r] = (long long)n * p.XH * p.XW;
-                L.xh0[r] = oh * p.ish; L.xw0[r] = ow * p.isw;
-            }
-        } else { L.xbase[r] = -1; L.xh0[r] = 0; L.xw0[r] = 0; }
+        const int row = (r * 4 + wave) * G::RW + rowin;
+        const unsigned mu = tile * TP + row;               // < 2^31 + TP: pixel counts are < 2^31 (host check)
+        const bool ok = valid & (mu < (unsigned)p.Mtotal);
+        const unsigned t = fdiv(mu, p.dOW);
+        const int ow = (int)(mu - t * (unsigned)p.OW);
+        const unsigned n = fdiv(t, p.dOH);
+        const int oh = (int)(t - n * (unsigned)p.OH);
+        const int h0 = oh * p.ish, w0 = ow * p.isw;
+        // 1x1 / stride 1 / no padding ("x_linear") is the same formula: XH == OH, XW == OW
+        xoff[r] = (int)(((n * (unsigned)p.XH + (unsigned)h0) * (unsigned)p.XW + (unsigned)w0) * (unsigned)p.ldx * G::ES);
+        xh0[r] = ok ? h0 : -100000;
+        xw0[r] = w0;
     }
 }
 
-// advance the loader by one step (possibly into the next tile of the band) and issue its global loads
-template <typename T, int TM, typename KT>
-__device__ __forceinline__ void g_issue(const GConvP& p, GLoader<T, TM>& L, bool first, int nk, long long ntiles, unsigned lstride,
-                                        KT ktab, const T* __restrict__ X, const T* __restrict__ Wg, int tid, int kc, int n0,
-                                        uint4 (&xreg)[GTile<T, TM>::XR], uint4 (&wreg)[GTile<T, TM>::WR]) {
-    using G = GTile<T, TM>;
-    if (first) {
-        L.valid = L.tile < ntiles;
-        if (L.valid) g_setup_rows<T, TM>(p, L, tid, kc);
-    } else if (L.valid) {
-        ++L.kt;
-        if (L.kt == nk) {
-            L.kt = 0;
-            L.tile += lstride;
-            L.valid = L.tile < ntiles;
-            if (L.valid) g_setup_rows<T, TM>(p, L, tid, kc);
-        } else {
-            L.cch += BK;
-            while (L.cch >= p.C) { L.cch -= p.C; ++L.tap; }
-        }
-    }
-    if (!L.valid) return;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    const bool tap_ok = L.tap < p.ntaps;
-    const int tq = tap_ok ? L.tap : 0;
-    const int dh = ktab[tq], dw = ktab[MAX_TAPS + tq];
-#pragma unroll
-    for (int r = 0; r < G::XR; ++r) {
-        xreg[r] = zero4;
-        if (p.x_linear) {
-            if (tap_ok && L.xbase[r] >= 0) xreg[r] = *reinterpret_cast<const uint4*>(X + L.xbase[r] * p.ldx + L.cch);
-        } else {
-            int ih = L.xh0[r] + dh, iw = L.xw0[r] + dw;
-            bool ok = tap_ok && L.xbase[r] >= 0 && ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW;
-            if (ok) xreg[r] = *reinterpret_cast<const uint4*>(X + (L.xbase[r] + (long long)ih * p.XW + iw) * p.ldx + L.cch);
-        }
-    }
-    const int wcol = tap_ok ? ktab[2 * MAX_TAPS + tq] * p.C + L.cch : 0;
-#pragma unroll
-    for (int r = 0; r < G::WR; ++r) {
-        int q = tid + 256 * r;
-        int row = q / G::CPR;
-        wreg[r] = zero4;
-        if (q < G::WCH && tap_ok && (n0 + row) < p.Nout)
-            wreg[r] = *reinterpret_cast<const uint4*>(Wg + (long long)(n0 + row) * p.ldw + wcol);
-    }
-}
-
+// issue the DMA of one step (k slice `kt` of the loader's current tile) into the LDS stage at byte offset `so`
 template <typename T, int TM>
-__device__ __forceinline__ void g_stage(T* sW, T* sX, int buf, int tid, int kc, const uint4 (&xreg)[GTile<T, TM>::XR],
-                                        const uint4 (&wreg)[GTile<T, TM>::WR]) {
-    using G = GTile<T, TM>;
-    T* dX = sX + buf * TP * G::LDR;
-    T* dW = sW + buf * TM * G::LDR;
+__device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T, TM>::XR], const int (&xh0)[GT<T, TM>::XR],
+                                        const int (&xw0)[GT<T, TM>::XR], const unsigned (&woff)[GT<T, TM>::WR], int kt,
+                                        const int4* sTap, unsigned lds_tiles, unsigned so, v4i32 rsX, v4i32 rsW, int wave, int kc) {
+    using G = GT<T, TM>;
+    const unsigned k0 = (unsigned)(kt * BK + kc * G::CE);
+    unsigned tap = fdiv(k0, p.dC);
+    const int cb = (int)(k0 - tap * (unsigned)p.C) * G::ES;
+    tap = tap < MAX_TAPS ? tap : MAX_TAPS;
+    const int4 te = sTap[tap];
 #pragma unroll
     for (int r = 0; r < G::XR; ++r) {
-        int row = (tid + 256 * r) / G::CPR;
-        *reinterpret_cast<uint4*>(dX + row * G::LDR + kc * G::CE) = xreg[r];
+        const unsigned ih = (unsigned)(xh0[r] + te.y), iw = (unsigned)(xw0[r] + te.z);
+        const bool ok = (ih < (unsigned)p.XH) & (iw < (unsigned)p.XW);
+        const unsigned off = ok ? (unsigned)(xoff[r] + te.x + cb) : G_OOB;
+        glds16(rsX, lds_tiles + so + (r * 4 + wave) * 1024, off);
     }
 #pragma unroll
     for (int r = 0; r < G::WR; ++r) {
-        int q = tid + 256 * r;
-        if (q < G::WCH) *reinterpret_cast<uint4*>(dW + (q / G::CPR) * G::LDR + kc * G::CE) = wreg[r];
+        const unsigned off = woff[r] + (unsigned)te.w + (unsigned)cb;
+        glds16(rsW, lds_tiles + so + G::XSTAGE + (r * 4 + wave) * 1024, off);
     }
 }
 
 template <typename T, int TM>
-__device__ __forceinline__ void g_mma(const T* sW, const T* sX, int buf, int wm, int wp, int lane,
-                                      float16v (&acc)[GTile<T, TM>::NI]) {
-    using G = GTile<T, TM>;
-    const T* cW = sW + buf * TM * G::LDR + (wm * 32 + (lane & 31)) * G::LDR + (lane >> 5) * 8;
-    const T* cX = sX + buf * TP * G::LDR + (wp * G::NI * 32 + (lane & 31)) * G::LDR + (lane >> 5) * 8;
+__device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int xrow, int swz, int lane,
+                                      float16v (&acc)[GT<T, TM>::NI]) {
+    using G = GT<T, TM>;
+    const unsigned char* bx = stage + xrow;
+    const unsigned char* bw = stage + G::XSTAGE + arow;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-        auto a = lds_frag(cW + kk * 16);
+        if constexpr (sizeof(T) == 2) {
+            const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
+            const half8 a = *reinterpret_cast<const half8*>(bw + slot);
 #pragma unroll
-        for (int ni = 0; ni < G::NI; ++ni) {
-            auto b = lds_frag(cX + ni * 32 * G::LDR + kk * 16);
-            mma_step(a, b, acc[ni]);
+            for (int ni = 0; ni < G::NI; ++ni) {
+                const half8 b = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
+                mma_step(a, b, acc[ni]);
+            }
+        } else {
+            const int c0 = kk * 4 + (lane >> 5) * 2;
+            const int s0 = (c0 ^ swz) * 16, s1 = ((c0 + 1) ^ swz) * 16;
+            Tr<float>::frag a;
+            {
+                const float4v u = *reinterpret_cast<const float4v*>(bw + s0), v = *reinterpret_cast<const float4v*>(bw + s1);
+                a.v[0] = u[0]; a.v[1] = u[1]; a.v[2] = u[2]; a.v[3] = u[3]; a.v[4] = v[0]; a.v[5] = v[1]; a.v[6] = v[2]; a.v[7] = v[3];
+            }
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni) {
+                const unsigned char* q = bx + ni * 32 * G::ROWB;
+                const float4v u = *reinterpret_cast<const float4v*>(q + s0), v = *reinterpret_cast<const float4v*>(q + s1);
+                Tr<float>::frag b;
+                b.v[0] = u[0]; b.v[1] = u[1]; b.v[2] = u[2]; b.v[3] = u[3]; b.v[4] = v[0]; b.v[5] = v[1]; b.v[6] = v[2]; b.v[7] = v[3];
+                mma_step(a, b, acc[ni]);
+            }
         }
     }
 }
 
-// tile finished: acc[ni][r] holds channel = cbase + 8*(r>>2) + (r&3), pixel = m0 + wp*NI*32 + ni*32 + (lane&31)
+// tile finished: acc[ni][r] holds channel = cbase + 8*(r>>2) + (r&3), pixel = m0 + wp*NI*32 + ni*32 + (lane&31).
+// Exactly NST buffer stores per thread (invalid pixels / channel groups use the out-of-range offset and are dropped
+// by the hardware), so the step loop's vmcnt arithmetic stays exact.
 template <typename T, int TM, int EM>
-__device__ __forceinline__ void g_epilogue(const GConvP& p, long long tile, int wp, int lane, int cbase, bool want_stats,
-                                           float16v (&acc)[GTile<T, TM>::NI], float (&ssum)[16], float (&ssq)[16]) {
-    using G = GTile<T, TM>;
-    const long long m0 = tile * TP;
+__device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int wp, int lane, int cbase, bool want_stats,
+                                           __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM>::NI], float (&ssum)[16],
+                                           float (&ssq)[16]) {
+    using G = GT<T, TM>;
+    constexpr int YES = (EM == 3) ? 4 : G::ES;       // bytes per output element
+    const unsigned m0 = tile * TP;
 #pragma unroll
     for (int ni = 0; ni < G::NI; ++ni) {
-        const long long m = m0 + wp * G::NI * 32 + ni * 32 + (lane & 31);
-        const bool pv = m < p.Mtotal;
-        long long yo = 0;
-        if (pv) {
-            if (p.y_linear) yo = m * p.ldy;
+        const unsigned m = m0 + wp * G::NI * 32 + ni * 32 + (lane & 31);
+        const bool pv = m < (unsigned)p.Mtotal;
+        unsigned yo = 0;
+        {
+            const unsigned mu = pv ? m : 0u;
+            if (p.y_linear) yo = mu * (unsigned)p.ldy * YES;
             else {
-                const unsigned mu = (unsigned)m;
-                unsigned t = mu / (unsigned)p.OW;
-                int ow = (int)(mu - t * (unsigned)p.OW);
-                unsigned nn = t / (unsigned)p.OH;
-                int oh = (int)(t - nn * (unsigned)p.OH);
-                yo = (((long long)nn * p.YH + (oh * p.osh + p.oah)) * p.YW + (ow * p.osw + p.oaw)) * p.ldy;
+                const unsigned t = fdiv(mu, p.dOW);
+                const int ow = (int)(mu - t * (unsigned)p.OW);
+                const unsigned nn = fdiv(t, p.dOH);
+                const int oh = (int)(t - nn * (unsigned)p.OH);
+                yo = ((nn * (unsigned)p.YH + (unsigned)(oh * p.osh + p.oah)) * (unsigned)p.YW + (unsigned)(ow * p.osw + p.oaw)) * (unsigned)p.ldy * YES;
             }
         }
 #pragma unroll
@@ -234,6 +272,16 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, long long tile, int 
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
+            if constexpr (EM == 3) {
+                // YOLOHead: fp32 logits + bias, NHWC [pixel][ldy] (ldy = Cout rounded up to 8), 16-byte stores;
+                // the (B, na, ny, nx, no) tensor the loss / decode see is a strided view of this buffer
+                const unsigned off = (pv && c < p.ldy) ? yo + (unsigned)c * 4u : G_OOB;
+                float4v f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = v[e] + ((p.shift && c + e < p.Nout) ? p.shift[c + e] : 0.0f);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, f), rsY, off, 0, 0);
+                continue;
+            }
             if constexpr (EM == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -244,18 +292,6 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, long long tile, int 
                     }
                 }
             }
-            if constexpr (EM == 3) {
-                // YOLOHead: fp32 logits + bias, NHWC [pixel][ldy] (ldy = Cout rounded up to 8), 16-byte stores;
-                // the (B, na, ny, nx, no) tensor the loss / decode see is a strided view of this buffer
-                if (pv && c < p.ldy) {
-                    float* Y = reinterpret_cast<float*>(p.y) + m * p.ldy + c;
-                    float4v f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] = v[e] + ((p.shift && c + e < p.Nout) ? p.shift[c + e] : 0.0f);
-                    *reinterpret_cast<float4v*>(Y) = f;
-                }
-                continue;
-            }
             if (want_stats) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -264,29 +300,27 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, long long tile, int 
                     ssq[g * 4 + e] += q * q;
                 }
             }
-            if (pv) {
-                T* Y = reinterpret_cast<T*>(p.y) + yo + c;
-                if (c + 3 < p.Nout && (p.ldy & 3) == 0) {
-                    if constexpr (EM == 1) {
+            const unsigned off = (pv && c < p.Nout) ? yo + (unsigned)c * G::ES : G_OOB;   // Nout % 4 == 0 (host check)
+            if constexpr (sizeof(T) == 2) {
+                if constexpr (EM == 1) {
+                    const half4 o = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(rsY, off, 0, 0));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)Y[e];
-                    }
-                    if constexpr (sizeof(T) == 2) {
-                        half4 h;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
-                        *reinterpret_cast<half4*>(Y) = h;
-                    } else {
-                        float4v f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) f[e] = v[e];
-                        *reinterpret_cast<float4v*>(Y) = f;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c + e < p.Nout) Y[e] = (T)(EM == 1 ? v[e] + (float)Y[e] : v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] += (float)o[e];
                 }
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, h), rsY, off, 0, 0);
+            } else {
+                if constexpr (EM == 1) {
+                    const float4v o = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += o[e];
+                }
+                float4v f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = v[e];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, f), rsY, off, 0, 0);
             }
         }
     }
@@ -323,18 +357,17 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int
 }
 
 template <typename T, int TM, int EM>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 128 ? 2 : (TM == 64 ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
-    using G = GTile<T, TM>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* sW = reinterpret_cast<T*>(smem_raw);                          // [2][TM][LDR]
-    T* sX = sW + 2 * TM * G::LDR;                                    // [2][TP][LDR]
-    float* sStat = reinterpret_cast<float*>(sX + 2 * TP * G::LDR);   // [2][TM]
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 && EM == 0)) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
+    using G = GT<T, TM>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    unsigned char* sTiles = smem_raw;                                             // [GNS][x tile | w tile]
+    int4* sTap = reinterpret_cast<int4*>(smem_raw + GNS * G::STAGE);              // [MAX_TAPS + 1]
+    float* sStat = reinterpret_cast<float*>(sTap + MAX_TAPS + 1);                 // [2][TM]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % G::WM, wp = wave / G::WM;
-    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ Wg = reinterpret_cast<const T*>(p.w);
 
     // ---- block -> (channel tile, XCD band, slot).  Workgroups are dealt round-robin to the 8 XCDs; all channel
     // tiles of one pixel tile go to the SAME XCD back to back, and each XCD walks a contiguous band of pixel tiles.
@@ -343,16 +376,51 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 128 ? 2 : (TM == 64 ?
     const unsigned nt = idx % (unsigned)p.ntn;
     const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
     const int n0 = (int)nt * TM;
-    const long long ntiles_all = (p.Mtotal + TP - 1) / TP;
-    const long long tpx = (ntiles_all + 7) / 8;
-    const long long band_lo = (long long)xcd * tpx;
-    const long long ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
+    const unsigned ntiles_all = (unsigned)((p.Mtotal + TP - 1) / TP);
+    const unsigned tpx = (ntiles_all + 7) / 8;
+    const unsigned band_lo = xcd * tpx;
+    const unsigned ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
     const unsigned lslot = idx / (unsigned)p.ntn;
     const unsigned lstride = (unsigned)p.nslots / 8u;
+    unsigned cur_tile = band_lo + lslot;
+    if (cur_tile >= ntiles) return;
 
+    // ---- tap table -> LDS: {x byte delta, dh, dw, w column byte offset}; entries >= ntaps never hit (K padding)
     typedef __attribute__((address_space(4))) const signed char* kptr_t;
     const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh);
-    const int kc = tid % G::CPR;
+    if (tid <= MAX_TAPS) {
+        int4 e;
+        const int tq = tid < MAX_TAPS ? tid : 0;
+        const int dh = ktab[tq], dw = ktab[MAX_TAPS + tq], wt = ktab[2 * MAX_TAPS + tq];
+        if (tid < p.ntaps) { e.x = (dh * p.XW + dw) * p.ldx * G::ES; e.y = dh; e.z = dw; e.w = wt * p.C * G::ES; }
+        else { e.x = 0; e.y = -100000; e.z = 0; e.w = 0x40000000; }
+        sTap[tid] = e;
+    }
+
+    const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
+    const unsigned lds_tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sTiles);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    // ---- loader lane geometry: this lane writes LDS bytes [piece*1024 + lane*16, +16) of a stage; the chunk it must
+    // FETCH for that position is the position's chunk slot XOR the row swizzle
+    const int slotc = lane & (G::CPR - 1);
+    const int rowin = lane / G::CPR;
+    const int lsw = sizeof(T) == 2 ? (lane >> 4) : ((((wave & 1) << 2) | (lane >> 4)) & 7);
+    const int kc = slotc ^ lsw;
+
+    int xoff[G::XR], xh0[G::XR], xw0[G::XR];
+    unsigned woff[G::WR];
+#pragma unroll
+    for (int r = 0; r < G::WR; ++r) {
+        const int row = (r * 4 + wave) * G::RW + rowin;
+        const bool ok = (row < TM) & (n0 + row < p.Nout);
+        woff[r] = ok ? (unsigned)(n0 + row) * (unsigned)p.ldw * G::ES : G_OOB;   // the k-chunk offset comes from g_issue
+    }
+
+    // ---- MFMA fragment geometry
+    const int arow = (wm * 32 + (lane & 31)) * G::ROWB;
+    const int xrow = (wp * G::NI * 32 + (lane & 31)) * G::ROWB;
+    const int swz = ((lane & 31) / G::RPB) & (G::CPR - 1);
 
     float16v acc[G::NI];
 #pragma unroll
@@ -367,359 +435,53 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 128 ? 2 : (TM == 64 ?
 
     int nk = (p.K + BK - 1) / BK;
     if (nk < 1) nk = 1;                      // K == 0 (tap-less dgrad residue class): one all-zero step
-    long long cur_tile = band_lo + lslot;
-    if (cur_tile >= ntiles) return;
     int cur_kt = 0;
 
-    GLoader<T, TM> L;
-    L.tile = cur_tile; L.kt = 0; L.tap = 0; L.cch = 0; L.valid = true;
-    // Prefetch depth: two register stages for the wide tiles; the 32-channel tile keeps one (its 4 workgroups
-    // per CU hide latency better than a deeper pipeline at 3 per CU -- measured).
-    constexpr bool DEEP = (TM != 32);
-    uint4 xA[G::XR], wA[G::WR];
-
-    if constexpr (DEEP) {
-        uint4 xB[G::XR], wB[G::WR];
-        // prologue: step 0 -> regs A -> LDS[0]; step 1 -> regs B (in flight)
-        g_issue<T, TM>(p, L, true, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xA, wA);
-        g_stage<T, TM>(sW, sX, 0, tid, kc, xA, wA);
-        g_issue<T, TM>(p, L, false, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xB, wB);
-        bool next_valid = L.valid;               // regs B hold a real step
-        __syncthreads();
-        // One half-iteration: compute the step in LDS[BUF]; regs `xn/wn` hold the following step (staged into
-        // LDS[BUF^1] afterwards); regs `xf/wf` are free and receive the loads of the step after that.
-#define G_HALF(BUF, xf, wf, xn, wn)                                                                              \
-        {                                                                                                        \
-            const bool have_next = next_valid;                                                                   \
-            g_issue<T, TM>(p, L, false, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xf, wf);                  \
-            next_valid = L.valid;                                                                                \
-            g_mma<T, TM>(sW, sX, BUF, wm, wp, lane, acc);                                                        \
-            if (cur_kt == nk - 1) g_epilogue<T, TM, EM>(p, cur_tile, wp, lane, cbase, want_stats, acc, ssum, ssq); \
-            if (have_next) g_stage<T, TM>(sW, sX, (BUF) ^ 1, tid, kc, xn, wn);                                   \
-            __syncthreads();                                                                                     \
-            if (!have_next) break;                                                                               \
-            ++cur_kt;                                                                                            \
-            if (cur_kt == nk) { cur_kt = 0; cur_tile += lstride; }                                               \
-        }
-        while (true) {
-            G_HALF(0, xA, wA, xB, wB)
-            G_HALF(1, xB, wB, xA, wA)
-        }
-#undef G_HALF
-    } else {
-        g_issue<T, TM>(p, L, true, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xA, wA);
-        g_stage<T, TM>(sW, sX, 0, tid, kc, xA, wA);
-        __syncthreads();
-        int buf = 0;
-        while (true) {
-            g_issue<T, TM>(p, L, false, nk, ntiles, lstride, ktab, X, Wg, tid, kc, n0, xA, wA);   // step s+1
-            const bool have_next = L.valid;
-            g_mma<T, TM>(sW, sX, buf, wm, wp, lane, acc);
-            if (cur_kt == nk - 1) g_epilogue<T, TM, EM>(p, cur_tile, wp, lane, cbase, want_stats, acc, ssum, ssq);
-            if (have_next) g_stage<T, TM>(sW, sX, buf ^ 1, tid, kc, xA, wA);
-            __syncthreads();
-            if (!have_next) break;
-            buf ^= 1;
-            ++cur_kt;
-            if (cur_kt == nk) { cur_kt = 0; cur_tile += lstride; }
-        }
+    // loader cursor, two steps ahead of the compute cursor; past the last step it keeps issuing (out-of-range, zero
+    // fill) so that every step has exactly LPS DMA instructions per thread
+    unsigned ld_tile = cur_tile;
+    int ld_kt = 0;
+    bool ld_valid = true;
+    g_setup_rows<T, TM>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
+    __syncthreads();                          // tap table visible
+#define G_ADVANCE()                                                                           \
+    {                                                                                         \
+        if (++ld_kt == nk) {                                                                  \
+            ld_kt = 0;                                                                        \
+            ld_tile += lstride;                                                               \
+            ld_valid = ld_valid && ld_tile < ntiles;                                          \
+            g_setup_rows<T, TM>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);      \
+        }                                                                                     \
     }
+    unsigned so0 = 0, so1 = G::STAGE, so2 = 2 * G::STAGE;
+    g_issue<T, TM>(p, xoff, xh0, xw0, woff, ld_kt, sTap, lds_tiles, so0, rsX, rsW, wave, kc);
+    G_ADVANCE()
+    g_issue<T, TM>(p, xoff, xh0, xw0, woff, ld_kt, sTap, lds_tiles, so1, rsX, rsW, wave, kc);
+    G_ADVANCE()
 
-    if (want_stats) g_stats_flush<T, TM>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Direct (halo-tiled) convolution for k x k > 1x1: the input patch of an 8x16 output tile (with halo) is
-// staged in LDS ONCE per 32-channel chunk and all k*k taps read their MFMA fragments from it at shifted
-// addresses, so global/L2 traffic for the activations drops from k*k x to ~(1 + halo) x.  Weights stream as
-// [TM x 32] tiles per (chunk, tap) step; the next step's weights and a slice of the next patch are
-// prefetched into registers while the MFMAs run (persistent over tiles, same epilogue as k_gconv).
-// ---------------------------------------------------------------------------------------------------
-#define DTH 8
-#define DTW 16
-#define DCK 32          // channels per LDS patch chunk
-#define DSL_MAX 3       // patch chunk loads per thread per step (upper bound)
-
-struct DConvP {
-    GConvP g;            // shared fields (x, w, y, dims, epilogue, taps)
-    int tyn, txn;        // tiles per image in y / x
-    int PH, PW;          // patch extent (pixels)
-    int dh_min, dw_min;  // smallest tap offsets
-    int sl;              // patch chunk loads per thread per step
-};
-
-template <typename T, int TM, int EM>
-__global__ __launch_bounds__(256) void k_dconv(DConvP dp) {
-    const GConvP& p = dp.g;
-    constexpr int CE = Tr<T>::CE;
-    constexpr int CPR = DCK / CE;            // 16-byte chunks per patch pixel
-    constexpr int LDR = DCK + Tr<T>::PADE;   // LDS row stride (elements) for both the patch and the weight tile
-    constexpr int WM = TM / 32, WP = 4 / WM, NI = TP / (32 * WP);
-    constexpr int WCH = TM * CPR;
-    constexpr int WR = (WCH + 255) / 256;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int patch_elems = dp.PH * dp.PW * LDR;
-    T* sW = reinterpret_cast<T*>(smem_raw);                        // [2][TM][LDR]
-    T* sP = sW + 2 * TM * LDR;                                     // [2][PH*PW][LDR]
-    float* sStat = reinterpret_cast<float*>(sP + 2 * patch_elems); // [2][TM]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wp = wave / WM;
-    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ Wg = reinterpret_cast<const T*>(p.w);
-
-    const unsigned L = blockIdx.x;
-    const unsigned xcd = L & 7u, idx = L >> 3;
-    const unsigned nt = idx % (unsigned)p.ntn;
-    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
-    const unsigned nslots = (unsigned)p.nslots;
-    const int n0 = (int)nt * TM;
-    const long long tiles_per_img = (long long)dp.tyn * dp.txn;
-    const long long ntiles_all = (long long)p.B * tiles_per_img;
-    const long long tpx = (ntiles_all + 7) / 8;
-    const long long band_lo = (long long)xcd * tpx;
-    const long long ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
-    const unsigned lslot = idx / (unsigned)p.ntn;
-    const unsigned lstride = nslots / 8u;
-
-    typedef __attribute__((address_space(4))) const signed char* kptr_t;
-    const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh);
-
-    const int nchunks = p.C / DCK;
-    const int nsteps = nchunks * p.ntaps;            // steps per tile: (chunk, tap)
-    const int patch_chunks = dp.PH * dp.PW * CPR;
-    const int kc = tid % CPR;
-
-    float16v acc[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    const bool want_stats = (EM == 0) && (p.stats != nullptr);
-    float ssum[16], ssq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
-    const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
-
-    // per-lane fragment geometry: pixel j of the tile -> (oy, ox)
-    int frag_off[NI];     // element offset of the lane's pixel inside the patch for tap offset (dh_min, dw_min)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int j = wp * NI * 32 + ni * 32 + (lane & 31);
-        const int oy = j / DTW, ox = j % DTW;
-        frag_off[ni] = ((oy * p.ish) * dp.PW + ox * p.isw) * LDR + (lane >> 5) * 8;
-    }
-
-    uint4 preg[DSL_MAX], wreg[WR];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    long long cur_tile = band_lo + lslot;
-    if (cur_tile >= ntiles) return;
-    // loader position (one step ahead of the compute position)
-    long long ld_tile = cur_tile;
-    int ld_step = 0;
-    int cur_step = 0;
-    int wbuf = 0, pbuf = 0;      // LDS buffers holding the CURRENT step's weights / CURRENT chunk's patch
-    bool first = true;
-
-    // tile origin of the patch being loaded
-    auto tile_origin = [&](long long tile, int& n, int& ih0, int& iw0) {
-        const unsigned tu = (unsigned)tile;
-        const unsigned nn = tu / (unsigned)tiles_per_img;
-        const unsigned r = tu - nn * (unsigned)tiles_per_img;
-        const unsigned ty = r / (unsigned)dp.txn, tx = r - ty * (unsigned)dp.txn;
-        n = (int)nn;
-        ih0 = (int)ty * DTH * p.ish + dp.dh_min;
-        iw0 = (int)tx * DTW * p.isw + dp.dw_min;
-    };
-    // loads slice `sl_idx` (0..ntaps-1) of the patch for (tile, chunk) into preg
-    auto load_patch_slice = [&](long long tile, int chunk, int slice) {
-        int n, ih0, iw0;
-        tile_origin(tile, n, ih0, iw0);
-#pragma unroll
-        for (int u = 0; u < DSL_MAX; ++u) {
-            preg[u] = zero4;
-            if (u < dp.sl) {
-                const int q = (slice * dp.sl + u) * 256 + tid;
-                if (q < patch_chunks) {
-                    const int pix = q / CPR;
-                    const int py = pix / dp.PW, px = pix - py * dp.PW;
-                    const int ih = ih0 + py, iw = iw0 + px;
-                    if (ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW)
-                        preg[u] = *reinterpret_cast<const uint4*>(X + (((long long)n * p.XH + ih) * p.XW + iw) * p.ldx + chunk * DCK + kc * CE);
-                }
-            }
-        }
-    };
-    auto store_patch_slice = [&](int buf, int slice) {
-        T* dP = sP + buf * patch_elems;
-#pragma unroll
-        for (int u = 0; u < DSL_MAX; ++u) {
-            if (u < dp.sl) {
-                const int q = (slice * dp.sl + u) * 256 + tid;
-                if (q < patch_chunks) *reinterpret_cast<uint4*>(dP + (q / CPR) * LDR + kc * CE) = preg[u];
-            }
-        }
-    };
-    auto load_w = [&](int step) {
-        const int chunk = step / p.ntaps, tap = step - chunk * p.ntaps;
-        const int wcol = ktab[2 * MAX_TAPS + tap] * p.C + chunk * DCK + kc * CE;
-#pragma unroll
-        for (int r = 0; r < WR; ++r) {
-            const int q = tid + 256 * r, row = q / CPR;
-            wreg[r] = zero4;
-            if (q < WCH && (n0 + row) < p.Nout) wreg[r] = *reinterpret_cast<const uint4*>(Wg + (long long)(n0 + row) * p.ldw + wcol);
-        }
-    };
-    auto store_w = [&](int buf) {
-        T* dW = sW + buf * TM * LDR;
-#pragma unroll
-        for (int r = 0; r < WR; ++r) {
-            const int q = tid + 256 * r;
-            if (q < WCH) *reinterpret_cast<uint4*>(dW + (q / CPR) * LDR + kc * CE) = wreg[r];
-        }
-    };
-
-    // ---- prologue: whole first patch (all slices) + first weight tile
-    for (int sidx = 0; sidx < p.ntaps; ++sidx) {
-        load_patch_slice(cur_tile, 0, sidx);
-        store_patch_slice(0, sidx);
-    }
-    load_w(0);
-    store_w(0);
-    __syncthreads();
-
+    bool after_epi = false;
     while (true) {
-        // ---------------- prefetch for the next step: its weight tile, and one slice of the NEXT chunk's patch
-        int nx_step = cur_step + 1;
-        long long nx_tile = cur_tile;
-        if (nx_step == nsteps) { nx_step = 0; nx_tile += lstride; }
-        const bool more = nx_tile < ntiles;
-        const int cur_chunk = cur_step / p.ntaps, cur_tap = cur_step - cur_chunk * p.ntaps;
-        // the patch that follows the current chunk
-        int pn_chunk = cur_chunk + 1;
-        long long pn_tile = cur_tile;
-        if (pn_chunk == nchunks) { pn_chunk = 0; pn_tile += lstride; }
-        const bool pmore = pn_tile < ntiles;
-        if (more) load_w(nx_step);
-        if (pmore) load_patch_slice(pn_tile, pn_chunk, cur_tap);
-
-        // ---------------- MFMAs of the current step
-        {
-            const int toff = ((ktab[cur_tap] - dp.dh_min) * dp.PW + (ktab[MAX_TAPS + cur_tap] - dp.dw_min)) * LDR;
-            const T* cW = sW + wbuf * TM * LDR + (wm * 32 + (lane & 31)) * LDR + (lane >> 5) * 8;
-            const T* cP = sP + pbuf * patch_elems + toff;
-#pragma unroll
-            for (int kk = 0; kk < DCK / 16; ++kk) {
-                auto a = lds_frag(cW + kk * 16);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    auto b = lds_frag(cP + frag_off[ni] + kk * 16);
-                    mma_step(a, b, acc[ni]);
-                }
-            }
+        // step s landed (this wave's part), then: everyone's part landed AND everyone finished reading step s-1
+        if (after_epi) wait_vm<G::LPS + G::NST>(); else wait_vm<G::LPS>();
+        __builtin_amdgcn_s_barrier();
+        g_issue<T, TM>(p, xoff, xh0, xw0, woff, ld_kt, sTap, lds_tiles, so2, rsX, rsW, wave, kc);       // step s+2 -> the stage step s-1 used
+        G_ADVANCE()
+        g_mma<T, TM>(sTiles + so0, arow, xrow, swz, lane, acc);
+        after_epi = false;
+        if (cur_kt == nk - 1) {
+            g_epilogue<T, TM, EM>(p, cur_tile, wp, lane, cbase, want_stats, rsY, acc, ssum, ssq);
+            after_epi = true;
         }
-        // ---------------- tile finished: epilogue
-        if (cur_step == nsteps - 1) {
-            const unsigned tu = (unsigned)cur_tile;
-            const unsigned nn = tu / (unsigned)tiles_per_img;
-            const unsigned rr = tu - nn * (unsigned)tiles_per_img;
-            const unsigned ty = rr / (unsigned)dp.txn, tx = rr - ty * (unsigned)dp.txn;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int j = wp * NI * 32 + ni * 32 + (lane & 31);
-                const int oh = (int)ty * DTH + j / DTW, ow = (int)tx * DTW + j % DTW;
-                const bool pv = oh < p.OH && ow < p.OW;
-                const long long yo = (((long long)nn * p.YH + (oh * p.osh + p.oah)) * p.YW + (ow * p.osw + p.oaw)) * p.ldy;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = cbase + 8 * g;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
-                    if constexpr (EM == 2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (c + e < p.Nout) {
-                                float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
-                                float u = v[e] * sc + sh;
-                                v[e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
-                            }
-                        }
-                    }
-                    if (want_stats) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
-                            ssum[g * 4 + e] += q;
-                            ssq[g * 4 + e] += q * q;
-                        }
-                    }
-                    if (pv) {
-                        T* Y = reinterpret_cast<T*>(p.y) + yo + c;
-                        if (c + 3 < p.Nout && (p.ldy & 3) == 0) {
-                            if constexpr (EM == 1) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)Y[e];
-                            }
-                            if constexpr (sizeof(T) == 2) {
-                                half4 h;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
-                                *reinterpret_cast<half4*>(Y) = h;
-                            } else {
-                                float4v f;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) f[e] = v[e];
-                                *reinterpret_cast<float4v*>(Y) = f;
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (c + e < p.Nout) Y[e] = (T)(EM == 1 ? v[e] + (float)Y[e] : v[e]);
-                        }
-                    }
-                }
-            }
+        if (++cur_kt == nk) {
+            cur_kt = 0;
+            cur_tile += lstride;
+            if (cur_tile >= ntiles) break;
         }
-        // ---------------- stage the prefetched data
-        if (more) store_w(wbuf ^ 1);
-        if (pmore) store_patch_slice(pbuf ^ 1, cur_tap);
-        __syncthreads();
-        if (!more) break;
-        wbuf ^= 1;
-        if (cur_tap == p.ntaps - 1) pbuf ^= 1;       // next step starts a new chunk: its patch is complete
-        cur_step = nx_step;
-        cur_tile = nx_tile;
+        const unsigned t = so0; so0 = so1; so1 = so2; so2 = t;
     }
-
-    if (want_stats) {
-        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = ssum[r], b = ssq[r];
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                a += __shfl_xor(a, off);
-                b += __shfl_xor(b, off);
-            }
-            if ((lane & 31) == 0) {
-                int cl = wm * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);
-                atomicAdd(&sStat[cl], a);
-                atomicAdd(&sStat[TM + cl], b);
-            }
-        }
-        __syncthreads();
-        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
-        for (int i = tid; i < TM; i += 256) {
-            if (n0 + i < p.Nout) {
-                atomicAdd(&st[n0 + i], sStat[i]);
-                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
-            }
-        }
-    }
+#undef G_ADVANCE
+    wait_vm<0>();                             // the trailing zero-fill DMAs must land before this LDS is released
+    if (want_stats) g_stats_flush<T, TM>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
 }
 
 static int g_num_cu = 0;
@@ -735,12 +497,16 @@ static int num_cus() {
 
 template <typename T, int TM, int EM>
 static int launch_gconv_em(GConvP p, hipStream_t s) {
-    constexpr int LDR = BK + Tr<T>::PADE;
-    size_t lds = (size_t)2 * (TM + TP) * LDR * sizeof(T) + 2 * TM * sizeof(float);
+    using G = GT<T, TM>;
+    const size_t lds = G::LDS;
     const long long ntiles = (p.Mtotal + TP - 1) / TP;
     p.ntn = (p.Nout + TM - 1) / TM;
-    // persistent grid: ~4 workgroups per CU in total, pixel-tile slots a multiple of the 8 XCDs
-    static const int bpc = getenv("AYOLO_GCONV_BPC") ? atoi(getenv("AYOLO_GCONV_BPC")) : 4;
+    // persistent grid: as many workgroups per CU as LDS / registers allow, pixel-tile slots a multiple of the 8 XCDs
+    static const int bpc_env = getenv("AYOLO_GCONV_BPC") ? atoi(getenv("AYOLO_GCONV_BPC")) : 0;
+    int bpc = (int)(160 * 1024 / lds);
+    const int bpc_max = sizeof(T) == 2 ? (TM == 128 ? 3 : 4) : 1;
+    if (bpc > bpc_max) bpc = bpc_max;
+    if (bpc_env > 0) bpc = bpc_env;
     long long want_slots = (long long)num_cus() * bpc / p.ntn;
     if (want_slots < 8) want_slots = 8;
     long long slots = ntiles < want_slots ? ntiles : want_slots;
@@ -758,77 +524,15 @@ static int launch_gconv_em(GConvP p, hipStream_t s) {
     return AYOLO_OK;
 }
 
-template <typename T, int TM, int EM>
-static int launch_dconv_em(DConvP dp, hipStream_t s) {
-    constexpr int LDR = DCK + Tr<T>::PADE;
-    GConvP& p = dp.g;
-    size_t lds = (size_t)2 * (TM + dp.PH * dp.PW) * LDR * sizeof(T) + 2 * TM * sizeof(float);
-    const long long ntiles = (long long)p.B * dp.tyn * dp.txn;
-    p.ntn = (p.Nout + TM - 1) / TM;
-    int blocks_per_cu = (int)(150 * 1024 / lds);
-    if (blocks_per_cu > 4) blocks_per_cu = 4;
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-    long long want_slots = (long long)num_cus() * blocks_per_cu / p.ntn;
-    if (want_slots < 8) want_slots = 8;
-    long long slots = ntiles < want_slots ? ntiles : want_slots;
-    slots = (slots + 7) / 8 * 8;
-    p.nslots = (int)slots;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dconv<T, TM, EM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
-    hipLaunchKernelGGL((k_dconv<T, TM, EM>), dim3((unsigned)(slots * p.ntn)), dim3(256), lds, s, dp);
-    AY_CHECK_LAUNCH("k_dconv");
-    return AYOLO_OK;
-}
-
-// Halo-tiled direct kernel is used for multi-tap convs on maps large enough to tile (>= 2 tiles per image) whose
-// channel count is a multiple of the 32-channel LDS chunk; everything else goes through k_gconv.
-static bool dconv_applicable(const GConvP& p, DConvP* out, int elem_size) {
-    static const bool disabled = getenv("AYOLO_NO_DCONV") != nullptr;
-    if (disabled || p.ntaps < 2 || p.C % DCK != 0 || p.epi == AYOLO_EPI_HEAD) return false;
-    if (p.ish != 1 || p.isw != 1) return false;   // strided forward: the 17x33 halo patch leaves one workgroup per CU (measured slower)
-    if (p.OH < DTH || p.OW < DTW) return false;
-    int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
-    for (int t = 0; t < p.ntaps; ++t) {
-        dh_min = p.dh[t] < dh_min ? p.dh[t] : dh_min; dh_max = p.dh[t] > dh_max ? p.dh[t] : dh_max;
-        dw_min = p.dw[t] < dw_min ? p.dw[t] : dw_min; dw_max = p.dw[t] > dw_max ? p.dw[t] : dw_max;
-    }
-    DConvP dp;
-    dp.g = p;
-    dp.tyn = (p.OH + DTH - 1) / DTH; dp.txn = (p.OW + DTW - 1) / DTW;
-    dp.PH = (DTH - 1) * p.ish + (dh_max - dh_min) + 1;
-    dp.PW = (DTW - 1) * p.isw + (dw_max - dw_min) + 1;
-    dp.dh_min = dh_min; dp.dw_min = dw_min;
-    const int cpr = DCK * elem_size / 16;
-    const int patch_chunks = dp.PH * dp.PW * cpr;
-    dp.sl = (patch_chunks + 256 * p.ntaps - 1) / (256 * p.ntaps);
-    if (dp.sl > DSL_MAX) return false;
-    const size_t lds_max = (size_t)2 * (128 + dp.PH * dp.PW) * (DCK + 16 / elem_size) * elem_size + 1024;
-    if (lds_max > 150 * 1024) return false;
-    // tile utilisation: skip when padding to 8x16 tiles wastes more than ~35 % of the MFMA work
-    const double util = (double)p.OH * p.OW / ((double)dp.tyn * DTH * dp.txn * DTW);
-    if (util < 0.65) return false;
-    *out = dp;
-    return true;
-}
-
 template <typename T, int TM>
 static int launch_gconv(const GConvP& p, hipStream_t s) {
-    DConvP dp;
-    if (dconv_applicable(p, &dp, (int)sizeof(T))) {
-        if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_dconv_em<T, TM, 2>(dp, s);
-        if (p.accumulate) return launch_dconv_em<T, TM, 1>(dp, s);
-        return launch_dconv_em<T, TM, 0>(dp, s);
-    }
     if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
     if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_gconv_em<T, TM, 2>(p, s);
     if (p.accumulate) return launch_gconv_em<T, TM, 1>(p, s);
     return launch_gconv_em<T, TM, 0>(p, s);
 }
 
-static int dispatch_gconv(int dtype, const GConvP& p, hipStream_t s) {
+static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
     int tm = p.Nout <= 32 ? 32 : (p.Nout <= 64 ? 64 : 128);
     if (dtype == AYOLO_F16) {
         if (tm == 32) return launch_gconv<half_t, 32>(p, s);
@@ -839,6 +543,36 @@ static int dispatch_gconv(int dtype, const GConvP& p, hipStream_t s) {
         if (tm == 64) return launch_gconv<float, 64>(p, s);
         return launch_gconv<float, 128>(p, s);
     }
+}
+
+// Fills the buffer-descriptor extents / division constants of k_gconv.  The descriptors address < 2 GiB (bit 31 of the
+// offset is the out-of-range marker): a larger activation is processed as independent batch halves (NHWC, batch
+// outermost; BN statistics accumulate across launches).
+static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
+    const long long es = dtype == AYOLO_F16 ? 2 : 4;
+    const long long yes = p.epi == AYOLO_EPI_HEAD ? 4 : es;
+    const long long LIM = (1ll << 31) - 4096;
+    const long long x_img = (long long)p.XH * p.XW * p.ldx * es;
+    const long long y_img = (long long)p.YH * p.YW * p.ldy * yes;
+    const long long w_bytes = (long long)p.Nout * p.ldw * es;
+    AY_CHECK_ARG(w_bytes < (1ll << 30), "conv: weight matrix of %lld bytes unsupported", w_bytes);
+    AY_CHECK_ARG(x_img < LIM && y_img < LIM, "conv: a single image of %lld / %lld bytes unsupported", x_img, y_img);
+    if (x_img * p.B >= LIM || y_img * p.B >= LIM) {
+        GConvP a = p, b = p;
+        a.B = p.B / 2; b.B = p.B - a.B;
+        a.Mtotal = (long long)a.B * p.OH * p.OW; b.Mtotal = (long long)b.B * p.OH * p.OW;
+        b.x = (const char*)p.x + x_img * a.B;
+        b.y = (char*)p.y + y_img * a.B;
+        int rc = dispatch_gconv(dtype, a, s);
+        return rc ? rc : dispatch_gconv(dtype, b, s);
+    }
+    if (p.epi != AYOLO_EPI_HEAD)
+        AY_CHECK_ARG(p.Nout % 4 == 0 && p.ldy % 4 == 0, "conv: Cout=%d / channel stride %d must be multiples of 4", p.Nout, p.ldy);
+    p.x_bytes = (unsigned)(x_img * p.B);
+    p.y_bytes = (unsigned)(y_img * p.B);
+    p.w_bytes = (unsigned)w_bytes;
+    p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)(p.C > 0 ? p.C : 1));
+    return dispatch_gconv_one(dtype, p, s);
 }
 
 static int check_desc(const ayolo_conv_desc* d, const char* who) {
@@ -1110,6 +844,9 @@ __global__ __launch_bounds__(256) void k_wgrad(WGradP p) {
 // through the transposing LDS read.
 // ---------------------------------------------------------------------------------------------------
 #define WD_MAXT 9
+#define DTH 8            // halo tile: 8 x 16 output pixels, 32-channel chunk
+#define DTW 16
+#define DCK 32
 struct WGradDP {
     WGradP w;
     int tyn, txn, PH, PW, dh_min, dw_min;
