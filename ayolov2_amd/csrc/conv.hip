@@ -9,8 +9,8 @@
 // NHWC without an LDS transpose.
 //   fp16 : v_mfma_f32_32x32x16_f16  (fp32 accumulate)
 //   fp32 : v_mfma_f32_32x32x2_f32   (exact fp32 -- the 1e-4 parity mode)
-// Tiles: TM in {32,64,128} output channels x 128 pixels x BK=32, 4 wavefronts, register-staged global->LDS
-// double buffer with padded rows (80 B / 144 B) so ds_read_b128 fragments are bank-conflict free.
+// Tiles: TM in {32,64,128} output channels x 128 pixels x BK=32 (gconv) / TM x 128 dw columns x 32 pixels (wgrad),
+// 4 wavefronts, operands staged global -> LDS by LDS-DMA into three XOR-swizzled stages (see k_gconv).
 //
 // Replaces kindle Conv/YOLOHead.conv forward (yolov5s.yaml:21-57) and the autograd backward torch/cuDNN ran
 // (scripts/train/yolo_trainer.py:329).
@@ -50,18 +50,7 @@ struct GConvP {
 };
 
 template <typename T> struct Tr;
-template <> struct Tr<half_t> {
-    static constexpr int CE = 8;            // elements per 16-byte chunk
-    static constexpr int PADE = 8;          // row padding (elements)
-    typedef half8 frag;                     // 8 k-values per lane per k16 step
-    typedef uint4 chunk;
-};
-template <> struct Tr<float> {
-    static constexpr int CE = 4;
-    static constexpr int PADE = 4;
-    struct frag { float v[8]; };
-    typedef uint4 chunk;
-};
+template <> struct Tr<float> { struct frag { float v[8]; }; };   // 8 k-values per lane: 8 v_mfma_f32_32x32x2_f32
 
 __device__ __forceinline__ void mma_step(const half8& a, const half8& b, float16v& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
@@ -70,15 +59,6 @@ __device__ __forceinline__ void mma_step(const Tr<float>::frag& a, const Tr<floa
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b.v[s], acc, 0, 0, 0);
 }
-__device__ __forceinline__ half8 lds_frag(const half_t* p) { return *reinterpret_cast<const half8*>(p); }
-__device__ __forceinline__ Tr<float>::frag lds_frag(const float* p) {
-    Tr<float>::frag f;
-    float4v a = *reinterpret_cast<const float4v*>(p), b = *reinterpret_cast<const float4v*>(p + 4);
-    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
-    return f;
-}
-
 __device__ __forceinline__ float cvt_round(float v, half_t*) { return (float)(half_t)v; }
 __device__ __forceinline__ float cvt_round(float v, float*) { return v; }
 
@@ -673,21 +653,54 @@ struct WGradP {
     long long P;                   // B*OH*OW
     long long chunk;               // pixels per split (multiple of 32)
     signed char dh[MAX_TAPS], dw_[MAX_TAPS];
+    unsigned x_bytes, y_bytes;     // buffer descriptor extents (k_wgrad)
+    unsigned gx, gy, splits;       // column tiles, channel tiles, pixel splits
+    FastDiv dOW, dOH, dC;
 };
 
-#define BP_MAX 64   // pixels per reduction step: 64 (fp16) / 32 (fp32)
-#define TNW 128 // dw columns per block tile
+#define TNW 128     // dw columns per block tile
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-// A/B fragments for v_mfma_f32_32x32x16_f16 out of a pixel-major LDS tile t[pixel][channel] via the gfx950
-// transposing LDS read: each 16-lane group reads a 4(pixel) x 16(channel) block, lane q supplies the address of
-// row q/4, channels (q%4)*4.. and receives channel q of all 4 rows.
-__device__ __forceinline__ half8 tr_frag(const half_t* tile, int ldt, int k0, int c0, int lane) {
-    const int q = lane & 15;
-    const half_t* p0 = tile + (k0 + (q >> 2)) * ldt + c0 + (q & 3) * 4;
+// A/B fragments for v_mfma_f32_32x32x16_f16 come out of the pixel-major LDS tiles t[pixel][channel] through the gfx950
+// transposing LDS read (tr_frag_sw below): each 16-lane group reads a 4(pixel) x 16(channel) block, lane q supplies the
+// address of row q/4, channels (q%4)*4.. and receives channel q of all 4 rows.
+// ---------------------------------------------------------------------------------------------------
+// k_wgrad: dw[n][tap*C + c] += sum_pixels dy[pixel][n] * x[pixel @ tap][c], split over pixel ranges.
+// Same machinery as k_gconv: both operand tiles ([32 pixels][TM channels] of dy, [32 pixels][128 dw columns] of x)
+// arrive by LDS-DMA two steps ahead (3 LDS stages, one raw barrier per step, counted vmcnt, branch-free loader with
+// out-of-range zero fill).  Both operands are pixel-major in HBM, i.e. k-major for this GEMM: they are staged as
+// they lie and transposed on the way to the MFMA by ds_read_b64_tr_b16.  The unpadded lane-linear image would put the
+// 4 pixel rows of one transposing read on the same banks; the 64-byte groups of a row are therefore XOR-swizzled by the
+// row (on the source address).  All column / channel tiles of one pixel split run on the SAME XCD back to back, so the
+// re-reads of dy (once per column tile) and x (once per tap) are L2 hits.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int TM>
+struct WT {
+    static constexpr int ES = sizeof(T), CE = 16 / ES;
+    static constexpr int BP = 32;                                  // pixels per step
+    static constexpr int XROWB = TNW * ES, YROWB = TM * ES;        // bytes per pixel row of the two tiles
+    static constexpr int XSTAGE = BP * XROWB;
+    static constexpr int YSTAGE = BP * YROWB < 4096 ? 4096 : BP * YROWB;
+    static constexpr int XR = XSTAGE / 4096, YR = YSTAGE / 4096, LPS = XR + YR;
+    static constexpr int XRW = 1024 / XROWB, YRW = 1024 / YROWB;   // pixel rows per wave-instruction
+    static constexpr int XCPR = XROWB / 16, YCPR = YROWB / 16;     // 16-byte chunks per row
+    static constexpr int STAGE = XSTAGE + YSTAGE;
+    static constexpr int WM = TM / 32, WN = 4 / WM, NI = TNW / (32 * WN);
+    // fp16 swizzle: 64-byte group g of row r is stored at group g ^ ((r / RPB) & (G - 1)), G = min(groups per row, 4)
+    static constexpr int XG = XROWB / 64 > 4 ? 4 : XROWB / 64, YG = YROWB / 64 > 4 ? 4 : YROWB / 64;
+    static constexpr int XRPB = XROWB >= 256 ? 1 : 256 / XROWB, YRPB = YROWB >= 256 ? 1 : 256 / YROWB;
+    static constexpr size_t LDS = (size_t)GNS * STAGE;
+};
+
+template <int ROWB, int G, int RPB>
+__device__ __forceinline__ half8 tr_frag_sw(const unsigned char* tile, int k0, int c0, int lane) {
+    const int q = lane & 15, rowl = q >> 2;
+    const int colb = (c0 + (q & 3) * 4) * 2;
+    const int sw = (rowl / RPB) & (G - 1);           // k0 is a multiple of 8: the row's swizzle only depends on rowl
+    const unsigned char* p0 = tile + (k0 + rowl) * ROWB + ((((colb >> 6) ^ sw) << 6) | (colb & 63));
     fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0));
-    fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0 + 4 * ldt));
+    fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0 + 4 * ROWB));
     half8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -695,138 +708,119 @@ __device__ __forceinline__ half8 tr_frag(const half_t* tile, int ldt, int k0, in
 }
 
 template <typename T, int TM>
-__global__ __launch_bounds__(256) void k_wgrad(WGradP p) {
-    constexpr int CE = Tr<T>::CE;
-    constexpr int BP = sizeof(T) == 2 ? 64 : 32;
-    constexpr int LDY = TM + Tr<T>::PADE;     // dy tile row stride
-    constexpr int LDX = TNW + Tr<T>::PADE;    // x tile row stride
-    constexpr int WM = TM / 32, WN = 4 / WM, NI = TNW / (32 * WN);
-    constexpr int XCPR = TNW / CE, YCPR = TM / CE;
-    constexpr int XR = (BP * XCPR) / 256;             // x chunks / thread (2 for f16, 4 for f32)
-    constexpr int YCH = BP * YCPR;
-    constexpr int YR = (YCH + 255) / 256;
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP p) {
+    using W = WT<T, TM>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % W::WM, wn = wave / W::WM;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* sY = reinterpret_cast<T*>(smem_raw);           // [2][BP][LDY]
-    T* sX = sY + 2 * BP * LDY;                        // [2][BP][LDX]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    const int n0 = blockIdx.y * TM;                   // output-channel tile
-    const int j0 = blockIdx.x * TNW;                  // dw column tile (tap*C + c)
-    const long long pbeg = (long long)blockIdx.z * p.chunk;
-    const long long pend = min(p.P, pbeg + p.chunk);
+    // block -> (tile, pixel split): split zz lives on XCD zz % 8 and its gx*gy tiles are consecutive there
+    const unsigned Lb = blockIdx.x, xcd = Lb & 7u, local = Lb >> 3;
+    const unsigned ntile = p.gx * p.gy;
+    const unsigned tile = local % ntile, zz = (local / ntile) * 8u + xcd;
+    if (zz >= p.splits) return;
+    const int j0 = (int)(tile % p.gx) * TNW;          // dw column tile (tap*C + c)
+    const int n0 = (int)(tile / p.gx) * TM;           // output-channel tile
+    const unsigned P = (unsigned)p.P;
+    const unsigned pbeg = zz * (unsigned)p.chunk;
+    const unsigned pend = pbeg + (unsigned)p.chunk < P ? pbeg + (unsigned)p.chunk : P;
     if (pbeg >= pend) return;
-    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
 
-    // x loader: this thread always loads the same dw column chunk, for XR different pixel rows
-    const int xcc = tid % XCPR;
-    const int xcol = j0 + xcc * CE;
+    const v4i32 rsX = make_srd(p.x, p.x_bytes), rsY = make_srd(p.dy, p.y_bytes);
+    const unsigned lds_tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)smem_raw);
+
+    // ---- x loader lanes: LDS position (row piece*XRW + xrowin, chunk slot xslot) <- source chunk xsrc of that row
+    const int xslot = lane % W::XCPR, xrowin = lane / W::XCPR;
+    int xsrc = xslot;
+    if constexpr (sizeof(T) == 2) xsrc = ((((xslot >> 2) ^ ((xrowin / W::XRPB) & (W::XG - 1))) << 2) | (xslot & 3));
+    const int xcol = j0 + xsrc * W::CE;
     const bool xcol_ok = xcol < p.K;
-    const int xtap = xcol_ok ? xcol / p.C : 0;
-    const int xc = xcol_ok ? xcol % p.C : 0;
-    const int xdh = p.dh[xtap], xdw = p.dw_[xtap];
-    const int ycc = tid % YCPR;
-    const bool ycol_ok = (n0 + ycc * CE) < p.N;
+    const unsigned xtap = fdiv(xcol_ok ? (unsigned)xcol : 0u, p.dC);
+    const int xcb = (int)((xcol_ok ? (unsigned)xcol : 0u) - xtap * (unsigned)p.C) * W::ES;
+    typedef __attribute__((address_space(4))) const signed char* kptr_t;
+    const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WGradP, dh);
+    const int xdh = ktab[xtap < MAX_TAPS ? xtap : 0], xdw = ktab[MAX_TAPS + (xtap < MAX_TAPS ? xtap : 0)];
+    // ---- dy loader lanes
+    const int yslot = lane % W::YCPR, yrowin = lane / W::YCPR;
+    int ysrc = yslot;
+    if constexpr (sizeof(T) == 2 && W::YG > 1) ysrc = ((((yslot >> 2) ^ ((yrowin / W::YRPB) & (W::YG - 1))) << 2) | (yslot & 3));
+    const bool ycol_ok = n0 + ysrc * W::CE < p.N;
+    const unsigned ycb = (unsigned)(n0 + ysrc * W::CE) * W::ES;
 
-    uint4 xreg[XR], yreg[YR];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    // pixel coordinates of this thread's x rows, advanced incrementally (no divisions in the loop)
-    int pn[XR], poh[XR], pow_[XR];
+    float16v acc[W::NI];
 #pragma unroll
-    for (int r = 0; r < XR; ++r) {
-        long long pp = pbeg + (tid + 256 * r) / XCPR;
-        pow_[r] = (int)(pp % p.OW);
-        long long t = pp / p.OW;
-        poh[r] = (int)(t % p.OH);
-        pn[r] = (int)(t / p.OH);
-    }
-
-    float16v acc[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < W::NI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const int nk = (int)((pend - pbeg + BP - 1) / BP);
-    for (int kt = -1; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) {
-            const long long pt = pbeg + (long long)(kt + 1) * BP;
-#pragma unroll
-            for (int r = 0; r < XR; ++r) {
-                int prow = (tid + 256 * r) / XCPR;
-                long long pp = pt + prow;
-                xreg[r] = zero4;
-                if (pp < pend && xcol_ok) {
-                    int ih = poh[r] * p.sh + xdh, iw = pow_[r] * p.sw + xdw;
-                    if (ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW)
-                        xreg[r] = *reinterpret_cast<const uint4*>(X + (((long long)pn[r] * p.XH + ih) * p.XW + iw) * p.ldx + xc);
-                }
-                pow_[r] += BP;
-                while (pow_[r] >= p.OW) { pow_[r] -= p.OW; ++poh[r]; }
-                while (poh[r] >= p.OH) { poh[r] -= p.OH; ++pn[r]; }
-            }
-#pragma unroll
-            for (int r = 0; r < YR; ++r) {
-                int q = tid + 256 * r;
-                int prow = q / YCPR;
-                long long pp = pt + prow;
-                yreg[r] = zero4;
-                if (q < YCH && pp < pend && ycol_ok)
-                    yreg[r] = *reinterpret_cast<const uint4*>(DY + pp * p.ldy + n0 + ycc * CE);
-            }
-        }
-        if (kt >= 0) {
-            const int buf = kt & 1;
-            const T* cY = sY + buf * BP * LDY;
-            const T* cX = sX + buf * BP * LDX;
-#pragma unroll
-            for (int kk = 0; kk < BP / 16; ++kk) {
-                const int k0 = kk * 16 + (lane >> 5) * 8;
-                if constexpr (sizeof(T) == 2) {
-                    const int csub = ((lane >> 4) & 1) * 16;
-                    half8 a = tr_frag(cY, LDY, k0, wm * 32 + csub, lane);
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        half8 b = tr_frag(cX, LDX, k0, wn * NI * 32 + ni * 32 + csub, lane);
-                        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ni], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int s8 = 0; s8 < 8; ++s8) {
-                        float a = cY[(k0 + s8) * LDY + wm * 32 + (lane & 31)];
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) {
-                            float b = cX[(k0 + s8) * LDX + wn * NI * 32 + ni * 32 + (lane & 31)];
-                            acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ni], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-        if (more) {
-            const int nb = (kt + 1) & 1;
-            T* dX = sX + nb * BP * LDX;
-            T* dY = sY + nb * BP * LDY;
-#pragma unroll
-            for (int r = 0; r < XR; ++r) {
-                int prow = (tid + 256 * r) / XCPR;
-                *reinterpret_cast<uint4*>(dX + prow * LDX + xcc * CE) = xreg[r];
-            }
-#pragma unroll
-            for (int r = 0; r < YR; ++r) {
-                int q = tid + 256 * r;
-                if (q < YCH) *reinterpret_cast<uint4*>(dY + (q / YCPR) * LDY + ycc * CE) = yreg[r];
-            }
-        }
-        __syncthreads();
+    const int nk = (int)((pend - pbeg + W::BP - 1) / W::BP);
+    // DMA of reduction step `st` into the stage at byte offset `so`; steps >= nk lie beyond pend: all rows zero-fill
+#define W_ISSUE(st, so)                                                                                             \
+    {                                                                                                               \
+        const unsigned pt = pbeg + (unsigned)(st) * W::BP;                                                          \
+        _Pragma("unroll") for (int r = 0; r < W::XR; ++r) {                                                         \
+            const unsigned pp = pt + (r * 4 + wave) * W::XRW + xrowin;                                              \
+            const unsigned t = fdiv(pp, p.dOW);                                                                     \
+            const int ow = (int)(pp - t * (unsigned)p.OW);                                                          \
+            const unsigned n = fdiv(t, p.dOH);                                                                      \
+            const int oh = (int)(t - n * (unsigned)p.OH);                                                           \
+            const unsigned ih = (unsigned)(oh * p.sh + xdh), iw = (unsigned)(ow * p.sw + xdw);                      \
+            const bool ok = (pp < pend) & xcol_ok & (ih < (unsigned)p.XH) & (iw < (unsigned)p.XW);                  \
+            const unsigned off = ok ? ((n * (unsigned)p.XH + ih) * (unsigned)p.XW + iw) * (unsigned)p.ldx * W::ES + (unsigned)xcb : G_OOB; \
+            glds16(rsX, lds_tiles + (so) + (r * 4 + wave) * 1024, off);                                             \
+        }                                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < W::YR; ++r) {                                                         \
+            const unsigned row = (r * 4 + wave) * W::YRW + yrowin;                                                  \
+            const unsigned pp = pt + row;                                                                           \
+            const bool ok = (row < (unsigned)W::BP) & (pp < pend) & ycol_ok;                                        \
+            const unsigned off = ok ? pp * (unsigned)p.ldy * W::ES + ycb : G_OOB;                                   \
+            glds16(rsY, lds_tiles + (so) + W::XSTAGE + (r * 4 + wave) * 1024, off);                                 \
+        }                                                                                                           \
     }
+
+    unsigned so0 = 0, so1 = W::STAGE, so2 = 2 * W::STAGE;
+    W_ISSUE(0, so0)
+    W_ISSUE(1, so1)
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vm<W::LPS>();                       // step kt landed (this wave's part) ...
+        __builtin_amdgcn_s_barrier();            // ... everyone's part landed, everyone finished reading step kt-1
+        W_ISSUE(kt + 2, so2)
+        const unsigned char* cX = smem_raw + so0;
+        const unsigned char* cY = smem_raw + so0 + W::XSTAGE;
+#pragma unroll
+        for (int kk = 0; kk < W::BP / 16; ++kk) {
+            const int k0 = kk * 16 + (lane >> 5) * 8;
+            if constexpr (sizeof(T) == 2) {
+                const int csub = ((lane >> 4) & 1) * 16;
+                const half8 a = tr_frag_sw<W::YROWB, W::YG, W::YRPB>(cY, k0, wm * 32 + csub, lane);
+#pragma unroll
+                for (int ni = 0; ni < W::NI; ++ni) {
+                    const half8 b = tr_frag_sw<W::XROWB, W::XG, W::XRPB>(cX, k0, wn * W::NI * 32 + ni * 32 + csub, lane);
+                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ni], 0, 0, 0);
+                }
+            } else {
+                const float* fY = reinterpret_cast<const float*>(cY);
+                const float* fX = reinterpret_cast<const float*>(cX);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const float a = fY[(k0 + s8) * TM + wm * 32 + (lane & 31)];
+#pragma unroll
+                    for (int ni = 0; ni < W::NI; ++ni) {
+                        const float b = fX[(k0 + s8) * TNW + wn * W::NI * 32 + ni * 32 + (lane & 31)];
+                        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ni], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const unsigned t = so0; so0 = so1; so1 = so2; so2 = t;
+    }
+#undef W_ISSUE
+    wait_vm<0>();                                // trailing zero-fill DMAs must land before this LDS is released
     // acc[ni][r]: row (out channel) = n0 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); col = j0 + wn*NI*32 + ni*32 + (lane&31)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        int col = j0 + wn * NI * 32 + ni * 32 + (lane & 31);
+    for (int ni = 0; ni < W::NI; ++ni) {
+        int col = j0 + wn * W::NI * 32 + ni * 32 + (lane & 31);
         if (col >= p.K) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -836,184 +830,63 @@ __global__ __launch_bounds__(256) void k_wgrad(WGradP p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Halo-tiled wgrad for multi-tap stride-1 convs (fp16).  The generic k_wgrad re-reads dy once per 128-column tile
-// of dw and x once per tap (PMC: 2.4x the algorithmic HBM bytes over a training step).  Here a workgroup owns
-// (TM output channels) x (one 32-channel chunk of the input) x ALL taps: per 8x16 pixel tile it stages the dy
-// tile and the x patch (with halo) in LDS once and every tap's MFMAs read shifted fragments of the same patch
-// through the transposing LDS read.
-// ---------------------------------------------------------------------------------------------------
-#define WD_MAXT 9
-#define DTH 8            // halo tile: 8 x 16 output pixels, 32-channel chunk
-#define DTW 16
-#define DCK 32
-struct WGradDP {
-    WGradP w;
-    int tyn, txn, PH, PW, dh_min, dw_min;
-    long long tiles_total, tiles_per_split;
-};
-
-template <int TM>
-__global__ __launch_bounds__(256) void k_wgrad_d(WGradDP dp) {
-    typedef half_t T;
-    const WGradP& p = dp.w;
-    constexpr int LDY = TM + 8;
-    constexpr int LDP = DCK + 8;
-    constexpr int WM = TM / 32, WT = 4 / WM;          // waves along channels / along taps
-    constexpr int TPW = (WD_MAXT + WT - 1) / WT;      // taps per wave (upper bound)
-    constexpr int YCH = TP * (TM / 8);                // dy chunks per tile
-    constexpr int YR = YCH / 256;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* sY = reinterpret_cast<T*>(smem_raw);           // [128][LDY]
-    T* sP = sY + TP * LDY;                            // [PH*PW][LDP]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wt = wave / WM;
-    const int chunk = blockIdx.x, n0 = blockIdx.y * TM;
-    const long long t_beg = (long long)blockIdx.z * dp.tiles_per_split;
-    const long long t_end = min(dp.tiles_total, t_beg + dp.tiles_per_split);
-    if (t_beg >= t_end) return;
-    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
-    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
-    const int tiles_per_img = dp.tyn * dp.txn;
-    const int patch_chunks = dp.PH * dp.PW * 4;
-
-    float16v acc[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-
-    const int q = lane & 15;
-    const int csub = ((lane >> 4) & 1) * 16;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    for (long long tile = t_beg; tile < t_end; ++tile) {
-        const int n = (int)(tile / tiles_per_img);
-        const int rr = (int)(tile - (long long)n * tiles_per_img);
-        const int ty = rr / dp.txn, tx = rr - ty * dp.txn;
-        // ---- stage dy tile: pixel j = (oy, ox), TM channels
-#pragma unroll
-        for (int r = 0; r < YR; ++r) {
-            const int qq = tid + 256 * r;
-            const int j = qq / (TM / 8), c8 = qq % (TM / 8);
-            const int oh = ty * DTH + j / DTW, ow = tx * DTW + j % DTW;
-            uint4 v = zero4;
-            if (oh < p.OH && ow < p.OW && (n0 + c8 * 8) < p.N)
-                v = *reinterpret_cast<const uint4*>(DY + (((long long)n * p.OH + oh) * p.OW + ow) * p.ldy + n0 + c8 * 8);
-            *reinterpret_cast<uint4*>(sY + j * LDY + c8 * 8) = v;
-        }
-        // ---- stage x patch (32 channels of this chunk, halo included)
-        const int ih0 = ty * DTH * p.sh + dp.dh_min, iw0 = tx * DTW * p.sw + dp.dw_min;
-        for (int qq = tid; qq < patch_chunks; qq += 256) {
-            const int pix = qq >> 2, kc4 = qq & 3;
-            const int py = pix / dp.PW, px = pix - py * dp.PW;
-            const int ih = ih0 + py, iw = iw0 + px;
-            uint4 v = zero4;
-            if (ih >= 0 && ih < p.XH && iw >= 0 && iw < p.XW)
-                v = *reinterpret_cast<const uint4*>(X + (((long long)n * p.XH + ih) * p.XW + iw) * p.ldx + chunk * DCK + kc4 * 8);
-            *reinterpret_cast<uint4*>(sP + pix * LDP + kc4 * 8) = v;
-        }
-        __syncthreads();
-        // ---- MFMAs: k = the 128 pixels of the tile, 16 per step (one tile row oy = kk)
-#pragma unroll
-        for (int kk = 0; kk < TP / 16; ++kk) {
-            const int k0 = kk * 16 + (lane >> 5) * 8;
-            half8 a = tr_frag(sY, LDY, k0, wm * 32 + csub, lane);
-            const int ox0 = (lane >> 5) * 8 + (q >> 2);            // first of this lane's 2 x 4 pixel rows
-#pragma unroll
-            for (int ti = 0; ti < TPW; ++ti) {
-                const int t = wt + ti * WT;
-                if (t < p.ntaps) {
-                    const int dh = p.dh[t] - dp.dh_min, dw = p.dw_[t] - dp.dw_min;
-                    const T* b0 = sP + ((kk * p.sh + dh) * dp.PW + (ox0 * p.sw + dw)) * LDP + csub + (q & 3) * 4;
-                    fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(b0));
-                    fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(b0 + 4 * p.sw * LDP));
-                    half8 b;
-                    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3];
-                    b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
-                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ti], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- acc[ti][r]: out channel = n0 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); dw column = t*C + chunk*32 + (lane&31)
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        const int t = wt + ti * WT;
-        if (t >= p.ntaps) continue;
-        const int col = t * p.C + chunk * DCK + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = n0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            if (row < p.N) unsafeAtomicAdd(&p.dw[(long long)row * p.K + col], acc[ti][r] * p.alpha);
-        }
-    }
-}
-
-template <int TM>
-static int launch_wgrad_d(const WGradDP& dp, dim3 grid, hipStream_t s) {
-    size_t lds = (size_t)(TP * (TM + 8) + dp.PH * dp.PW * (DCK + 8)) * sizeof(half_t);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_d<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
-    hipLaunchKernelGGL((k_wgrad_d<TM>), grid, dim3(256), lds, s, dp);
-    AY_CHECK_LAUNCH("k_wgrad_d");
-    return AYOLO_OK;
-}
-
-// returns 1 when the halo-tiled kernel was launched, 0 when it does not apply, < 0 on error
-static int try_wgrad_d(const ayolo_conv_desc* d, const WGradP& p, hipStream_t s) {
-    static const bool disabled = getenv("AYOLO_NO_WGRAD_D") != nullptr;
-    // one workgroup per 32-channel chunk re-reads dy C/32 times: only a win for single-chunk layers (measured)
-    if (disabled || d->dtype != AYOLO_F16 || p.ntaps < 2 || p.ntaps > WD_MAXT || p.C != DCK) return 0;
-    if (p.sh != 1 || p.sw != 1 || p.OH < DTH || p.OW < DTW || p.ldy % 8 != 0) return 0;
-    WGradDP dp;
-    dp.w = p;
-    int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
-    for (int t = 0; t < p.ntaps; ++t) {
-        dh_min = p.dh[t] < dh_min ? p.dh[t] : dh_min; dh_max = p.dh[t] > dh_max ? p.dh[t] : dh_max;
-        dw_min = p.dw_[t] < dw_min ? p.dw_[t] : dw_min; dw_max = p.dw_[t] > dw_max ? p.dw_[t] : dw_max;
-    }
-    dp.tyn = (p.OH + DTH - 1) / DTH; dp.txn = (p.OW + DTW - 1) / DTW;
-    const double util = (double)p.OH * p.OW / ((double)dp.tyn * DTH * dp.txn * DTW);
-    if (util < 0.65) return 0;
-    dp.PH = (DTH - 1) * p.sh + (dh_max - dh_min) + 1;
-    dp.PW = (DTW - 1) * p.sw + (dw_max - dw_min) + 1;
-    dp.dh_min = dh_min; dp.dw_min = dw_min;
-    dp.tiles_total = (long long)p.B * dp.tyn * dp.txn;
-    const int tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
-    const long long nxy = (long long)(p.C / DCK) * ((p.N + tm - 1) / tm);
-    long long splits = (2048 + nxy - 1) / nxy;
-    if (splits > dp.tiles_total / 2) splits = dp.tiles_total / 2;
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    dp.tiles_per_split = (dp.tiles_total + splits - 1) / splits;
-    splits = (dp.tiles_total + dp.tiles_per_split - 1) / dp.tiles_per_split;
-    dim3 grid((unsigned)(p.C / DCK), (unsigned)((p.N + tm - 1) / tm), (unsigned)splits);
-    int rc = tm == 32 ? launch_wgrad_d<32>(dp, grid, s) : (tm == 64 ? launch_wgrad_d<64>(dp, grid, s) : launch_wgrad_d<128>(dp, grid, s));
-    return rc == AYOLO_OK ? 1 : rc;
-}
-
 template <typename T, int TM>
-static int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
-    constexpr int LDY = TM + Tr<T>::PADE, LDX = TNW + Tr<T>::PADE;
-    constexpr int BP = sizeof(T) == 2 ? 64 : 32;
-    size_t lds = (size_t)2 * BP * (LDY + LDX) * sizeof(T);
-    dim3 grid((unsigned)((p.K + TNW - 1) / TNW), (unsigned)((p.N + TM - 1) / TM), (unsigned)splits);
+static int launch_wgrad(WGradP p, hipStream_t s) {
+    using W = WT<T, TM>;
+    p.gx = (unsigned)((p.K + TNW - 1) / TNW);
+    p.gy = (unsigned)((p.N + TM - 1) / TM);
+    const long long tiles = (long long)p.gx * p.gy;
+    // split the pixel reduction so that ~3 workgroups per CU are in flight, each with >= 8 reduction steps
+    const int bpc = sizeof(T) == 2 ? 3 : 1;
+    long long want = ((long long)num_cus() * bpc + tiles - 1) / tiles;
+    long long max_splits = (p.P + 8 * W::BP - 1) / (8 * W::BP);
+    long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits < 1) splits = 1;
+    long long chunk = (p.P + splits - 1) / splits;
+    chunk = (chunk + W::BP - 1) / W::BP * W::BP;
+    splits = (p.P + chunk - 1) / chunk;
+    p.chunk = chunk;
+    p.splits = (unsigned)splits;
+    const long long blocks = tiles * ((splits + 7) / 8 * 8);
+    AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+                            (int)W::LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_wgrad<T, TM>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_wgrad<T, TM>), dim3((unsigned)blocks), dim3(256), W::LDS, s, p);
     AY_CHECK_LAUNCH("k_wgrad");
     return AYOLO_OK;
+}
+
+static int wgrad_dispatch(const ayolo_conv_desc* d, WGradP p, hipStream_t st) {
+    // buffer descriptors address < 2 GiB: larger activations are reduced as independent batch halves (dw accumulates)
+    const long long es = d->dtype == AYOLO_F16 ? 2 : 4;
+    const long long LIM = (1ll << 31) - 4096;
+    const long long x_img = (long long)p.XH * p.XW * p.ldx * es, y_img = (long long)p.OH * p.OW * p.ldy * es;
+    AY_CHECK_ARG(x_img < LIM && y_img < LIM, "conv_wgrad: a single image of %lld / %lld bytes unsupported", x_img, y_img);
+    if (x_img * p.B >= LIM || y_img * p.B >= LIM) {
+        WGradP a = p, b = p;
+        a.B = p.B / 2; b.B = p.B - a.B;
+        a.P = (long long)a.B * p.OH * p.OW; b.P = (long long)b.B * p.OH * p.OW;
+        b.x = (const char*)p.x + x_img * a.B;
+        b.dy = (const char*)p.dy + y_img * a.B;
+        int rc = wgrad_dispatch(d, a, st);
+        return rc ? rc : wgrad_dispatch(d, b, st);
+    }
+    p.x_bytes = (unsigned)(x_img * p.B); p.y_bytes = (unsigned)(y_img * p.B);
+    p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)p.C);
+    const int tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
+    if (d->dtype == AYOLO_F16) {
+        if (tm == 32) return launch_wgrad<half_t, 32>(p, st);
+        if (tm == 64) return launch_wgrad<half_t, 64>(p, st);
+        return launch_wgrad<half_t, 128>(p, st);
+    } else {
+        if (tm == 32) return launch_wgrad<float, 32>(p, st);
+        if (tm == 64) return launch_wgrad<float, 64>(p, st);
+        return launch_wgrad<float, 128>(p, st);
+    }
 }
 
 extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha,
@@ -1034,32 +907,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
             p.dh[i * d->kw + j] = (signed char)(i - d->ph);
             p.dw_[i * d->kw + j] = (signed char)(j - d->pw);
         }
-    {
-        int rd = try_wgrad_d(d, p, (hipStream_t)s);
-        if (rd != 0) return rd < 0 ? rd : AYOLO_OK;
-    }
-    const int tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
-    const long long tiles = (long long)((p.K + TNW - 1) / TNW) * ((p.N + tm - 1) / tm);
-    // split the pixel reduction so that ~4 blocks per CU are in flight, each with >= 8 reduction steps
-    long long want = (1024 + tiles - 1) / tiles;
-    long long max_splits = (p.P + 8 * BP_MAX - 1) / (8 * BP_MAX);
-    long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    long long chunk = (p.P + splits - 1) / splits;
-    chunk = (chunk + BP_MAX - 1) / BP_MAX * BP_MAX;
-    splits = (p.P + chunk - 1) / chunk;
-    p.chunk = chunk;
-    hipStream_t st = (hipStream_t)s;
-    if (d->dtype == AYOLO_F16) {
-        if (tm == 32) return launch_wgrad<half_t, 32>(p, (int)splits, st);
-        if (tm == 64) return launch_wgrad<half_t, 64>(p, (int)splits, st);
-        return launch_wgrad<half_t, 128>(p, (int)splits, st);
-    } else {
-        if (tm == 32) return launch_wgrad<float, 32>(p, (int)splits, st);
-        if (tm == 64) return launch_wgrad<float, 64>(p, (int)splits, st);
-        return launch_wgrad<float, 128>(p, (int)splits, st);
-    }
+    return wgrad_dispatch(d, p, (hipStream_t)s);
 }
 
 // ---------------------------------------------------------------------------------------------------
