@@ -133,7 +133,29 @@ __global__ __launch_bounds__(256) void k_affine_act(const T* z, int ldz, T* a, i
             sc[i] = scale ? scale[cg * VE + i] : 1.0f;
             sh[i] = shift ? shift[cg * VE + i] : 0.0f;
         }
-        for (long long pix = (long long)blockIdx.x * RPB + prow; pix < npix; pix += (long long)gridDim.x * RPB) {
+        const long long stride = (long long)gridDim.x * RPB;
+        long long pix = (long long)blockIdx.x * RPB + prow;
+        // four pixels per iteration: all loads issued before the first use
+        for (; pix + 3 * stride < npix; pix += 4 * stride) {
+            float v[4][VE], r[4][VE];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, v[j]);
+            if (res) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) load_vec<T>(res + (pix + j * stride) * ldr + cg * VE, r[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    float u = v[j][i] * sc[i] + sh[i];
+                    u = act ? silu_t<T>(u) : u;
+                    v[j][i] = res ? u + r[j][i] : u;
+                }
+                store_vec<T>(a + (pix + j * stride) * lda + cg * VE, v[j]);
+            }
+        }
+        for (; pix < npix; pix += stride) {
             float v[VE];
             load_vec<T>(z + pix * ldz + cg * VE, v);
 #pragma unroll
@@ -199,9 +221,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
                                                        const float* mean, const float* invstd, const float* gamma,
                                                        const float* beta, int act, float* sums, int reps) {
     constexpr int VE = VecT<T>::VE;
-    extern __shared__ float bs[];   // [2][C] block sums
-    for (int i = threadIdx.x; i < 2 * C; i += 256) bs[i] = 0.0f;
-    __syncthreads();
+    extern __shared__ float bs[];   // [RPB][2*C] per-pixel-row partial sums (<= 16 KiB)
     const int CG = C / VE;
     const int CGT = CG < 256 ? CG : 256;
     const int RPB = 256 / CGT;
@@ -218,21 +238,23 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
             }
             const long long stride = (long long)gridDim.x * RPB;
             long long pix = (long long)blockIdx.x * RPB + prow;
-            // two pixels per iteration: four independent 16-byte loads in flight per lane
-            for (; pix + stride < npix; pix += 2 * stride) {
-                float z0[VE], d0[VE], z1[VE], d1[VE];
-                load_vec<T>(z + pix * ldz + cg * VE, z0);
-                load_vec<T>(da + pix * ldda + cg * VE, d0);
-                load_vec<T>(z + (pix + stride) * ldz + cg * VE, z1);
-                load_vec<T>(da + (pix + stride) * ldda + cg * VE, d1);
+            // four pixels per iteration: eight independent 16-byte loads in flight per lane
+            for (; pix + 3 * stride < npix; pix += 4 * stride) {
+                float zz[4][VE], dd[4][VE];
 #pragma unroll
-                for (int i = 0; i < VE; ++i) {
-                    float xa = (z0[i] - mu[i]) * is[i], xb = (z1[i] - mu[i]) * is[i];
-                    float dua = d0[i] * act_grad_t<T>(xa * ga[i] + be[i], act);
-                    float dub = d1[i] * act_grad_t<T>(xb * ga[i] + be[i], act);
-                    s1[i] += dua + dub;
-                    s2[i] += dua * xa + dub * xb;
+                for (int j = 0; j < 4; ++j) {
+                    load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, zz[j]);
+                    load_vec<T>(da + (pix + j * stride) * ldda + cg * VE, dd[j]);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) {
+                        const float xa = (zz[j][i] - mu[i]) * is[i];
+                        const float du = dd[j][i] * act_grad_t<T>(xa * ga[i] + be[i], act);
+                        s1[i] += du;
+                        s2[i] += du * xa;
+                    }
             }
             for (; pix < npix; pix += stride) {
                 float z0[VE], d0[VE];
@@ -246,16 +268,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
                     s2[i] += dua * xa;
                 }
             }
+            float* row = bs + (size_t)prow * 2 * C + cg * VE;
 #pragma unroll
-            for (int i = 0; i < VE; ++i) {
-                atomicAdd(&bs[cg * VE + i], s1[i]);
-                atomicAdd(&bs[C + cg * VE + i], s2[i]);
-            }
+            for (int i = 0; i < VE; ++i) { row[i] = s1[i]; row[C + i] = s2[i]; }
         }
     }
     __syncthreads();
+    // column sums over the RPB pixel rows (plain LDS reads, no LDS atomics), one global atomic per channel sum
     float* dst = sums + (size_t)(blockIdx.x % (unsigned)reps) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&dst[i], bs[i]);
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float t = 0.0f;
+        for (int r = 0; r < RPB; ++r) t += bs[(size_t)r * 2 * C + i];
+        atomicAdd(&dst[i], t);
+    }
 }
 
 extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const void* da, int ldda, int64_t npix, int C,
@@ -266,10 +291,12 @@ extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const 
     AY_CHECK_ARG(z && da && sums && save_mean && save_invstd, "bn_bwd_reduce: null pointer");
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && C <= 2048, "bn_bwd_reduce: C=%d", C);
     if (npix == 0) return AYOLO_OK;
-    unsigned grid = grid_pixels(npix, C, ve, 8);
-    if (grid > 2048) grid = 2048;
+    // >= 32 pixels per thread, at most 4 workgroups per CU: the per-workgroup tail (2*C global atomics) stays small
+    unsigned grid = grid_pixels(npix, C, ve, 32);
+    if (grid > 1024) grid = 1024;
+    const int cg_ = C / ve, cgt_ = cg_ < 256 ? cg_ : 256, rpb_ = 256 / cgt_;
     DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_reduce<T>, dim3(grid), dim3(256),
-                                         2 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
+                                         (size_t)rpb_ * 2 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
                                          (long long)npix, C, save_mean, save_invstd, gamma, beta, act, sums, sum_reps);)
     AY_CHECK_LAUNCH("k_bn_bwd_reduce");
     return AYOLO_OK;
@@ -283,6 +310,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sh[];   // [6][C]: mean, invstd, gamma, beta, sum_du/n, sum_dux/n
     const float invn = 1.0f / (float)npix;
+    // cooperative prologue: replica sums once per workgroup, then every thread keeps ITS channel group in registers
     for (int i = threadIdx.x; i < C; i += 256) {
         sh[i] = mean[i]; sh[C + i] = invstd[i];
         sh[2 * C + i] = gamma ? gamma[i] : 1.0f; sh[3 * C + i] = beta ? beta[i] : 0.0f;
@@ -296,22 +324,50 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     }
     __syncthreads();
     const int CG = C / VE;
-    const long long total = npix * CG;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-        long long pix = t / CG;
-        int cg = (int)(t - pix * CG);
-        float zv[VE], dv[VE];
-        load_vec<T>(z + pix * ldz + cg * VE, zv);
-        load_vec<T>(da + pix * ldda + cg * VE, dv);
+    const int CGT = CG < 256 ? CG : 256;
+    const int RPB = 256 / CGT;
+    const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
+    if (prow >= RPB) return;
+    for (int cg = cgl; cg < CG; cg += CGT) {
+        float mu[VE], is[VE], ga[VE], be[VE], m1[VE], m2[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
-            int c = cg * VE + i;
-            float xh = (zv[i] - sh[c]) * sh[C + c];
-            float u = xh * sh[2 * C + c] + sh[3 * C + c];
-            float du = dv[i] * act_grad_t<T>(u, act);
-            dv[i] = sh[2 * C + c] * sh[C + c] * (du - sh[4 * C + c] - xh * sh[5 * C + c]);
+            const int c = cg * VE + i;
+            mu[i] = sh[c]; is[i] = sh[C + c]; ga[i] = sh[2 * C + c]; be[i] = sh[3 * C + c];
+            m1[i] = sh[4 * C + c]; m2[i] = sh[5 * C + c];
         }
-        store_vec<T>(dz + pix * lddz + cg * VE, dv);
+        const long long stride = (long long)gridDim.x * RPB;
+        long long pix = (long long)blockIdx.x * RPB + prow;
+        for (; pix + stride < npix; pix += 2 * stride) {
+            float zz[2][VE], dd[2][VE];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, zz[j]);
+                load_vec<T>(da + (pix + j * stride) * ldda + cg * VE, dd[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    const float xh = (zz[j][i] - mu[i]) * is[i];
+                    const float du = dd[j][i] * act_grad_t<T>(xh * ga[i] + be[i], act);
+                    dd[j][i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
+                }
+                store_vec<T>(dz + (pix + j * stride) * lddz + cg * VE, dd[j]);
+            }
+        }
+        for (; pix < npix; pix += stride) {
+            float zv[VE], dv[VE];
+            load_vec<T>(z + pix * ldz + cg * VE, zv);
+            load_vec<T>(da + pix * ldda + cg * VE, dv);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                const float xh = (zv[i] - mu[i]) * is[i];
+                const float du = dv[i] * act_grad_t<T>(xh * ga[i] + be[i], act);
+                dv[i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
+            }
+            store_vec<T>(dz + pix * lddz + cg * VE, dv);
+        }
     }
 }
 
@@ -325,8 +381,9 @@ extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const v
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && lddz % ve == 0 && C <= 2048, "bn_bwd_apply: C=%d", C);
     if (npix == 0) return AYOLO_OK;
     // the per-workgroup prologue stages (6 + 2*reps)*C floats in LDS: scale the elements per workgroup with C
-    const int per_thread = C >= 256 ? 16 : (C >= 128 ? 8 : 4);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(grid_for(npix * (C / ve), 256 * per_thread)), dim3(256),
+    unsigned grid = grid_pixels(npix, C, ve, C >= 256 ? 16 : 8);
+    if (grid > 2048) grid = 2048;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(grid), dim3(256),
                                          6 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
                                          (T*)dz, lddz, (long long)npix, C, save_mean, save_invstd, gamma, beta, act,
                                          sums, sum_reps, dgamma, dbeta, grad_scale);)
