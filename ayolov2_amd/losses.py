@@ -43,6 +43,67 @@ class FocalLoss(nn.Module):
         return loss.mean() if self.reduction == "mean" else loss.sum() if self.reduction == "sum" else loss
 
 
+class _FusedLossFn(torch.autograd.Function):
+    """Value and analytic gradient of the whole loss in six HIP launches (csrc/loss.hip) instead of ~600 torch kernels
+    and their autograd graph.  Same arithmetic as the torch-op path below (which stays as the reference semantics for
+    focal loss / autobalance / sort_obj_iou and for CPU tensors)."""
+
+    @staticmethod
+    def forward(ctx, cfg, tcls, tbox, indices, anchors, *preds):
+        from . import _lib
+        from .ops import _stream
+        dev = preds[0].device
+        nl = len(preds)
+        cells = [p.shape[0] * p.shape[1] * p.shape[2] * p.shape[3] for p in preds]
+        ns = [int(indices[i][0].shape[0]) for i in range(nl)]
+        own = torch.zeros(sum(cells), dtype=torch.int32, device=dev)
+        score = torch.empty(max(sum(ns), 1), dtype=torch.float32, device=dev)
+        acc = torch.empty(3 * nl + 1, dtype=torch.float64, device=dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        arr = (_lib.LossLevel * nl)()
+        keep = []
+        co = no_ = 0
+        for i, p in enumerate(preds):
+            L = arr[i]
+            L.pred = p.data_ptr()
+            L.sb, L.sa, L.sy, L.sx = p.stride(0), p.stride(1), p.stride(2), p.stride(3)
+            L.B, L.na, L.ny, L.nx, L.no = p.shape
+            L.n = ns[i]
+            if ns[i]:
+                cols = [indices[i][0], indices[i][1], indices[i][2], indices[i][3], tcls[i]]
+                cols = [c.contiguous() if c.dtype == torch.int64 else c.long().contiguous() for c in cols]
+                tb, an = tbox[i].float().contiguous(), anchors[i].float().contiguous()
+                keep += cols + [tb, an]
+                L.b, L.a, L.gj, L.gi, L.tcls = (c.data_ptr() for c in cols)
+                L.tbox, L.anch = tb.data_ptr(), an.data_ptr()
+            L.own = own.data_ptr() + 4 * co
+            L.score = score.data_ptr() + 4 * no_
+            L.balance = float(cfg["balance"][i])
+            L.grad = None
+            co += cells[i]
+            no_ += ns[i]
+        consts = (cfg["cp"], cfg["cn"], cfg["cls_pw"], cfg["obj_pw"], cfg["gr"], cfg["box"], cfg["obj"], cfg["cls"])
+        _lib.call("ayolo_yolo_loss_fwd", arr, nl, *consts, acc.data_ptr(), out.data_ptr(), _stream())
+        ctx.arr, ctx.consts, ctx.keep = arr, consts, keep + [own, score]
+        ctx.save_for_backward(*preds)
+        items = out[1:5]
+        ctx.mark_non_differentiable(items)
+        return out[0:1], items
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_items):
+        from . import _lib
+        from .ops import _stream
+        g = g_loss.detach().reshape(-1)[:1].float().contiguous()
+        grads = []
+        for i, p in enumerate(ctx.saved_tensors):
+            gr = torch.empty(p.shape, dtype=torch.float32, device=p.device)       # contiguous (B,na,ny,nx,no)
+            ctx.arr[i].grad = gr.data_ptr()
+            grads.append(gr)
+        _lib.call("ayolo_yolo_loss_bwd", ctx.arr, len(grads), *ctx.consts, g.data_ptr(), _stream())
+        return (None, None, None, None, None, *grads)
+
+
 class ComputeLoss:
     def __init__(self, model: nn.Module, autobalance: bool = False) -> None:
         self.sort_obj_iou = False
@@ -60,6 +121,12 @@ class ComputeLoss:
         self.BCEcls, self.BCEobj, self.gr, self.hyp, self.autobalance = bce_cls, bce_obj, 1.0, hyp, autobalance
         self.na, self.nc, self.nl, self.anchors = head.na, head.nc, head.nl, head.anchors
         self._anchors_cpu = None
+        self.fused = True          # use csrc/loss.hip when the configuration allows (see _fusable)
+
+    def _fusable(self, preds) -> bool:
+        return (self.fused and self.hyp["fl_gamma"] <= 0 and not self.autobalance and not self.sort_obj_iou
+                and all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 5 and p.stride(4) == 1 for p in preds)
+                and len(preds) <= 8)
 
     def prepare(self, targets: torch.Tensor, pred_shapes, device=None):
         """Target assignment done on the HOST (labels come from the CPU data loader) before / while the forward
@@ -129,6 +196,12 @@ class ComputeLoss:
         lbox = torch.zeros(1, device=device)
         lobj = torch.zeros(1, device=device)
         tcls, tbox, indices, anchors = prepared if prepared is not None else self.build_targets(preds, targets)
+        if self._fusable(preds):
+            cfg = {"balance": self.balance, "cp": self.cp, "cn": self.cn, "cls_pw": float(self.hyp["cls_pw"]),
+                   "obj_pw": float(self.hyp["obj_pw"]), "gr": float(self.gr), "box": float(self.hyp["box"]),
+                   "obj": float(self.hyp["obj"]), "cls": float(self.hyp["cls"])}
+            loss_bs, items = _FusedLossFn.apply(cfg, tcls, tbox, indices, anchors, *preds)
+            return loss_bs, items
         for i, pi in enumerate(preds):
             b, a, gj, gi = indices[i]
             tobj = torch.zeros_like(pi[..., 0], device=device)

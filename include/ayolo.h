@@ -141,6 +141,35 @@ int ayolo_head_decode(const float* raw, const int64_t* raw_strides /* host int64
                       float stride, float* out, int64_t rows_total, int64_t row_off, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * YOLO loss, value and analytic gradient (scripts/loss/losses.py:227-300 `ComputeLoss.__call__`; box term
+ * scripts/utils/metrics.py:60-135 `bbox_iou(..., c_iou=True)`; BCEWithLogitsLoss(pos_weight) for objectness / class).
+ * One entry per detection level; the matched rows come from `build_targets` (losses.py:303-391).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ayolo_loss_level {
+    const float* pred;         /* logits (B,na,ny,nx,no) fp32: element strides of (b,a,y,x) below, o contiguous     */
+    int64_t sb, sa, sy, sx;
+    int B, na, ny, nx, no;
+    int n;                     /* matched target rows of this level                                               */
+    const int64_t* b; const int64_t* a; const int64_t* gj; const int64_t* gi;   /* [n] cell of each row             */
+    const int64_t* tcls;       /* [n] class of each row                                                          */
+    const float* tbox;         /* [n][4] target box (x, y relative to the cell; w, h in grid units)              */
+    const float* anch;         /* [n][2] anchor (grid units) of each row                                         */
+    int* own;                  /* [B*na*ny*nx] zeroed by the caller before _fwd: 1 + index of the row that owns the
+                                * cell's objectness target (the last row in order, as a sequential index_put)    */
+    float* score;              /* [n] objectness target of each row: (1-gr) + gr*clamp(ciou, 0), written by _fwd  */
+    float balance;             /* objectness balance of the level (losses.py:204-206)                            */
+    float* grad;               /* _bwd only: d(out[0]) / d pred, (B,na,ny,nx,no) CONTIGUOUS fp32, fully written    */
+} ayolo_loss_level;
+/* out[5] = {loss*B, lbox*h_box, lobj*h_obj, lcls*h_cls, loss}; acc: scratch double[3*nl] (zeroed by the call).
+ * cp / cn: smoothed positive / negative class targets; gr: IoU ratio of the objectness target. */
+int ayolo_yolo_loss_fwd(const ayolo_loss_level* lv, int nl, float cp, float cn, float cls_pw, float obj_pw, float gr,
+                        float h_box, float h_obj, float h_cls, double* acc, float* out, ayolo_stream s);
+/* grad_out: DEVICE pointer to d(objective)/d(out[0]) (e.g. the GradScaler scale) -- no host synchronisation.
+ * Needs own / score as left by _fwd on the same inputs. */
+int ayolo_yolo_loss_bwd(const ayolo_loss_level* lv, int nl, float cp, float cn, float cls_pw, float obj_pw, float gr,
+                        float h_box, float h_obj, float h_cls, const float* grad_out, ayolo_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * NMS (scripts/utils/metrics.py:285-443 `non_max_suppression`, scripts/utils/nms.py:15-116 `batched_nms`,
  * torchvision.ops.nms / ops.boxes.batched_nms call sites metrics.py:385,394,421 nms.py:66,71,102,
  * scripts/utils/metrics.py:138-164 `box_iou`).
