@@ -182,6 +182,110 @@ static unsigned grid_pixels(long long npix, int C, int ve, int min_iters) {
     return (unsigned)b;
 }
 
+// Training-mode BatchNorm + activation in ONE pass over z (k_bn_finalize folded into the prologue): every workgroup
+// derives scale/shift of all channels from the replicated sum / sum-of-squares accumulators into LDS (fp64, as
+// k_bn_finalize), workgroup 0 also writes save_mean / save_invstd and updates the running statistics.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a, int lda, long long npix, int C,
+                                                      const float* stats, int reps, double count, const float* gamma,
+                                                      const float* beta, float eps, float momentum, float* rmean, float* rvar,
+                                                      float* smean, float* sinv, int act, const T* res, int ldr) {
+    constexpr int VE = VecT<T>::VE;
+    extern __shared__ float sc_sh[];   // [2][C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < reps; ++r) {
+            s1 += (double)stats[(size_t)r * 2 * C + c];
+            s2 += (double)stats[(size_t)r * 2 * C + C + c];
+        }
+        const double icount = 1.0 / count;            // uniform: one fp64 reciprocal, then multiplies only
+        const double mean = s1 * icount;
+        double var = s2 * icount - mean * mean;       // the cancellation-prone step stays in fp64
+        if (var < 0) var = 0;
+        const float invstd = 1.0f / sqrtf((float)var + eps);
+        const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+        const float sc = g * invstd;
+        sc_sh[c] = sc;
+        sc_sh[C + c] = b - (float)mean * sc;
+        if (blockIdx.x == 0) {
+            if (smean) smean[c] = (float)mean;
+            if (sinv) sinv[c] = invstd;
+            if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
+            if (rvar) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+            }
+        }
+    }
+    __syncthreads();
+    const int CG = C / VE;
+    const int CGT = CG < 256 ? CG : 256;
+    const int RPB = 256 / CGT;
+    const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
+    if (prow >= RPB) return;
+    for (int cg = cgl; cg < CG; cg += CGT) {
+        float sc[VE], sh[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) { sc[i] = sc_sh[cg * VE + i]; sh[i] = sc_sh[C + cg * VE + i]; }
+        const long long stride = (long long)gridDim.x * RPB;
+        long long pix = (long long)blockIdx.x * RPB + prow;
+        for (; pix + 3 * stride < npix; pix += 4 * stride) {
+            float v[4][VE], r[4][VE];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, v[j]);
+            if (res) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) load_vec<T>(res + (pix + j * stride) * ldr + cg * VE, r[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    float u = v[j][i] * sc[i] + sh[i];
+                    u = act ? silu_t<T>(u) : u;
+                    v[j][i] = res ? u + r[j][i] : u;
+                }
+                store_vec<T>(a + (pix + j * stride) * lda + cg * VE, v[j]);
+            }
+        }
+        for (; pix < npix; pix += stride) {
+            float v[VE];
+            load_vec<T>(z + pix * ldz + cg * VE, v);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                float u = v[i] * sc[i] + sh[i];
+                v[i] = act ? silu_t<T>(u) : u;
+            }
+            if (res) {
+                float r[VE];
+                load_vec<T>(res + pix * ldr + cg * VE, r);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[i] += r[i];
+            }
+            store_vec<T>(a + pix * lda + cg * VE, v);
+        }
+    }
+}
+
+extern "C" int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* stats,
+                                  int stat_reps, double count, const float* gamma, const float* beta, float eps, float momentum,
+                                  float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
+                                  const void* residual, int ldr, ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(z && a && stats && count > 0, "bn_train_act: bad args");
+    AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && lda % ve == 0 && (!residual || ldr % ve == 0) && C <= 2048,
+                 "bn_train_act: C=%d ldz=%d lda=%d", C, ldz, lda);
+    if (npix == 0) return AYOLO_OK;
+    unsigned grid = grid_pixels(npix, C, ve, 16);
+    if (grid > 1024) grid = 1024;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_train_act<T>, dim3(grid), dim3(256), 2 * C * sizeof(float), (hipStream_t)s,
+                                         (const T*)z, ldz, (T*)a, lda, (long long)npix, C, stats, stat_reps > 0 ? stat_reps : 1,
+                                         count, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
+                                         act, (const T*)residual, ldr);)
+    AY_CHECK_LAUNCH("k_bn_train_act");
+    return AYOLO_OK;
+}
+
 extern "C" int ayolo_affine_act_res(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C,
                                     const float* scale, const float* shift, int act, const void* residual, int ldr,
                                     ayolo_stream s);

@@ -31,7 +31,7 @@ from .modules import C3, SPPF, Bottleneck, Concat, Conv, UpSample, YOLOHead, _ac
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_CAST_WEIGHT, OP_BN_FINALIZE, OP_AFFINE_ACT, OP_BN_BWD_REDUCE,
  OP_BN_BWD_APPLY, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_PACK_INPUT, OP_HEAD_GRAD_PACK,
- OP_COPY2D, OP_MEMSET, OP_BN_EVAL_AFFINE) = range(1, 18)
+ OP_COPY2D, OP_MEMSET, OP_BN_EVAL_AFFINE, OP_BN_TRAIN_ACT) = range(1, 19)
 
 
 class Op(ctypes.Structure):
@@ -193,22 +193,21 @@ class TrainPlan:
         d_fwd = geo.desc(dt, ldx, Cout)
         code = ops.dtype_code(dt)
         op_conv = _op(OP_CONV_FWD, i=(EPI_NONE, R, 0), p=(xk, wc, z.t, None, None, None), conv=d_fwd)
-        op_fin = _op(OP_BN_FINALIZE, i=(R, Cout), d=(float(npix),), f=(bn.eps, bn.momentum),
-                     p=(None, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, None, None, None))
         res_t = residual.t if residual is not None else None
         ldr = ops.nhwc_info(res_t)[4] if res_t is not None else 0
-        op_act = _op(OP_AFFINE_ACT, i=(code, Cout, lda, Cout, act, ldr), l=(npix,), p=(z.t, a.t, None, None, res_t))
-        self.fwd += [op_conv, op_fin, op_act]
+        # batch statistics -> scale/shift, running-stat update and a = act(bn(z)) (+ residual) in one kernel
+        op_act = _op(OP_BN_TRAIN_ACT, i=(code, Cout, lda, Cout, R, act, ldr), l=(npix,), d=(float(npix),),
+                     f=(bn.eps, bn.momentum),
+                     p=(z.t, a.t, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, None, res_t))
+        self.fwd += [op_conv, op_act]
 
         def bind_fwd():
             st = self.stats.view(st_off, R * 2 * Cout)
             sm = self.small.view(sm_off, 4 * Cout)
             op_conv.p[5] = st.data_ptr()
-            op_fin.p[0] = st.data_ptr()
-            for k in range(4):     # save_mean, save_invstd, scale, shift
-                op_fin.p[5 + k] = sm[k * Cout:(k + 1) * Cout].data_ptr()
-            op_act.p[2] = sm[2 * Cout:3 * Cout].data_ptr()
-            op_act.p[3] = sm[3 * Cout:4 * Cout].data_ptr()
+            op_act.p[2] = st.data_ptr()
+            op_act.p[7] = sm[0:Cout].data_ptr()              # save_mean
+            op_act.p[8] = sm[Cout:2 * Cout].data_ptr()       # save_invstd
 
         self.late.append(bind_fwd)
         if bn.num_batches_tracked is not None:

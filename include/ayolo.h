@@ -93,6 +93,12 @@ int ayolo_cast_weight(const float* w32, int Cout, int kh, int kw, int Cin, int C
 int ayolo_bn_finalize(const float* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                       float* save_invstd, float* scale, float* shift, ayolo_stream s);
+/* ayolo_bn_finalize + ayolo_affine_act(_res) in one pass over z: a = act(batchnorm_train(z)) (+ residual), running
+ * statistics updated and save_mean / save_invstd written (all four nullable) by the kernel itself. */
+int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* stats,
+                       int stat_reps, double count, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
+                       const void* residual, int ldr, ayolo_stream s);
 /* a = act(z*scale[c] + shift[c]); act: 0 identity, 1 SiLU.  z: npix x C (ldz), a: npix x C (lda). */
 int ayolo_affine_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* scale,
                      const float* shift, int act, ayolo_stream s);
@@ -243,7 +249,7 @@ enum {
     AYOLO_OP_CONV_FWD = 1, AYOLO_OP_CONV_DGRAD, AYOLO_OP_CONV_WGRAD, AYOLO_OP_CAST_WEIGHT, AYOLO_OP_BN_FINALIZE,
     AYOLO_OP_AFFINE_ACT, AYOLO_OP_BN_BWD_REDUCE, AYOLO_OP_BN_BWD_APPLY, AYOLO_OP_MAXPOOL_FWD, AYOLO_OP_MAXPOOL_BWD,
     AYOLO_OP_UPSAMPLE_FWD, AYOLO_OP_UPSAMPLE_BWD, AYOLO_OP_PACK_INPUT, AYOLO_OP_HEAD_GRAD_PACK, AYOLO_OP_COPY2D,
-    AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE
+    AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT
 };
 typedef struct ayolo_op {
     int kind;
