@@ -928,6 +928,31 @@ __global__ void k_cast_weight(const float* w32, int Cout, int taps, int Cin, int
     if (wt) wt[((long long)c * taps + tap) * Cout_pad + co] = (T)v;
 }
 
+// all layers of a model in ONE launch: blockIdx.y = job (table in device memory, written once when the plan is built)
+template <typename T>
+__global__ __launch_bounds__(256) void k_cast_weights(const ayolo_cast_job* jobs) {
+    const ayolo_cast_job J = jobs[blockIdx.y];
+    const unsigned tot = (unsigned)J.Cout_pad * (unsigned)J.taps * (unsigned)J.Cin_pad;
+    T* w = reinterpret_cast<T*>(J.w);
+    T* wt = reinterpret_cast<T*>(J.wt);
+    for (unsigned t = blockIdx.x * 256 + threadIdx.x; t < tot; t += gridDim.x * 256) {
+        const unsigned c = t % (unsigned)J.Cin_pad, r = t / (unsigned)J.Cin_pad;
+        const unsigned tap = r % (unsigned)J.taps, co = r / (unsigned)J.taps;
+        const float v = (c < (unsigned)J.Cin && co < (unsigned)J.Cout) ? J.w32[((size_t)co * J.taps + tap) * J.Cin + c] : 0.0f;
+        if (w) w[t] = (T)v;
+        if (wt) wt[((size_t)c * J.taps + tap) * J.Cout_pad + co] = (T)v;
+    }
+}
+
+extern "C" int ayolo_cast_weights(const ayolo_cast_job* jobs_dev, int njobs, int dtype, ayolo_stream s) {
+    AY_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535, "cast_weights: njobs=%d", njobs);
+    dim3 grid(64, (unsigned)njobs);
+    if (dtype == AYOLO_F16) hipLaunchKernelGGL(k_cast_weights<half_t>, grid, dim3(256), 0, (hipStream_t)s, jobs_dev);
+    else hipLaunchKernelGGL(k_cast_weights<float>, grid, dim3(256), 0, (hipStream_t)s, jobs_dev);
+    AY_CHECK_LAUNCH("k_cast_weights");
+    return AYOLO_OK;
+}
+
 extern "C" int ayolo_cast_weight(const float* w32, int Cout, int kh, int kw, int Cin, int Cout_pad, int Cin_pad, int dtype,
                                  void* w, void* wt, ayolo_stream s) {
     AY_CHECK_ARG(w32 && (w || wt), "cast_weight: null pointer");

@@ -777,29 +777,59 @@ extern "C" int ayolo_head_decode(const float* raw, const int64_t* raw_strides, i
 template <typename T>
 __global__ __launch_bounds__(256) void k_head_grad_pack(const float* draw, int B, int na, int ny, int nx, int no, T* dz,
                                                         int ldz, float* dbias) {
-    // thread = channel (coalesced in o for reads, in c for writes); pixels strided over the grid; the bias
-    // partial lives in a register, one global atomic per (block, channel)
-    const long long hw = (long long)ny * nx, npix = (long long)B * hw;
+    // thread = one 8-channel group of the NHWC row (one 16-byte fp16 / two 16-byte fp32 stores); a workgroup covers
+    // 256 / (ldz/8) pixels per iteration, pixels strided over the grid; bias partials live in registers, one global
+    // atomic per (workgroup, channel)
+    const unsigned hw = (unsigned)(ny * nx);
+    const long long npix = (long long)B * hw;
     const int Cc = na * no;
-    for (int c = threadIdx.x; c < ldz; c += 256) {
-        const int a = c < Cc ? c / no : 0, o = c < Cc ? c - a * no : 0;
-        float acc = 0.0f;
-        for (long long pix = blockIdx.x; pix < npix; pix += gridDim.x) {
-            float v = 0.0f;
-            if (c < Cc) {
-                long long b = pix / hw, p = pix - b * hw;
-                v = draw[((b * na + a) * hw + p) * no + o];
-            }
-            acc += v;
-            dz[pix * ldz + c] = (T)v;
+    const int CG = ldz / 8;                      // channel groups per pixel (host: ldz % 8 == 0, CG <= 256)
+    const int RPB = 256 / CG;
+    const int cg = threadIdx.x % CG, prow = threadIdx.x / CG;
+    int aa[8], oo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cg * 8 + i;
+        aa[i] = c < Cc ? c / no : -1;
+        oo[i] = c < Cc ? c - aa[i] * no : 0;
+    }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long pix = (long long)blockIdx.x * RPB + prow; prow < RPB && pix < npix; pix += (long long)gridDim.x * RPB) {
+        const unsigned b = (unsigned)(pix / hw), p = (unsigned)(pix - (long long)b * hw);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = aa[i] >= 0 ? draw[(((long long)b * na + aa[i]) * hw + p) * no + oo[i]] : 0.0f;
+            acc[i] += v[i];
         }
-        if (dbias && c < Cc) atomicAdd(&dbias[c], acc);
+        T out[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] = (T)v[i];
+        T* dst = dz + pix * ldz + cg * 8;
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
+        else {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
+            *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(out + 4);
+        }
+    }
+    if (dbias) {
+        // workgroup-level sum over its pixel rows in LDS, then ONE global atomic per (workgroup, channel)
+        __shared__ float sb[2048];
+        for (int c = threadIdx.x; c < ldz; c += 256) sb[c] = 0.0f;
+        __syncthreads();
+        if (prow < RPB) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (aa[i] >= 0) atomicAdd(&sb[cg * 8 + i], acc[i]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < Cc; c += 256) atomicAdd(&dbias[c], sb[c]);
     }
 }
 
 extern "C" int ayolo_head_grad_pack(const float* draw, int B, int na, int ny, int nx, int no, int dtype, void* dz, int ldz,
                                     float* dbias, ayolo_stream s) {
-    AY_CHECK_ARG(draw && dz && ldz >= na * no && ldz <= 4096, "head_grad_pack: bad args");
+    AY_CHECK_ARG(draw && dz && ldz >= na * no && ldz % 8 == 0 && ldz <= 2048, "head_grad_pack: bad args (ldz=%d)", ldz);
     long long total = (long long)B * ny * nx * ldz;
     long long npix = (long long)B * ny * nx;
     (void)total;

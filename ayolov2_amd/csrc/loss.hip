@@ -14,6 +14,7 @@
 #include "common.h"
 
 #define LOSS_MAX_LEVELS 8
+#define LOSS_SLOTS 64        // hashed fp64 accumulators per (level, term): spreads the atomics of a launch
 
 struct LossP {
     ayolo_loss_level lv[LOSS_MAX_LEVELS];
@@ -104,7 +105,7 @@ __device__ __forceinline__ CIoU ciou_eval(const float p[4], const float t[4], fl
     return r;
 }
 
-// acc layout: double acc[nl][3] = {sum (1 - ciou), sum objectness BCE, sum class BCE}
+// acc layout: double acc[nl][3][LOSS_SLOTS] = {sum (1 - ciou), sum objectness BCE, sum class BCE}, slot = workgroup % LOSS_SLOTS
 template <bool BWD>
 __global__ __launch_bounds__(256) void k_loss_rows(LossP P, double* acc, const float* grad_out) {
     const int l = blockIdx.y;
@@ -129,8 +130,9 @@ __global__ __launch_bounds__(256) void k_loss_rows(LossP P, double* acc, const f
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cls += __shfl_xor(cls, off);
         if (lane == 0) {
-            atomicAdd(&acc[l * 3 + 0], (double)(1.0f - r.ciou));
-            if (nc > 1) atomicAdd(&acc[l * 3 + 2], (double)cls);
+            const int slot = blockIdx.x % LOSS_SLOTS;
+            atomicAdd(&acc[(l * 3 + 0) * LOSS_SLOTS + slot], (double)(1.0f - r.ciou));
+            if (nc > 1) atomicAdd(&acc[(l * 3 + 2) * LOSS_SLOTS + slot], (double)cls);
             L.score[row] = (1.0f - P.gr) + P.gr * fmaxf(r.ciou, 0.0f);
             atomicMax(&L.own[cell], row + 1);        // duplicate cells: the LAST row's objectness target wins
         }
@@ -170,7 +172,8 @@ __global__ __launch_bounds__(256) void k_loss_obj(LossP P, double* acc) {
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&acc[l * 3 + 1], (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]);
+    if (threadIdx.x == 0)
+        atomicAdd(&acc[(l * 3 + 1) * LOSS_SLOTS + blockIdx.x % LOSS_SLOTS], (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]);
 }
 
 __global__ void k_loss_finalize(LossP P, const double* acc, float* out) {
@@ -179,11 +182,15 @@ __global__ void k_loss_finalize(LossP P, const double* acc, float* out) {
     for (int l = 0; l < P.nl; ++l) {
         const ayolo_loss_level& L = P.lv[l];
         const double cells = (double)L.B * L.na * L.ny * L.nx;
-        if (L.n > 0) {
-            lbox += (float)(acc[l * 3 + 0] / (double)L.n);
-            if (L.no - 5 > 1) lcls += (float)(acc[l * 3 + 2] / ((double)L.n * (double)(L.no - 5)));
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < LOSS_SLOTS; ++k) {
+            s0 += acc[(l * 3 + 0) * LOSS_SLOTS + k]; s1 += acc[(l * 3 + 1) * LOSS_SLOTS + k]; s2 += acc[(l * 3 + 2) * LOSS_SLOTS + k];
         }
-        lobj += (float)(acc[l * 3 + 1] / cells) * L.balance;
+        if (L.n > 0) {
+            lbox += (float)(s0 / (double)L.n);
+            if (L.no - 5 > 1) lcls += (float)(s2 / ((double)L.n * (double)(L.no - 5)));
+        }
+        lobj += (float)(s1 / cells) * L.balance;
     }
     lbox *= P.h_box; lobj *= P.h_obj; lcls *= P.h_cls;
     const float loss = lbox + lobj + lcls;
@@ -209,10 +216,11 @@ __global__ __launch_bounds__(256) void k_loss_grad_dense(LossP P, const float* g
     const long long total = cells * L.no, total4 = total / 4;
     const float k = grad_out[0] * (float)L.B * P.h_obj * L.balance / (float)cells;
     const unsigned no = (unsigned)L.no;
+    const bool small = total < (1ll << 32);
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total4; q += (long long)gridDim.x * 256) {
         float4v o4 = {0.0f, 0.0f, 0.0f, 0.0f};
         const long long e0 = q * 4;
-        const long long c0 = e0 / no;
+        const long long c0 = small ? (long long)((unsigned)e0 / no) : e0 / no;      // 32-bit division when it fits
         const unsigned r0 = (unsigned)(e0 - c0 * no);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -257,7 +265,7 @@ extern "C" int ayolo_yolo_loss_fwd(const ayolo_loss_level* lv, int nl, float cp,
     if (rc) return rc;
     AY_CHECK_ARG(acc && out, "yolo_loss_fwd: null pointer");
     hipStream_t st = (hipStream_t)s;
-    rc = ayolo_fill_zero(acc, (size_t)nl * 3 * sizeof(double) < 16 ? 16 : ((size_t)nl * 3 * sizeof(double) + 15) / 16 * 16, s);
+    rc = ayolo_fill_zero(acc, (size_t)nl * 3 * LOSS_SLOTS * sizeof(double), s);
     if (rc) return rc;
     if (max_n > 0) {
         hipLaunchKernelGGL(k_loss_rows<false>, dim3((unsigned)((max_n + 3) / 4), (unsigned)nl), dim3(256), 0, st, P, acc, (const float*)nullptr);

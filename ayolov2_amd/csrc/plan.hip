@@ -60,6 +60,9 @@ extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
         case AYOLO_OP_CAST_WEIGHT:
             rc = ayolo_cast_weight((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.p[1], o.p[2], s);
             break;
+        case AYOLO_OP_CAST_WEIGHTS:
+            rc = ayolo_cast_weights((const ayolo_cast_job*)o.p[0], o.i[0], o.i[1], s);
+            break;
         case AYOLO_OP_BN_FINALIZE:
             rc = ayolo_bn_finalize((const float*)o.p[0], o.i[0], o.i[1], o.d[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
                                    o.f[1], (float*)o.p[3], (float*)o.p[4], (float*)o.p[5], (float*)o.p[6], (float*)o.p[7],

@@ -58,7 +58,7 @@ class _FusedLossFn(torch.autograd.Function):
         ns = [int(indices[i][0].shape[0]) for i in range(nl)]
         own = torch.zeros(sum(cells), dtype=torch.int32, device=dev)
         score = torch.empty(max(sum(ns), 1), dtype=torch.float32, device=dev)
-        acc = torch.empty(3 * nl + 1, dtype=torch.float64, device=dev)
+        acc = torch.empty(3 * nl * 64, dtype=torch.float64, device=dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
         arr = (_lib.LossLevel * nl)()
         keep = []

@@ -31,7 +31,7 @@ from .modules import C3, SPPF, Bottleneck, Concat, Conv, UpSample, YOLOHead, _ac
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_CAST_WEIGHT, OP_BN_FINALIZE, OP_AFFINE_ACT, OP_BN_BWD_REDUCE,
  OP_BN_BWD_APPLY, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_PACK_INPUT, OP_HEAD_GRAD_PACK,
- OP_COPY2D, OP_MEMSET, OP_BN_EVAL_AFFINE, OP_BN_TRAIN_ACT) = range(1, 19)
+ OP_COPY2D, OP_MEMSET, OP_BN_EVAL_AFFINE, OP_BN_TRAIN_ACT, OP_CAST_WEIGHTS) = range(1, 20)
 
 
 class Op(ctypes.Structure):
@@ -256,6 +256,21 @@ class TrainPlan:
         self.bwd_emitters.append(emit_bwd)
         return a
 
+    def _batched_casts(self) -> List[Op]:
+        """All per-layer fp32 -> compute-dtype weight casts (and transposes) as ONE launch: the job table lives in
+        device memory and is written once here (parameter storages are stable for the lifetime of the plan)."""
+        if not self.casts:
+            return []
+        import numpy as np
+        job_t = np.dtype([("w32", "<u8"), ("w", "<u8"), ("wt", "<u8"), ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"),
+                          ("Cout_pad", "<i4"), ("Cin_pad", "<i4"), ("reserved", "<i4")])
+        jobs = np.zeros(len(self.casts), dtype=job_t)
+        for k, o in enumerate(self.casts):
+            jobs[k] = (o.p[0] or 0, o.p[1] or 0, o.p[2] or 0, o.i[0], o.i[1] * o.i[2], o.i[3], o.i[4], o.i[5], 0)
+        tab = torch.from_numpy(jobs.view(np.uint8).copy()).to(self.device)
+        self.keep.append(tab)
+        return [_op(OP_CAST_WEIGHTS, i=(len(self.casts), self.casts[0].i[6]), p=(tab,))]
+
     # ------------------------------------------------------------------ composite blocks
     def _bottleneck(self, b: Bottleneck, x: Act, dst: Optional[Act]) -> Act:
         y1 = self._conv_block(b.cv1, x, None)
@@ -435,7 +450,7 @@ class TrainPlan:
         for fn in self.late:
             fn()
         head_ops = [_op(OP_MEMSET, l=(self.stats.buf.numel() * 4,), p=(self.stats.buf,))]
-        self.fwd = head_ops + self.casts + self.fwd
+        self.fwd = head_ops + self._batched_casts() + self.fwd
         self.bwd = [_op(OP_MEMSET, l=(self.sums.buf.numel() * 4,), p=(self.sums.buf,)),
                     _op(OP_MEMSET, l=(self.gradarena.buf.numel() * 4,), p=(self.gradarena.buf,))]
         for emit in reversed(self.bwd_emitters):
@@ -486,15 +501,17 @@ class TrainPlan:
             self.bwd_arr[idx].p[0] = d.data_ptr()
         _lib.check(_lib.lib().ayolo_run_ops(self.bwd_arr, len(self.bwd), torch.cuda.current_stream().cuda_stream), "ayolo_run_ops(backward)")
         self._d_keep = keep
-        ga = self.gradarena
+        # The arena is scratch that the next backward zeroes: hand out gradients that OWN their memory (autograd steals
+        # them as p.grad and may keep them across steps for gradient accumulation) -- one flat copy, views into it.
+        flat = self.gradarena.buf.clone()
         grads = []
         for p in self.params:
             off, n, view_fn = self.param_grad_view[id(p)]
-            g = view_fn(ga.view(off, n))
+            g = view_fn(flat[off:off + n])
             if g.stride() != p.stride() and g.is_contiguous(memory_format=torch.channels_last) and p.dim() == 4 \
                     and p.shape[2] == 1 and p.shape[3] == 1:
                 g = g.as_strided(p.shape, p.stride())                # 1x1 kernels: same memory, the parameter's strides
-            grads.append(g.clone() if p.grad is not None else g)     # never alias an accumulating .grad
+            grads.append(g)
         return grads
 
 

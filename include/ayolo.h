@@ -84,6 +84,14 @@ int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, fl
 int ayolo_cast_weight(const float* w32, int Cout, int kh, int kw, int Cin, int Cout_pad, int Cin_pad, int dtype,
                       void* w, void* wt, ayolo_stream s);
 
+/* The same cast for every layer of a model in one launch.  `jobs_dev` is a DEVICE array (written once by the caller;
+ * each entry must have Cout_pad*taps*Cin_pad < 2^32). */
+typedef struct ayolo_cast_job {
+    const float* w32; void* w; void* wt;      /* as ayolo_cast_weight (w / wt nullable)                           */
+    int Cout, taps, Cin, Cout_pad, Cin_pad, reserved;
+} ayolo_cast_job;
+int ayolo_cast_weights(const ayolo_cast_job* jobs_dev, int njobs, int dtype, ayolo_stream s);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm (training statistics) + SiLU, NHWC.  kindle Conv = Conv2d -> BatchNorm2d -> SiLU.
  * ---------------------------------------------------------------------------------------------- */
@@ -166,7 +174,7 @@ typedef struct ayolo_loss_level {
     float balance;             /* objectness balance of the level (losses.py:204-206)                            */
     float* grad;               /* _bwd only: d(out[0]) / d pred, (B,na,ny,nx,no) CONTIGUOUS fp32, fully written    */
 } ayolo_loss_level;
-/* out[5] = {loss*B, lbox*h_box, lobj*h_obj, lcls*h_cls, loss}; acc: scratch double[3*nl] (zeroed by the call).
+/* out[5] = {loss*B, lbox*h_box, lobj*h_obj, lcls*h_cls, loss}; acc: scratch double[3*nl*64] (zeroed by the call).
  * cp / cn: smoothed positive / negative class targets; gr: IoU ratio of the objectness target. */
 int ayolo_yolo_loss_fwd(const ayolo_loss_level* lv, int nl, float cp, float cn, float cls_pw, float obj_pw, float gr,
                         float h_box, float h_obj, float h_cls, double* acc, float* out, ayolo_stream s);
@@ -249,7 +257,7 @@ enum {
     AYOLO_OP_CONV_FWD = 1, AYOLO_OP_CONV_DGRAD, AYOLO_OP_CONV_WGRAD, AYOLO_OP_CAST_WEIGHT, AYOLO_OP_BN_FINALIZE,
     AYOLO_OP_AFFINE_ACT, AYOLO_OP_BN_BWD_REDUCE, AYOLO_OP_BN_BWD_APPLY, AYOLO_OP_MAXPOOL_FWD, AYOLO_OP_MAXPOOL_BWD,
     AYOLO_OP_UPSAMPLE_FWD, AYOLO_OP_UPSAMPLE_BWD, AYOLO_OP_PACK_INPUT, AYOLO_OP_HEAD_GRAD_PACK, AYOLO_OP_COPY2D,
-    AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT
+    AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT, AYOLO_OP_CAST_WEIGHTS
 };
 typedef struct ayolo_op {
     int kind;

@@ -183,3 +183,24 @@ def test_plan_equals_module_path():
     for k, p in m.named_parameters():
         e_plan, e_mod = _rel(p.grad.float().cpu(), pr[k].grad), _rel(pb[k].grad.float().cpu(), pr[k].grad)
         assert e_plan < 2e-3 and e_mod < 2e-3, f"{k}: plan-vs-cpu {e_plan:.2e}, module-vs-cpu {e_mod:.2e}"
+
+
+def test_plan_gradient_accumulation():
+    """Two backward passes without zero_grad accumulate in p.grad (the trainer's `accumulate` > 1,
+    yolo_trainer.py:334-336): the plan must hand out gradients that own their memory."""
+    import copy
+    m, _ = _pair("n", seed=5)
+    m2 = copy.deepcopy(m)
+    m2.use_plan = False
+    m.train(); m2.train()
+    xs = [torch.rand(2, 3, 64, 64).cuda(), torch.rand(2, 3, 64, 64).cuda()]
+    for mod in (m, m2):
+        for x in xs:
+            gen = torch.Generator().manual_seed(3)
+            out = mod(x)
+            sum((t * torch.randn(t.shape, generator=gen).cuda()).sum() for t in out).backward()
+    g1 = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+    g2 = {n: p.grad.detach().cpu() for n, p in m2.named_parameters()}
+    for n in g1:
+        scale = float(g2[n].abs().max()) + 1e-12
+        assert float((g1[n] - g2[n]).abs().max()) <= 2e-3 * scale + 1e-6, n
