@@ -16,6 +16,7 @@
 // (scripts/train/yolo_trainer.py:329).
 #include "common.h"
 #include <stdlib.h>
+#include <math.h>
 
 #define MAX_TAPS 36
 #define BK 32
@@ -836,10 +837,16 @@ static int launch_wgrad(WGradP p, hipStream_t s) {
     p.gx = (unsigned)((p.K + TNW - 1) / TNW);
     p.gy = (unsigned)((p.N + TM - 1) / TM);
     const long long tiles = (long long)p.gx * p.gy;
-    // split the pixel reduction so that ~3 workgroups per CU are in flight, each with >= 8 reduction steps
+    // Split the pixel reduction.  More splits = more workgroups in flight but N*K fp32 atomics per split: with a step
+    // time t_step per workgroup and an L2 atomic rate R the cost A*s + B/(tiles*s) is minimal at
+    // s* = sqrt(steps_per_tile * t_step * R / (N*K))  (measured: t_step*R ~ 1.5e5), capped by ~3 workgroups per CU.
+    static const double ka = getenv("AYOLO_WGRAD_KA") ? atof(getenv("AYOLO_WGRAD_KA")) : 1.5e5;
     const int bpc = sizeof(T) == 2 ? 3 : 1;
-    long long want = ((long long)num_cus() * bpc + tiles - 1) / tiles;
-    long long max_splits = (p.P + 8 * W::BP - 1) / (8 * W::BP);
+    long long cap = ((long long)num_cus() * bpc + tiles - 1) / tiles;
+    const double steps_per_tile = (double)p.P / W::BP;
+    long long want = (long long)(sqrt(steps_per_tile * ka / ((double)p.N * (double)p.K)) + 0.5);
+    if (want > cap) want = cap;
+    long long max_splits = (p.P + 4 * W::BP - 1) / (4 * W::BP);
     long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits < 1) splits = 1;
     long long chunk = (p.P + splits - 1) / splits;
