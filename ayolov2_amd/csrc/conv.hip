@@ -48,6 +48,10 @@ struct GConvP {
     signed char dh[MAX_TAPS], dw[MAX_TAPS], wt[MAX_TAPS];
     unsigned x_bytes, w_bytes, y_bytes;      // extents for the buffer descriptors (k_gconv)
     FastDiv dOW, dOH, dC;
+    // "classes": sub-problems that share the pixel tiles and the x rows but have their own tap subset and output
+    // offset -- the residue classes of a strided dgrad walked back to back by the same workgroup (ncls == 1 otherwise)
+    int ncls;
+    int ctap0[4], cnt[4], coah[4], coaw[4];  // first tap / tap count / output offsets of each class
 };
 
 template <typename T> struct Tr;
@@ -164,12 +168,13 @@ __device__ __forceinline__ void g_setup_rows(const GConvP& p, unsigned tile, boo
 template <typename T, int TM>
 __device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T, TM>::XR], const int (&xh0)[GT<T, TM>::XR],
                                         const int (&xw0)[GT<T, TM>::XR], const unsigned (&woff)[GT<T, TM>::WR], int kt,
-                                        const int4* sTap, unsigned lds_tiles, unsigned so, v4i32 rsX, v4i32 rsW, int wave, int kc) {
+                                        int tap0, int ntap, const int4* sTap, unsigned lds_tiles, unsigned so, v4i32 rsX,
+                                        v4i32 rsW, int wave, int kc) {
     using G = GT<T, TM>;
     const unsigned k0 = (unsigned)(kt * BK + kc * G::CE);
     unsigned tap = fdiv(k0, p.dC);
     const int cb = (int)(k0 - tap * (unsigned)p.C) * G::ES;
-    tap = tap < MAX_TAPS ? tap : MAX_TAPS;
+    tap = tap < (unsigned)ntap ? (unsigned)tap0 + tap : MAX_TAPS;     // beyond the class's taps (K padding): never in range
     const int4 te = sTap[tap];
 #pragma unroll
     for (int r = 0; r < G::XR; ++r) {
@@ -225,9 +230,9 @@ __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int 
 // Exactly NST buffer stores per thread (invalid pixels / channel groups use the out-of-range offset and are dropped
 // by the hardware), so the step loop's vmcnt arithmetic stays exact.
 template <typename T, int TM, int EM>
-__device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int wp, int lane, int cbase, bool want_stats,
-                                           __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM>::NI], float (&ssum)[16],
-                                           float (&ssq)[16]) {
+__device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int oah, int oaw, int wp, int lane, int cbase,
+                                           bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM>::NI],
+                                           float (&ssum)[16], float (&ssq)[16]) {
     using G = GT<T, TM>;
     constexpr int YES = (EM == 3) ? 4 : G::ES;       // bytes per output element
     const unsigned m0 = tile * TP;
@@ -244,7 +249,7 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int w
                 const int ow = (int)(mu - t * (unsigned)p.OW);
                 const unsigned nn = fdiv(t, p.dOH);
                 const int oh = (int)(t - nn * (unsigned)p.OH);
-                yo = ((nn * (unsigned)p.YH + (unsigned)(oh * p.osh + p.oah)) * (unsigned)p.YW + (unsigned)(ow * p.osw + p.oaw)) * (unsigned)p.ldy * YES;
+                yo = ((nn * (unsigned)p.YH + (unsigned)(oh * p.osh + oah)) * (unsigned)p.YW + (unsigned)(ow * p.osw + oaw)) * (unsigned)p.ldy * YES;
             }
         }
 #pragma unroll
@@ -414,30 +419,35 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 &&
     for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
     const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
 
-    int nk = (p.K + BK - 1) / BK;
-    if (nk < 1) nk = 1;                      // K == 0 (tap-less dgrad residue class): one all-zero step
-    int cur_kt = 0;
+    // steps of a class: its taps * C in 32-wide slices; a tap-less class (1x1 strided dgrad) is one all-zero step
+#define G_NK(c) ((p.cnt[c] * p.C + BK - 1) / BK < 1 ? 1 : (p.cnt[c] * p.C + BK - 1) / BK)
+    int cur_kt = 0, cur_cls = 0, cur_nk = G_NK(0);
 
     // loader cursor, two steps ahead of the compute cursor; past the last step it keeps issuing (out-of-range, zero
     // fill) so that every step has exactly LPS DMA instructions per thread
     unsigned ld_tile = cur_tile;
-    int ld_kt = 0;
+    int ld_kt = 0, ld_cls = 0, ld_nk = cur_nk;
     bool ld_valid = true;
     g_setup_rows<T, TM>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
     __syncthreads();                          // tap table visible
+#define G_ISSUE(so) g_issue<T, TM>(p, xoff, xh0, xw0, woff, ld_kt, p.ctap0[ld_cls], p.cnt[ld_cls], sTap, lds_tiles, so, rsX, rsW, wave, kc);
 #define G_ADVANCE()                                                                           \
     {                                                                                         \
-        if (++ld_kt == nk) {                                                                  \
+        if (++ld_kt == ld_nk) {                                                               \
             ld_kt = 0;                                                                        \
-            ld_tile += lstride;                                                               \
-            ld_valid = ld_valid && ld_tile < ntiles;                                          \
-            g_setup_rows<T, TM>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);      \
+            if (++ld_cls == p.ncls) {                                                         \
+                ld_cls = 0;                                                                   \
+                ld_tile += lstride;                                                           \
+                ld_valid = ld_valid && ld_tile < ntiles;                                      \
+                g_setup_rows<T, TM>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);   \
+            }                                                                                 \
+            ld_nk = G_NK(ld_cls);                                                             \
         }                                                                                     \
     }
     unsigned so0 = 0, so1 = G::STAGE, so2 = 2 * G::STAGE;
-    g_issue<T, TM>(p, xoff, xh0, xw0, woff, ld_kt, sTap, lds_tiles, so0, rsX, rsW, wave, kc);
+    G_ISSUE(so0)
     G_ADVANCE()
-    g_issue<T, TM>(p, xoff, xh0, xw0, woff, ld_kt, sTap, lds_tiles, so1, rsX, rsW, wave, kc);
+    G_ISSUE(so1)
     G_ADVANCE()
 
     bool after_epi = false;
@@ -445,21 +455,27 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 &&
         // step s landed (this wave's part), then: everyone's part landed AND everyone finished reading step s-1
         if (after_epi) wait_vm<G::LPS + G::NST>(); else wait_vm<G::LPS>();
         __builtin_amdgcn_s_barrier();
-        g_issue<T, TM>(p, xoff, xh0, xw0, woff, ld_kt, sTap, lds_tiles, so2, rsX, rsW, wave, kc);       // step s+2 -> the stage step s-1 used
+        G_ISSUE(so2)                                     // step s+2 -> the stage step s-1 used
         G_ADVANCE()
         g_mma<T, TM>(sTiles + so0, arow, xrow, swz, lane, acc);
         after_epi = false;
-        if (cur_kt == nk - 1) {
-            g_epilogue<T, TM, EM>(p, cur_tile, wp, lane, cbase, want_stats, rsY, acc, ssum, ssq);
+        if (cur_kt == cur_nk - 1) {
+            g_epilogue<T, TM, EM>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq);
             after_epi = true;
         }
-        if (++cur_kt == nk) {
+        if (++cur_kt == cur_nk) {
             cur_kt = 0;
-            cur_tile += lstride;
-            if (cur_tile >= ntiles) break;
+            if (++cur_cls == p.ncls) {
+                cur_cls = 0;
+                cur_tile += lstride;
+                if (cur_tile >= ntiles) break;
+            }
+            cur_nk = G_NK(cur_cls);
         }
         const unsigned t = so0; so0 = so1; so1 = so2; so2 = t;
     }
+#undef G_ISSUE
+#undef G_NK
 #undef G_ADVANCE
     wait_vm<0>();                             // the trailing zero-fill DMAs must land before this LDS is released
     if (want_stats) g_stats_flush<T, TM>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
@@ -553,6 +569,9 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     p.y_bytes = (unsigned)(y_img * p.B);
     p.w_bytes = (unsigned)w_bytes;
     p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)(p.C > 0 ? p.C : 1));
+    if (p.ncls <= 0) {                       // ordinary launch: one class = all taps
+        p.ncls = 1; p.ctap0[0] = 0; p.cnt[0] = p.ntaps; p.coah[0] = p.oah; p.coaw[0] = p.oaw;
+    }
     return dispatch_gconv_one(dtype, p, s);
 }
 
@@ -609,6 +628,15 @@ extern "C" int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const 
     const int ce = d->dtype == AYOLO_F16 ? 8 : 4;
     AY_CHECK_ARG(d->Cout % ce == 0 && d->ldy % ce == 0, "conv_dgrad: Cout=%d ldy=%d must be multiples of %d", d->Cout,
                  d->ldy, ce);
+    // Residue classes (a, b) = (h mod sh, w mod sw).  When every class has the same output grid (H % sh == W % sw == 0)
+    // ONE launch walks all of them per dy tile: dy is read from HBM once instead of once per class (the later classes
+    // hit L2) and the classes' interleaved half-line writes of dx meet in L2.  Otherwise one launch per class.
+    static const bool no_merge = getenv("AYOLO_NO_DGRAD_MERGE") != nullptr;
+    const int ncls_all = d->sh * d->sw;
+    const bool merge = !no_merge && ncls_all > 1 && ncls_all <= 4 && d->H % d->sh == 0 && d->W % d->sw == 0 &&
+                       d->kh * d->kw <= MAX_TAPS;
+    GConvP m{};
+    int mt = 0;
     for (int a = 0; a < d->sh; ++a)
         for (int b = 0; b < d->sw; ++b) {
             GConvP p{};
@@ -623,22 +651,35 @@ extern "C" int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const 
             p.y_linear = (d->sh == 1 && d->sw == 1) ? 1 : 0;
             p.x_linear = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0) ? 1 : 0;
             p.Mtotal = (long long)d->B * p.OH * p.OW;
+            if (merge && a == 0 && b == 0) m = p;
+            const int cls = a * d->sw + b;
             int nt = 0;
             for (int i = 0; i < d->kh; ++i) {
                 if ((a + d->ph - i) % d->sh != 0) continue;
                 for (int j = 0; j < d->kw; ++j) {
                     if ((b + d->pw - j) % d->sw != 0) continue;
                     // floor division for negative numerators is not needed: exact multiples only
-                    p.dh[nt] = (signed char)((a + d->ph - i) / d->sh);
-                    p.dw[nt] = (signed char)((b + d->pw - j) / d->sw);
-                    p.wt[nt] = (signed char)(i * d->kw + j);
+                    GConvP& q = merge ? m : p;
+                    const int t = merge ? mt + nt : nt;
+                    q.dh[t] = (signed char)((a + d->ph - i) / d->sh);
+                    q.dw[t] = (signed char)((b + d->pw - j) / d->sw);
+                    q.wt[t] = (signed char)(i * d->kw + j);
                     ++nt;
                 }
+            }
+            if (merge) {
+                m.ctap0[cls] = mt; m.cnt[cls] = nt; m.coah[cls] = a; m.coaw[cls] = b;
+                mt += nt;
+                continue;
             }
             p.ntaps = nt; p.K = nt * p.C;   // nt == 0: no tap reaches this residue class -> the kernel writes zeros
             rc = dispatch_gconv(d->dtype, p, (hipStream_t)s);
             if (rc) return rc;
         }
+    if (merge) {
+        m.ncls = ncls_all; m.ntaps = mt; m.K = mt * m.C;
+        return dispatch_gconv(d->dtype, m, (hipStream_t)s);
+    }
     return AYOLO_OK;
 }
 
