@@ -130,7 +130,10 @@ __device__ __forceinline__ v4i32 make_srd(const void* ptr, unsigned bytes) {
 // 64 lanes x 16 B: global (srd base + voff, zero when voff is beyond the descriptor) -> LDS [lds_addr + lane*16, +16)
 __device__ __forceinline__ void glds16(v4i32 srd, unsigned lds_addr, unsigned voff) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+    // s_nop 2: (a) one wait state between the M0 write and the LDS-DMA; (b) with the two s_mov it makes five wait states
+    // between any VALU that wrote a descriptor SGPR just before this statement (v_readlane of a spilled SGPR) and the
+    // VMEM instruction reading it -- hipcc does not look inside the string
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(lds_addr), "s"(srd)
                  : "memory");
@@ -458,8 +461,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 &&
         G_ISSUE(so2)                                     // step s+2 -> the stage step s-1 used
         G_ADVANCE()
         g_mma<T, TM>(sTiles + so0, arow, xrow, swz, lane, acc);
+        // The last MFMA's result must not be read for passes+2 wait states.  hipcc (ROCm 7.2) covers that hazard inside a
+        // basic block but was seen to miss it across the loop back edge (fp32 head variant: the next iteration opened
+        // with v_accvgpr_read of the accumulator's last register, which came back stale) -- pad it here, explicitly.
+        if constexpr (sizeof(T) == 4) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
         after_epi = false;
         if (cur_kt == cur_nk - 1) {
+            if constexpr (sizeof(T) == 2) asm volatile("s_nop 11" ::: "memory");   // fp16: accumulators are only read here
             g_epilogue<T, TM, EM>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq);
             after_epi = true;
         }
@@ -855,6 +863,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
                 }
             }
         }
+        if constexpr (sizeof(T) == 4) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // see k_gconv: MFMA result hazard across the back edge
         const unsigned t = so0; so0 = so1; so1 = so2; so2 = t;
     }
 #undef W_ISSUE

@@ -67,6 +67,30 @@ def test_conv_fwd_dgrad_wgrad(shape, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 20), (2, 128, 8, 10), (2, 256, 4, 5), (2, 128, 32, 40), (1, 32, 8, 8), (2, 64, 1, 5)])
+def test_head_conv(shape, dt):
+    """YOLOHead 1x1 conv + bias into the (B, na, ny, nx, no) fp32 layout (the EPI_HEAD epilogue), every element checked
+    (a stale last accumulator register once survived the whole-network tolerance)."""
+    from ayolov2_amd import functional as F_
+    B, Cin, H, W = shape
+    g = torch.Generator().manual_seed(B + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(255, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(255, generator=g)
+    if dt == torch.float16:
+        x, w = x.half().float(), w.half().float()
+    ref = F.conv2d(x, w, b).view(B, 3, 85, H, W).permute(0, 1, 3, 4, 2)
+    xg = x.cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    if dt == torch.float16:
+        with torch.autocast("cuda", dtype=torch.float16):
+            raw = F_.HeadConvFn.apply(xg, w.cuda(), b.cuda(), 3, 85, F_._WeightCache())
+    else:
+        raw = F_.HeadConvFn.apply(xg, w.cuda(), b.cuda(), 3, 85, F_._WeightCache())
+    assert raw.dtype == torch.float32 and raw.shape == ref.shape
+    assert _rel_err(raw.cpu(), ref) < (1e-5 if dt == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
 def test_stem_conv(dt):
     """6x6/s2/p2 on a 3-channel NCHW image (fp16: pixel-pair packed 6x3 conv; fp32: channel-padded)."""
     from ayolov2_amd.modules import Conv
