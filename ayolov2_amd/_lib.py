@@ -24,7 +24,8 @@ class LossLevel(ctypes.Structure):
     _fields_ = ([("pred", c_void_p)] + [(n, c_int64) for n in ("sb", "sa", "sy", "sx")]
                 + [(n, c_int) for n in ("B", "na", "ny", "nx", "no", "n")]
                 + [(n, c_void_p) for n in ("b", "a", "gj", "gi", "tcls", "tbox", "anch", "own", "score")]
-                + [("balance", c_float), ("grad", c_void_p)])
+                + [("balance", c_float), ("grad", c_void_p), ("head", c_void_p), ("next", c_void_p), ("rowbox", c_void_p),
+                   ("dz", c_void_p), ("ldz", c_int), ("dz_dtype", c_int), ("dbias", c_void_p)])
 
 
 class AyoloError(RuntimeError):
@@ -56,6 +57,7 @@ _SIGNATURES = {
     "ayolo_copy2d": [c_int, _P, c_int, _P, c_int, c_int64, c_int, c_int, _P],
     "ayolo_yolo_loss_fwd": [POINTER(LossLevel), c_int] + [c_float] * 8 + [_P, _P, _P],
     "ayolo_yolo_loss_bwd": [POINTER(LossLevel), c_int] + [c_float] * 8 + [_P, _P],
+    "ayolo_yolo_loss_bwd_packed": [POINTER(LossLevel), c_int] + [c_float] * 8 + [_P, _P],
     "ayolo_head_decode": [_P, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int64, c_int64, _P],
     "ayolo_nms_candidates": [_P, c_int, c_int, c_int, c_float, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_uint32, c_int,
                              _P],

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void k_loss_rows(LossP P, double* acc, const f
             if (nc > 1) atomicAdd(&acc[(l * 3 + 2) * LOSS_SLOTS + slot], (double)cls);
             L.score[row] = (1.0f - P.gr) + P.gr * fmaxf(r.ciou, 0.0f);
             atomicMax(&L.own[cell], row + 1);        // duplicate cells: the LAST row's objectness target wins
+            if (L.head) L.next[row] = atomicExch(&L.head[cell], row + 1);   // all rows of the cell (packed backward)
         }
     } else {
         const float g = grad_out[0] * (float)L.B;    // d (loss * bs)
@@ -238,6 +239,106 @@ __global__ __launch_bounds__(256) void k_loss_grad_dense(LossP P, const float* g
     }
 }
 
+// ---- packed backward: gradient written as the head conv's dz (NHWC, compute dtype) + dbias ------------------------------
+__global__ __launch_bounds__(256) void k_loss_rowbox(LossP P, const float* grad_out) {
+    const int l = blockIdx.y;
+    const ayolo_loss_level& L = P.lv[l];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= L.n) return;
+    const long long b = L.b[row], a = L.a[row], gj = L.gj[row], gi = L.gi[row];
+    const float* ps = L.pred + b * L.sb + a * L.sa + gj * L.sy + gi * L.sx;
+    float p[4], t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { p[i] = ps[i]; t[i] = L.tbox[(long long)row * 4 + i]; }
+    const CIoU r = ciou_eval<true>(p, t, L.anch[(long long)row * 2], L.anch[(long long)row * 2 + 1]);
+    const float k = -grad_out[0] * (float)L.B * P.h_box / (float)L.n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) L.rowbox[(long long)row * 4 + i] = k * r.d[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_loss_grad_packed(LossP P, const float* grad_out) {
+    const int l = blockIdx.y;
+    const ayolo_loss_level& L = P.lv[l];
+    const unsigned hw = (unsigned)(L.ny * L.nx);
+    const long long npix = (long long)L.B * hw;
+    const long long cells = npix * L.na;
+    const int no = L.no, nc = no - 5, Cc = L.na * no, ldz = L.ldz;
+    const int CG = ldz / 8, RPB = 256 / CG;
+    const int cg = threadIdx.x % CG, prow = threadIdx.x / CG;
+    const float g = grad_out[0] * (float)L.B;
+    const float k_obj = g * P.h_obj * L.balance / (float)cells;
+    const float k_cls = (L.n > 0 && nc > 1) ? g * P.h_cls / ((float)L.n * (float)nc) : 0.0f;
+    int aa[8], oo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cg * 8 + i;
+        aa[i] = c < Cc ? c / no : -1;
+        oo[i] = c < Cc ? c - aa[i] * no : 0;
+    }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    T* dz = reinterpret_cast<T*>(L.dz);
+    // the group spans at most two anchors (no >= 8); only one channel in 85 is dense (objectness), rows are rare:
+    // one list-head load per anchor decides whether anything but that channel is non-zero
+    int a_lo = -1, a_hi = -1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (aa[i] >= 0) { if (a_lo < 0) a_lo = aa[i]; a_hi = aa[i]; }
+    }
+    const unsigned nx = (unsigned)L.nx;
+    for (long long pix = (long long)blockIdx.x * RPB + prow; prow < RPB && pix < npix; pix += (long long)gridDim.x * RPB) {
+        const unsigned pu = (unsigned)pix;
+        const unsigned b = pu / hw, pp = pu - b * hw;
+        const unsigned y = pp / nx, x = pp - y * nx;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (a_lo >= 0) {
+            const long long cell_lo = ((long long)b * L.na + a_lo) * hw + pp;
+            const int h_lo = L.head[cell_lo];
+            const int h_hi = a_hi != a_lo ? L.head[cell_lo + hw] : h_lo;
+            const float* ps0 = L.pred + (long long)b * L.sb + (long long)y * L.sy + (long long)x * L.sx;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (aa[i] < 0) continue;
+                const int o = oo[i];
+                if (o == 4) {
+                    const long long cell = cell_lo + (long long)(aa[i] - a_lo) * hw;
+                    const int ow = L.own[cell];
+                    v[i] = k_obj * bce_logits_grad(ps0[(long long)aa[i] * L.sa + 4], ow ? L.score[ow - 1] : 0.0f, P.obj_pw);
+                } else {
+                    int h = aa[i] == a_lo ? h_lo : h_hi;
+                    if (h) {
+                        const float* ps = ps0 + (long long)aa[i] * L.sa;
+                        for (; h; h = L.next[h - 1]) {                    // rows matched to this cell (usually none)
+                            const int row = h - 1;
+                            if (o < 4) v[i] += L.rowbox[(long long)row * 4 + o];
+                            else if (nc > 1) v[i] += k_cls * bce_logits_grad(ps[o], (o - 5) == (int)L.tcls[row] ? P.cp : P.cn, P.cls_pw);
+                        }
+                    }
+                }
+                acc[i] += v[i];
+            }
+        }
+        T out[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] = (T)v[i];
+        T* dst = dz + pix * ldz + cg * 8;
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
+        if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(out + 4);
+    }
+    if (L.dbias) {
+        __shared__ float sb[2048];
+        for (int c = threadIdx.x; c < ldz; c += 256) sb[c] = 0.0f;
+        __syncthreads();
+        if (prow < RPB) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (aa[i] >= 0) atomicAdd(&sb[cg * 8 + i], acc[i]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < Cc; c += 256) atomicAdd(&L.dbias[c], sb[c]);
+    }
+}
+
 static int loss_pack(LossP* P, const ayolo_loss_level* lv, int nl, float cp, float cn, float cls_pw, float obj_pw, float gr,
                      float h_box, float h_obj, float h_cls, int need_grad, int* max_n) {
     AY_CHECK_ARG(lv && nl > 0 && nl <= LOSS_MAX_LEVELS, "yolo_loss: nl=%d", nl);
@@ -293,5 +394,31 @@ extern "C" int ayolo_yolo_loss_bwd(const ayolo_loss_level* lv, int nl, float cp,
         hipLaunchKernelGGL(k_loss_rows<true>, dim3((unsigned)((max_n + 3) / 4), (unsigned)nl), dim3(256), 0, st, P, (double*)nullptr, grad_out);
         AY_CHECK_LAUNCH("k_loss_grad_rows");
     }
+    return AYOLO_OK;
+}
+
+extern "C" int ayolo_yolo_loss_bwd_packed(const ayolo_loss_level* lv, int nl, float cp, float cn, float cls_pw, float obj_pw,
+                                          float gr, float h_box, float h_obj, float h_cls, const float* grad_out,
+                                          ayolo_stream s) {
+    LossP P{};
+    int max_n = 0;
+    int rc = loss_pack(&P, lv, nl, cp, cn, cls_pw, obj_pw, gr, h_box, h_obj, h_cls, 0, &max_n);
+    if (rc) return rc;
+    AY_CHECK_ARG(grad_out, "yolo_loss_bwd_packed: null grad_out");
+    int dt = lv[0].dz_dtype;
+    for (int l = 0; l < nl; ++l) {
+        const ayolo_loss_level& L = lv[l];
+        AY_CHECK_ARG(L.dz && L.head && L.ldz >= L.na * L.no && L.ldz % 8 == 0 && L.ldz <= 2048 && L.dz_dtype == dt,
+                     "yolo_loss_bwd_packed: level %d (ldz=%d)", l, L.ldz);
+        AY_CHECK_ARG(L.n == 0 || (L.next && L.rowbox), "yolo_loss_bwd_packed: level %d rows", l);
+    }
+    hipStream_t st = (hipStream_t)s;
+    if (max_n > 0) {
+        hipLaunchKernelGGL(k_loss_rowbox, dim3((unsigned)((max_n + 255) / 256), (unsigned)nl), dim3(256), 0, st, P, grad_out);
+        AY_CHECK_LAUNCH("k_loss_rowbox");
+    }
+    if (dt == AYOLO_F16) hipLaunchKernelGGL(k_loss_grad_packed<half_t>, dim3(1024, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+    else hipLaunchKernelGGL(k_loss_grad_packed<float>, dim3(1024, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+    AY_CHECK_LAUNCH("k_loss_grad_packed");
     return AYOLO_OK;
 }

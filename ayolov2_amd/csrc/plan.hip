@@ -47,6 +47,8 @@ extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
             t_prev = t;
         }
         switch (o.kind) {
+        case AYOLO_OP_NOP:
+            break;
         case AYOLO_OP_CONV_FWD:
             rc = ayolo_conv_fwd(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const float*)o.p[3], (const float*)o.p[4],
                                 (float*)o.p[5], o.i[1], o.i[2], s);

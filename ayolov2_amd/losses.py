@@ -56,8 +56,9 @@ class _FusedLossFn(torch.autograd.Function):
         nl = len(preds)
         cells = [p.shape[0] * p.shape[1] * p.shape[2] * p.shape[3] for p in preds]
         ns = [int(indices[i][0].shape[0]) for i in range(nl)]
-        own = torch.zeros(sum(cells), dtype=torch.int32, device=dev)
-        score = torch.empty(max(sum(ns), 1), dtype=torch.float32, device=dev)
+        own = torch.zeros(2 * sum(cells), dtype=torch.int32, device=dev)          # [own | head], one fill
+        score = torch.empty(max(sum(ns), 1) * 6, dtype=torch.float32, device=dev)  # [score | next (int32) | rowbox x4]
+        nrow = max(sum(ns), 1)
         acc = torch.empty(3 * nl * 64, dtype=torch.float64, device=dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
         arr = (_lib.LossLevel * nl)()
@@ -77,7 +78,10 @@ class _FusedLossFn(torch.autograd.Function):
                 L.b, L.a, L.gj, L.gi, L.tcls = (c.data_ptr() for c in cols)
                 L.tbox, L.anch = tb.data_ptr(), an.data_ptr()
             L.own = own.data_ptr() + 4 * co
+            L.head = own.data_ptr() + 4 * (sum(cells) + co)
             L.score = score.data_ptr() + 4 * no_
+            L.next = score.data_ptr() + 4 * (nrow + no_)
+            L.rowbox = score.data_ptr() + 4 * (2 * nrow + 4 * no_)
             L.balance = float(cfg["balance"][i])
             L.grad = None
             co += cells[i]
@@ -85,6 +89,7 @@ class _FusedLossFn(torch.autograd.Function):
         consts = (cfg["cp"], cfg["cn"], cfg["cls_pw"], cfg["obj_pw"], cfg["gr"], cfg["box"], cfg["obj"], cfg["cls"])
         _lib.call("ayolo_yolo_loss_fwd", arr, nl, *consts, acc.data_ptr(), out.data_ptr(), _stream())
         ctx.arr, ctx.consts, ctx.keep = arr, consts, keep + [own, score]
+        ctx.packed_ok = bool(cfg.get("packed", True))
         ctx.save_for_backward(*preds)
         items = out[1:5]
         ctx.mark_non_differentiable(items)
@@ -93,15 +98,51 @@ class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_items):
         from . import _lib
-        from .ops import _stream
+        from .ops import _stream, dtype_code
         g = g_loss.detach().reshape(-1)[:1].float().contiguous()
+        preds = ctx.saved_tensors
+        # Packed mode: every logit tensor is a YOLOHead output of this package (tagged by HeadConvFn / the plan), whose
+        # backward understands the side channel: the gradient is written directly as that conv's backward operand
+        # (NHWC, compute dtype) + bias gradient, and autograd only carries a zero-stride placeholder that points to it.
+        tags = [getattr(p, "_ayolo_head", None) for p in preds]
+        if ctx.packed_ok and all(t is not None for t in tags) and len({t[1] for t in tags}) == 1:
+            grads = []
+            for i, (p, (ldz, dt)) in enumerate(zip(preds, tags)):
+                B, na, ny, nx, no = p.shape
+                dz = torch.empty((B * ny * nx, ldz), dtype=dt, device=p.device)
+                dbias = torch.zeros(na * no, dtype=torch.float32, device=p.device)
+                L = ctx.arr[i]
+                L.dz, L.ldz, L.dz_dtype, L.dbias = dz.data_ptr(), ldz, dtype_code(dt), dbias.data_ptr()
+                ph = torch.zeros((), dtype=torch.float32, device=p.device).expand(p.shape)
+                ph._ayolo_packed = (dz, dbias)
+                grads.append(ph)
+            _lib.call("ayolo_yolo_loss_bwd_packed", ctx.arr, len(grads), *ctx.consts, g.data_ptr(), _stream())
+            return (None, None, None, None, None, *grads)
         grads = []
-        for i, p in enumerate(ctx.saved_tensors):
+        for i, p in enumerate(preds):
             gr = torch.empty(p.shape, dtype=torch.float32, device=p.device)       # contiguous (B,na,ny,nx,no)
             ctx.arr[i].grad = gr.data_ptr()
             grads.append(gr)
         _lib.call("ayolo_yolo_loss_bwd", ctx.arr, len(grads), *ctx.consts, g.data_ptr(), _stream())
         return (None, None, None, None, None, *grads)
+
+
+def take_packed_head_grad(draw, ldz: int, dtype):
+    """For YOLOHead backward implementations: returns (dz, dbias) when `draw` is the placeholder of a packed loss
+    gradient produced for exactly this layout, else None.  A placeholder that lost its payload raises (it must never
+    be consumed as a real, all-zero gradient)."""
+    if draw is None:
+        return None
+    pk = getattr(draw, "_ayolo_packed", None)
+    if pk is not None:
+        dz, dbias = pk
+        if dz.shape[1] == ldz and dz.dtype == dtype:
+            return dz, dbias
+        raise RuntimeError("packed head gradient has the wrong layout for this head")
+    if draw.dim() == 5 and all(s == 0 for s in draw.stride()) and draw.numel() > 1:
+        raise RuntimeError("packed head-gradient placeholder without payload reached a YOLOHead backward; "
+                           "set ComputeLoss.packed_head_grad = False")
+    return None
 
 
 class ComputeLoss:
@@ -122,6 +163,7 @@ class ComputeLoss:
         self.na, self.nc, self.nl, self.anchors = head.na, head.nc, head.nl, head.anchors
         self._anchors_cpu = None
         self.fused = True          # use csrc/loss.hip when the configuration allows (see _fusable)
+        self.packed_head_grad = True   # hand the gradient to this package's YOLOHead backward in its operand layout
 
     def _fusable(self, preds) -> bool:
         return (self.fused and self.hyp["fl_gamma"] <= 0 and not self.autobalance and not self.sort_obj_iou
@@ -199,7 +241,7 @@ class ComputeLoss:
         if self._fusable(preds):
             cfg = {"balance": self.balance, "cp": self.cp, "cn": self.cn, "cls_pw": float(self.hyp["cls_pw"]),
                    "obj_pw": float(self.hyp["obj_pw"]), "gr": float(self.gr), "box": float(self.hyp["box"]),
-                   "obj": float(self.hyp["obj"]), "cls": float(self.hyp["cls"])}
+                   "obj": float(self.hyp["obj"]), "cls": float(self.hyp["cls"]), "packed": self.packed_head_grad}
             loss_bs, items = _FusedLossFn.apply(cfg, tcls, tbox, indices, anchors, *preds)
             return loss_bs, items
         for i, pi in enumerate(preds):

@@ -132,6 +132,7 @@ class TrainPlan:
         self.bn_counters: List[torch.Tensor] = []
         self.raw_specs = []
         self.draw_ops: List[Op] = []
+        self._head_dz: Dict[int, Tuple[int, int]] = {}
         self.pack_op: Optional[Op] = None
         self._compile()
 
@@ -486,21 +487,46 @@ class TrainPlan:
             torch._foreach_add_(self.bn_counters, 1)
         self._fwd_done = torch.cuda.Event()
         self._fwd_done.record()
-        return [buf.as_strided(shape, strides) for buf, shape, strides in self.raw_specs]
+        raws = [buf.as_strided(shape, strides) for buf, shape, strides in self.raw_specs]
+        for r, (buf, _, _) in zip(raws, self.raw_specs):
+            r._ayolo_head = (buf.shape[-1], self.dt)      # the fused loss may hand its gradient over in dz layout
+        return raws
 
     def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
+        from .losses import take_packed_head_grad
         keep = []
+        late_bias = []
         for idx, lvl in zip(self.draw_idx, self.draw_levels):
             d = draws[lvl]
             buf, shape, _ = self.raw_specs[lvl]
+            op, dg, wg = self.bwd_arr[idx], self.bwd_arr[idx + 1], self.bwd_arr[idx + 2]   # pack, head dgrad, head wgrad
+            if idx not in self._head_dz:
+                self._head_dz[idx] = (op.p[1], op.p[2])
+            dz0, dbias0 = self._head_dz[idx]
+            pk = take_packed_head_grad(d, buf.shape[-1], self.dt)
+            if pk is not None:
+                # gradient already in the head conv's operand layout: skip the pack op, point dgrad / wgrad at it
+                op.kind = 0
+                dg.p[0] = pk[0].data_ptr()
+                wg.p[1] = pk[0].data_ptr()
+                keep += [pk[0], pk[1]]
+                if dbias0:
+                    late_bias.append((dbias0, pk[1]))
+                continue
+            op.kind = OP_HEAD_GRAD_PACK
+            dg.p[0] = dz0
+            wg.p[1] = dz0
             if d is None:
                 d = torch.zeros(shape, dtype=torch.float32, device=self.device)
             if d.dtype != torch.float32 or not d.is_contiguous():
                 d = d.float().contiguous()
             keep.append(d)
-            self.bwd_arr[idx].p[0] = d.data_ptr()
+            op.p[0] = d.data_ptr()
         _lib.check(_lib.lib().ayolo_run_ops(self.bwd_arr, len(self.bwd), torch.cuda.current_stream().cuda_stream), "ayolo_run_ops(backward)")
         self._d_keep = keep
+        for ptr, dbias in late_bias:         # bias gradient of a packed head level -> its slot in the gradient arena
+            off = (ptr - self.gradarena.buf.data_ptr()) // 4
+            self.gradarena.buf[off:off + dbias.numel()].copy_(dbias)
         # The arena is scratch that the next backward zeroes: hand out gradients that OWN their memory (autograd steals
         # them as p.grad and may keep them across steps for gradient accumulation) -- one flat copy, views into it.
         flat = self.gradarena.buf.clone()

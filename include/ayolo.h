@@ -172,7 +172,12 @@ typedef struct ayolo_loss_level {
                                 * cell's objectness target (the last row in order, as a sequential index_put)    */
     float* score;              /* [n] objectness target of each row: (1-gr) + gr*clamp(ciou, 0), written by _fwd  */
     float balance;             /* objectness balance of the level (losses.py:204-206)                            */
-    float* grad;               /* _bwd only: d(out[0]) / d pred, (B,na,ny,nx,no) CONTIGUOUS fp32, fully written    */
+    float* grad;               /* _bwd (dense): d(out[0]) / d pred, (B,na,ny,nx,no) CONTIGUOUS fp32, fully written   */
+    /* packed backward (ayolo_yolo_loss_bwd_packed): the gradient goes straight into the head conv's backward operand */
+    int* head; int* next;      /* [B*na*ny*nx] zeroed by the caller before _fwd / [n]: per-cell list of its rows     */
+    float* rowbox;             /* [n][4] scratch: box-logit gradients of each row                                   */
+    void* dz; int ldz; int dz_dtype;   /* NHWC [B*ny*nx][ldz] of dz_dtype (channel = a*no + o, channels >= na*no zero) */
+    float* dbias;              /* [na*no] fp32, zeroed by the caller: sum over pixels (nullable)                    */
 } ayolo_loss_level;
 /* out[5] = {loss*B, lbox*h_box, lobj*h_obj, lcls*h_cls, loss}; acc: scratch double[3*nl*64] (zeroed by the call).
  * cp / cn: smoothed positive / negative class targets; gr: IoU ratio of the objectness target. */
@@ -182,6 +187,10 @@ int ayolo_yolo_loss_fwd(const ayolo_loss_level* lv, int nl, float cp, float cn, 
  * Needs own / score as left by _fwd on the same inputs. */
 int ayolo_yolo_loss_bwd(const ayolo_loss_level* lv, int nl, float cp, float cn, float cls_pw, float obj_pw, float gr,
                         float h_box, float h_obj, float h_cls, const float* grad_out, ayolo_stream s);
+/* Same gradient, written directly as the YOLOHead conv's backward operand (what ayolo_head_grad_pack would produce from
+ * the dense gradient): lv[l].dz / dbias instead of lv[l].grad.  Needs head / next as left by _fwd. */
+int ayolo_yolo_loss_bwd_packed(const ayolo_loss_level* lv, int nl, float cp, float cn, float cls_pw, float obj_pw, float gr,
+                               float h_box, float h_obj, float h_cls, const float* grad_out, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * NMS (scripts/utils/metrics.py:285-443 `non_max_suppression`, scripts/utils/nms.py:15-116 `batched_nms`,
@@ -254,6 +263,7 @@ int ayolo_bn_eval_affine(const float* gamma, const float* beta, const float* run
  * static buffers) enqueued by ONE host call.  Field use per kind: see csrc/plan.hip.
  * ---------------------------------------------------------------------------------------------- */
 enum {
+    AYOLO_OP_NOP = 0,          /* skipped (a slot the host disabled for this run) */
     AYOLO_OP_CONV_FWD = 1, AYOLO_OP_CONV_DGRAD, AYOLO_OP_CONV_WGRAD, AYOLO_OP_CAST_WEIGHT, AYOLO_OP_BN_FINALIZE,
     AYOLO_OP_AFFINE_ACT, AYOLO_OP_BN_BWD_REDUCE, AYOLO_OP_BN_BWD_APPLY, AYOLO_OP_MAXPOOL_FWD, AYOLO_OP_MAXPOOL_BWD,
     AYOLO_OP_UPSAMPLE_FWD, AYOLO_OP_UPSAMPLE_BWD, AYOLO_OP_PACK_INPUT, AYOLO_OP_HEAD_GRAD_PACK, AYOLO_OP_COPY2D,

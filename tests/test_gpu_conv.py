@@ -22,7 +22,7 @@ SHAPES = [
 
 
 def _tol(dt):
-    return (1e-4, 1e-4) if dt == torch.float32 else (2e-2, 2e-2)
+    return (1e-4, 1e-4) if dt == torch.float32 else (3e-3, 3e-3)   # fp16: same rounded operands, fp32 accumulate -> only the output rounding
 
 
 def _rel_err(got, want):

@@ -104,3 +104,43 @@ def test_fused_loss_equals_torch_path(variant):
     for a, b in zip(gf, gt):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, float((a - b).abs().max()) / scale
+
+
+def _mini_hyp():
+    return dict(box=0.05, cls=0.5, obj=1.0, cls_pw=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+
+
+@pytest.mark.parametrize("use_plan", [True, False])
+def test_packed_head_gradient_end_to_end(use_plan):
+    """The loss hands its gradient to the YOLOHead backward directly in the conv's operand layout (no dense fp32
+    gradient, no repack): parameter gradients must equal the dense route's, on the plan and on the module path, with
+    duplicate-cell rows in the batch."""
+    import copy
+    from ayolov2_amd import YOLOModel
+    from ayolov2_amd.losses import ComputeLoss
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ayolov2_amd", "configs", "yolov5n.yaml")
+    torch.manual_seed(4)
+    m = YOLOModel(cfg).cuda().train()
+    m.hyp, m.gr, m.nc = _mini_hyp(), 1.0, 80
+    m.use_plan = use_plan
+    m2 = copy.deepcopy(m)
+    x = torch.rand(4, 3, 128, 160).cuda()
+    nt = 40
+    targets = torch.cat((torch.randint(0, 4, (nt, 1)).float(), torch.randint(0, 80, (nt, 1)).float(),
+                         torch.rand(nt, 2) * 0.9 + 0.05, torch.rand(nt, 2) * 0.3 + 0.02), 1)
+    targets = torch.cat((targets, targets[:8]), 0)
+    outs = []
+    for mod, packed in ((m, True), (m2, False)):
+        cl = ComputeLoss(mod)
+        cl.packed_head_grad = packed
+        preds = mod(x)
+        prepared = cl.prepare(targets, [tuple(p.shape) for p in preds], device=x.device)
+        loss, items = cl(preds, targets.cuda(), prepared=prepared)
+        (loss * 64.0).backward()
+        outs.append((loss.detach().cpu(), {n: p.grad.detach().float().cpu() for n, p in mod.named_parameters()}))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-7)
+    for n, g1 in outs[0][1].items():
+        g2 = outs[1][1][n]
+        scale = float(g2.abs().max()) + 1e-12
+        # the dense route rounds the fp32 gradient to the compute dtype in a second pass; same values, same order
+        assert float((g1 - g2).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((g1 - g2).abs().max()) / scale)
