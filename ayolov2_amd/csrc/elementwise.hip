@@ -5,6 +5,7 @@
 // Replaces the BatchNorm2d / SiLU / MaxPool2d / Upsample / cat / sigmoid kernels torch launched for kindle's
 // Conv, SPPF, UpSample, Concat and YOLOHead modules.
 #include "common.h"
+#include <stdlib.h>
 
 template <typename T> struct VecT;
 template <> struct VecT<half_t> { static constexpr int VE = 8; };
@@ -395,9 +396,11 @@ extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const 
     AY_CHECK_ARG(z && da && sums && save_mean && save_invstd, "bn_bwd_reduce: null pointer");
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && C <= 2048, "bn_bwd_reduce: C=%d", C);
     if (npix == 0) return AYOLO_OK;
-    // >= 32 pixels per thread, at most 4 workgroups per CU: the per-workgroup tail (2*C global atomics) stays small
-    unsigned grid = grid_pixels(npix, C, ve, 32);
-    if (grid > 1024) grid = 1024;
+    // >= 16 pixels per thread, at most 4 workgroups per CU (measured best): the per-workgroup tail (2*C atomics) stays small
+    static const int red_iters = getenv("AYOLO_RED_ITERS") ? atoi(getenv("AYOLO_RED_ITERS")) : 16;
+    static const int red_cap = getenv("AYOLO_RED_CAP") ? atoi(getenv("AYOLO_RED_CAP")) : 1024;
+    unsigned grid = grid_pixels(npix, C, ve, red_iters);
+    if (grid > (unsigned)red_cap) grid = (unsigned)red_cap;
     const int cg_ = C / ve, cgt_ = cg_ < 256 ? cg_ : 256, rpb_ = 256 / cgt_;
     DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_reduce<T>, dim3(grid), dim3(256),
                                          (size_t)rpb_ * 2 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
