@@ -25,7 +25,9 @@ def smooth_bce(eps: float = 0.1) -> Tuple[float, float]:
 
 
 def _unwrap(model: nn.Module) -> nn.Module:
-    return model.module if isinstance(model, (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel)) else model
+    if isinstance(model, (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel)) or type(model).__name__ == "FlatGradDDP":
+        return model.module
+    return model
 
 
 class FocalLoss(nn.Module):

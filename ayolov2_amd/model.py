@@ -116,6 +116,9 @@ class YOLOModel(nn.Module):
                 raws = plan_forward_train(self, x)     # static-plan fast path (None: unsupported structure)
                 if raws is not None:
                     return raws
+            if getattr(self, "_ayolo_grad_sync", None) is not None:
+                raise RuntimeError("FlatGradDDP needs the plan executor (model not plannable / use_plan off): "
+                                   "wrap with torch DistributedDataParallel instead")
             ops.ARENA.reset()          # one fill for all BN accumulators of this step
         outs: List[Any] = []
         for i, m in enumerate(self.model):

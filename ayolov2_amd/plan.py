@@ -527,6 +527,9 @@ class TrainPlan:
         for ptr, dbias in late_bias:         # bias gradient of a packed head level -> its slot in the gradient arena
             off = (ptr - self.gradarena.buf.data_ptr()) // 4
             self.gradarena.buf[off:off + dbias.numel()].copy_(dbias)
+        sync = getattr(self.model, "_ayolo_grad_sync", None)
+        if sync is not None:                 # FlatGradDDP: one all-reduce of the whole arena (RCCL), averaged
+            sync.reduce_flat(self.gradarena.buf)
         # The arena is scratch that the next backward zeroes: hand out gradients that OWN their memory (autograd steals
         # them as p.grad and may keep them across steps for gradient accumulation) -- one flat copy, views into it.
         flat = self.gradarena.buf.clone()

@@ -63,7 +63,11 @@ def build_train_objects(model_name, device, world_size):
     loss_fn = ComputeLoss(model)
     run_model = model
     if world_size > 1:
-        run_model = nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
+        if os.environ.get("AYOLO_TORCH_DDP") == "1":
+            run_model = nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
+        else:
+            from ayolov2_amd.trainer import FlatGradDDP      # one all-reduce of the plan's flat gradient arena per step
+            run_model = FlatGradDDP(model)
     scaler = torch.amp.GradScaler("cuda")
     return model, run_model, opt, loss_fn, scaler
 

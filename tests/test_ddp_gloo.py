@@ -87,3 +87,37 @@ def test_ddp_two_ranks_gloo(tmp_path):
     for k in a:
         if a[k].dtype.is_floating_point:
             assert torch.allclose(a[k], ref[k], rtol=1e-4, atol=1e-6), k
+
+
+def _flat_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from ayolov2_amd.trainer import FlatGradDDP
+    dist.init_process_group("gloo")
+    torch.manual_seed(10 + rank)                      # ranks start from DIFFERENT parameters
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
+    w = FlatGradDDP(net)
+    sync = net._ayolo_grad_sync
+    flat = torch.arange(8, dtype=torch.float32) * (rank + 1)      # what the plan's gradient arena would hold
+    sync.reduce_flat(flat)
+    import pickle
+    restored = pickle.loads(pickle.dumps(sync))                    # checkpoints pickle the model: no process group inside
+    assert restored.world == 1 and restored.group is None
+    assert len(list(w.modules())) == len(list(net.modules())) + 1  # the sync object is not a submodule (no cycle)
+    torch.save({"state": {k: v.clone() for k, v in net.state_dict().items()}, "flat": flat}, os.path.join(out, f"flat{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_ddp_two_ranks_gloo(tmp_path):
+    """FlatGradDDP (the plan executor's data-parallel wrapper): rank-0 broadcast of parameters and buffers at
+    construction, one averaged all-reduce of the flat gradient arena."""
+    port = _free_port()
+    mp.spawn(_flat_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "flat0.pt"))
+    b = torch.load(os.path.join(tmp_path, "flat1.pt"))
+    for k in a["state"]:
+        assert torch.equal(a["state"][k], b["state"][k]), f"not broadcast: {k}"
+    want = torch.arange(8, dtype=torch.float32) * 1.5               # mean of x1 and x2
+    assert torch.equal(a["flat"], want) and torch.equal(b["flat"], want)
