@@ -626,3 +626,68 @@ extern "C" int ayolo_merge_boxes(const float* det, uint32_t n, float offset_scal
     AY_CHECK_LAUNCH("k_merge_boxes");
     return AYOLO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Validator matching (scripts/utils/train_utils.py:294-333 `YoloValidator.process_batch`), every image of a batch
+// in one go and without the per-image D2H + numpy argsort / unique of the reference:
+//   candidate pairs (label l, detection d): same class and IoU(l, d) >= iouv[0]
+//   sort by IoU descending, unique by detection  ->  each detection keeps its best label
+//   unique by label (in detection order)         ->  each label keeps its LOWEST-index detection (detections arrive
+//                                                    sorted by confidence, so: its most confident one)
+//   correct[d][j] = IoU >= iouv[j] for the surviving pairs, false elsewhere.
+// IoU ties between the labels of one detection resolve to the higher label index.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_match_best(const float* det, const int* det_img, int64_t N, const float* lab, const int* lab_off, const float* iouv,
+                             int* best_l, float* best_iou, int* owner) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= N) return;
+    const float* q = det + d * 6;
+    const float bx1 = q[0], by1 = q[1], bx2 = q[2], by2 = q[3], cls = q[5];
+    const float ba = (bx2 - bx1) * (by2 - by1);
+    const int img = det_img[d];
+    const float thr0 = iouv[0];
+    int bl = -1;
+    float bi = -1.0f;
+    for (int l = lab_off[img]; l < lab_off[img + 1]; ++l) {
+        const float* p = lab + (int64_t)l * 5;
+        if (p[0] != cls) continue;
+        const float aa = (p[3] - p[1]) * (p[4] - p[2]);
+        const float v = iou_pair(p[1], p[2], p[3], p[4], aa, bx1, by1, bx2, by2, ba);
+        if (v >= thr0 && v >= bi) { bi = v; bl = l; }
+    }
+    best_l[d] = bl;
+    best_iou[d] = bi;
+    if (bl >= 0) atomicMin(&owner[bl], (int)d);
+}
+
+__global__ void k_match_correct(const int* best_l, const float* best_iou, const int* owner, int64_t N, const float* iouv, int niou,
+                                unsigned char* correct) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * niou) return;
+    const int64_t d = t / niou;
+    const int j = (int)(t - d * niou);
+    const int bl = best_l[d];
+    correct[t] = (bl >= 0 && owner[bl] == (int)d && best_iou[d] >= iouv[j]) ? 1 : 0;
+}
+
+extern "C" int ayolo_match_detections(const float* det, const int* det_img, int64_t N, const float* lab, const int* lab_off,
+                                      int64_t M, const float* iouv_dev, int niou, int* best_l, float* best_iou, int* owner,
+                                      unsigned char* correct, ayolo_stream s) {
+    if (N == 0) return AYOLO_OK;
+    AY_CHECK_ARG(det && det_img && lab_off && iouv_dev && best_l && best_iou && correct && niou > 0 && N < (1ll << 31) && M < (1ll << 31),
+                 "match_detections: bad args");
+    AY_CHECK_ARG(M == 0 || (lab && owner), "match_detections: labels");
+    hipStream_t st = (hipStream_t)s;
+    if (M > 0) {
+        hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)cdiv64(M, 256)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(owner), (uint32_t)M,
+                           0x7fffffffu);
+        AY_CHECK_LAUNCH("k_fill_u32");
+    }
+    hipLaunchKernelGGL(k_match_best, dim3((unsigned)cdiv64(N, 128)), dim3(128), 0, st, det, det_img, N, lab, lab_off, iouv_dev, best_l,
+                       best_iou, owner);
+    AY_CHECK_LAUNCH("k_match_best");
+    hipLaunchKernelGGL(k_match_correct, dim3((unsigned)cdiv64(N * niou, 256)), dim3(256), 0, st, best_l, best_iou, owner, N, iouv_dev,
+                       niou, correct);
+    AY_CHECK_LAUNCH("k_match_correct");
+    return AYOLO_OK;
+}

@@ -355,3 +355,65 @@ def head_decode(raw: Sequence[np.ndarray], anchors_px: np.ndarray, strides: Sequ
         y[..., 2:4] = (s[..., 2:4] * 2.0) ** 2 * np.asarray(anchors_px[i], np.float64).reshape(1, na, 1, 1, 2)
         outs.append(y.reshape(B, -1, no))
     return np.concatenate(outs, 1).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+# validator matching + AP (scripts/utils/train_utils.py:294-333, scripts/utils/metrics.py:446-548)
+# --------------------------------------------------------------------------------------------------
+def process_batch(detections: np.ndarray, labels: np.ndarray, iouv: np.ndarray) -> np.ndarray:
+    """detections (N,6) x1,y1,x2,y2,conf,cls; labels (M,5) cls,x1,y1,x2,y2 -> correct (N, len(iouv)) bool.
+    Follows train_utils.py:311-332 step by step (float32 arithmetic like the torch original)."""
+    detections = np.asarray(detections, np.float32)
+    labels = np.asarray(labels, np.float32)
+    iouv = np.asarray(iouv, np.float32)
+    correct = np.zeros((detections.shape[0], iouv.shape[0]), bool)
+    if detections.shape[0] == 0 or labels.shape[0] == 0:
+        return correct
+    iou = box_iou(labels[:, 1:], detections[:, :4])
+    x = np.where((iou >= iouv[0]) & (labels[:, 0:1] == detections[:, 5]))
+    if x[0].shape[0]:
+        matches = np.concatenate((np.stack(x, 1).astype(np.float32), iou[x[0], x[1]][:, None].astype(np.float32)), 1)
+        if x[0].shape[0] > 1:
+            matches = matches[matches[:, 2].argsort()[::-1]]
+            matches = matches[np.unique(matches[:, 1], return_index=True)[1]]
+            matches = matches[np.unique(matches[:, 0], return_index=True)[1]]
+        correct[matches[:, 1].astype(np.int64)] = matches[:, 2:3] >= iouv
+    return correct
+
+
+def compute_ap(recall, precision):
+    """metrics.py:446-473: 101-point interpolated AP of the precision envelope."""
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([1.0], precision, [0.0]))
+    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
+    x = np.linspace(0, 1, 101)
+    integrate = getattr(np, "trapezoid", None) or np.trapz          # numpy 2 renamed trapz
+    ap = integrate(np.interp(x, mrec, mpre), x)
+    return ap, mpre, mrec
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls):
+    """metrics.py:476-548 without the plotting branch: (p, r, ap, f1, unique_classes)."""
+    i = np.argsort(-conf)
+    tp, conf, pred_cls = tp[i], conf[i], pred_cls[i]
+    unique_classes = np.unique(target_cls)
+    nc = unique_classes.shape[0]
+    px = np.linspace(0, 1, 1000)
+    ap, p, r = np.zeros((nc, tp.shape[1])), np.zeros((nc, 1000)), np.zeros((nc, 1000))
+    for ci, c in enumerate(unique_classes):
+        i = pred_cls == c
+        n_l = (target_cls == c).sum()
+        n_p = i.sum()
+        if n_p == 0 or n_l == 0:
+            continue
+        fpc = (1 - tp[i]).cumsum(0)
+        tpc = tp[i].cumsum(0)
+        recall = tpc / (n_l + 1e-16)
+        r[ci] = np.interp(-px, -conf[i], recall[:, 0], left=0)
+        precision = tpc / (tpc + fpc)
+        p[ci] = np.interp(-px, -conf[i], precision[:, 0], left=1)
+        for j in range(tp.shape[1]):
+            ap[ci, j], _, _ = compute_ap(recall[:, j], precision[:, j])
+    f1 = 2 * p * r / (p + r + 1e-16)
+    i = f1.mean(0).argmax()
+    return p[:, i], r[:, i], ap, f1[:, i], unique_classes.astype("int32")

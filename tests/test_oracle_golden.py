@@ -124,3 +124,22 @@ def test_g7_tucker(golden_dir):
     # reconstruction error small (synthetic low multilinear rank + noise)
     rec = np.einsum("abhw,oa,ib->oihw", core, last[:, :, 0, 0], first[:, :, 0, 0].T)
     assert np.abs(rec - w).mean() < 0.02
+
+
+def test_validator_matching_and_ap_vs_golden(golden_dir):
+    """G8: the reference's own YoloValidator.process_batch / ap_per_class outputs (train_utils.py:294-333,
+    metrics.py:476-548) vs the oracle restatement and vs the product's host-side AP."""
+    import numpy as np
+    from oracle import ops_ref
+    from ayolov2_amd.validator import ap_per_class
+    g = np.load(os.path.join(golden_dir, "g8_validator.npz"))
+    for i in range(int(g["n_img"])):
+        if f"correct{i}" in g.files:
+            np.testing.assert_array_equal(ops_ref.process_batch(g[f"det{i}"], g[f"lab{i}"], g["iouv"]), g[f"correct{i}"])
+    for fn in (ops_ref.ap_per_class, ap_per_class):
+        p, r, ap, f1, cls = fn(g["tp"], g["conf"], g["pcls"], g["tcls"])
+        np.testing.assert_allclose(p, g["ap_p"], rtol=1e-12)
+        np.testing.assert_allclose(r, g["ap_r"], rtol=1e-12)
+        np.testing.assert_allclose(ap, g["ap"], rtol=1e-12)
+        np.testing.assert_allclose(f1, g["ap_f1"], rtol=1e-12)
+        np.testing.assert_array_equal(cls, g["ap_cls"])

@@ -76,10 +76,65 @@ def synth_pred(B, N, nc, img, mu_obj, seed):
     return torch.cat((xy, wh, obj, cls), 2).float()
 
 
+def g8_validator():
+    """G8: YoloValidator.process_batch (train_utils.py:294-333) on seeded detections / labels of several images and
+    ap_per_class (metrics.py:476-548) on the stacked statistics -- the reference's own functions, run here."""
+    from scripts.utils import metrics as rm
+    from scripts.utils import train_utils as rt
+    rng = np.random.default_rng(8)
+    iouv = torch.linspace(0.5, 0.95, 10)
+
+    class FakeSelf:
+        pass
+
+    fs = FakeSelf()
+    fs.iouv = iouv
+    g8 = {"iouv": iouv.numpy()}
+    stats = []
+    n_img = 6
+    for i in range(n_img):
+        m = int(rng.integers(0, 9)) if i != 2 else 0            # image 2: no labels
+        n = int(rng.integers(5, 40)) if i != 4 else 0           # image 4: no detections
+        lab_xy = rng.uniform(20, 500, (m, 2)).astype(np.float32)
+        lab = np.concatenate([rng.integers(0, 5, (m, 1)).astype(np.float32), lab_xy,
+                              lab_xy + rng.uniform(20, 140, (m, 2)).astype(np.float32)], 1)
+        det = np.zeros((n, 6), np.float32)
+        for k in range(n):
+            if m and rng.uniform() < 0.7:                        # jittered copy of a label (several per label)
+                j = int(rng.integers(0, m))
+                det[k, :4] = lab[j, 1:] + rng.normal(0, 6, 4)
+                det[k, 5] = lab[j, 0] if rng.uniform() < 0.85 else float(rng.integers(0, 5))
+            else:
+                xy = rng.uniform(0, 520, 2)
+                det[k, :4] = [xy[0], xy[1], xy[0] + rng.uniform(10, 150), xy[1] + rng.uniform(10, 150)]
+                det[k, 5] = float(rng.integers(0, 5))
+            det[k, 4] = rng.uniform(0.01, 1.0)
+        det = det[np.argsort(-det[:, 4])].astype(np.float32)     # NMS output order
+        g8[f"det{i}"], g8[f"lab{i}"] = det, lab
+        if n == 0:
+            continue
+        if m:
+            correct = rt.YoloValidator.process_batch(fs, torch.from_numpy(det), torch.from_numpy(lab)).numpy()
+        else:
+            correct = np.zeros((n, 10), bool)
+        g8[f"correct{i}"] = correct
+        stats.append((correct, det[:, 4], det[:, 5], lab[:, 0]))
+    g8["n_img"] = n_img
+    tp, conf, pcls, tcls = [np.concatenate(x, 0) for x in zip(*stats)]
+    tcls = np.concatenate([g8[f"lab{i}"][:, 0] for i in range(n_img)])   # labels of images without detections count too
+    p, r, ap, f1, cls = rm.ap_per_class(tp, conf, pcls, tcls, plot=False)
+    g8.update(ap_p=p, ap_r=r, ap=ap, ap_f1=f1, ap_cls=cls, tp=tp, conf=conf, pcls=pcls, tcls=tcls)
+    np.savez_compressed(os.path.join(OUT, "g8_validator.npz"), **g8)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8_validator()
+        print("g8 written")
+        return
     from scripts.utils import general as rg
     from scripts.utils import metrics as rm
     from scripts.utils import nms as rn
@@ -258,6 +313,8 @@ def main():
     g7["conv_loss"] = float(loss)
     g7["conv_shapes"] = np.array([list(m.weight.shape) for m in seq])
     np.savez_compressed(os.path.join(OUT, "g7_tucker.npz"), **g7)
+
+    g8_validator()
 
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
