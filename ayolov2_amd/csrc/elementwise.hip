@@ -843,6 +843,28 @@ extern "C" int ayolo_head_grad_pack(const float* draw, int B, int na, int ny, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ModelEMA.update (scripts/utils/torch_utils.py:405-416): v = v*d; v += (1-d)*m  for every floating tensor of the
+// state dict, all tensors in ONE launch (job table in device memory, blockIdx.y = tensor).  Same two-step rounding as
+// the reference's in-place ops (this file is built with -ffp-contract=off).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ema_update(const ayolo_ema_job* jobs, float d) {
+    const ayolo_ema_job J = jobs[blockIdx.y];
+    const float omd = 1.0f - d;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < J.n; i += (long long)gridDim.x * 256) {
+        float v = J.ema[i] * d;
+        v += omd * J.src[i];
+        J.ema[i] = v;
+    }
+}
+
+extern "C" int ayolo_ema_update(const ayolo_ema_job* jobs_dev, int njobs, float decay, ayolo_stream s) {
+    AY_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535, "ema_update: njobs=%d", njobs);
+    hipLaunchKernelGGL(k_ema_update, dim3(32, (unsigned)njobs), dim3(256), 0, (hipStream_t)s, jobs_dev, decay);
+    AY_CHECK_LAUNCH("k_ema_update");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // misc
 // ---------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";

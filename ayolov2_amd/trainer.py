@@ -22,6 +22,71 @@ RANK = int(os.getenv("RANK", -1))
 WORLD_SIZE = int(os.getenv("WORLD_SIZE", 1))
 
 
+class ModelEMA:
+    """Exponential moving average of every floating tensor of the state dict, with the reference's interface and
+    arithmetic (scripts/utils/torch_utils.py:377-426).  On the GPU the ~180 tensors are updated by ONE kernel launch
+    (``ayolo_ema_update``) instead of two torch ops per tensor."""
+
+    def __init__(self, model: nn.Module, decay: float = 0.9999, updates: int = 0) -> None:
+        import math
+        from copy import deepcopy
+        plans = model.__dict__.pop("_plans", None)          # cached executor plans own GBs of activations: not part of the EMA
+        try:
+            self.ema = deepcopy(model).eval()                # FP32 EMA
+        finally:
+            if plans is not None:
+                model.__dict__["_plans"] = plans
+        self.updates = updates
+        self.decay = lambda x: decay * (1 - math.exp(-x / 2000))
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+        self._jobs = None
+
+    def _job_table(self, model: nn.Module):
+        import numpy as np
+        msd = model.state_dict()
+        pairs = []
+        for k, v in self.ema.state_dict().items():
+            if v.dtype.is_floating_point:
+                src = msd[k if k in msd else f"module.{k}"]
+                pairs.append((v, src))
+        key = tuple((v.data_ptr(), s.data_ptr()) for v, s in pairs)
+        if self._jobs is None or self._jobs[0] != key:
+            def dense(t):                                   # one dense block of memory (any of the two layouts in use)
+                return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+            ok = all(v.is_cuda and s.is_cuda and v.dtype == torch.float32 and s.dtype == torch.float32 and v.shape == s.shape
+                     and v.stride() == s.stride() and dense(v) for v, s in pairs)
+            tab = None
+            if ok and pairs:
+                job_t = np.dtype([("ema", "<u8"), ("src", "<u8"), ("n", "<i8")])
+                jobs = np.zeros(len(pairs), dtype=job_t)
+                for i, (v, s_) in enumerate(pairs):
+                    jobs[i] = (v.data_ptr(), s_.data_ptr(), v.numel())
+                tab = torch.from_numpy(jobs.view(np.uint8).copy()).to(pairs[0][0].device)
+            self._jobs = (key, tab, pairs)
+        return self._jobs
+
+    def update(self, model: nn.Module) -> None:
+        with torch.no_grad():
+            self.updates += 1
+            d = self.decay(self.updates)
+            _, tab, pairs = self._job_table(model)
+            if tab is not None:
+                from . import _lib
+                _lib.call("ayolo_ema_update", tab.data_ptr(), len(pairs), float(d), torch.cuda.current_stream().cuda_stream)
+                return
+            for v, src in pairs:                             # CPU / mixed-dtype state: the reference's two in-place ops
+                v *= d
+                v += (1.0 - d) * src.detach()
+
+    def update_attr(self, model: nn.Module, include=(), exclude=("process_group", "reducer")) -> None:
+        for k, v in model.__dict__.items():
+            if (len(include) and k not in include) or k.startswith("_") or k in exclude:
+                continue
+            setattr(self.ema, k, v)
+
+
 class _FlatSync:
     """What the plan calls at the end of backward (a plain object: it must not become a submodule of the model)."""
 
@@ -99,7 +164,7 @@ class TrainModelBuilder:
     def prepare(self) -> Tuple[nn.Module, Optional[Any], torch.device]:
         torch.manual_seed(1 + max(self.rank, 0))
         self.model.to(self.device)
-        ema = None
+        ema = ModelEMA(self.model) if self.rank in (-1, 0) else None          # train_model_builder.py:130
         if self.cuda and self.rank != -1 and self.cfg.get("train", {}).get("sync_bn", False):
             raise NotImplementedError("sync_bn: the HIP BatchNorm keeps statistics local (reference default)")
         if self.rank != -1:
@@ -108,8 +173,9 @@ class TrainModelBuilder:
 
 
 def training_step(model: nn.Module, loss_fn, optimizer: torch.optim.Optimizer, scaler, imgs: torch.Tensor,
-                  targets: torch.Tensor, world_size: int = 1, amp: bool = True):
-    """autocast forward -> ComputeLoss -> (x world_size under DDP) -> scaled backward -> step (accumulate = 1)."""
+                  targets: torch.Tensor, world_size: int = 1, amp: bool = True, ema: Optional["ModelEMA"] = None):
+    """autocast forward -> ComputeLoss -> (x world_size under DDP) -> scaled backward -> step (accumulate = 1) -> EMA
+    (yolo_trainer.py:322-338)."""
     with torch.autocast(imgs.device.type, dtype=torch.float16, enabled=amp and imgs.is_cuda):
         pred = model(imgs)
         loss, items = loss_fn(pred, targets)
@@ -123,4 +189,6 @@ def training_step(model: nn.Module, loss_fn, optimizer: torch.optim.Optimizer, s
         loss.backward()
         optimizer.step()
     optimizer.zero_grad(set_to_none=True)
+    if ema is not None:
+        ema.update(model)
     return loss.detach(), items

@@ -95,6 +95,11 @@ int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, fl
 int ayolo_cast_weight(const float* w32, int Cout, int kh, int kw, int Cin, int Cout_pad, int Cin_pad, int dtype,
                       void* w, void* wt, ayolo_stream s);
 
+/* ModelEMA.update (scripts/utils/torch_utils.py:405-416) for every floating tensor of a state dict in one launch:
+ * ema = ema*decay; ema += (1-decay)*src.  `jobs_dev` is a DEVICE array written once by the caller. */
+typedef struct ayolo_ema_job { float* ema; const float* src; int64_t n; } ayolo_ema_job;
+int ayolo_ema_update(const ayolo_ema_job* jobs_dev, int njobs, float decay, ayolo_stream s);
+
 /* The same cast for every layer of a model in one launch.  `jobs_dev` is a DEVICE array (written once by the caller;
  * each entry must have Cout_pad*taps*Cin_pad < 2^32). */
 typedef struct ayolo_cast_job {

@@ -204,3 +204,33 @@ def test_plan_gradient_accumulation():
     for n in g1:
         scale = float(g2[n].abs().max()) + 1e-12
         assert float((g1[n] - g2[n]).abs().max()) <= 2e-3 * scale + 1e-6, n
+
+
+def test_model_ema_fused_update():
+    """ModelEMA.update (torch_utils.py:405-416) as one HIP launch over the whole state dict vs the reference's
+    per-tensor in-place arithmetic; the decay ramp and the non-float buffers (num_batches_tracked) as in the reference."""
+    import math
+    from ayolov2_amd.trainer import ModelEMA
+    m, _ = _pair("n", seed=9)
+    ema = ModelEMA(m, decay=0.9999, updates=0)
+    ref = {k: v.detach().clone().cpu() for k, v in ema.ema.state_dict().items()}
+    for step in range(3):
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(torch.randn_like(p) * 0.01)
+            for b in m.buffers():
+                if b.dtype.is_floating_point:
+                    b.add_(0.05)
+        ema.update(m)
+        d = 0.9999 * (1 - math.exp(-(step + 1) / 2000))
+        msd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        for k, v in ref.items():
+            if v.dtype.is_floating_point:
+                v *= d
+                v += (1.0 - d) * msd[k]
+    assert ema.updates == 3 and ema._jobs[1] is not None, "the fused path must be the one that ran"
+    for k, v in ema.ema.state_dict().items():
+        if v.dtype.is_floating_point:
+            torch.testing.assert_close(v.cpu(), ref[k], rtol=0, atol=0)
+        else:
+            assert torch.equal(v.cpu(), ref[k])
