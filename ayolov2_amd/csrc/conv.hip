@@ -20,7 +20,6 @@
 
 #define MAX_TAPS 36
 #define BK 32
-#define TP 128   // pixels per block tile
 
 // exact unsigned division by a runtime constant (Granlund-Montgomery round-up form), all 32-bit numerators
 struct FastDiv { unsigned m, s1, s2; };
@@ -91,7 +90,7 @@ typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <typename T, int TM>
+template <typename T, int TM, int TPX = 128>
 struct GT {
     static constexpr int ES = sizeof(T);
     static constexpr int CE = 16 / ES;              // elements per 16-byte chunk
@@ -99,7 +98,10 @@ struct GT {
     static constexpr int CPR = ROWB / 16;           // chunks per row: 4 / 8
     static constexpr int RPB = 256 / ROWB;          // rows per 256-byte bank row: 4 / 2
     static constexpr int RW = 1024 / ROWB;          // rows written by one wave-instruction: 16 / 8
-    static constexpr int XSTAGE = TP * ROWB;        // 8 KiB / 16 KiB
+    // pixels per block tile: 128, or 256 for the narrow channel tiles on multi-step reductions (K >= 128) so that a
+    // wave still has 4-8 MFMAs per barrier
+    static constexpr int TP = TPX;
+    static constexpr int XSTAGE = TP * ROWB;        // 8-16 KiB / 16-32 KiB
     static constexpr int XR = XSTAGE / 4096;        // x DMA instructions per thread per step
     static constexpr int WSTAGE = TM * ROWB < 4096 ? 4096 : TM * ROWB;
     static constexpr int WR = WSTAGE / 4096;
@@ -146,14 +148,14 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
 
 // pixel decode of the loader's rows for pixel tile `tile` (invalid tile / rows beyond Mtotal -> never in range).
 // Branch-free on purpose (selects only): see the header comment.
-template <typename T, int TM>
+template <typename T, int TM, int TPX>
 __device__ __forceinline__ void g_setup_rows(const GConvP& p, unsigned tile, bool valid, int wave, int rowin, int kc,
-                                             int (&xoff)[GT<T, TM>::XR], int (&xh0)[GT<T, TM>::XR], int (&xw0)[GT<T, TM>::XR]) {
-    using G = GT<T, TM>;
+                                             int (&xoff)[GT<T, TM, TPX>::XR], int (&xh0)[GT<T, TM, TPX>::XR], int (&xw0)[GT<T, TM, TPX>::XR]) {
+    using G = GT<T, TM, TPX>;
 #pragma unroll
     for (int r = 0; r < G::XR; ++r) {
         const int row = (r * 4 + wave) * G::RW + rowin;
-        const unsigned mu = tile * TP + row;               // < 2^31 + TP: pixel counts are < 2^31 (host check)
+        const unsigned mu = tile * G::TP + row;            // < 2^31 + TP: pixel counts are < 2^31 (host check)
         const bool ok = valid & (mu < (unsigned)p.Mtotal);
         const unsigned t = fdiv(mu, p.dOW);
         const int ow = (int)(mu - t * (unsigned)p.OW);
@@ -168,12 +170,12 @@ __device__ __forceinline__ void g_setup_rows(const GConvP& p, unsigned tile, boo
 }
 
 // issue the DMA of one step (k slice `kt` of the loader's current tile) into the LDS stage at byte offset `so`
-template <typename T, int TM>
-__device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T, TM>::XR], const int (&xh0)[GT<T, TM>::XR],
-                                        const int (&xw0)[GT<T, TM>::XR], const unsigned (&woff)[GT<T, TM>::WR], int kt,
+template <typename T, int TM, int TPX>
+__device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T, TM, TPX>::XR], const int (&xh0)[GT<T, TM, TPX>::XR],
+                                        const int (&xw0)[GT<T, TM, TPX>::XR], const unsigned (&woff)[GT<T, TM, TPX>::WR], int kt,
                                         int tap0, int ntap, const int4* sTap, unsigned lds_tiles, unsigned so, v4i32 rsX,
                                         v4i32 rsW, int wave, int kc) {
-    using G = GT<T, TM>;
+    using G = GT<T, TM, TPX>;
     const unsigned k0 = (unsigned)(kt * BK + kc * G::CE);
     unsigned tap = fdiv(k0, p.dC);
     const int cb = (int)(k0 - tap * (unsigned)p.C) * G::ES;
@@ -193,10 +195,10 @@ __device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T,
     }
 }
 
-template <typename T, int TM>
+template <typename T, int TM, int TPX>
 __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int xrow, int swz, int lane,
-                                      float16v (&acc)[GT<T, TM>::NI]) {
-    using G = GT<T, TM>;
+                                      float16v (&acc)[GT<T, TM, TPX>::NI]) {
+    using G = GT<T, TM, TPX>;
     const unsigned char* bx = stage + xrow;
     const unsigned char* bw = stage + G::XSTAGE + arow;
 #pragma unroll
@@ -232,13 +234,13 @@ __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int 
 // tile finished: acc[ni][r] holds channel = cbase + 8*(r>>2) + (r&3), pixel = m0 + wp*NI*32 + ni*32 + (lane&31).
 // Exactly NST buffer stores per thread (invalid pixels / channel groups use the out-of-range offset and are dropped
 // by the hardware), so the step loop's vmcnt arithmetic stays exact.
-template <typename T, int TM, int EM>
+template <typename T, int TM, int EM, int TPX>
 __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int oah, int oaw, int wp, int lane, int cbase,
-                                           bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM>::NI],
+                                           bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM, TPX>::NI],
                                            float (&ssum)[16], float (&ssq)[16]) {
-    using G = GT<T, TM>;
+    using G = GT<T, TM, TPX>;
     constexpr int YES = (EM == 3) ? 4 : G::ES;       // bytes per output element
-    const unsigned m0 = tile * TP;
+    const unsigned m0 = tile * G::TP;
 #pragma unroll
     for (int ni = 0; ni < G::NI; ++ni) {
         const unsigned m = m0 + wp * G::NI * 32 + ni * 32 + (lane & 31);
@@ -345,9 +347,9 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int
     }
 }
 
-template <typename T, int TM, int EM>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 && EM == 0)) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
-    using G = GT<T, TM>;
+template <typename T, int TM, int EM, int TPX>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && EM == 0)) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
+    using G = GT<T, TM, TPX>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     unsigned char* sTiles = smem_raw;                                             // [GNS][x tile | w tile]
     int4* sTap = reinterpret_cast<int4*>(smem_raw + GNS * G::STAGE);              // [MAX_TAPS + 1]
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 &&
     const unsigned nt = idx % (unsigned)p.ntn;
     const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
     const int n0 = (int)nt * TM;
-    const unsigned ntiles_all = (unsigned)((p.Mtotal + TP - 1) / TP);
+    const unsigned ntiles_all = (unsigned)((p.Mtotal + G::TP - 1) / G::TP);
     const unsigned tpx = (ntiles_all + 7) / 8;
     const unsigned band_lo = xcd * tpx;
     const unsigned ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
@@ -431,9 +433,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 &&
     unsigned ld_tile = cur_tile;
     int ld_kt = 0, ld_cls = 0, ld_nk = cur_nk;
     bool ld_valid = true;
-    g_setup_rows<T, TM>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
+    g_setup_rows<T, TM, TPX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
     __syncthreads();                          // tap table visible
-#define G_ISSUE(so) g_issue<T, TM>(p, xoff, xh0, xw0, woff, ld_kt, p.ctap0[ld_cls], p.cnt[ld_cls], sTap, lds_tiles, so, rsX, rsW, wave, kc);
+#define G_ISSUE(so) g_issue<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, p.ctap0[ld_cls], p.cnt[ld_cls], sTap, lds_tiles, so, rsX, rsW, wave, kc);
 #define G_ADVANCE()                                                                           \
     {                                                                                         \
         if (++ld_kt == ld_nk) {                                                               \
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 &&
                 ld_cls = 0;                                                                   \
                 ld_tile += lstride;                                                           \
                 ld_valid = ld_valid && ld_tile < ntiles;                                      \
-                g_setup_rows<T, TM>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);   \
+                g_setup_rows<T, TM, TPX>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);   \
             }                                                                                 \
             ld_nk = G_NK(ld_cls);                                                             \
         }                                                                                     \
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 &&
         __builtin_amdgcn_s_barrier();
         G_ISSUE(so2)                                     // step s+2 -> the stage step s-1 used
         G_ADVANCE()
-        g_mma<T, TM>(sTiles + so0, arow, xrow, swz, lane, acc);
+        g_mma<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, acc);
         // The last MFMA's result must not be read for passes+2 wait states.  hipcc (ROCm 7.2) covers that hazard inside a
         // basic block but was seen to miss it across the loop back edge (fp32 head variant: the next iteration opened
         // with v_accvgpr_read of the accumulator's last register, which came back stale) -- pad it here, explicitly.
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (((TM == 128 || (TM == 64 &&
         after_epi = false;
         if (cur_kt == cur_nk - 1) {
             if constexpr (sizeof(T) == 2) asm volatile("s_nop 11" ::: "memory");   // fp16: accumulators are only read here
-            g_epilogue<T, TM, EM>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq);
+            g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq);
             after_epi = true;
         }
         if (++cur_kt == cur_nk) {
@@ -500,16 +502,16 @@ static int num_cus() {
     return g_num_cu;
 }
 
-template <typename T, int TM, int EM>
-static int launch_gconv_em(GConvP p, hipStream_t s) {
-    using G = GT<T, TM>;
+template <typename T, int TM, int EM, int TPX>
+static int launch_gconv_tp(GConvP p, hipStream_t s) {
+    using G = GT<T, TM, TPX>;
     const size_t lds = G::LDS;
-    const long long ntiles = (p.Mtotal + TP - 1) / TP;
+    const long long ntiles = (p.Mtotal + G::TP - 1) / G::TP;
     p.ntn = (p.Nout + TM - 1) / TM;
     // persistent grid: as many workgroups per CU as LDS / registers allow, pixel-tile slots a multiple of the 8 XCDs
     static const int bpc_env = getenv("AYOLO_GCONV_BPC") ? atoi(getenv("AYOLO_GCONV_BPC")) : 0;
     int bpc = (int)(160 * 1024 / lds);
-    const int bpc_max = sizeof(T) == 2 ? (TM == 128 ? 3 : 4) : 1;
+    const int bpc_max = sizeof(T) == 2 ? (G::LDS > 56 * 1024 ? 2 : (TM == 128 ? 3 : 4)) : 1;
     if (bpc > bpc_max) bpc = bpc_max;
     if (bpc_env > 0) bpc = bpc_env;
     long long want_slots = (long long)num_cus() * bpc / p.ntn;
@@ -520,13 +522,25 @@ static int launch_gconv_em(GConvP p, hipStream_t s) {
     dim3 grid((unsigned)(slots * p.ntn));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gconv<T, TM, EM>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX>), grid, dim3(256), lds, s, p);
     AY_CHECK_LAUNCH("k_gconv");
     return AYOLO_OK;
+}
+
+template <typename T, int TM, int EM>
+static int launch_gconv_em(const GConvP& p, hipStream_t s) {
+    // 256-pixel tiles for the narrow channel tiles when the reduction has >= 4 steps (measured: 3x3 / stem layers gain
+    // 10-15 %, one- and two-step 1x1 layers prefer the 128-pixel tile's higher occupancy)
+    if constexpr (TM < 128) {
+        static const int force = getenv("AYOLO_GCONV_TP") ? atoi(getenv("AYOLO_GCONV_TP")) : 0;
+        const bool wide = force ? force == 256 : (p.ntaps * p.C >= 128 && p.Mtotal >= 256 * 512);
+        if (wide) return launch_gconv_tp<T, TM, EM, 256>(p, s);
+    }
+    return launch_gconv_tp<T, TM, EM, 128>(p, s);
 }
 
 template <typename T, int TM>
