@@ -106,8 +106,10 @@ class YoloValidator:
     cfg_hyp needs ``conf_t`` / ``iou_t``; ``single_cls`` as in cfg_train (train_utils.py:461-469)."""
 
     def __init__(self, model: torch.nn.Module, device: torch.device, cfg_hyp: Dict[str, Any], single_cls: bool = False,
-                 half: bool = False, hybrid_label: bool = False, nms_type: str = "nms", loss_fn=None) -> None:
+                 half: bool = False, hybrid_label: bool = False, nms_type: str = "nms", loss_fn=None, tta: bool = False,
+                 tta_scales: Sequence[float] = (1, 0.83, 0.67), tta_flips: Sequence[Optional[int]] = (None, 3, None)) -> None:
         self.model, self.device, self.cfg_hyp = model, device, cfg_hyp
+        self.tta, self.tta_scales, self.tta_flips = tta, list(tta_scales), list(tta_flips)
         self.single_cls, self.half, self.hybrid_label, self.nms_type, self.loss_fn = single_cls, half, hybrid_label, nms_type, loss_fn
         self.iouv = torch.linspace(0.5, 0.95, 10).to(device)        # mAP@0.5:0.95 (train_utils.py:236-237)
         self.niou = self.iouv.numel()
@@ -139,7 +141,11 @@ class YoloValidator:
         imgs = imgs.half() if self.half else imgs.float()
         targets = targets.to(self.device, non_blocking=True)
         _, _, height, width = imgs.shape
-        outs = self.model(imgs)
+        if self.tta:                                                 # train_utils.py:425-433
+            from .tta import inference_with_tta
+            outs = inference_with_tta(self.model, imgs, self.tta_scales, self.tta_flips)
+        else:
+            outs = self.model(imgs)
         out, train_out = (outs[0], outs[1]) if isinstance(outs, (tuple, list)) and len(outs) == 2 else (outs, None)
         if self.loss_fn is not None and train_out is not None:
             self.loss += self.loss_fn([x.float() for x in train_out], targets)[1][:3]

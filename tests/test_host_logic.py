@@ -180,3 +180,45 @@ def test_decompose_model_surface():
     for c in swapped:
         assert len(c.conv) == 3 and c.conv.kernel_size == (3, 3) and hasattr(c.conv, "in_channels")
     assert sum(p.numel() for p in m.parameters()) < before
+
+
+def test_tta_vs_golden(golden_dir):
+    """G9: inference_with_tta / scale_img / descale_pred / clip_augmented against the reference's own run
+    (tta_utils.py:15-86) around a deterministic YOLO-shaped stand-in model."""
+    from ayolov2_amd import tta
+    g = np.load(os.path.join(golden_dir, "g9_tta.npz"))
+
+    class Head:
+        nl = 3
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = [None, Head()]
+            self.stride = torch.tensor([8.0, 16.0, 32.0])
+
+        def forward(self, x):
+            B, _, H, W = x.shape
+            outs = []
+            for s_ in (8, 16, 32):
+                ny, nx = H // s_, W // s_
+                pooled = torch.nn.functional.adaptive_avg_pool2d(x, (ny, nx))
+                yy, xx = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nx, dtype=torch.float32), indexing="ij")
+                rows = []
+                for a in range(3):
+                    cx = (xx + 0.5) * s_ + pooled[:, 0] * 3
+                    cy = (yy + 0.5) * s_ + pooled[:, 1] * 3
+                    w_ = torch.full_like(cx, 10.0 * (a + 1)) + pooled[:, 2]
+                    h_ = torch.full_like(cx, 7.0 * (a + 1)) + pooled[:, 0]
+                    rest = pooled.mean(1, keepdim=True).expand(B, 4, ny, nx).permute(0, 2, 3, 1)
+                    rows.append(torch.cat((torch.stack((cx, cy, w_, h_), -1), rest), -1).reshape(B, ny * nx, 8))
+                outs.append(torch.cat(rows, 1))
+            return torch.cat(outs, 1), None
+
+    x = torch.from_numpy(g["x"])
+    flips = [None if f == 0 else int(f) for f in g["flips"]]
+    y, none = tta.inference_with_tta(Fake(), x, [float(s) for s in g["scales"]], flips)
+    assert none is None
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(tta.scale_img(x, 0.83, gs=32).numpy(), g["scaled_083"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(tta.scale_img(x, 0.5, same_shape=True, gs=32).numpy(), g["scaled_same"], rtol=1e-6, atol=1e-6)

@@ -127,6 +127,48 @@ def g8_validator():
     np.savez_compressed(os.path.join(OUT, "g8_validator.npz"), **g8)
 
 
+def g9_tta():
+    """G9: inference_with_tta / scale_img / descale_pred / clip_augmented (tta_utils.py:15-86, torch_utils.py:305-331)
+    around a deterministic stand-in model (a YOLO-shaped function of the input), the reference's own code run here."""
+    from scripts.utils import tta_utils as rt
+    from scripts.utils import torch_utils as rtu
+
+    class Head:
+        nl = 3
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = [None, Head()]
+            self.stride = torch.tensor([8.0, 16.0, 32.0])
+
+        def forward(self, x):
+            B, _, H, W = x.shape
+            outs = []
+            for s_ in (8, 16, 32):
+                ny, nx = H // s_, W // s_
+                pooled = torch.nn.functional.adaptive_avg_pool2d(x, (ny, nx))          # (B,3,ny,nx)
+                yy, xx = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nx, dtype=torch.float32), indexing="ij")
+                rows = []
+                for a in range(3):
+                    cx = (xx + 0.5) * s_ + pooled[:, 0] * 3
+                    cy = (yy + 0.5) * s_ + pooled[:, 1] * 3
+                    w_ = torch.full_like(cx, 10.0 * (a + 1)) + pooled[:, 2]
+                    h_ = torch.full_like(cx, 7.0 * (a + 1)) + pooled[:, 0]
+                    rest = pooled.mean(1, keepdim=True).expand(B, 4, ny, nx).permute(0, 2, 3, 1)
+                    rows.append(torch.cat((torch.stack((cx, cy, w_, h_), -1), rest), -1).reshape(B, ny * nx, 8))
+                outs.append(torch.cat(rows, 1))
+            return torch.cat(outs, 1), None
+
+    m = Fake()
+    x = torch.rand(1, 3, 96, 128, generator=torch.Generator().manual_seed(9))
+    s_, f_ = [1, 0.83, 0.67], [None, 3, None]
+    y, _ = rt.inference_with_tta(m, x, s_, f_)
+    g9 = dict(x=x.numpy(), scales=np.array(s_), flips=np.array([0, 3, 0]), y=y.numpy(),
+              scaled_083=rtu.scale_img(x, 0.83, gs=32).numpy(), scaled_same=rtu.scale_img(x, 0.5, same_shape=True, gs=32).numpy())
+    np.savez_compressed(os.path.join(OUT, "g9_tta.npz"), **g9)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
@@ -134,6 +176,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8_validator()
         print("g8 written")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        g9_tta()
+        print("g9 written")
         return
     from scripts.utils import general as rg
     from scripts.utils import metrics as rm
@@ -315,6 +361,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g7_tucker.npz"), **g7)
 
     g8_validator()
+    g9_tta()
 
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
