@@ -41,17 +41,6 @@ int ayolo_version(void);
 const char* ayolo_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
- * Validator matching (scripts/utils/train_utils.py:294-333 `YoloValidator.process_batch`) for all images of a batch:
- * det [N][6] = x1,y1,x2,y2,conf,cls (each image's rows in NMS output order), det_img[N] image of each row,
- * lab [M][5] = cls,x1,y1,x2,y2 grouped by image with lab_off[B+1]; iouv_dev: niou ascending thresholds (device).
- * correct [N][niou] (uint8).  Scratch: best_l[N], best_iou[N], owner[M].  Same result as the reference's
- * IoU-sorted np.unique-by-detection then np.unique-by-label, without its device->host copies.
- * ---------------------------------------------------------------------------------------------- */
-int ayolo_match_detections(const float* det, const int* det_img, int64_t N, const float* lab, const int* lab_off, int64_t M,
-                           const float* iouv_dev, int niou, int* best_l, float* best_iou, int* owner,
-                           unsigned char* correct, ayolo_stream s);
-
-/* ------------------------------------------------------------------------------------------------
  * Convolution (kindle `Conv.forward` / `YOLOHead.conv[i]`: yolov5s.yaml:21-57; autograd backward of the
  * same: scripts/train/yolo_trainer.py:329).
  * ---------------------------------------------------------------------------------------------- */
@@ -273,6 +262,17 @@ int ayolo_affine_act_res(int dtype, const void* z, int ldz, void* a, int lda, in
 /* inference BatchNorm folded to an affine: scale = gamma/sqrt(var+eps), shift = beta - mean*scale (+ bias*scale) */
 int ayolo_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                          const float* conv_bias, float eps, int C, float* scale, float* shift, ayolo_stream s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Validator matching (scripts/utils/train_utils.py:294-333 `YoloValidator.process_batch`) for all images of a batch:
+ * det [N][6] = x1,y1,x2,y2,conf,cls (each image's rows in NMS output order), det_img[N] image of each row,
+ * lab [M][5] = cls,x1,y1,x2,y2 grouped by image with lab_off[B+1]; iouv_dev: niou ascending thresholds (device).
+ * correct [N][niou] (uint8).  Scratch: best_l[N], best_iou[N], owner[M].  Same result as the reference's
+ * IoU-sorted np.unique-by-detection then np.unique-by-label, without its device->host copies.
+ * ---------------------------------------------------------------------------------------------- */
+int ayolo_match_detections(const float* det, const int* det_img, int64_t N, const float* lab, const int* lab_off, int64_t M,
+                           const float* iouv_dev, int niou, int* best_l, float* best_iou, int* owner,
+                           unsigned char* correct, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched launch: a pre-compiled straight-line program of the calls above (one model forward or backward over
