@@ -17,7 +17,9 @@ SHAPES = [
     (2, 16, 48, 3, 1, 1, 12, 12),      # Cout not a multiple of 32
     (2, 32, 64, 3, 1, 1, 24, 32),      # halo-tiled direct fwd/dgrad + halo-tiled wgrad (8x16 tiles, exact fit)
     (1, 64, 160, 3, 1, 1, 20, 40),     # halo-tiled, ragged tiles, Cout > 128
-    (2, 128, 32, 3, 1, 1, 8, 16),      # halo-tiled, 4 channel chunks, single tile per image
+    (2, 128, 32, 3, 1, 1, 8, 16),      # 4 channel chunks, single tile per image
+    (2, 32, 64, 3, 2, 1, 13, 17),      # stride 2 on odd sizes: dgrad residue classes differ in size -> one launch per class
+    (1, 64, 32, 1, 2, 0, 16, 16),      # 1x1 stride 2: three tap-less residue classes (zero gradient rows)
 ]
 
 
@@ -211,3 +213,18 @@ def test_maxpool_upsample(dt):
     yg.backward(gy.cuda().to(dt))
     np.testing.assert_array_equal(yg.detach().float().cpu().numpy(), yr.detach().numpy())
     assert _rel_err(xg.grad.float().cpu(), xr.grad) <= rt
+
+
+def test_wide_pixel_tile_variants():
+    """k_gconv's 256-pixel-tile instantiations are chosen only for large maps (>= 131072 output pixels); force them
+    (AYOLO_GCONV_TP=256, read once per process) on the small shapes so that every element is checked, fp32 and fp16."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AYOLO_GCONV_TP="256")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith(("ok ", "BAD"))]
+    assert out.returncode == 0 and len(lines) >= 30, out.stderr[-2000:]
+    bad = [l for l in lines if l.startswith("BAD")]
+    assert not bad, "\n".join(bad)
