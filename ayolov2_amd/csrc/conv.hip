@@ -905,7 +905,8 @@ static int launch_wgrad(WGradP p, hipStream_t s) {
     // time t_step per workgroup and an L2 atomic rate R the cost A*s + B/(tiles*s) is minimal at
     // s* = sqrt(steps_per_tile * t_step * R / (N*K))  (measured: t_step*R ~ 1.5e5), capped by ~3 workgroups per CU.
     static const double ka = getenv("AYOLO_WGRAD_KA") ? atof(getenv("AYOLO_WGRAD_KA")) : 1.5e5;
-    const int bpc = sizeof(T) == 2 ? 3 : 1;
+    static const int bpc_env = getenv("AYOLO_WGRAD_BPC") ? atoi(getenv("AYOLO_WGRAD_BPC")) : 0;
+    const int bpc = bpc_env > 0 ? bpc_env : (sizeof(T) == 2 ? 3 : 1);
     long long cap = ((long long)num_cus() * bpc + tiles - 1) / tiles;
     const double steps_per_tile = (double)p.P / W::BP;
     long long want = (long long)(sqrt(steps_per_tile * ka / ((double)p.N * (double)p.K)) + 0.5);

@@ -57,6 +57,12 @@ def _op(kind, i=(), f=(), d=(), l=(), p=(), conv: Optional[ConvDesc] = None) -> 
     return o
 
 
+import os as _os
+
+OP_SIDE = 0x100
+WGRAD_SIDE_STREAM = _os.environ.get("AYOLO_WGRAD_STREAM", "1") == "1"
+
+
 class PlanUnsupported(Exception):
     pass
 
@@ -148,6 +154,15 @@ class TrainPlan:
         self.param_grad_view[id(p)] = (off, numel_pad, view_fn)
         return off
 
+    def _dz(self, n: int) -> torch.Tensor:
+        """Backward operand dz of one layer: a slice of the shared scratch buffer, or -- when weight gradients run on the
+        side stream and therefore outlive the layer's turn -- a buffer of its own."""
+        if WGRAD_SIDE_STREAM:
+            t = torch.empty(n, dtype=self.dt, device=self.device)
+            self.keep.append(t)
+            return t
+        return self.dz_buf[:n]
+
     # ------------------------------------------------------------------ conv + BN + act
     def _conv_block(self, mod: Conv, x: Optional[Act], dst: Optional[Act], residual: Optional[Act] = None,
                     image: bool = False) -> Act:
@@ -237,7 +252,7 @@ class TrainPlan:
             ga = self.gradarena
             dgam = ga.view(gg_off, Cout) if gg_off is not None else None
             dbet = ga.view(gb_off, Cout) if gb_off is not None else None
-            dz = self.dz_buf[:npix * Cout]
+            dz = self._dz(npix * Cout)
             self.bwd.append(_op(OP_BN_BWD_REDUCE, i=(code, Cout, ldda, Cout, act, R), l=(npix,),
                                 p=(z.t, da, sm[0:Cout], sm[Cout:2 * Cout], bn.weight, bn.bias, su)))
             self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Cout, ldda, Cout, Cout, act, R), l=(npix,), f=(1.0,),
@@ -252,7 +267,8 @@ class TrainPlan:
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
                                     conv=geo.desc(dt, ops.nhwc_info(dx)[4], Cout)))
                 x_act.mark_init()
-            self.bwd.append(_op(OP_CONV_WGRAD, f=(1.0,), p=(xk, dz, ga.view(gw_off, Cout * K)), conv=geo.desc(dt, ldx, Cout)))
+            self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(xk, dz, ga.view(gw_off, Cout * K)),
+                                conv=geo.desc(dt, ldx, Cout)))
 
         self.bwd_emitters.append(emit_bwd)
         return a
@@ -356,7 +372,7 @@ class TrainPlan:
 
             def emit(x=x, geo=geo, wt=wt, cp=cp, Cin=Cin, Cout=Cout, B=B, H=H, W=W, gw_off=gw_off, gb_off=gb_off, ldx=ldx, npix=npix):
                 ga = self.gradarena
-                dz = self.dz_buf[:npix * cp]
+                dz = self._dz(npix * cp)
                 op = _op(OP_HEAD_GRAD_PACK, i=(B, head.na, H, W, head.no, code, cp),
                          p=(None, dz, ga.view(gb_off, Cout) if gb_off is not None else None))
                 self.draw_ops.append(op)
@@ -365,7 +381,8 @@ class TrainPlan:
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x.is_init()),), p=(dz, wt, dx),
                                     conv=geo.desc(dt, ops.nhwc_info(dx)[4], cp, cout=cp)))
                 x.mark_init()
-                self.bwd.append(_op(OP_CONV_WGRAD, f=(1.0,), p=(x.t, dz, ga.view(gw_off, cp * Cin)), conv=geo.desc(dt, ldx, cp, cout=cp)))
+                self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(x.t, dz, ga.view(gw_off, cp * Cin)),
+                                    conv=geo.desc(dt, ldx, cp, cout=cp)))
 
             self.bwd_emitters.append(emit)
 

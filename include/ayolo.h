@@ -278,6 +278,8 @@ int ayolo_match_detections(const float* det, const int* det_img, int64_t N, cons
  * Batched launch: a pre-compiled straight-line program of the calls above (one model forward or backward over
  * static buffers) enqueued by ONE host call.  Field use per kind: see csrc/plan.hip.
  * ---------------------------------------------------------------------------------------------- */
+#define AYOLO_OP_SIDE 0x100   /* OR-ed into kind: run on the executor's side stream (after everything enqueued so far;
+                               * joined at the end of the list) */
 enum {
     AYOLO_OP_NOP = 0,          /* skipped (a slot the host disabled for this run) */
     AYOLO_OP_CONV_FWD = 1, AYOLO_OP_CONV_DGRAD, AYOLO_OP_CONV_WGRAD, AYOLO_OP_CAST_WEIGHT, AYOLO_OP_BN_FINALIZE,
