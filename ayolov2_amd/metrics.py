@@ -12,6 +12,8 @@ The reference's 10 s wall-clock ``time_limit`` break (metrics.py:328,439-441) is
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -24,6 +26,7 @@ from .general import xywh2xyxy  # noqa: F401  (re-exported like the reference mo
 
 MAX_WH = 4096
 MAX_NMS = 30000
+NMS_BY_CLASS = os.environ.get("AYOLO_NMS_BY_CLASS", "1") != "0"      # per-(image, class) segments in the `nms` branch
 
 
 def _stream():
@@ -192,6 +195,75 @@ def _greedy_nms(cand: _Candidates, seg_n: np.ndarray, iou_thres: float, scales: 
     return out, out_idx, kept
 
 
+def _greedy_nms_by_class(cand: _Candidates, seg_n: np.ndarray, iou_thres: float, nc: int, max_det: int,
+                         output: List[torch.Tensor]) -> bool:
+    """Class-aware greedy NMS of the `nms` branch (metrics.py:383-388: boxes offset by cls * 4096) evaluated per (image,
+    class) segment instead of over all candidate pairs of an image.  The offset makes boxes of different classes
+    disjoint whenever the candidates' coordinates span less than 4096, so the global greedy scan in confidence order
+    equals independent per-class scans; with ~80 classes that is ~80x fewer box pairs.  Same kernels, same arithmetic on
+    the offset boxes (both boxes of a pair carry the same offset); the kept boxes of an image are merged back in
+    confidence order and cut to `max_det`.  Returns False (nothing done) when the span condition does not hold."""
+    dev = cand.device
+    B = len(seg_n)
+    tot = int(seg_n.sum())
+    if tot == 0:
+        return True
+    # rows of the conf-sorted per-image segments that take part (max_nms cut), their image id and class
+    parts = [torch.arange(int(cand.offsets[b]), int(cand.offsets[b]) + int(seg_n[b]), device=dev) for b in range(B) if seg_n[b]]
+    sel = torch.cat(parts)
+    img = torch.repeat_interleave(torch.arange(B, device=dev), torch.from_numpy(seg_n.astype(np.int64)).to(dev))
+    rows1 = cand.sdet.index_select(0, sel)                                   # (tot, 6), per image in confidence order
+    key2 = img * nc + rows1[:, 5].long()
+    key2s, perm = torch.sort(key2, stable=True)                               # (image, class) groups, confidence order inside
+    counts2 = torch.bincount(key2s, minlength=B * nc)
+    span = torch.stack((rows1[:, :4].amax(), -rows1[:, :4].amin()))
+    host = torch.cat((counts2.float(), span)).cpu().numpy()                   # one sync: segment sizes + coordinate span
+    if not (host[-2] + host[-1] < float(MAX_WH)):
+        return False
+    n2 = host[:-2].astype(np.int64)
+    rows2 = rows1.index_select(0, perm).contiguous()
+    nseg = B * nc
+    off2 = np.concatenate(([0], np.cumsum(n2)))[:-1].astype(np.int64)
+    max_n = int(n2.max())
+    max_out = max(1, min(max_det, max_n))
+    words = (n2 + 63) // 64
+    mask_sizes = n2 * words
+    mask_off = np.concatenate(([0], np.cumsum(mask_sizes)))[:-1].astype(np.int64)
+    mask = torch.empty(max(int(mask_sizes.sum()), 1), dtype=torch.int64, device=dev)
+    seg_off_d = torch.from_numpy(off2.astype(np.int32)).to(dev)
+    seg_n_d = torch.from_numpy(n2.astype(np.int32)).to(dev)
+    mask_off_d = torch.from_numpy(mask_off).to(dev)
+    scales_d = torch.full((nseg,), float(MAX_WH), dtype=torch.float32, device=dev)
+    out = torch.empty((nseg, max_out, 6), dtype=torch.float32, device=dev)
+    out_idx = torch.empty((nseg, max_out), dtype=torch.int32, device=dev)
+    out_count = torch.zeros(nseg, dtype=torch.int32, device=dev)
+    thr_f = thr_as_float_for_double_compare(iou_thres)
+    call("ayolo_nms_mask", rows2.data_ptr(), seg_off_d.data_ptr(), seg_n_d.data_ptr(), mask_off_d.data_ptr(), nseg, max_n, thr_f,
+         0.0, scales_d.data_ptr(), 0, mask.data_ptr(), _stream())
+    call("ayolo_nms_reduce", rows2.data_ptr(), seg_off_d.data_ptr(), seg_n_d.data_ptr(), mask_off_d.data_ptr(), mask.data_ptr(),
+         nseg, max_out, out.data_ptr(), out_idx.data_ptr(), out_count.data_ptr(), max_n, _stream())
+    # merge: position of every kept row in its image's confidence order, first max_det per image
+    valid = torch.arange(max_out, device=dev)[None, :] < out_count[:, None]   # (nseg, max_out)
+    pos2 = (seg_off_d.long()[:, None] + out_idx.long())[valid]                # rows of rows2
+    rank1 = perm[pos2]                                                        # rows of rows1 (image-major, confidence order)
+    rank1, _ = torch.sort(rank1)
+    img_k = img[rank1]
+    start1 = torch.from_numpy(np.concatenate(([0], np.cumsum(seg_n)))[:-1].astype(np.int64)).to(dev)
+    kept_per_img = torch.bincount(img_k, minlength=B)
+    first = torch.cumsum(kept_per_img, 0) - kept_per_img
+    within = torch.arange(rank1.numel(), device=dev) - first[img_k]
+    take = within < max_det
+    res = rows1.index_select(0, rank1[take])
+    kept = torch.clamp(kept_per_img, max=max_det).cpu().numpy()               # sync: final counts
+    o = 0
+    for b in range(B):
+        k = int(kept[b])
+        if k:
+            output[b] = res[o:o + k]
+        o += k
+    return True
+
+
 def _tv_batched_strategy(cand: _Candidates, seg_n: np.ndarray, class_agnostic: bool):
     """torchvision 0.10.1 ops.boxes.batched_nms: per-class NMS when boxes.numel() > 4000, else the coordinate
     trick offset = idx * (boxes.max() + 1).  Returns (scales tensor, modes array)."""
@@ -258,6 +330,9 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_
             scales, modes = _tv_batched_strategy(cand, seg_n, agnostic)
         else:
             scales, modes = (0.0 if agnostic else float(MAX_WH)), np.zeros(B, dtype=np.int64)
+        if nms_type == "nms" and not agnostic and nc > 1 and NMS_BY_CLASS and int(seg_n.max()) > 512:
+            if _greedy_nms_by_class(cand, seg_n, iou_thres, nc, max_det, output):
+                return output
         out, out_idx, kept = _greedy_nms(cand, seg_n, iou_thres, scales, modes, max_det)
         for b in range(B):
             k = int(kept[b])
