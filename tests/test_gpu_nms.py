@@ -139,3 +139,35 @@ def test_head_decode_vs_oracle():
         ops.head_decode(r.cuda(), torch.from_numpy(anchors[i].reshape(3, 2)).cuda(), strides[i], out, off)
         off += 3 * r.shape[2] * r.shape[3]
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-4)
+
+
+def test_nms_per_class_segments_equal_all_pairs(monkeypatch):
+    """The class-aware `nms` branch runs per (image, class) segment when the candidates' coordinates span < 4096 (the
+    reference's class offset).  Both routes must give the oracle's rows: (a) ordinary boxes -> segmented route,
+    (b) a few boxes wider than the offset -> the all-pairs route is taken, (c) the segmented route switched off."""
+    from ayolov2_amd import metrics as M
+    pred = synth_pred(2, 20000, 80, 640, -7.0, seed=5)
+    pred[:, :64, 4] = 0.9                      # equal confidences across classes: tie order = candidate order
+    pred[:, :64, 5:] = 0.0
+    pred[:, :64, 5 + (torch.arange(64) % 7)] = 0.8
+    want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    calls = []
+    orig = M._greedy_nms_by_class
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        calls.append(r)
+        return r
+
+    monkeypatch.setattr(M, "_greedy_nms_by_class", spy)
+    _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.6, multi_label=True), want, True, "segmented")
+    assert calls == [True]
+    wide = pred.clone()
+    wide[0, 100:104, 2:4] = 9000.0             # boxes wider than the class offset: classes are no longer disjoint
+    wide[0, 100:104, 4] = 0.95
+    want_w = ops_ref.non_max_suppression(wide.numpy(), conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    _cmp(M.non_max_suppression(wide.cuda(), 0.001, 0.6, multi_label=True), want_w, True, "wide boxes")
+    assert calls == [True, False]
+    monkeypatch.setattr(M, "NMS_BY_CLASS", False)
+    _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.6, multi_label=True), want, True, "all pairs")
+    assert len(calls) == 2
