@@ -71,6 +71,10 @@ _SIGNATURES = {
     "ayolo_gather_rows": [_P, _P, _P, c_uint32, c_int, _P],
     "ayolo_nms_mask": [_P, _P, _P, _P, c_int, c_uint32, c_float, c_float, _P, c_int, _P, _P],
     "ayolo_nms_reduce": [_P, _P, _P, _P, _P, c_int, c_uint32, _P, _P, _P, c_uint32, _P],
+    "ayolo_nms_class_keys": [_P, _P, _P, c_int, c_int, c_uint32, _P, _P, _P, _P, _P],
+    "ayolo_nms_class_layout": [_P, c_uint32, c_int, _P, _P, _P, _P, _P],
+    "ayolo_nms_class_merge": [_P, _P, _P, _P, _P, c_int, c_uint32, _P, c_int, c_uint32, c_uint32, _P, _P, _P, _P, _P,
+                              POINTER(c_size_t), _P],
     "ayolo_box_iou": [_P, c_int64, _P, c_int64, _P, _P],
     "ayolo_iou_colmax": [_P, _P, c_float, c_uint32, _P, _P],
     "ayolo_matrix_nms_decay": [_P, _P, c_float, c_uint32, _P, _P, _P],

@@ -27,125 +27,188 @@ struct CandParams {
     uint32_t capacity;
     int seq_bits;
     int order_by_seq;
+    int cpb;                 // chunks of CAND_ROWS rows per workgroup
+    int64_t nchunks;
 };
 
 __device__ __forceinline__ bool class_ok(const uint64_t* m, int c) {
     return m == nullptr || ((m[c >> 6] >> (c & 63)) & 1ull);
 }
 
+// One workgroup walks `cpb` consecutive chunks of CAND_ROWS rows.  Hits are staged in LDS (CAND_STAGE slots) and
+// output slots are reserved with ONE returning global atomic per flush: with a reservation per 64-row chunk the
+// 12 600 same-address atomics of the 8 x 100 800 workload serialised in L2 (~12 ns each) and were the whole
+// 0.30 ms of this kernel.  The next chunk is prefetched into registers while the current one is scanned.
+#define CAND_STAGE 512
+#define CAND_SPAN 8
+#define CAND_NPRE 6          // 16-byte prefetch registers per lane: covers no <= 96
+
 __global__ __launch_bounds__(256) void k_candidates(CandParams p) {
-    // Two passes over the chunk held in LDS: (1) count hits, (2) emit them.  Slots are reserved with ONE global
-    // atomic per workgroup (plus one per image the chunk touches) -- a per-hit or per-wave atomic on the 1 + B
-    // counters serialises in L2 and was 95 % of this kernel's time.
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ unsigned s_total, s_base, s_local;
-    __shared__ unsigned s_img_cnt[2];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint64_t* stage_key = reinterpret_cast<uint64_t*>(lds_raw);
+    float* stage_det = reinterpret_cast<float*>(lds_raw + (size_t)CAND_STAGE * 8);
+    float* lds = reinterpret_cast<float*>(lds_raw + (size_t)CAND_STAGE * 32);
+    __shared__ unsigned s_total, s_local, s_fill, s_base;
+    __shared__ unsigned s_img[CAND_SPAN];
     const int nc = p.no - 5;
-    const int64_t total_rows = (int64_t)p.B * p.rows_per_img;
-    const int64_t r0 = (int64_t)blockIdx.x * CAND_ROWS;
-    const int nrows = (int)min((int64_t)CAND_ROWS, total_rows - r0);
     const int tid = threadIdx.x;
-    if (tid == 0) { s_total = 0; s_local = 0; s_img_cnt[0] = 0; s_img_cnt[1] = 0; }
+    const int64_t total_rows = (int64_t)p.B * p.rows_per_img;
+    const int64_t c0 = (int64_t)blockIdx.x * p.cpb;
+    const int64_t c1 = min(c0 + (int64_t)p.cpb, p.nchunks);
+    const int img_lo = (int)((c0 * CAND_ROWS) / p.rows_per_img);
+    const int img_hi = (int)((min(c1 * CAND_ROWS, total_rows) - 1) / p.rows_per_img);
+    const bool img_in_lds = (img_hi - img_lo) < CAND_SPAN;
+    if (tid == 0) s_fill = 0;
+    if (tid < CAND_SPAN) s_img[tid] = 0;
 
-    const int nelem = nrows * p.no;
-    if (p.rows == nullptr) {
-        const float* src = p.pred + r0 * p.no;   // rows_per_img == N: flattened rows are contiguous
-        for (int e = tid; e < nelem; e += 256) lds[e] = src[e];
-    } else {
-        for (int e = tid; e < nelem; e += 256) {
-            int rr = e / p.no, cc = e - rr * p.no;
-            int64_t r = r0 + rr;
-            int img = (int)(r / p.rows_per_img);
-            int prop = p.rows[r];
-            lds[e] = p.pred[((int64_t)img * p.N + prop) * p.no + cc];
-        }
-    }
-    __syncthreads();
+    const int n4 = (CAND_ROWS * p.no) >> 2;       // CAND_ROWS is a multiple of 4: a full chunk is whole 16-byte words
+    const bool vec_ok = p.rows == nullptr && p.no <= 16 * CAND_NPRE &&
+                        ((reinterpret_cast<uintptr_t>(p.pred) & 15) == 0);
+    // two chunks in flight per workgroup (register prefetch, depth 2): with one, the four resident workgroups of a
+    // CU keep ~87 KB outstanding, about half of what HBM latency x bandwidth asks for
+    f4v preA[CAND_NPRE], preB[CAND_NPRE];
+    auto prefetch = [&](f4v (&pre)[CAND_NPRE], int64_t ch) {
+        const f4v* s4 = reinterpret_cast<const f4v*>(p.pred + ch * CAND_ROWS * p.no);
+#pragma unroll
+        for (int k = 0; k < CAND_NPRE; ++k) pre[k] = __builtin_nontemporal_load(s4 + min(tid + 256 * k, n4 - 1));
+    };
+    auto full_chunk = [&](int64_t ch) { return vec_ok && ch < c1 && (ch + 1) * CAND_ROWS <= total_rows; };
+    bool haveA = full_chunk(c0), haveB = full_chunk(c0 + 1);
+    if (haveA) prefetch(preA, c0);
+    if (haveB) prefetch(preB, c0 + 1);
 
-    // a chunk of CAND_ROWS rows spans at most two images (CAND_ROWS <= rows_per_img is checked on the host)
-    const int img0 = (int)(r0 / p.rows_per_img);
     constexpr int TPR = 256 / CAND_ROWS;         // threads per row
     const int pr = tid / TPR, sub = tid % TPR;
-    const bool row_ok = pr < nrows;
-    const int64_t r = r0 + pr;
-    const int img = row_ok ? (int)(r / p.rows_per_img) : img0;
-    const uint32_t rowpos = row_ok ? (uint32_t)(r - (int64_t)img * p.rows_per_img) : 0u;
     const float* L = lds + pr * p.no;
-    const float obj = row_ok ? L[4] : 0.0f;
-    const bool pass = row_ok && (!p.require_obj || obj > p.ct);
-
-    float best = -INFINITY;
-    int besti = 0;
-    if (!p.multi_label) {
-        // best class: first maximal index (torch.max semantics), conf = cls*obj computed before the max
-        for (int c = sub; c < nc; c += TPR) {
-            float v = row_ok ? L[5 + c] * obj : -INFINITY;
-            if (v > best) { best = v; besti = c; }
-        }
-        for (int off = 1; off < TPR; off <<= 1) {
-            float ov = __shfl_xor(best, off);
-            int oi = __shfl_xor(besti, off);
-            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-        }
-    }
     const int iters = p.multi_label ? (nc + TPR - 1) / TPR : 1;
-
-    // ---- pass 1: count
-    unsigned mine = 0;
-    for (int it = 0; it < iters; ++it) {
-        bool hit;
-        if (p.multi_label) {
-            int c = sub + it * TPR;
-            float conf = (c < nc && row_ok) ? L[5 + c] * obj : 0.0f;
-            hit = pass && c < nc && conf > p.ct && class_ok(p.class_mask, c);
-        } else {
-            hit = pass && sub == 0 && best > p.ct && class_ok(p.class_mask, besti);
+    const bool mask_path = iters <= 64;          // nc <= 256
+    uint64_t allow = ~0ull;                      // bit it: class sub + it*TPR passes the `classes` filter
+    if (p.multi_label && mask_path && p.class_mask != nullptr) {
+        allow = 0;
+        for (int it = 0; it < iters; ++it) {
+            const int c = sub + it * TPR;
+            if (c < nc && class_ok(p.class_mask, c)) allow |= 1ull << it;
         }
-        mine += hit ? 1u : 0u;
     }
-    if (mine) {
-        atomicAdd(&s_total, mine);
-        atomicAdd(&s_img_cnt[img - img0], mine);
-    }
-    __syncthreads();
-    if (tid == 0 && s_total) {
-        s_base = atomicAdd(&p.counters[0], s_total);
-        if (s_img_cnt[0]) atomicAdd(&p.counters[1 + img0], s_img_cnt[0]);
-        if (s_img_cnt[1]) atomicAdd(&p.counters[2 + img0], s_img_cnt[1]);
-    }
-    __syncthreads();
-    if (s_total == 0) return;
-    const unsigned base = s_base;
 
-    // box (general.py:297-321 with ratio = wh = 1, pad = 0): c -/+ size/2
-    float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-    if (row_ok) {
-        float hw = L[2] / 2.0f, hh = L[3] / 2.0f;
-        x1 = 1.0f * (L[0] - hw) + 0.0f;
-        y1 = 1.0f * (L[1] - hh) + 0.0f;
-        x2 = 1.0f * (L[0] + hw) + 0.0f;
-        y2 = 1.0f * (L[1] + hh) + 0.0f;
-    }
-    // ---- pass 2: emit (order inside the workgroup is irrelevant: keys are unique and sorted afterwards)
-    unsigned my_off = mine ? atomicAdd(&s_local, mine) : 0u;
-    for (int it = 0; it < iters; ++it) {
-        int c;
-        float conf;
-        bool hit;
-        if (p.multi_label) {
-            c = sub + it * TPR;
-            conf = (c < nc && row_ok) ? L[5 + c] * obj : 0.0f;
-            hit = pass && c < nc && conf > p.ct && class_ok(p.class_mask, c);
+    auto do_chunk = [&](int64_t ch, f4v (&pre)[CAND_NPRE], bool& have_pre) {
+        const int64_t r0 = ch * CAND_ROWS;
+        const int nrows = (int)min((int64_t)CAND_ROWS, total_rows - r0);
+        // ---- chunk -> LDS (the previous chunk ended on a barrier)
+        if (have_pre) {
+            f4v* l4 = reinterpret_cast<f4v*>(lds);
+#pragma unroll
+            for (int k = 0; k < CAND_NPRE; ++k)
+                if (tid + 256 * k < n4) l4[tid + 256 * k] = pre[k];
         } else {
-            c = besti;
-            conf = best;
-            hit = pass && sub == 0 && conf > p.ct && class_ok(p.class_mask, c);
+            const int nelem = nrows * p.no;
+            if (p.rows == nullptr) {
+                const float* src = p.pred + r0 * p.no;   // rows_per_img == N: flattened rows are contiguous
+                for (int e = tid; e < nelem; e += 256) lds[e] = src[e];
+            } else {
+                for (int e = tid; e < nelem; e += 256) {
+                    int rr = e / p.no, cc = e - rr * p.no;
+                    int64_t r = r0 + rr;
+                    int img = (int)(r / p.rows_per_img);
+                    int prop = p.rows[r];
+                    lds[e] = p.pred[((int64_t)img * p.N + prop) * p.no + cc];
+                }
+            }
         }
-        if (!hit) continue;
-        uint32_t slot = base + my_off++;
-        if (slot < p.capacity) {
-            float* d = p.det + (size_t)slot * 6;
-            d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = conf; d[5] = (float)c;
+        have_pre = full_chunk(ch + 2);
+        if (have_pre) prefetch(pre, ch + 2);
+        if (tid == 0) { s_total = 0; s_local = 0; }
+        __syncthreads();
+
+        const bool row_ok = pr < nrows;
+        const int64_t r = r0 + pr;
+        // rows_per_img >= CAND_ROWS (or B == 1): a chunk touches at most two images -- one wave-uniform division
+        const int img_c = (int)(r0 / p.rows_per_img);
+        const int64_t img_c_end = (int64_t)(img_c + 1) * p.rows_per_img;
+        const int img = row_ok ? img_c + (r >= img_c_end ? 1 : 0) : img_lo;
+        const uint32_t rowpos = row_ok ? (uint32_t)(r - (r >= img_c_end ? img_c_end : img_c_end - p.rows_per_img)) : 0u;
+        const float obj = row_ok ? L[4] : 0.0f;
+        const bool pass = row_ok && (!p.require_obj || obj > p.ct);
+
+        float best = -INFINITY;
+        int besti = 0;
+        if (!p.multi_label) {
+            // best class: first maximal index (torch.max semantics), conf = cls*obj computed before the max
+            for (int c = sub; c < nc; c += TPR) {
+                float v = row_ok ? L[5 + c] * obj : -INFINITY;
+                if (v > best) { best = v; besti = c; }
+            }
+            for (int off = 1; off < TPR; off <<= 1) {
+                float ov = __shfl_xor(best, off);
+                int oi = __shfl_xor(besti, off);
+                if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+            }
+        }
+
+        // ---- pass 1: count.  Up to 64 classes per lane the hits are kept as a bit mask (branch-free loop, LDS reads
+        // pipelined by the unroll) and pass 2 only visits the set bits.
+        unsigned mine = 0;
+        uint64_t hm = 0;
+        if (!p.multi_label) {
+            hm = (pass && sub == 0 && best > p.ct && class_ok(p.class_mask, besti)) ? 1ull : 0ull;
+            mine = (unsigned)hm;
+        } else if (mask_path) {
+#pragma unroll 4
+            for (int it = 0; it < iters; ++it) {
+                const int c = sub + it * TPR;
+                const float conf = L[5 + min(c, nc - 1)] * obj;
+                const bool hit = pass & (c < nc) & (conf > p.ct);
+                hm |= (uint64_t)(hit ? 1u : 0u) << it;
+            }
+            hm &= allow;
+            mine = (unsigned)__popcll(hm);
+        } else {
+            for (int it = 0; it < iters; ++it) {
+                int c = sub + it * TPR;
+                float conf = (c < nc && row_ok) ? L[5 + c] * obj : 0.0f;
+                mine += (pass && c < nc && conf > p.ct && class_ok(p.class_mask, c)) ? 1u : 0u;
+            }
+        }
+        if (mine) {
+            atomicAdd(&s_total, mine);
+            if (img_in_lds) atomicAdd(&s_img[img - img_lo], mine);
+            else atomicAdd(&p.counters[1 + img], mine);
+        }
+        __syncthreads();
+        const unsigned tot = s_total;
+        if (tot == 0) { __syncthreads(); return; }
+        unsigned fill = s_fill;
+        const bool direct = tot > CAND_STAGE;    // a dense chunk bypasses the staging buffer
+        if (direct || fill + tot > CAND_STAGE) {
+            // one reservation covers the staged hits and, for a dense chunk, this chunk's own
+            if (tid == 0) s_base = atomicAdd(&p.counters[0], fill + (direct ? tot : 0u));
+            __syncthreads();
+            const unsigned fb = s_base;
+            for (unsigned e = tid; e < fill * 6; e += 256)
+                if (fb + e / 6 < p.capacity) p.det[(size_t)fb * 6 + e] = stage_det[e];
+            for (unsigned e = tid; e < fill; e += 256)
+                if (fb + e < p.capacity) p.keys[fb + e] = stage_key[e];
+            __syncthreads();
+            if (direct && tid == 0) s_base = fb + fill;   // read below, after the barrier that follows pass 2's setup
+            fill = 0;
+            if (tid == 0) s_fill = 0;
+            __syncthreads();
+        }
+        const unsigned base = s_base;
+
+        // box (general.py:297-321 with ratio = wh = 1, pad = 0): c -/+ size/2
+        float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+        if (row_ok) {
+            float hw = L[2] / 2.0f, hh = L[3] / 2.0f;
+            x1 = 1.0f * (L[0] - hw) + 0.0f;
+            y1 = 1.0f * (L[1] - hh) + 0.0f;
+            x2 = 1.0f * (L[0] + hw) + 0.0f;
+            y2 = 1.0f * (L[1] + hh) + 0.0f;
+        }
+        // ---- pass 2: emit (order inside the workgroup is irrelevant: keys are unique and sorted afterwards)
+        unsigned my_off = mine ? atomicAdd(&s_local, mine) : 0u;
+        auto emit = [&](int c, float conf) {
             uint64_t seq = p.multi_label ? (uint64_t)rowpos * (uint64_t)nc + (uint64_t)c : (uint64_t)rowpos;
             uint64_t key;
             if (p.order_by_seq) {
@@ -154,9 +217,57 @@ __global__ __launch_bounds__(256) void k_candidates(CandParams p) {
                 uint32_t cb = ~__float_as_uint(conf);   // conf > ct >= 0: bits monotonic
                 key = ((uint64_t)img << (32 + p.seq_bits)) | ((uint64_t)cb << p.seq_bits) | seq;
             }
-            p.keys[slot] = key;
+            if (direct) {
+                uint32_t slot = base + my_off++;
+                if (slot < p.capacity) {
+                    float* d = p.det + (size_t)slot * 6;
+                    d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = conf; d[5] = (float)c;
+                    p.keys[slot] = key;
+                }
+            } else {
+                unsigned idx = fill + my_off++;
+                float* d = stage_det + idx * 6;
+                d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = conf; d[5] = (float)c;
+                stage_key[idx] = key;
+            }
+        };
+        if (!p.multi_label) {
+            if (hm) emit(besti, best);
+        } else if (mask_path) {
+            while (hm) {
+                const int it = __ffsll((unsigned long long)hm) - 1;
+                hm &= hm - 1;
+                const int c = sub + it * TPR;
+                emit(c, L[5 + c] * obj);
+            }
+        } else if (mine) {
+            for (int it = 0; it < iters; ++it) {
+                int c = sub + it * TPR;
+                float conf = (c < nc && row_ok) ? L[5 + c] * obj : 0.0f;
+                if (pass && c < nc && conf > p.ct && class_ok(p.class_mask, c)) emit(c, conf);
+            }
         }
+        if (!direct && tid == 0) s_fill = fill + tot;
+        __syncthreads();
+    };
+    for (int64_t ch = c0; ch < c1; ch += 2) {
+        do_chunk(ch, preA, haveA);
+        if (ch + 1 < c1) do_chunk(ch + 1, preB, haveB);
     }
+
+    // ---- final flush
+    __syncthreads();
+    const unsigned fill = s_fill;
+    if (fill) {
+        if (tid == 0) s_base = atomicAdd(&p.counters[0], fill);
+        __syncthreads();
+        const unsigned fb = s_base;
+        for (unsigned e = tid; e < fill * 6; e += 256)
+            if (fb + e / 6 < p.capacity) p.det[(size_t)fb * 6 + e] = stage_det[e];
+        for (unsigned e = tid; e < fill; e += 256)
+            if (fb + e < p.capacity) p.keys[fb + e] = stage_key[e];
+    }
+    if (img_in_lds && tid < CAND_SPAN && s_img[tid]) atomicAdd(&p.counters[1 + img_lo + tid], s_img[tid]);
 }
 
 static int bits_for(uint64_t n) {   // bits needed to represent values in [0, n)
@@ -189,12 +300,17 @@ extern "C" int ayolo_nms_candidates(const float* pred, int B, int N, int no, flo
         ayolo_set_error("nms_candidates: key needs %d bits (B*rows*nc too large)", total_bits);
         return AYOLO_EINVAL;
     }
-    CandParams p{pred, B, N, no, conf_thres, multi_label, require_obj, class_mask, rows, rows_per_img,
-                 det, keys, counters, capacity, seq_bits, order_by_seq};
     AY_CHECK_ARG(rows_per_img >= CAND_ROWS || B == 1, "nms_candidates: fewer than %d rows per image with B > 1", CAND_ROWS);
     int64_t total_rows = (int64_t)B * rows_per_img;
-    int64_t nblk = cdiv64(total_rows, CAND_ROWS);
-    size_t lds = (size_t)CAND_ROWS * no * sizeof(float);
+    int64_t nchunks = cdiv64(total_rows, CAND_ROWS);
+    // one resident wave of workgroups (4 per CU at ~38 KB LDS each); more chunks per workgroup = fewer reservations
+    const char* env = getenv("AYOLO_CAND_CPB");   // test hook: force several chunks per workgroup at small sizes
+    const int env_cpb = env ? atoi(env) : 0;
+    int cpb = env_cpb > 0 ? env_cpb : (int)std::max<int64_t>(1, cdiv64(nchunks, (int64_t)256 * 4)   /* MI355X: 256 CUs */);
+    int64_t nblk = cdiv64(nchunks, cpb);
+    CandParams p{pred, B, N, no, conf_thres, multi_label, require_obj, class_mask, rows, rows_per_img,
+                 det, keys, counters, capacity, seq_bits, order_by_seq, cpb, nchunks};
+    size_t lds = (size_t)CAND_STAGE * 32 + (size_t)CAND_ROWS * no * sizeof(float);
     AY_CHECK_ARG(lds <= 64 * 1024, "nms_candidates: no=%d too large", no);
     hipLaunchKernelGGL(k_candidates, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)s, p);
     AY_CHECK_LAUNCH("k_candidates");
@@ -459,6 +575,182 @@ extern "C" int ayolo_nms_reduce(const float* sdet, const uint32_t* seg_off, cons
     hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(64), lds, (hipStream_t)s, sdet, seg_off, seg_n, mask_off, mask,
                        max_out, out, out_idx, out_count);
     AY_CHECK_LAUNCH("k_nms_reduce");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-class route of the `nms` branch (metrics.py:383-388, boxes offset by cls * 4096): regroup the conf-sorted
+// image segments into (image, class) segments, and merge the kept rows back into per-image confidence order.
+// These four entry points replace ~45 torch launches (sort / bincount / index / cumsum chains) with 8.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int seg_of(const uint32_t* off, int n, uint32_t i) {
+    // largest b in [0, n) with off[b] <= i (off ascending, off[0] == 0, duplicates = empty segments)
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t float_order(float f) {   // monotonic map float -> uint32 (NaN above +inf)
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+#define CK_RPT 4      // rows per thread: 1024-row tiles, one pair of span atomics per workgroup
+__global__ __launch_bounds__(256) void k_class_keys(const float* sdet, const uint32_t* seg_off, const uint32_t* sel_off,
+                                                    int B, int nc, uint32_t tot, float* rows1, uint64_t* keys,
+                                                    uint32_t* vals, uint32_t* span) {
+    __shared__ uint32_t s_hi[4], s_lo[4];
+    uint32_t hi = 0, lo = 0;      // order codes of max(coord) and max(-coord); 0 is below every float
+#pragma unroll
+    for (int k = 0; k < CK_RPT; ++k) {
+        const uint32_t i = (blockIdx.x * CK_RPT + k) * 256 + threadIdx.x;
+        if (i >= tot) continue;
+        const int b = seg_of(sel_off, B, i);
+        const size_t g = (size_t)seg_off[b] + (i - sel_off[b]);
+        const float2* src = reinterpret_cast<const float2*>(sdet + g * 6);
+        float2 a = src[0], c = src[1], d = src[2];
+        float2* dst = reinterpret_cast<float2*>(rows1 + (size_t)i * 6);
+        dst[0] = a; dst[1] = c; dst[2] = d;
+        keys[i] = (uint64_t)((int64_t)b * nc + (int64_t)d.y);
+        vals[i] = i;
+        hi = max(max(hi, float_order(a.x)), max(float_order(a.y), max(float_order(c.x), float_order(c.y))));
+        lo = max(max(lo, float_order(-a.x)), max(float_order(-a.y), max(float_order(-c.x), float_order(-c.y))));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+        lo = max(lo, (uint32_t)__shfl_xor((int)lo, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_hi[threadIdx.x >> 6] = hi; s_lo[threadIdx.x >> 6] = lo; }
+    __syncthreads();
+    // same-address atomics serialise in L2 (~12 ns each): one pair per workgroup, and only for a new maximum
+    if (threadIdx.x == 0) {
+        hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        lo = max(max(s_lo[0], s_lo[1]), max(s_lo[2], s_lo[3]));
+        if (hi > __hip_atomic_load(&span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&span[0], hi);
+        if (lo > __hip_atomic_load(&span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&span[1], lo);
+    }
+}
+
+extern "C" int ayolo_nms_class_keys(const float* sdet, const uint32_t* seg_off, const uint32_t* sel_off, int B, int nc,
+                                    uint32_t tot, float* rows1, uint64_t* keys, uint32_t* vals, uint32_t* span,
+                                    ayolo_stream s) {
+    AY_CHECK_ARG(sdet && seg_off && sel_off && rows1 && keys && vals && span, "nms_class_keys: null pointer");
+    AY_CHECK_ARG(B > 0 && nc > 0, "nms_class_keys: B=%d nc=%d", B, nc);
+    if (tot == 0) return AYOLO_OK;
+    hipLaunchKernelGGL(k_class_keys, dim3(cdiv((int)tot, 256 * CK_RPT)), dim3(256), 0, (hipStream_t)s, sdet, seg_off, sel_off, B,
+                       nc, tot, rows1, keys, vals, span);
+    AY_CHECK_LAUNCH("k_class_keys");
+    return AYOLO_OK;
+}
+
+// one workgroup: segment s = run of key == s in the sorted keys; exclusive scans give the row and mask offsets
+__global__ __launch_bounds__(1024) void k_class_layout(const uint64_t* keys_sorted, uint32_t tot, int nseg,
+                                                       uint32_t* seg_off2, uint32_t* seg_n2, uint64_t* mask_off,
+                                                       int64_t* summary) {
+    __shared__ unsigned long long s_scan[1024];
+    __shared__ unsigned long long s_carry;
+    __shared__ unsigned s_max;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_carry = 0; s_max = 0; }
+    __syncthreads();
+    for (int base = 0; base < nseg; base += 1024) {
+        const int sg = base + tid;
+        uint32_t start = 0, n = 0;
+        if (sg < nseg) {
+            // lower_bound(keys, sg) and lower_bound(keys, sg + 1)
+            uint32_t lo = 0, hi = tot;
+            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (keys_sorted[m] < (uint64_t)sg) lo = m + 1; else hi = m; }
+            start = lo;
+            hi = tot;
+            while (lo < hi) { uint32_t m = (lo + hi) >> 1; if (keys_sorted[m] < (uint64_t)sg + 1) lo = m + 1; else hi = m; }
+            n = lo - start;
+            seg_off2[sg] = start;
+            seg_n2[sg] = n;
+            atomicMax(&s_max, n);
+        }
+        unsigned long long w = (unsigned long long)n * ((n + 63) / 64);
+        s_scan[tid] = w;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {       // Hillis-Steele inclusive scan
+            unsigned long long add = tid >= off ? s_scan[tid - off] : 0ull;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        const unsigned long long carry = s_carry;
+        if (sg < nseg) mask_off[sg] = carry + s_scan[tid] - w;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + s_scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) { summary[0] = (int64_t)s_max; summary[1] = (int64_t)s_carry; }
+}
+
+extern "C" int ayolo_nms_class_layout(const uint64_t* keys_sorted, uint32_t tot, int nseg, uint32_t* seg_off2,
+                                      uint32_t* seg_n2, uint64_t* mask_off, int64_t* summary, ayolo_stream s) {
+    AY_CHECK_ARG(keys_sorted && seg_off2 && seg_n2 && mask_off && summary, "nms_class_layout: null pointer");
+    AY_CHECK_ARG(nseg > 0, "nms_class_layout: nseg=%d", nseg);
+    hipLaunchKernelGGL(k_class_layout, dim3(1), dim3(1024), 0, (hipStream_t)s, keys_sorted, tot, nseg, seg_off2, seg_n2,
+                       mask_off, summary);
+    AY_CHECK_LAUNCH("k_class_layout");
+    return AYOLO_OK;
+}
+
+__global__ void k_class_mark(const int32_t* out_idx, const uint32_t* out_count, const uint32_t* seg_off2,
+                             const uint32_t* perm, int nseg, uint32_t max_out, uint32_t* flags) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sg = t / max_out, k = t - sg * max_out;
+    if (sg < (uint32_t)nseg && k < out_count[sg]) flags[perm[seg_off2[sg] + (uint32_t)out_idx[(size_t)sg * max_out + k]]] = 1u;
+}
+
+__global__ __launch_bounds__(256) void k_class_emit(const float* rows1, const uint32_t* flags, const uint32_t* scan,
+                                                    const uint32_t* sel_off, int B, uint32_t tot, uint32_t max_det,
+                                                    float* out, uint32_t* kept) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < (uint32_t)B) {
+        const uint32_t end_all = scan[tot - 1] + flags[tot - 1];
+        const uint32_t a = sel_off[i], b = sel_off[i + 1];
+        const uint32_t va = a < tot ? scan[a] : end_all, vb = b < tot ? scan[b] : end_all;
+        kept[i] = min(max_det, vb - va);
+    }
+    if (i >= tot || !flags[i]) return;
+    const int b = seg_of(sel_off, B, i);
+    const uint32_t within = scan[i] - scan[sel_off[b]];
+    if (within >= max_det) return;
+    const float2* src = reinterpret_cast<const float2*>(rows1 + (size_t)i * 6);
+    float2* dst = reinterpret_cast<float2*>(out + ((size_t)b * max_det + within) * 6);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+extern "C" int ayolo_nms_class_merge(const float* rows1, const int32_t* out_idx, const uint32_t* out_count,
+                                     const uint32_t* seg_off2, const uint32_t* perm, int nseg, uint32_t max_out,
+                                     const uint32_t* sel_off, int B, uint32_t tot, uint32_t max_det, uint32_t* flags,
+                                     uint32_t* scan, float* out, uint32_t* kept, void* ws, size_t* ws_bytes,
+                                     ayolo_stream s) {
+    AY_CHECK_ARG(ws_bytes, "nms_class_merge: ws_bytes null");
+    size_t need = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, flags, scan, (int)tot, (hipStream_t)s);
+    if (e != hipSuccess) { ayolo_set_error("nms_class_merge: scan size query: %s", hipGetErrorString(e)); return AYOLO_ELAUNCH; }
+    if (ws == nullptr) { *ws_bytes = need; return AYOLO_OK; }
+    if (*ws_bytes < need) { ayolo_set_error("nms_class_merge: workspace %zu < %zu", *ws_bytes, need); return AYOLO_ENOSPC; }
+    AY_CHECK_ARG(rows1 && out_idx && out_count && seg_off2 && perm && sel_off && flags && scan && out && kept,
+                 "nms_class_merge: null pointer");
+    AY_CHECK_ARG(tot > 0 && B > 0 && nseg > 0 && max_out > 0 && max_det > 0,
+                 "nms_class_merge: bad sizes");
+    hipStream_t st = (hipStream_t)s;
+    const uint64_t nthreads = (uint64_t)nseg * max_out;
+    hipLaunchKernelGGL(k_class_mark, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, out_idx, out_count,
+                       seg_off2, perm, nseg, max_out, flags);
+    AY_CHECK_LAUNCH("k_class_mark");
+    e = hipcub::DeviceScan::ExclusiveSum(ws, need, flags, scan, (int)tot, st);
+    if (e != hipSuccess) { ayolo_set_error("nms_class_merge: scan: %s", hipGetErrorString(e)); return AYOLO_ELAUNCH; }
+    const uint32_t nthr = tot > (uint32_t)B ? tot : (uint32_t)B;
+    hipLaunchKernelGGL(k_class_emit, dim3(cdiv((int)nthr, 256)), dim3(256), 0, st, rows1, flags, scan, sel_off, B, tot,
+                       max_det, out, kept);
+    AY_CHECK_LAUNCH("k_class_emit");
     return AYOLO_OK;
 }
 

@@ -208,59 +208,69 @@ def _greedy_nms_by_class(cand: _Candidates, seg_n: np.ndarray, iou_thres: float,
     tot = int(seg_n.sum())
     if tot == 0:
         return True
-    # rows of the conf-sorted per-image segments that take part (max_nms cut), their image id and class
-    parts = [torch.arange(int(cand.offsets[b]), int(cand.offsets[b]) + int(seg_n[b]), device=dev) for b in range(B) if seg_n[b]]
-    sel = torch.cat(parts)
-    img = torch.repeat_interleave(torch.arange(B, device=dev), torch.from_numpy(seg_n.astype(np.int64)).to(dev))
-    rows1 = cand.sdet.index_select(0, sel)                                   # (tot, 6), per image in confidence order
-    key2 = img * nc + rows1[:, 5].long()
-    key2s, perm = torch.sort(key2, stable=True)                               # (image, class) groups, confidence order inside
-    counts2 = torch.bincount(key2s, minlength=B * nc)
-    span = torch.stack((rows1[:, :4].amax(), -rows1[:, :4].amin()))
-    host = torch.cat((counts2.float(), span)).cpu().numpy()                   # one sync: segment sizes + coordinate span
-    if not (host[-2] + host[-1] < float(MAX_WH)):
-        return False
-    n2 = host[:-2].astype(np.int64)
-    rows2 = rows1.index_select(0, perm).contiguous()
     nseg = B * nc
-    off2 = np.concatenate(([0], np.cumsum(n2)))[:-1].astype(np.int64)
-    max_n = int(n2.max())
+    st = _stream()
+    sel_off = np.concatenate(([0], np.cumsum(seg_n))).astype(np.int64)         # (B+1,) compact start of every image
+    meta = torch.from_numpy(np.concatenate((cand.offsets[:B], sel_off)).astype(np.int32)).to(dev)
+    seg_off_d, sel_off_d = meta[:B], meta[B:]
+    # zeroed scratch, one fill: [summary (2 x int64) | span (2) | out_count (nseg) | kept (B) | flags (tot)]
+    zi = torch.zeros(6 + nseg + B + tot, dtype=torch.int32, device=dev)
+    summary, span_d = zi[0:4], zi[4:6]
+    out_count, kept_d, flags = zi[6:6 + nseg], zi[6 + nseg:6 + nseg + B], zi[6 + nseg + B:]
+    rows1 = torch.empty((tot, 6), dtype=torch.float32, device=dev)             # per image, in confidence order
+    keys = torch.empty((2, tot), dtype=torch.int64, device=dev)
+    vals = torch.empty((3, tot), dtype=torch.int32, device=dev)                # [iota | perm | scan scratch]
+    call("ayolo_nms_class_keys", cand.sdet.data_ptr(), seg_off_d.data_ptr(), sel_off_d.data_ptr(), B, nc, tot,
+         rows1.data_ptr(), keys[0].data_ptr(), vals[0].data_ptr(), span_d.data_ptr(), st)
+    # stable radix sort on (image, class): groups in key order, confidence order inside
+    key_bits = max(1, int(nseg - 1).bit_length())
+    ws_bytes = _lib.c_size_t(0)
+    call("ayolo_sort_pairs_u64", keys[0].data_ptr(), keys[1].data_ptr(), vals[0].data_ptr(), vals[1].data_ptr(), tot, 0,
+         key_bits, None, ws_bytes, st)
+    ws = torch.empty(max(int(ws_bytes.value), 16), dtype=torch.uint8, device=dev)
+    ws_bytes = _lib.c_size_t(ws.numel())
+    call("ayolo_sort_pairs_u64", keys[0].data_ptr(), keys[1].data_ptr(), vals[0].data_ptr(), vals[1].data_ptr(), tot, 0,
+         key_bits, ws.data_ptr(), ws_bytes, st)
+    perm = vals[1]
+    lay32 = torch.empty(2 * nseg, dtype=torch.int32, device=dev)
+    mask_off_d = torch.empty(nseg, dtype=torch.int64, device=dev)
+    seg_off2, seg_n2 = lay32[:nseg], lay32[nseg:]
+    call("ayolo_nms_class_layout", keys[1].data_ptr(), tot, nseg, seg_off2.data_ptr(), seg_n2.data_ptr(),
+         mask_off_d.data_ptr(), summary.data_ptr(), st)
+    host = zi[:6].cpu().numpy()                                               # one sync: layout summary + coordinate span
+    max_n, mask_words = (int(v) for v in host[:4].view(np.int64))
+    codes = host[4:6].view(np.uint32)
+    bits = np.where(codes & np.uint32(0x80000000), codes & np.uint32(0x7FFFFFFF), ~codes).astype(np.uint32)
+    hi, lo = bits.view(np.float32)                                            # max(coord), max(-coord) = -min(coord)
+    if not (hi + lo < np.float32(MAX_WH)):
+        return False
+    rows2 = torch.empty((tot, 6), dtype=torch.float32, device=dev)
+    call("ayolo_gather_rows", rows1.data_ptr(), perm.data_ptr(), rows2.data_ptr(), tot, 6, st)
     max_out = max(1, min(max_det, max_n))
-    words = (n2 + 63) // 64
-    mask_sizes = n2 * words
-    mask_off = np.concatenate(([0], np.cumsum(mask_sizes)))[:-1].astype(np.int64)
-    mask = torch.empty(max(int(mask_sizes.sum()), 1), dtype=torch.int64, device=dev)
-    seg_off_d = torch.from_numpy(off2.astype(np.int32)).to(dev)
-    seg_n_d = torch.from_numpy(n2.astype(np.int32)).to(dev)
-    mask_off_d = torch.from_numpy(mask_off).to(dev)
+    mask = torch.empty(max(mask_words, 1), dtype=torch.int64, device=dev)
     scales_d = torch.full((nseg,), float(MAX_WH), dtype=torch.float32, device=dev)
     out = torch.empty((nseg, max_out, 6), dtype=torch.float32, device=dev)
     out_idx = torch.empty((nseg, max_out), dtype=torch.int32, device=dev)
-    out_count = torch.zeros(nseg, dtype=torch.int32, device=dev)
     thr_f = thr_as_float_for_double_compare(iou_thres)
-    call("ayolo_nms_mask", rows2.data_ptr(), seg_off_d.data_ptr(), seg_n_d.data_ptr(), mask_off_d.data_ptr(), nseg, max_n, thr_f,
-         0.0, scales_d.data_ptr(), 0, mask.data_ptr(), _stream())
-    call("ayolo_nms_reduce", rows2.data_ptr(), seg_off_d.data_ptr(), seg_n_d.data_ptr(), mask_off_d.data_ptr(), mask.data_ptr(),
-         nseg, max_out, out.data_ptr(), out_idx.data_ptr(), out_count.data_ptr(), max_n, _stream())
-    # merge: position of every kept row in its image's confidence order, first max_det per image
-    valid = torch.arange(max_out, device=dev)[None, :] < out_count[:, None]   # (nseg, max_out)
-    pos2 = (seg_off_d.long()[:, None] + out_idx.long())[valid]                # rows of rows2
-    rank1 = perm[pos2]                                                        # rows of rows1 (image-major, confidence order)
-    rank1, _ = torch.sort(rank1)
-    img_k = img[rank1]
-    start1 = torch.from_numpy(np.concatenate(([0], np.cumsum(seg_n)))[:-1].astype(np.int64)).to(dev)
-    kept_per_img = torch.bincount(img_k, minlength=B)
-    first = torch.cumsum(kept_per_img, 0) - kept_per_img
-    within = torch.arange(rank1.numel(), device=dev) - first[img_k]
-    take = within < max_det
-    res = rows1.index_select(0, rank1[take])
-    kept = torch.clamp(kept_per_img, max=max_det).cpu().numpy()               # sync: final counts
-    o = 0
+    call("ayolo_nms_mask", rows2.data_ptr(), seg_off2.data_ptr(), seg_n2.data_ptr(), mask_off_d.data_ptr(), nseg, max_n, thr_f,
+         0.0, scales_d.data_ptr(), 0, mask.data_ptr(), st)
+    call("ayolo_nms_reduce", rows2.data_ptr(), seg_off2.data_ptr(), seg_n2.data_ptr(), mask_off_d.data_ptr(), mask.data_ptr(),
+         nseg, max_out, out.data_ptr(), out_idx.data_ptr(), out_count.data_ptr(), max_n, st)
+    # merge: kept rows back into their image's confidence order, first max_det per image
+    res = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
+    margs = (rows1.data_ptr(), out_idx.data_ptr(), out_count.data_ptr(), seg_off2.data_ptr(), perm.data_ptr(), nseg, max_out,
+             sel_off_d.data_ptr(), B, tot, max_det, flags.data_ptr(), vals[2].data_ptr(), res.data_ptr(), kept_d.data_ptr())
+    ws_bytes = _lib.c_size_t(0)
+    call("ayolo_nms_class_merge", *margs, None, ws_bytes, st)
+    if int(ws_bytes.value) > ws.numel():
+        ws = torch.empty(int(ws_bytes.value), dtype=torch.uint8, device=dev)
+    ws_bytes = _lib.c_size_t(ws.numel())
+    call("ayolo_nms_class_merge", *margs, ws.data_ptr(), ws_bytes, st)
+    kept = kept_d.cpu().numpy()                                               # sync: final counts
     for b in range(B):
         k = int(kept[b])
         if k:
-            output[b] = res[o:o + k]
-        o += k
+            output[b] = res[b, :k]
     return True
 
 

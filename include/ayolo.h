@@ -242,6 +242,25 @@ int ayolo_nms_mask(const float* sdet, const uint32_t* seg_off, const uint32_t* s
 int ayolo_nms_reduce(const float* sdet, const uint32_t* seg_off, const uint32_t* seg_n, const uint64_t* mask_off,
                      const uint64_t* mask, int B, uint32_t max_out, float* out, int32_t* out_idx,
                      uint32_t* out_count, uint32_t max_n, ayolo_stream s);
+/* Per-class route of the `nms` branch (metrics.py:383-388: torchvision nms on boxes + cls * 4096).  When the box
+ * coordinates span less than 4096 the offset makes classes disjoint, so the greedy scan runs per (image, class)
+ * segment.  class_keys: compact the selected rows of each image (segment b of sdet starts at seg_off[b]; its first
+ * sel_off[b+1]-sel_off[b] rows take part) into rows1[tot][6], emit key = b*nc + cls and val = compact index for a
+ * stable sort, and atomically max the order codes of max(coord) / max(-coord) into span[2] (zeroed by the caller;
+ * code = bits|0x80000000 for non-negative floats, ~bits otherwise). */
+int ayolo_nms_class_keys(const float* sdet, const uint32_t* seg_off, const uint32_t* sel_off, int B, int nc,
+                         uint32_t tot, float* rows1, uint64_t* keys, uint32_t* vals, uint32_t* span, ayolo_stream s);
+/* class_layout: from the sorted keys, segment sg = run of key == sg: seg_off2 / seg_n2 / mask_off (the arguments
+ * ayolo_nms_mask and ayolo_nms_reduce take) and summary = {max segment length, total mask words}. */
+int ayolo_nms_class_layout(const uint64_t* keys_sorted, uint32_t tot, int nseg, uint32_t* seg_off2, uint32_t* seg_n2,
+                           uint64_t* mask_off, int64_t* summary, ayolo_stream s);
+/* class_merge: kept rows of all segments (out_idx / out_count of ayolo_nms_reduce, perm = sorted vals) back into
+ * per-image confidence order, first max_det per image: out[B][max_det][6], kept[B].  flags[tot] zeroed by the
+ * caller, scan[tot] scratch; ws_bytes queried with ws == NULL. */
+int ayolo_nms_class_merge(const float* rows1, const int32_t* out_idx, const uint32_t* out_count,
+                          const uint32_t* seg_off2, const uint32_t* perm, int nseg, uint32_t max_out,
+                          const uint32_t* sel_off, int B, uint32_t tot, uint32_t max_det, uint32_t* flags,
+                          uint32_t* scan, float* out, uint32_t* kept, void* ws, size_t* ws_bytes, ayolo_stream s);
 /* Dense IoU (metrics.py:138-164): out[N][M]. */
 int ayolo_box_iou(const float* a, int64_t N, const float* b, int64_t M, float* out, ayolo_stream s);
 /* fast_nms / matrix_nms column reductions over the upper-triangular IoU of n boxes (never materialised):

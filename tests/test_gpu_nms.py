@@ -171,3 +171,20 @@ def test_nms_per_class_segments_equal_all_pairs(monkeypatch):
     monkeypatch.setattr(M, "NMS_BY_CLASS", False)
     _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.6, multi_label=True), want, True, "all pairs")
     assert len(calls) == 2
+
+
+@pytest.mark.parametrize("cpb", ["1", "5"])
+def test_candidates_staged_and_dense_chunks(monkeypatch, cpb):
+    """k_candidates walks several 64-row chunks per workgroup: sparse chunks are staged in LDS, a chunk with more
+    hits than the staging buffer is written directly, empty chunks are skipped -- all three interleaved here."""
+    from ayolov2_amd.metrics import non_max_suppression
+    monkeypatch.setenv("AYOLO_CAND_CPB", cpb)
+    pred = synth_pred(2, 64 * 13 + 7, 80, 640, 3.0, seed=21)
+    chunk = (torch.arange(pred.shape[1]) // 64)
+    pred[:, chunk % 3 == 2, 4] = 0                                    # empty chunks
+    sparse = (chunk % 3 == 1) & (torch.arange(pred.shape[1]) % 64 > 2)
+    pred[:, sparse, 4] = 0                                            # three live rows per chunk
+    for ml in (True, False):
+        want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.65, multi_label=ml)
+        got = non_max_suppression(pred.cuda(), conf_thres=0.001, iou_thres=0.65, multi_label=ml)
+        _cmp(got, want, True, f"cpb={cpb} multi_label={ml}")
