@@ -75,6 +75,12 @@ _SIGNATURES = {
     "ayolo_nms_class_layout": [_P, c_uint32, c_int, _P, _P, _P, _P, _P],
     "ayolo_nms_class_merge": [_P, _P, _P, _P, _P, c_int, c_uint32, _P, c_int, c_uint32, c_uint32, _P, _P, _P, _P, _P,
                               POINTER(c_size_t), _P],
+    "ayolo_trt_nms_key_bits": [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+    "ayolo_trt_nms_candidates": [_P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, c_uint32, _P],
+    "ayolo_trt_nms_layout": [_P, c_uint32, c_int, c_int, c_int, c_uint32, _P, _P, _P, _P],
+    "ayolo_trt_nms_mask": [_P, _P, _P, _P, c_int, c_uint32, c_float, _P, _P],
+    "ayolo_trt_nms_final_keys": [_P, _P, c_int, c_int, c_uint32, _P, _P, POINTER(c_int), _P],
+    "ayolo_trt_nms_emit": [_P, _P, _P, c_int, c_int, c_uint32, c_uint32, _P, _P, _P, _P, _P],
     "ayolo_box_iou": [_P, c_int64, _P, c_int64, _P, _P],
     "ayolo_iou_colmax": [_P, _P, c_float, c_uint32, _P, _P],
     "ayolo_matrix_nms_decay": [_P, _P, c_float, c_uint32, _P, _P, _P],

@@ -29,6 +29,9 @@ struct CandParams {
     int order_by_seq;
     int cpb;                 // chunks of CAND_ROWS rows per workgroup
     int64_t nchunks;
+    int key_mode;            // 0: image | ~conf | seq (or image | seq);  2: image | class | ~conf | row (fixed-shape NMS)
+    int cls_bits;            // key_mode 2: width of the class field
+    int box_xyxy;            // rows already carry x1 y1 x2 y2 (head exported with out_xyxy)
 };
 
 __device__ __forceinline__ bool class_ok(const uint64_t* m, int c) {
@@ -199,7 +202,9 @@ __global__ __launch_bounds__(256) void k_candidates(CandParams p) {
 
         // box (general.py:297-321 with ratio = wh = 1, pad = 0): c -/+ size/2
         float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-        if (row_ok) {
+        if (row_ok && p.box_xyxy) {
+            x1 = L[0]; y1 = L[1]; x2 = L[2]; y2 = L[3];
+        } else if (row_ok) {
             float hw = L[2] / 2.0f, hh = L[3] / 2.0f;
             x1 = 1.0f * (L[0] - hw) + 0.0f;
             y1 = 1.0f * (L[1] - hh) + 0.0f;
@@ -211,7 +216,11 @@ __global__ __launch_bounds__(256) void k_candidates(CandParams p) {
         auto emit = [&](int c, float conf) {
             uint64_t seq = p.multi_label ? (uint64_t)rowpos * (uint64_t)nc + (uint64_t)c : (uint64_t)rowpos;
             uint64_t key;
-            if (p.order_by_seq) {
+            if (p.key_mode == 2) {
+                uint32_t cb = ~__float_as_uint(conf);
+                key = ((((uint64_t)img << p.cls_bits) | (uint64_t)c) << (32 + p.seq_bits)) | ((uint64_t)cb << p.seq_bits) |
+                      (uint64_t)rowpos;
+            } else if (p.order_by_seq) {
                 key = ((uint64_t)img << p.seq_bits) | seq;
             } else {
                 uint32_t cb = ~__float_as_uint(conf);   // conf > ct >= 0: bits monotonic
@@ -286,6 +295,22 @@ extern "C" int ayolo_nms_key_bits(int B, int rows_per_img, int nc_eff, int order
     return tb <= 64 ? AYOLO_OK : AYOLO_EINVAL;
 }
 
+static int run_candidates(CandParams p, int no, ayolo_stream s) {
+    AY_CHECK_ARG(p.rows_per_img >= CAND_ROWS || p.B == 1, "nms_candidates: fewer than %d rows per image with B > 1", CAND_ROWS);
+    int64_t total_rows = (int64_t)p.B * p.rows_per_img;
+    p.nchunks = cdiv64(total_rows, CAND_ROWS);
+    // one resident wave of workgroups (4 per CU at ~38 KB LDS each); more chunks per workgroup = fewer reservations
+    const char* env = getenv("AYOLO_CAND_CPB");   // test hook: force several chunks per workgroup at small sizes
+    const int env_cpb = env ? atoi(env) : 0;
+    p.cpb = env_cpb > 0 ? env_cpb : (int)std::max<int64_t>(1, cdiv64(p.nchunks, (int64_t)256 * 4));   /* MI355X: 256 CUs */
+    int64_t nblk = cdiv64(p.nchunks, p.cpb);
+    size_t lds = (size_t)CAND_STAGE * 32 + (size_t)CAND_ROWS * no * sizeof(float);
+    AY_CHECK_ARG(lds <= 64 * 1024, "nms_candidates: no=%d too large", no);
+    hipLaunchKernelGGL(k_candidates, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)s, p);
+    AY_CHECK_LAUNCH("k_candidates");
+    return AYOLO_OK;
+}
+
 extern "C" int ayolo_nms_candidates(const float* pred, int B, int N, int no, float conf_thres, int multi_label,
                                     int require_obj, const uint64_t* class_mask, const int32_t* rows,
                                     int rows_per_img, float* det, uint64_t* keys, uint32_t* counters,
@@ -300,21 +325,9 @@ extern "C" int ayolo_nms_candidates(const float* pred, int B, int N, int no, flo
         ayolo_set_error("nms_candidates: key needs %d bits (B*rows*nc too large)", total_bits);
         return AYOLO_EINVAL;
     }
-    AY_CHECK_ARG(rows_per_img >= CAND_ROWS || B == 1, "nms_candidates: fewer than %d rows per image with B > 1", CAND_ROWS);
-    int64_t total_rows = (int64_t)B * rows_per_img;
-    int64_t nchunks = cdiv64(total_rows, CAND_ROWS);
-    // one resident wave of workgroups (4 per CU at ~38 KB LDS each); more chunks per workgroup = fewer reservations
-    const char* env = getenv("AYOLO_CAND_CPB");   // test hook: force several chunks per workgroup at small sizes
-    const int env_cpb = env ? atoi(env) : 0;
-    int cpb = env_cpb > 0 ? env_cpb : (int)std::max<int64_t>(1, cdiv64(nchunks, (int64_t)256 * 4)   /* MI355X: 256 CUs */);
-    int64_t nblk = cdiv64(nchunks, cpb);
     CandParams p{pred, B, N, no, conf_thres, multi_label, require_obj, class_mask, rows, rows_per_img,
-                 det, keys, counters, capacity, seq_bits, order_by_seq, cpb, nchunks};
-    size_t lds = (size_t)CAND_STAGE * 32 + (size_t)CAND_ROWS * no * sizeof(float);
-    AY_CHECK_ARG(lds <= 64 * 1024, "nms_candidates: no=%d too large", no);
-    hipLaunchKernelGGL(k_candidates, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)s, p);
-    AY_CHECK_LAUNCH("k_candidates");
-    return AYOLO_OK;
+                 det, keys, counters, capacity, seq_bits, order_by_seq, 0, 0, 0, 0, 0};
+    return run_candidates(p, no, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -430,6 +443,9 @@ __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// IOU 0: torchvision (area = w*h, pairs without overlap skipped).  IOU 1: TensorRT batchedNMSPlugin with
+// isNormalized = 0 (allClassNMS jaccardOverlap: +1 on every extent, disjoint boxes intersect in the unit box).
+template <int IOU>
 __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ sdet, const uint32_t* seg_off,
                                                  const uint32_t* seg_n, const uint64_t* mask_off, float thr,
                                                  float offset_scale, const float* per_img_offset,
@@ -457,8 +473,14 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ sdet,
         float o = cc * scale;
         cx1 = d[0] + o; cy1 = d[1] + o; cx2 = d[2] + o; cy2 = d[3] + o;
     }
-    const float rarea = (rx2 - rx1) * (ry2 - ry1);
-    const float carea = (cx2 - cx1) * (cy2 - cy1);
+    float rarea, carea;
+    if (IOU == 0) {
+        rarea = (rx2 - rx1) * (ry2 - ry1);
+        carea = (cx2 - cx1) * (cy2 - cy1);
+    } else {   // bboxSize: 0 for an inverted box, else (w + 1) * (h + 1)
+        rarea = (rx2 < rx1 || ry2 < ry1) ? 0.0f : ((rx2 - rx1) + 1.0f) * ((ry2 - ry1) + 1.0f);
+        carea = (cx2 < cx1 || cy2 < cy1) ? 0.0f : ((cx2 - cx1) + 1.0f) * ((cy2 - cy1) + 1.0f);
+    }
     const bool cvalid = cj < n;
 
     uint64_t myword = 0;
@@ -468,9 +490,19 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ sdet,
         const float ia = rl(rarea, i), ic = rl(rc, i);
         float xx1 = fmaxf(ix1, cx1), yy1 = fmaxf(iy1, cy1);
         float xx2 = fminf(ix2, cx2), yy2 = fminf(iy2, cy2);
-        float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-        float inter = w * h;
-        bool cand = cvalid && (rb * 64 + i) < n && cj > (rb * 64 + i) && inter > 0.0f;
+        float w, h, inter;
+        bool cand = cvalid && (rb * 64 + i) < n && cj > (rb * 64 + i);
+        if (IOU == 0) {
+            w = fmaxf(0.0f, xx2 - xx1); h = fmaxf(0.0f, yy2 - yy1);
+            inter = w * h;
+            cand = cand && inter > 0.0f;
+        } else {
+            const bool disjoint = (cx1 > ix2) | (cx2 < ix1) | (cy1 > iy2) | (cy2 < iy1);   // intersectBbox -> (0,0,0,0)
+            w = disjoint ? 1.0f : (xx2 - xx1) + 1.0f;
+            h = disjoint ? 1.0f : (yy2 - yy1) + 1.0f;
+            inter = w * h;
+            cand = cand && w > 0.0f && h > 0.0f;
+        }
         if (class_aware) cand = cand && (ic == cc);
         uint64_t any = __ballot(cand);
         uint64_t word = 0;
@@ -490,7 +522,7 @@ extern "C" int ayolo_nms_mask(const float* sdet, const uint32_t* seg_off, const 
     if (max_n == 0 || B == 0) return AYOLO_OK;
     unsigned nb = (max_n + 63) / 64;
     AY_CHECK_ARG(nb <= 65535 && B <= 65535, "nms_mask: grid too large");
-    hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb, B), dim3(64), 0, (hipStream_t)s, sdet, seg_off, seg_n, mask_off,
+    hipLaunchKernelGGL(k_nms_mask<0>, dim3(nb, nb, B), dim3(64), 0, (hipStream_t)s, sdet, seg_off, seg_n, mask_off,
                        thr_f, offset_scale, per_img_offset, class_aware, 0, mask);
     AY_CHECK_LAUNCH("k_nms_mask");
     return AYOLO_OK;
@@ -751,6 +783,158 @@ extern "C" int ayolo_nms_class_merge(const float* rows1, const int32_t* out_idx,
     hipLaunchKernelGGL(k_class_emit, dim3(cdiv((int)nthr, 256)), dim3(256), 0, st, rows1, flags, scan, sel_off, B, tot,
                        max_det, out, kept);
     AY_CHECK_LAUNCH("k_class_emit");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fixed-shape batched NMS with the TensorRT BatchedNMS_TRT contract the reference builds into its engines
+// (scripts/model_converter/model_converter.py:268-388: shareLocation 1, backgroundLabelId -1, isNormalized 0,
+// clipBoxes 0; outputs consumed by train_utils.py:262-283).  Every buffer has a size fixed by (B, N, nc, topK,
+// keepTopK, capacity); no host read-back anywhere, so the sequence can be captured in a hipGraph.
+//   candidates (key = image | class | ~score | row) -> radix sort -> per (image, class) top-K layout ->
+//   IoU bit matrix (plugin jaccard) -> greedy scan -> keys (image | ~score | class | rank) -> sort -> emit
+// ---------------------------------------------------------------------------------------------------
+extern "C" int ayolo_trt_nms_key_bits(int B, int N, int nc, int* row_bits, int* cls_bits, int* img_bits) {
+    int rb = bits_for((uint64_t)N), cb = bits_for((uint64_t)nc + 1), ib = bits_for((uint64_t)B + 1);
+    if (row_bits) *row_bits = rb;
+    if (cls_bits) *cls_bits = cb;
+    if (img_bits) *img_bits = ib;
+    return rb + 32 + cb + ib <= 64 ? AYOLO_OK : AYOLO_EINVAL;
+}
+
+__global__ void k_fill_u64(uint64_t* v, uint64_t n, uint64_t value) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = value;
+}
+
+extern "C" int ayolo_trt_nms_candidates(const float* pred, int B, int N, int no, float score_thres, int box_xyxy,
+                                        float* det, uint64_t* keys, uint32_t* counters, uint32_t capacity,
+                                        ayolo_stream s) {
+    AY_CHECK_ARG(pred && det && keys && counters, "trt_nms_candidates: null pointer");
+    AY_CHECK_ARG(B > 0 && N > 0 && no > 5 && capacity > 0, "trt_nms_candidates: bad dims B=%d N=%d no=%d", B, N, no);
+    int rb, cb, ib;
+    if (ayolo_trt_nms_key_bits(B, N, no - 5, &rb, &cb, &ib) != AYOLO_OK) {
+        ayolo_set_error("trt_nms_candidates: key needs %d bits", rb + 32 + cb + ib);
+        return AYOLO_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)s;
+    // unused slots sort behind every candidate: all-ones class field >= nc by construction of cls_bits
+    hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)cdiv64(capacity, 256)), dim3(256), 0, st, keys, (uint64_t)capacity, ~0ull);
+    AY_CHECK_LAUNCH("k_fill_u64");
+    hipLaunchKernelGGL(k_fill_u32, dim3(cdiv(1 + B, 256)), dim3(256), 0, st, counters, (uint32_t)(1 + B), 0u);
+    AY_CHECK_LAUNCH("k_fill_u32");
+    CandParams p{pred, B, N, no, score_thres, 1, 0, nullptr, nullptr, N, det, keys, counters, capacity, rb, 0, 0, 0, 2, cb,
+                 box_xyxy};
+    return run_candidates(p, no, s);
+}
+
+// segment sg = (image, class): the first min(count, top_k) sorted keys whose high field equals sg
+__global__ void k_trt_layout(const uint64_t* keys_sorted, uint32_t cap, int B, int nc, int cls_bits, int shift,
+                             uint32_t top_k, uint32_t* seg_off2, uint32_t* seg_n2, uint64_t* mask_off) {
+    const int sg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sg >= B * nc) return;
+    const uint64_t pre = (((uint64_t)(sg / nc)) << cls_bits) | (uint64_t)(sg % nc);
+    uint32_t lo = 0, hi = cap;
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if ((keys_sorted[m] >> shift) < pre) lo = m + 1; else hi = m; }
+    const uint32_t start = lo;
+    hi = cap;
+    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if ((keys_sorted[m] >> shift) <= pre) lo = m + 1; else hi = m; }
+    seg_off2[sg] = start;
+    seg_n2[sg] = min(lo - start, top_k);
+    mask_off[sg] = (uint64_t)sg * top_k * ((top_k + 63) / 64);
+}
+
+extern "C" int ayolo_trt_nms_layout(const uint64_t* keys_sorted, uint32_t capacity, int B, int N, int nc,
+                                    uint32_t top_k, uint32_t* seg_off2, uint32_t* seg_n2, uint64_t* mask_off,
+                                    ayolo_stream s) {
+    AY_CHECK_ARG(keys_sorted && seg_off2 && seg_n2 && mask_off && top_k > 0, "trt_nms_layout: bad args");
+    int rb, cb, ib;
+    AY_CHECK_ARG(ayolo_trt_nms_key_bits(B, N, nc, &rb, &cb, &ib) == AYOLO_OK, "trt_nms_layout: key too wide");
+    hipLaunchKernelGGL(k_trt_layout, dim3(cdiv(B * nc, 256)), dim3(256), 0, (hipStream_t)s, keys_sorted, capacity, B, nc,
+                       cb, 32 + rb, top_k, seg_off2, seg_n2, mask_off);
+    AY_CHECK_LAUNCH("k_trt_layout");
+    return AYOLO_OK;
+}
+
+extern "C" int ayolo_trt_nms_mask(const float* sdet, const uint32_t* seg_off, const uint32_t* seg_n,
+                                  const uint64_t* mask_off, int nseg, uint32_t max_n, float iou_thres, uint64_t* mask,
+                                  ayolo_stream s) {
+    if (max_n == 0 || nseg == 0) return AYOLO_OK;
+    unsigned nb = (max_n + 63) / 64;
+    AY_CHECK_ARG(nb <= 65535 && nseg <= 65535, "trt_nms_mask: grid too large");
+    hipLaunchKernelGGL(k_nms_mask<1>, dim3(nb, nb, nseg), dim3(64), 0, (hipStream_t)s, sdet, seg_off, seg_n, mask_off,
+                       iou_thres, 0.0f, (const float*)nullptr, 0, 0, mask);
+    AY_CHECK_LAUNCH("k_nms_mask<trt>");
+    return AYOLO_OK;
+}
+
+// kept rows of every (image, class) -> key image | ~score | class | rank, value = row of `out`; the rest ~0
+__global__ void k_trt_final_keys(const float* out, const uint32_t* out_count, int nseg, uint32_t max_out, int nc,
+                                 int cls_bits, int rank_bits, uint64_t* fkeys, uint32_t* fvals) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint32_t)nseg * max_out) return;
+    const uint32_t sg = t / max_out, k = t - sg * max_out;
+    uint64_t key = ~0ull;
+    if (k < out_count[sg]) {
+        const uint32_t sb = ~__float_as_uint(out[(size_t)t * 6 + 4]);
+        key = ((((uint64_t)(sg / nc) << 32) | sb) << (cls_bits + rank_bits)) | ((uint64_t)(sg % nc) << rank_bits) | k;
+    }
+    fkeys[t] = key;
+    fvals[t] = t;
+}
+
+__global__ void k_trt_emit(const uint64_t* fkeys_sorted, const uint32_t* fvals_sorted, uint32_t E, const float* out,
+                           int shift, uint32_t keep, int32_t* num_det, float* boxes, float* scores, float* classes) {
+    __shared__ uint32_t s_start, s_cnt;
+    const uint64_t b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = E;
+        while (lo < hi) { uint32_t m = (lo + hi) >> 1; if ((fkeys_sorted[m] >> shift) < b) lo = m + 1; else hi = m; }
+        s_start = lo;
+        hi = E;
+        while (lo < hi) { uint32_t m = (lo + hi) >> 1; if ((fkeys_sorted[m] >> shift) <= b) lo = m + 1; else hi = m; }
+        s_cnt = min(lo - s_start, keep);
+        num_det[b] = (int32_t)s_cnt;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < keep; j += blockDim.x) {
+        float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, -1.f};          // gatherNMSOutputs padding: box 0, score 0, class -1
+        if (j < s_cnt) {
+            const float* r = out + (size_t)fvals_sorted[s_start + j] * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = r[c];
+        }
+        float* bo = boxes + (b * keep + j) * 4;
+        bo[0] = v[0]; bo[1] = v[1]; bo[2] = v[2]; bo[3] = v[3];
+        scores[b * keep + j] = v[4];
+        classes[b * keep + j] = v[5];
+    }
+}
+
+extern "C" int ayolo_trt_nms_final_keys(const float* out, const uint32_t* out_count, int B, int nc, uint32_t max_out,
+                                        uint64_t* fkeys, uint32_t* fvals, int* total_bits, ayolo_stream s) {
+    const int cb = bits_for((uint64_t)nc + 1), kb = bits_for((uint64_t)max_out), ib = bits_for((uint64_t)B + 1);
+    AY_CHECK_ARG(ib + 32 + cb + kb <= 64, "trt_nms_final_keys: key too wide");
+    if (total_bits) *total_bits = ib + 32 + cb + kb;
+    if (out == nullptr) return AYOLO_OK;                          // size query
+    AY_CHECK_ARG(out_count && fkeys && fvals && max_out > 0, "trt_nms_final_keys: bad args");
+    const uint64_t E = (uint64_t)B * nc * max_out;
+    hipLaunchKernelGGL(k_trt_final_keys, dim3((unsigned)cdiv64(E, 256)), dim3(256), 0, (hipStream_t)s, out, out_count,
+                       B * nc, max_out, nc, cb, kb, fkeys, fvals);
+    AY_CHECK_LAUNCH("k_trt_final_keys");
+    return AYOLO_OK;
+}
+
+extern "C" int ayolo_trt_nms_emit(const uint64_t* fkeys_sorted, const uint32_t* fvals_sorted, const float* out, int B,
+                                  int nc, uint32_t max_out, uint32_t keep_top_k, int32_t* num_det, float* boxes,
+                                  float* scores, float* classes, ayolo_stream s) {
+    AY_CHECK_ARG(fkeys_sorted && fvals_sorted && out && num_det && boxes && scores && classes && keep_top_k > 0,
+                 "trt_nms_emit: bad args");
+    const int cb = bits_for((uint64_t)nc + 1), kb = bits_for((uint64_t)max_out);
+    hipLaunchKernelGGL(k_trt_emit, dim3(B), dim3(128), 0, (hipStream_t)s, fkeys_sorted, fvals_sorted,
+                       (uint32_t)((uint64_t)B * nc * max_out), out, 32 + cb + kb, keep_top_k, num_det, boxes, scores,
+                       classes);
+    AY_CHECK_LAUNCH("k_trt_emit");
     return AYOLO_OK;
 }
 

@@ -131,6 +131,11 @@ class YoloValidator:
     def process_batch(self, detections: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         return process_batch(detections, labels, self.iouv)
 
+    def convert_trt_out(self, out: torch.Tensor, n_objs: torch.Tensor) -> List[torch.Tensor]:
+        """Fixed-shape NMS output ``(B, keepTopK, 6)`` + per-image counts -> the validator's ragged rows
+        (train_utils.py:262-283); the counts are the one host read of this path."""
+        return [out[i, :int(n)] for i, n in enumerate(n_objs.tolist())]
+
     @torch.no_grad()
     def validation_step(self, val_batch, batch_idx: int = 0) -> None:
         imgs, targets, paths, shapes = val_batch
@@ -147,13 +152,17 @@ class YoloValidator:
         else:
             outs = self.model(imgs)
         out, train_out = (outs[0], outs[1]) if isinstance(outs, (tuple, list)) and len(outs) == 2 else (outs, None)
-        if self.loss_fn is not None and train_out is not None:
+        trt_case = isinstance(train_out, torch.Tensor)               # engine with the NMS plugin appended (train_utils.py:456-457)
+        if self.loss_fn is not None and train_out is not None and not trt_case:
             self.loss += self.loss_fn([x.float() for x in train_out], targets)[1][:3]
         targets = self.convert_target(targets, width, height)
         targets_cpu = self.convert_target(targets_cpu, width, height)
         lb = [targets[targets[:, 0] == i, 1:] for i in range(imgs.shape[0])] if self.hybrid_label else None
-        out = non_max_suppression(out, self.cfg_hyp["conf_t"], self.cfg_hyp["iou_t"], multi_label=True, labels=lb or (),
-                                  agnostic=self.single_cls, nms_type=self.nms_type)
+        if trt_case:
+            out = self.convert_trt_out(out, train_out)
+        else:
+            out = non_max_suppression(out, self.cfg_hyp["conf_t"], self.cfg_hyp["iou_t"], multi_label=True, labels=lb or (),
+                                      agnostic=self.single_cls, nms_type=self.nms_type)
         self.statistics_per_image(imgs, out, targets, shapes, paths, targets_cpu=targets_cpu)
 
     def statistics_per_image(self, img: torch.Tensor, out: List[torch.Tensor], targets: torch.Tensor, shapes, paths=None,

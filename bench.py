@@ -197,7 +197,20 @@ def nms_extra(device):
         non_max_suppression(pred, 0.001, 0.65, multi_label=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    return {"nms_boxes_per_s": round(n_cand / dt, 1), "nms_proposals_per_s": round(B * N / dt, 1), "nms_ms_per_batch": round(dt * 1e3, 3),
+    # fixed-shape variant (TensorRT BatchedNMS_TRT contract): no host read-back, so calls queue back to back
+    from ayolov2_amd.fixed_nms import BatchedNMS
+    fx = BatchedNMS(nc, top_k=512, keep_top_k=100, score_threshold=0.001, iou_threshold=0.65)
+    for _ in range(2):
+        fx.from_prediction(pred, box_xyxy=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fx.from_prediction(pred, box_xyxy=False)
+    torch.cuda.synchronize()
+    dtf = (time.perf_counter() - t0) / reps
+    fixed = {"fixed_nms_ms_per_batch": round(dtf * 1e3, 3), "fixed_nms_proposals_per_s": round(B * N / dtf, 1),
+             "fixed_nms_config": "topK 512 keepTopK 100, capacity B*N pairs, overflow=%s" % bool(fx.overflow)}
+    return {**fixed, "nms_boxes_per_s": round(n_cand / dt, 1), "nms_proposals_per_s": round(B * N / dt, 1), "nms_ms_per_batch": round(dt * 1e3, 3),
             "nms_candidates": n_cand, "nms_workload": f"{B}x{N}x{nc + 5} fp32, conf 0.001 iou 0.65 multi_label",
             "nms_filter_hbm_gbs_lower_bound": round(B * N * (nc + 5) * 4 / dt / 1e9, 1)}
 

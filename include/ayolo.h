@@ -261,6 +261,28 @@ int ayolo_nms_class_merge(const float* rows1, const int32_t* out_idx, const uint
                           const uint32_t* seg_off2, const uint32_t* perm, int nseg, uint32_t max_out,
                           const uint32_t* sel_off, int B, uint32_t tot, uint32_t max_det, uint32_t* flags,
                           uint32_t* scan, float* out, uint32_t* kept, void* ws, size_t* ws_bytes, ayolo_stream s);
+/* Fixed-shape batched NMS with the TensorRT BatchedNMS_TRT contract of the reference's engines
+ * (scripts/model_converter/model_converter.py:268-388; outputs read by train_utils.py:262-283): per (image, class)
+ * the topK boxes with score = obj*cls > scoreThreshold, greedy NMS with the plugin's jaccard (isNormalized = 0: +1 on
+ * every extent), then the keepTopK best of an image.  All sizes are fixed by (B, N, nc, topK, keepTopK, capacity) and
+ * nothing is read back by the host.  Sequence: trt_nms_candidates -> sort_pairs_u64 (capacity keys, vals = iota) ->
+ * gather_rows -> trt_nms_layout -> trt_nms_mask -> nms_reduce -> trt_nms_final_keys -> sort_pairs_u64 -> trt_nms_emit.
+ * key = image | class | ~score | row; unused slots hold ~0 and sort last; counters[0] > capacity means overflow
+ * (candidates were dropped: rerun with a larger capacity). */
+int ayolo_trt_nms_key_bits(int B, int N, int nc, int* row_bits, int* cls_bits, int* img_bits);
+int ayolo_trt_nms_candidates(const float* pred, int B, int N, int no, float score_thres, int box_xyxy, float* det,
+                             uint64_t* keys, uint32_t* counters, uint32_t capacity, ayolo_stream s);
+int ayolo_trt_nms_layout(const uint64_t* keys_sorted, uint32_t capacity, int B, int N, int nc, uint32_t top_k,
+                         uint32_t* seg_off2, uint32_t* seg_n2, uint64_t* mask_off, ayolo_stream s);
+int ayolo_trt_nms_mask(const float* sdet, const uint32_t* seg_off, const uint32_t* seg_n, const uint64_t* mask_off,
+                       int nseg, uint32_t max_n, float iou_thres, uint64_t* mask, ayolo_stream s);
+/* out == NULL: only report the key width in *total_bits */
+int ayolo_trt_nms_final_keys(const float* out, const uint32_t* out_count, int B, int nc, uint32_t max_out,
+                             uint64_t* fkeys, uint32_t* fvals, int* total_bits, ayolo_stream s);
+/* num_det[B], boxes[B][keep][4], scores[B][keep], classes[B][keep] (padding: 0 / 0 / -1) */
+int ayolo_trt_nms_emit(const uint64_t* fkeys_sorted, const uint32_t* fvals_sorted, const float* out, int B, int nc,
+                       uint32_t max_out, uint32_t keep_top_k, int32_t* num_det, float* boxes, float* scores,
+                       float* classes, ayolo_stream s);
 /* Dense IoU (metrics.py:138-164): out[N][M]. */
 int ayolo_box_iou(const float* a, int64_t N, const float* b, int64_t M, float* out, ayolo_stream s);
 /* fast_nms / matrix_nms column reductions over the upper-triangular IoU of n boxes (never materialised):

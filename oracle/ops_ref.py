@@ -15,6 +15,10 @@ that float32 results are the same IEEE sequence the reference's torch-CPU path p
 * ``bbox_iou``             scripts/utils/metrics.py:60-135
 * ``non_max_suppression``  scripts/utils/metrics.py:285-443
 * ``batched_nms``          scripts/utils/nms.py:15-116
+* ``batched_nms_trt``      TensorRT OSS ``batchedNMSPlugin`` ("BatchedNMS_TRT" v1) with the fields the reference sets
+  (scripts/model_converter/model_converter.py:268-388); third-party binary, NOT in /root/reference: restated from the
+  published plugin source (sortScoresPerClass -> allClassNMS -> sortScoresPerImage -> gatherNMSOutputs).
+  "parity unpinned" at that leaf.
 * ``tv_nms`` / ``tv_batched_nms``  torchvision==0.10.1 (environment.yml:28; NOT vendored, restated from
   the published source -- see oracle/nms_oracle.c header).  "parity unpinned" at that leaf.
 
@@ -417,3 +421,62 @@ def ap_per_class(tp, conf, pred_cls, target_cls):
     f1 = 2 * p * r / (p + r + 1e-16)
     i = f1.mean(0).argmax()
     return p[:, i], r[:, i], ap, f1[:, i], unique_classes.astype("int32")
+
+
+def _trt_bbox_size(b: np.ndarray) -> np.float32:
+    """allClassNMS.cu bboxSize with normalized = false: 0 for an inverted box, else (w + 1) * (h + 1)."""
+    if b[2] < b[0] or b[3] < b[1]:
+        return np.float32(0.0)
+    return np.float32((np.float32(b[2] - b[0]) + np.float32(1.0)) * (np.float32(b[3] - b[1]) + np.float32(1.0)))
+
+
+def _trt_jaccard(a: np.ndarray, b: np.ndarray) -> np.float32:
+    """allClassNMS.cu jaccardOverlap with normalized = false (offset 1): disjoint boxes intersect in (0, 0, 0, 0),
+    whose extents become 0 + 1."""
+    if b[0] > a[2] or b[2] < a[0] or b[1] > a[3] or b[3] < a[1]:
+        ix1 = iy1 = ix2 = iy2 = np.float32(0.0)
+    else:
+        ix1, iy1 = max(a[0], b[0]), max(a[1], b[1])
+        ix2, iy2 = min(a[2], b[2]), min(a[3], b[3])
+    w = np.float32(np.float32(ix2 - ix1) + np.float32(1.0))
+    h = np.float32(np.float32(iy2 - iy1) + np.float32(1.0))
+    if w > 0 and h > 0:
+        inter = np.float32(w * h)
+        return np.float32(inter / np.float32(np.float32(_trt_bbox_size(a) + _trt_bbox_size(b)) - inter))
+    return np.float32(0.0)
+
+
+def batched_nms_trt(boxes, scores, top_k: int = 512, keep_top_k: int = 100, score_threshold: float = 0.001,
+                    iou_threshold: float = 0.65):
+    """BatchedNMS_TRT (shareLocation = 1, backgroundLabelId = -1, isNormalized = 0, clipBoxes = 0), the layer
+    scripts/model_converter/model_converter.py:268-388 appends to the engine.  boxes (B, N, 4) xyxy, scores (B, N, nc).
+    Returns (num_detections (B, 1) int32, nmsed_boxes (B, keep, 4), nmsed_scores (B, keep), nmsed_classes (B, keep));
+    padding rows are box 0, score 0, class -1 (gatherNMSOutputs)."""
+    boxes, scores = _f32(boxes), _f32(scores)
+    B, N, nc = scores.shape
+    thr, it = np.float32(score_threshold), np.float32(iou_threshold)
+    num = np.zeros((B, 1), np.int32)
+    ob = np.zeros((B, keep_top_k, 4), np.float32)
+    osc = np.zeros((B, keep_top_k), np.float32)
+    ocl = np.full((B, keep_top_k), -1.0, np.float32)
+    for b in range(B):
+        kept = []                                        # (score, class, position in the class's sorted list, box index)
+        for c in range(nc):
+            sc = scores[b, :, c]
+            idx = np.nonzero(sc > thr)[0]                # sortScoresPerClass: others get score 0 / index -1
+            idx = idx[argsort_desc(sc[idx])][:top_k]     # stable descending, top K fed to the NMS step
+            alive = np.ones(len(idx), bool)
+            for i in range(len(idx)):
+                if not alive[i]:
+                    continue
+                kept.append((sc[idx[i]], c, i, idx[i]))
+                for j in range(i + 1, len(idx)):
+                    if alive[j] and _trt_jaccard(boxes[b, idx[i]], boxes[b, idx[j]]) > it:
+                        alive[j] = False
+        # sortScoresPerImage: stable descending over the (class, position) array
+        kept.sort(key=lambda t: (-float(t[0]), t[1], t[2]))
+        kept = kept[:keep_top_k]
+        num[b, 0] = len(kept)
+        for j, (s_, c, _, i) in enumerate(kept):
+            ob[b, j], osc[b, j], ocl[b, j] = boxes[b, i], s_, c
+    return num, ob, osc, ocl

@@ -143,3 +143,25 @@ def test_validator_matching_and_ap_vs_golden(golden_dir):
         np.testing.assert_allclose(ap, g["ap"], rtol=1e-12)
         np.testing.assert_allclose(f1, g["ap_f1"], rtol=1e-12)
         np.testing.assert_array_equal(cls, g["ap_cls"])
+
+
+def test_trt_batched_nms_restatement_hand_cases():
+    """Known answers for the BatchedNMS_TRT restatement (third-party plugin: parity unpinned, so the arithmetic is at
+    least pinned by hand): +1 extents, strict '>' on the IoU, the unit-box quirk of disjoint boxes, padding values."""
+    a, b = np.float32([0, 0, 9, 9]), np.float32([5, 0, 14, 9])                 # 10x10 boxes (with the +1), overlap 5x10
+    assert ops_ref._trt_bbox_size(a) == np.float32(100)
+    assert ops_ref._trt_jaccard(a, b) == np.float32(50) / np.float32(150)
+    assert ops_ref._trt_jaccard(a, np.float32([100, 100, 109, 109])) == np.float32(1) / np.float32(199)
+    assert ops_ref._trt_bbox_size(np.float32([5, 5, 4, 9])) == 0
+    boxes = np.float32([[[0, 0, 9, 9], [5, 0, 14, 9], [0, 0, 9, 9], [50, 50, 59, 59]]])
+    scores = np.float32([[[0.9, 0.0], [0.8, 0.7], [0.9, 0.05], [0.2, 0.6]]])
+    thr = float(np.float32(50) / np.float32(150))
+    num, ob, osc, ocl = ops_ref.batched_nms_trt(boxes, scores, top_k=4, keep_top_k=5, score_threshold=0.1, iou_threshold=thr)
+    # class 0: box 0 (0.9) keeps, box 2 is identical (suppressed), box 1 has IoU == thr exactly (kept: strict '>'), box 3 kept
+    # class 1: box 1 (0.7), box 3 (0.6); box 2's 0.05 is under the score threshold
+    assert num[0, 0] == 5
+    np.testing.assert_array_equal(osc[0], np.float32([0.9, 0.8, 0.7, 0.6, 0.2]))
+    np.testing.assert_array_equal(ocl[0], np.float32([0, 0, 1, 1, 0]))
+    np.testing.assert_array_equal(ob[0, 0], boxes[0, 0])
+    num, ob, osc, ocl = ops_ref.batched_nms_trt(boxes, scores, top_k=4, keep_top_k=5, score_threshold=0.95, iou_threshold=0.5)
+    assert num[0, 0] == 0 and (ocl == -1).all() and (osc == 0).all() and (ob == 0).all()
