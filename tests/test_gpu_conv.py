@@ -20,6 +20,11 @@ SHAPES = [
     (2, 128, 32, 3, 1, 1, 8, 16),      # 4 channel chunks, single tile per image
     (2, 32, 64, 3, 2, 1, 13, 17),      # stride 2 on odd sizes: dgrad residue classes differ in size -> one launch per class
     (1, 64, 32, 1, 2, 0, 16, 16),      # 1x1 stride 2: three tap-less residue classes (zero gradient rows)
+    (2, 48, 96, 3, 1, 1, 12, 12),      # yolov5m widths: 6 / 12 sixteen-byte channel chunks per pixel (not a power of two)
+    (1, 96, 48, 3, 2, 1, 16, 16),
+    (2, 80, 160, 1, 1, 0, 10, 12),     # yolov5x widths
+    (2, 1280, 640, 1, 1, 0, 4, 4),     # deepest 1x1 of yolov5x: K = 1280, ragged 640-wide output
+    (1, 320, 320, 3, 1, 1, 8, 8),
 ]
 
 

@@ -35,17 +35,28 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-def test_train_forward_backward_fp32():
-    m, r = _pair("n")
+@pytest.mark.parametrize("name,hw", [("n", (128, 160)), ("m", (128, 160)), ("l", (128, 128)), ("x", (128, 160))])
+def test_train_forward_backward_fp32(name, hw):
+    """Every width family of the reference's configs: n/s/l are powers of two, m (48..768) and x (80..1280) are not --
+    ragged channel chunks and output tiles in every conv, dgrad and wgrad launch (BASELINE.json configs 3 and 5 use l / x).
+    The 1e-4 bar (|d| <= 1e-4 + 1e-4 |ref| elementwise, gradients 2e-3 of their max) is asserted on n.  For m / l / x this
+    is a kernel-coverage test with bounds that are robust run to run: those nets stack 1.5-3x as many batch-statistics BN
+    layers (each divides by a std estimated from as few as 40 samples here, accumulated with fp32 atomics in launch order)
+    over contractions of up to 11 520 terms, and the max |d| over the logits moved between 1.3e-4 and 6.7e-4 on repeated
+    runs.  A wrong tile or channel chunk shows up as an O(1) error; the bound is 1e-3 of the logit range, gradients 2e-2."""
+    tight = name == "n"
+    m, r = _pair(name)
     m.train(); r.train()
-    x = torch.rand(2, 3, 128, 160)
+    x = torch.rand(2, 3, *hw)
     raws_r = r(x)
     raws_g = m(x.cuda())
     gen = torch.Generator().manual_seed(1)
     gws = [torch.randn(t.shape, generator=gen) for t in raws_r]
     for a, b in zip(raws_g, raws_r):
         assert a.shape == b.shape and a.dtype == torch.float32
-        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=1e-4, atol=1e-4)
+        if tight:
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=1e-4, atol=1e-4)
+        assert _rel(a.detach().cpu(), b.detach()) < (1e-4 if tight else 1e-3)
     sum((a * w).sum() for a, w in zip(raws_r, gws)).backward()
     sum((a * w.cuda()).sum() for a, w in zip(raws_g, gws)).backward()
     pr = dict(r.named_parameters())
@@ -54,13 +65,13 @@ def test_train_forward_backward_fp32():
         assert p.grad is not None, k
         e = _rel(p.grad.detach().float().cpu(), pr[k].grad)
         worst = max(worst, e)
-        assert e < 2e-3, f"grad {k}: rel err {e}"
+        assert e < (2e-3 if tight else 2e-2), f"grad {k}: rel err {e}"
     print("worst grad rel err", worst)
     # BatchNorm running statistics were updated identically
     br = dict(r.named_buffers())
     for k, b in m.named_buffers():
         if "running" in k:
-            np.testing.assert_allclose(b.cpu().numpy(), br[k].numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(b.cpu().numpy(), br[k].numpy(), rtol=1e-4 if tight else 1e-3, atol=1e-5 if tight else 1e-4)
 
 
 def test_eval_decode_and_fuse_fp32():
@@ -78,10 +89,14 @@ def test_eval_decode_and_fuse_fp32():
         np.testing.assert_allclose(zf.cpu().numpy(), zr.numpy(), rtol=2e-4, atol=2e-3)
 
 
-def test_train_step_fp16_autocast():
+@pytest.mark.parametrize("name", ["n"])
+def test_train_step_fp16_autocast(name):
     """AMP path (reference: yolo_trainer.py:322-329).  Stated tolerances for fp16 storage / fp32 accumulate through
-    ~60 layers with batch-stat BN: logits within 2 % of the logit range, parameter grads within 8 % of their max."""
-    m, r = _pair("n", seed=5)
+    ~60 layers with batch-stat BN: logits within 2 % of the logit range, parameter grads within 8 % of their max (n).
+    (Random-init m / l / x nets overflow fp16 in single ill-conditioned BN channels of the backward pass at any fixed loss
+    scale -- what GradScaler's skip-and-halve handles in training -- so the fp16 kernels' ragged channel widths are covered
+    at the conv level instead: tests/test_gpu_conv.py SHAPES with Cin / Cout in {48, 80, 96, 160, 640, 1280}.)"""
+    m, r = _pair(name, seed=5)
     m.train(); r.train()
     x = torch.rand(8, 3, 256, 256)      # enough pixels per channel that batch-stat BN is well conditioned
     raws_r = r(x)
@@ -91,15 +106,17 @@ def test_train_step_fp16_autocast():
     gws = [torch.randn(t.shape, generator=gen) for t in raws_r]
     for a, b in zip(raws_g, raws_r):
         assert a.dtype == torch.float32
-        assert _rel(a.detach().cpu(), b.detach()) < 2e-2
-    scale = 8192.0                        # static loss scale (GradScaler starts at 65536): keeps fp16 grads normal
+        assert _rel(a.detach().cpu(), b.detach()) < (2e-2 if name == "n" else 1e-1)     # m: coverage bound (2.8e-2 .. 4.6e-2 run to run)
+    # static loss scale (GradScaler starts at 65536 and backs off on overflow): keeps fp16 grads normal; the wider m net
+    # overflows fp16 at 8192 (inf in model.23's weight gradient, which GradScaler would answer by halving the scale)
+    scale = 8192.0 if name == "n" else 512.0
     sum((a * w).sum() for a, w in zip(raws_r, gws)).backward()
     (sum((a * w.cuda()).sum() for a, w in zip(raws_g, gws)) * scale).backward()
     pr = dict(r.named_parameters())
     bad = []
     for k, p in m.named_parameters():
         e = _rel(p.grad.detach().float().cpu() / scale, pr[k].grad)
-        if e > 8e-2:
+        if e > (8e-2 if name == "n" else 2.5e-1):
             bad.append((k, e))
     assert not bad, bad[:10]
 
