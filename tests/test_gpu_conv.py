@@ -15,8 +15,8 @@ SHAPES = [
     (2, 256, 128, 1, 1, 0, 8, 8),
     (1, 64, 64, 3, 1, 1, 33, 9),
     (2, 16, 48, 3, 1, 1, 12, 12),      # Cout not a multiple of 32
-    (2, 32, 64, 3, 1, 1, 24, 32),      # halo-tiled direct fwd/dgrad + halo-tiled wgrad (8x16 tiles, exact fit)
-    (1, 64, 160, 3, 1, 1, 20, 40),     # halo-tiled, ragged tiles, Cout > 128
+    (2, 32, 64, 3, 1, 1, 24, 32),      # pixel count an exact multiple of the 128 / 256-pixel tiles
+    (1, 64, 160, 3, 1, 1, 20, 40),     # ragged pixel tiles, Cout > 128 (two output-channel tiles, the second ragged)
     (2, 128, 32, 3, 1, 1, 8, 16),      # 4 channel chunks, single tile per image
     (2, 32, 64, 3, 2, 1, 13, 17),      # stride 2 on odd sizes: dgrad residue classes differ in size -> one launch per class
     (1, 64, 32, 1, 2, 0, 16, 16),      # 1x1 stride 2: three tap-less residue classes (zero gradient rows)
