@@ -257,6 +257,65 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
                 yo = ((nn * (unsigned)p.YH + (unsigned)(oh * p.osh + oah)) * (unsigned)p.YW + (unsigned)(ow * p.osw + oaw)) * (unsigned)p.ldy * YES;
             }
         }
+        if constexpr (sizeof(T) == 2 && EM != 3) {
+            // fp16 outputs: lanes l and l+32 hold channels +0..3 / +4..7 of the SAME pixel for each 8-channel group.
+            // Four v_permlane32_swap per group pair give every lane 8 consecutive channels, so the tile leaves in 16-byte
+            // stores (2 per lane and pixel block instead of 4 of 8 bytes: half the requests the L2 has to take).
+            float v[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[g][e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
+            if constexpr (EM == 2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = cbase + 8 * g + e;
+                        if (c < p.Nout) {
+                            float sc = p.scale ? p.scale[c] : 1.0f, sh = p.shift ? p.shift[c] : 0.0f;
+                            float u = v[g][e] * sc + sh;
+                            v[g][e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
+                        }
+                    }
+            }
+            if (want_stats) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float q = pv ? cvt_round(v[g][e], (T*)nullptr) : 0.0f;
+                        ssum[g * 4 + e] += q;
+                        ssq[g * 4 + e] += q * q;
+                    }
+            }
+            const int hsel = lane >> 5;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const v2u32 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * j][e]), __float_as_uint(v[2 * j + 1][e]),
+                                                                     false, false);
+                    v[2 * j][e] = __uint_as_float(r[0]);
+                    v[2 * j + 1][e] = __uint_as_float(r[1]);
+                }
+                const int c = cbase - 4 * hsel + 8 * (2 * j + hsel);          // 8 channels: v[2j][0..3], v[2j+1][0..3]
+                const unsigned off = (pv && c < p.Nout) ? yo + (unsigned)c * 2u : G_OOB;   // Nout % 8 == 0 (host check)
+                float w8[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w8[e] = v[2 * j][e]; w8[4 + e] = v[2 * j + 1][e]; }
+                if constexpr (EM == 1) {
+                    const half8 o = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w8[e] += (float)o[e];
+                }
+                half8 h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (half_t)w8[e];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, h), rsY, off, 0, 0);
+            }
+            continue;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c = cbase + 8 * g;
@@ -350,6 +409,8 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int
 template <typename T, int TM, int EM, int TPX>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && EM == 0)) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
     using G = GT<T, TM, TPX>;
+    // stores per thread and epilogue (the step loop's vmcnt arithmetic): fp16 tiles leave in 16-byte stores
+    constexpr int NSTK = (sizeof(T) == 2 && EM != 3) ? G::NI * 2 : G::NST;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     unsigned char* sTiles = smem_raw;                                             // [GNS][x tile | w tile]
     int4* sTap = reinterpret_cast<int4*>(smem_raw + GNS * G::STAGE);              // [MAX_TAPS + 1]
@@ -458,7 +519,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     bool after_epi = false;
     while (true) {
         // step s landed (this wave's part), then: everyone's part landed AND everyone finished reading step s-1
-        if (after_epi) wait_vm<G::LPS + G::NST>(); else wait_vm<G::LPS>();
+        if (after_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
         __builtin_amdgcn_s_barrier();
         G_ISSUE(so2)                                     // step s+2 -> the stage step s-1 used
         G_ADVANCE()
@@ -585,8 +646,11 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
         int rc = dispatch_gconv(dtype, a, s);
         return rc ? rc : dispatch_gconv(dtype, b, s);
     }
-    if (p.epi != AYOLO_EPI_HEAD)
+    if (p.epi != AYOLO_EPI_HEAD) {
         AY_CHECK_ARG(p.Nout % 4 == 0 && p.ldy % 4 == 0, "conv: Cout=%d / channel stride %d must be multiples of 4", p.Nout, p.ldy);
+        AY_CHECK_ARG(dtype != AYOLO_F16 || (p.Nout % 8 == 0 && p.ldy % 8 == 0),
+                     "conv: fp16 outputs leave in 16-byte stores: Cout=%d / channel stride %d must be multiples of 8", p.Nout, p.ldy);
+    }
     p.x_bytes = (unsigned)(x_img * p.B);
     p.y_bytes = (unsigned)(y_img * p.B);
     p.w_bytes = (unsigned)w_bytes;
