@@ -48,7 +48,8 @@ typedef struct ayolo_conv_desc {
     int dtype;            /* AYOLO_F16 | AYOLO_F32 (x, w, y element type)                            */
     int B, H, W;          /* input spatial dims                                                      */
     int Cin, ldx;         /* channels read, channel stride (elements) of the x buffer (>= Cin)       */
-    int Cout, ldy;        /* channels written, channel stride of the y buffer                        */
+    int Cout, ldy;        /* channels written, channel stride of the y buffer: both multiples of 8   *
+                           * for fp16 (tiles leave in 16-byte stores), of 4 for fp32 (EPI_HEAD: any Cout) */
     int kh, kw, sh, sw, ph, pw;
     int Ho, Wo;           /* output spatial dims                                                     */
 } ayolo_conv_desc;
