@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libayolo_hip.so")
+# AYOLO_LIB selects another build of the same ABI (A/B timing of two kernel versions on one box: tools/ab_bench.sh)
+LIB_PATH = os.environ.get("AYOLO_LIB") or os.path.join(_HERE, "libayolo_hip.so")
 
 F16, F32 = 0, 1
 EPI_NONE, EPI_AFFINE, EPI_AFFINE_SILU, EPI_HEAD = 0, 1, 2, 3
