@@ -201,16 +201,29 @@ __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int 
     using G = GT<T, TM, TPX>;
     const unsigned char* bx = stage + xrow;
     const unsigned char* bw = stage + G::XSTAGE + arow;
+    if constexpr (sizeof(T) == 2) {
+        // All fragments of the step are fetched before the first MFMA.  Left to itself hipcc reuses ONE register quad for
+        // every B fragment (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, eight times per step): the wave then pays the LDS
+        // latency per MFMA instead of once per step.  The scheduling barrier keeps the two phases apart; the compiler's
+        // counted lgkmcnt waits release the MFMAs one by one as the fragments arrive.
+        half8 a[BK / 16], b[BK / 16][G::NI];
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
+            a[kk] = *reinterpret_cast<const half8*>(bw + slot);
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni) b[kk][ni] = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni) mma_step(a[kk], b[kk][ni], acc[ni]);
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
         if constexpr (sizeof(T) == 2) {
-            const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
-            const half8 a = *reinterpret_cast<const half8*>(bw + slot);
-#pragma unroll
-            for (int ni = 0; ni < G::NI; ++ni) {
-                const half8 b = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
-                mma_step(a, b, acc[ni]);
-            }
         } else {
             const int c0 = kk * 4 + (lane >> 5) * 2;
             const int s0 = (c0 ^ swz) * 16, s1 = ((c0 + 1) ^ swz) * 16;
@@ -916,17 +929,29 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
         W_ISSUE(kt + 2, so2)
         const unsigned char* cX = smem_raw + so0;
         const unsigned char* cY = smem_raw + so0 + W::XSTAGE;
+        if constexpr (sizeof(T) == 2) {
+            // every fragment of the step first, then the MFMAs back to back (see g_mma: hipcc otherwise serialises
+            // ds_read -> lgkmcnt(0) -> v_mfma through one register quad)
+            half8 fa[W::BP / 16], fb[W::BP / 16][W::NI];
+            const int csub = ((lane >> 4) & 1) * 16;
+#pragma unroll
+            for (int kk = 0; kk < W::BP / 16; ++kk) {
+                const int k0 = kk * 16 + (lane >> 5) * 8;
+                fa[kk] = tr_frag_sw<W::YROWB, W::YG, W::YRPB>(cY, k0, wm * 32 + csub, lane);
+#pragma unroll
+                for (int ni = 0; ni < W::NI; ++ni)
+                    fb[kk][ni] = tr_frag_sw<W::XROWB, W::XG, W::XRPB>(cX, k0, wn * W::NI * 32 + ni * 32 + csub, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < W::BP / 16; ++kk)
+#pragma unroll
+                for (int ni = 0; ni < W::NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk], fb[kk][ni], acc[ni], 0, 0, 0);
+        }
 #pragma unroll
         for (int kk = 0; kk < W::BP / 16; ++kk) {
             const int k0 = kk * 16 + (lane >> 5) * 8;
             if constexpr (sizeof(T) == 2) {
-                const int csub = ((lane >> 4) & 1) * 16;
-                const half8 a = tr_frag_sw<W::YROWB, W::YG, W::YRPB>(cY, k0, wm * 32 + csub, lane);
-#pragma unroll
-                for (int ni = 0; ni < W::NI; ++ni) {
-                    const half8 b = tr_frag_sw<W::XROWB, W::XG, W::XRPB>(cX, k0, wn * W::NI * 32 + ni * 32 + csub, lane);
-                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[ni], 0, 0, 0);
-                }
             } else {
                 const float* fY = reinterpret_cast<const float*>(cY);
                 const float* fX = reinterpret_cast<const float*>(cX);
