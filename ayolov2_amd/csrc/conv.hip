@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_cast_weights(const ayolo_cast_job* jobs
         const unsigned tap = r % (unsigned)J.taps, co = r / (unsigned)J.taps;
         const float v = (c < (unsigned)J.Cin && co < (unsigned)J.Cout) ? J.w32[((size_t)co * J.taps + tap) * J.Cin + c] : 0.0f;
         if (w) w[t] = (T)v;
-        if (wt) wt[((size_t)c * J.taps + tap) * J.Cout_pad + co] = (T)v;
+        if (wt) wt[((size_t)c * J.taps + tap) * (J.wt_ld > 0 ? J.wt_ld : J.Cout_pad) + co] = (T)v;
     }
 }
 

@@ -31,14 +31,18 @@ __device__ __forceinline__ void store_vec(T* p, const float (&v)[VecT<T>::VE]) {
 // instantiation uses v_exp_f32 / v_rcp_f32 (error ~1e-6 relative, far below the fp16 output rounding) so these
 // HBM-bound passes are not VALU-limited.
 template <typename T> __device__ __forceinline__ float sigmoid_t(float u) {
-    if constexpr (sizeof(T) == 2) return __frcp_rn(1.0f + __expf(-u));
+    // fp16 storage: v_exp_f32 + v_rcp_f32 (1 ulp each).  NOT __frcp_rn: without fast-math that is a correctly rounded
+    // division (v_div_scale / v_rcp / 4 fma / v_div_fmas / v_div_fixup, ~10 VALU ops per element) which made the three
+    // BN passes VALU-bound (28 ops per element in k_bn_bwd_reduce at 180 VGPRs).
+    if constexpr (sizeof(T) == 2) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
     else return 1.0f / (1.0f + expf(-u));
 }
 template <typename T> __device__ __forceinline__ float silu_t(float u) { return u * sigmoid_t<T>(u); }
 template <typename T> __device__ __forceinline__ float act_grad_t(float u, int act) {
     if (!act) return 1.0f;
     float sg = sigmoid_t<T>(u);
-    return sg * (1.0f + u * (1.0f - sg));
+    if constexpr (sizeof(T) == 2) return sg * __builtin_fmaf(u, 1.0f - sg, 1.0f);
+    else return sg * (1.0f + u * (1.0f - sg));
 }
 
 static unsigned grid_for(long long work_items, int per_block) {
@@ -117,10 +121,60 @@ extern "C" int ayolo_bn_eval_affine(const float* gamma, const float* beta, const
 // ---------------------------------------------------------------------------------------------------
 // Thread mapping shared by the three BN/SiLU passes: a thread owns ONE 16-byte channel group (its per-channel
 // constants live in registers) and walks pixels with a grid stride -- no index divisions, no LDS, coalesced
-// 16-byte accesses (a wave covers consecutive channel groups of consecutive pixels).
-template <typename T>
+// 16-byte accesses (a wave covers consecutive channel groups of consecutive pixels).  Activation / residual are
+// compile-time (a runtime `act ? :` per element left 50 branches in the unrolled loop body).
+template <typename T, int ACT, int RES>
+__device__ __forceinline__ void affine_act_rows(const T* z, int ldz, T* a, int lda, long long npix, int cg,
+                                                const float (&sc)[VecT<T>::VE], const float (&sh)[VecT<T>::VE],
+                                                const T* res, int ldr, long long pix, long long stride) {
+    constexpr int VE = VecT<T>::VE;
+    // four pixels per iteration: all loads issued before the first use
+    for (; pix + 3 * stride < npix; pix += 4 * stride) {
+        float v[4][VE], r[4][VE];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, v[j]);
+        if constexpr (RES) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_vec<T>(res + (pix + j * stride) * ldr + cg * VE, r[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                float u;
+                if constexpr (sizeof(T) == 2) u = __builtin_fmaf(v[j][i], sc[i], sh[i]);
+                else u = v[j][i] * sc[i] + sh[i];
+                if constexpr (ACT) u = silu_t<T>(u);
+                if constexpr (RES) u += r[j][i];
+                v[j][i] = u;
+            }
+            store_vec<T>(a + (pix + j * stride) * lda + cg * VE, v[j]);
+        }
+    }
+    for (; pix < npix; pix += stride) {
+        float v[VE];
+        load_vec<T>(z + pix * ldz + cg * VE, v);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            float u;
+            if constexpr (sizeof(T) == 2) u = __builtin_fmaf(v[i], sc[i], sh[i]);
+            else u = v[i] * sc[i] + sh[i];
+            if constexpr (ACT) u = silu_t<T>(u);
+            v[i] = u;
+        }
+        if constexpr (RES) {
+            float r[VE];
+            load_vec<T>(res + pix * ldr + cg * VE, r);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) v[i] += r[i];
+        }
+        store_vec<T>(a + pix * lda + cg * VE, v);
+    }
+}
+
+template <typename T, int ACT, int RES>
 __global__ __launch_bounds__(256) void k_affine_act(const T* z, int ldz, T* a, int lda, long long npix, int C,
-                                                    const float* scale, const float* shift, int act, const T* res, int ldr) {
+                                                    const float* scale, const float* shift, const T* res, int ldr) {
     constexpr int VE = VecT<T>::VE;
     const int CG = C / VE;
     const int CGT = CG < 256 ? CG : 256;
@@ -134,46 +188,15 @@ __global__ __launch_bounds__(256) void k_affine_act(const T* z, int ldz, T* a, i
             sc[i] = scale ? scale[cg * VE + i] : 1.0f;
             sh[i] = shift ? shift[cg * VE + i] : 0.0f;
         }
-        const long long stride = (long long)gridDim.x * RPB;
-        long long pix = (long long)blockIdx.x * RPB + prow;
-        // four pixels per iteration: all loads issued before the first use
-        for (; pix + 3 * stride < npix; pix += 4 * stride) {
-            float v[4][VE], r[4][VE];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, v[j]);
-            if (res) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) load_vec<T>(res + (pix + j * stride) * ldr + cg * VE, r[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int i = 0; i < VE; ++i) {
-                    float u = v[j][i] * sc[i] + sh[i];
-                    u = act ? silu_t<T>(u) : u;
-                    v[j][i] = res ? u + r[j][i] : u;
-                }
-                store_vec<T>(a + (pix + j * stride) * lda + cg * VE, v[j]);
-            }
-        }
-        for (; pix < npix; pix += stride) {
-            float v[VE];
-            load_vec<T>(z + pix * ldz + cg * VE, v);
-#pragma unroll
-            for (int i = 0; i < VE; ++i) {
-                float u = v[i] * sc[i] + sh[i];
-                v[i] = act ? silu_t<T>(u) : u;
-            }
-            if (res) {
-                float r[VE];
-                load_vec<T>(res + pix * ldr + cg * VE, r);
-#pragma unroll
-                for (int i = 0; i < VE; ++i) v[i] += r[i];
-            }
-            store_vec<T>(a + pix * lda + cg * VE, v);
-        }
+        affine_act_rows<T, ACT, RES>(z, ldz, a, lda, npix, cg, sc, sh, res, ldr, (long long)blockIdx.x * RPB + prow,
+                                     (long long)gridDim.x * RPB);
     }
 }
+
+// launch one of the four (ACT, RES) instantiations
+#define DISPATCH_AR(act, res, ...)                                                   \
+    if (act) { if (res) { constexpr int ACT = 1, RES = 1; __VA_ARGS__ } else { constexpr int ACT = 1, RES = 0; __VA_ARGS__ } } \
+    else { if (res) { constexpr int ACT = 0, RES = 1; __VA_ARGS__ } else { constexpr int ACT = 0, RES = 0; __VA_ARGS__ } }
 
 static unsigned grid_pixels(long long npix, int C, int ve, int min_iters) {
     int cg = C / ve, cgt = cg < 256 ? cg : 256, rpb = 256 / cgt;
@@ -186,18 +209,20 @@ static unsigned grid_pixels(long long npix, int C, int ve, int min_iters) {
 // Training-mode BatchNorm + activation in ONE pass over z (k_bn_finalize folded into the prologue): every workgroup
 // derives scale/shift of all channels from the replicated sum / sum-of-squares accumulators into LDS (fp64, as
 // k_bn_finalize), workgroup 0 also writes save_mean / save_invstd and updates the running statistics.
-template <typename T>
+template <typename T, int ACT, int RES>
 __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a, int lda, long long npix, int C,
-                                                      const float* stats, int reps, double count, const float* gamma,
+                                                      const float* stats, int reps, int sld, double count, const float* gamma,
                                                       const float* beta, float eps, float momentum, float* rmean, float* rvar,
-                                                      float* smean, float* sinv, int act, const T* res, int ldr) {
+                                                      float* smean, float* sinv, const T* res, int ldr) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sc_sh[];   // [2][C]
+    // stats: [reps][2][sld] accumulators of the producing conv; this layer's channels start at `stats` (sld > C when the
+    // conv computed several layers at once -- C3's cv1 | cv2 -- and this is one channel slice of it)
     for (int c = threadIdx.x; c < C; c += 256) {
         double s1 = 0.0, s2 = 0.0;
         for (int r = 0; r < reps; ++r) {
-            s1 += (double)stats[(size_t)r * 2 * C + c];
-            s2 += (double)stats[(size_t)r * 2 * C + C + c];
+            s1 += (double)stats[(size_t)r * 2 * sld + c];
+            s2 += (double)stats[(size_t)r * 2 * sld + sld + c];
         }
         const double icount = 1.0 / count;            // uniform: one fp64 reciprocal, then multiplies only
         const double mean = s1 * icount;
@@ -228,61 +253,29 @@ __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a,
         float sc[VE], sh[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) { sc[i] = sc_sh[cg * VE + i]; sh[i] = sc_sh[C + cg * VE + i]; }
-        const long long stride = (long long)gridDim.x * RPB;
-        long long pix = (long long)blockIdx.x * RPB + prow;
-        for (; pix + 3 * stride < npix; pix += 4 * stride) {
-            float v[4][VE], r[4][VE];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, v[j]);
-            if (res) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) load_vec<T>(res + (pix + j * stride) * ldr + cg * VE, r[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int i = 0; i < VE; ++i) {
-                    float u = v[j][i] * sc[i] + sh[i];
-                    u = act ? silu_t<T>(u) : u;
-                    v[j][i] = res ? u + r[j][i] : u;
-                }
-                store_vec<T>(a + (pix + j * stride) * lda + cg * VE, v[j]);
-            }
-        }
-        for (; pix < npix; pix += stride) {
-            float v[VE];
-            load_vec<T>(z + pix * ldz + cg * VE, v);
-#pragma unroll
-            for (int i = 0; i < VE; ++i) {
-                float u = v[i] * sc[i] + sh[i];
-                v[i] = act ? silu_t<T>(u) : u;
-            }
-            if (res) {
-                float r[VE];
-                load_vec<T>(res + pix * ldr + cg * VE, r);
-#pragma unroll
-                for (int i = 0; i < VE; ++i) v[i] += r[i];
-            }
-            store_vec<T>(a + pix * lda + cg * VE, v);
-        }
+        affine_act_rows<T, ACT, RES>(z, ldz, a, lda, npix, cg, sc, sh, res, ldr, (long long)blockIdx.x * RPB + prow,
+                                     (long long)gridDim.x * RPB);
     }
 }
 
 extern "C" int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* stats,
-                                  int stat_reps, double count, const float* gamma, const float* beta, float eps, float momentum,
+                                  int stat_reps, int stat_ld, double count, const float* gamma, const float* beta, float eps, float momentum,
                                   float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
                                   const void* residual, int ldr, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
     AY_CHECK_ARG(z && a && stats && count > 0, "bn_train_act: bad args");
+    if (stat_ld <= 0) stat_ld = C;
+    AY_CHECK_ARG(stat_ld >= C, "bn_train_act: stat_ld=%d < C=%d", stat_ld, C);
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && lda % ve == 0 && (!residual || ldr % ve == 0) && C <= 2048,
                  "bn_train_act: C=%d ldz=%d lda=%d", C, ldz, lda);
     if (npix == 0) return AYOLO_OK;
     unsigned grid = grid_pixels(npix, C, ve, 16);
     if (grid > 1024) grid = 1024;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_train_act<T>, dim3(grid), dim3(256), 2 * C * sizeof(float), (hipStream_t)s,
-                                         (const T*)z, ldz, (T*)a, lda, (long long)npix, C, stats, stat_reps > 0 ? stat_reps : 1,
-                                         count, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
-                                         act, (const T*)residual, ldr);)
+    DISPATCH_T(dtype, DISPATCH_AR(act, residual != nullptr,
+               hipLaunchKernelGGL((k_bn_train_act<T, ACT, RES>), dim3(grid), dim3(256), 2 * C * sizeof(float), (hipStream_t)s,
+                                  (const T*)z, ldz, (T*)a, lda, (long long)npix, C, stats, stat_reps > 0 ? stat_reps : 1,
+                                  stat_ld, count, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd,
+                                  (const T*)residual, ldr);))
     AY_CHECK_LAUNCH("k_bn_train_act");
     return AYOLO_OK;
 }
@@ -303,9 +296,9 @@ extern "C" int ayolo_affine_act_res(int dtype, const void* z, int ldz, void* a, 
     AY_CHECK_ARG(z && a && C > 0 && C % ve == 0 && ldz % ve == 0 && lda % ve == 0, "affine_act: C=%d ldz=%d lda=%d", C, ldz, lda);
     AY_CHECK_ARG(C <= 8192, "affine_act: C too large");
     if (npix == 0) return AYOLO_OK;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_affine_act<T>, dim3(grid_pixels(npix, C, ve, 4)), dim3(256),
-                                         0, (hipStream_t)s, (const T*)z, ldz, (T*)a, lda,
-                                         (long long)npix, C, scale, shift, act, (const T*)residual, ldr);)
+    DISPATCH_T(dtype, DISPATCH_AR(act, residual != nullptr,
+               hipLaunchKernelGGL((k_affine_act<T, ACT, RES>), dim3(grid_pixels(npix, C, ve, 4)), dim3(256), 0, (hipStream_t)s,
+                                  (const T*)z, ldz, (T*)a, lda, (long long)npix, C, scale, shift, (const T*)residual, ldr);))
     AY_CHECK_LAUNCH("k_affine_act");
     return AYOLO_OK;
 }
@@ -321,10 +314,25 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     return sg * (1.0f + u * (1.0f - sg));
 }
 
-template <typename T>
+// Per-channel constants of the backward passes.  fp16 storage folds them so that one element costs two fmas before the
+// activation derivative (u = z*A + Bc, xhat = z*invstd + nmi); the fp32 instantiation keeps the reference's operation
+// order ((z - mean) * invstd, xhat * gamma + beta) for the 1e-4 parity mode.
+template <typename T, int ACT>
+__device__ __forceinline__ void bn_bwd_elem(float z, float da, float mu, float is, float ga, float be, float A, float Bc,
+                                            float nmi, float& xh, float& du) {
+    if constexpr (sizeof(T) == 2) {
+        xh = __builtin_fmaf(z, is, nmi);
+        du = ACT ? da * act_grad_t<T>(__builtin_fmaf(z, A, Bc), 1) : da;
+    } else {
+        xh = (z - mu) * is;
+        du = da * act_grad_t<T>(xh * ga + be, ACT);
+    }
+}
+
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, const T* da, int ldda, long long npix, int C,
                                                        const float* mean, const float* invstd, const float* gamma,
-                                                       const float* beta, int act, float* sums, int reps) {
+                                                       const float* beta, float* sums, int reps) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float bs[];   // [RPB][2*C] per-pixel-row partial sums (<= 16 KiB)
     const int CG = C / VE;
@@ -333,12 +341,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
     const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
     if (prow < RPB) {
         for (int cg = cgl; cg < CG; cg += CGT) {
-            float mu[VE], is[VE], ga[VE], be[VE], s1[VE], s2[VE];
+            float mu[VE], is[VE], ga[VE], be[VE], A[VE], Bc[VE], nmi[VE], s1[VE], s2[VE];
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
                 const int c = cg * VE + i;
                 mu[i] = mean[c]; is[i] = invstd[c];
                 ga[i] = gamma ? gamma[c] : 1.0f; be[i] = beta ? beta[c] : 0.0f;
+                A[i] = is[i] * ga[i]; Bc[i] = be[i] - mu[i] * A[i]; nmi[i] = -mu[i] * is[i];
                 s1[i] = 0.0f; s2[i] = 0.0f;
             }
             const long long stride = (long long)gridDim.x * RPB;
@@ -355,10 +364,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < VE; ++i) {
-                        const float xa = (zz[j][i] - mu[i]) * is[i];
-                        const float du = dd[j][i] * act_grad_t<T>(xa * ga[i] + be[i], act);
+                        float xa, du;
+                        bn_bwd_elem<T, ACT>(zz[j][i], dd[j][i], mu[i], is[i], ga[i], be[i], A[i], Bc[i], nmi[i], xa, du);
                         s1[i] += du;
-                        s2[i] += du * xa;
+                        if constexpr (sizeof(T) == 2) s2[i] = __builtin_fmaf(du, xa, s2[i]);
+                        else s2[i] += du * xa;
                     }
             }
             for (; pix < npix; pix += stride) {
@@ -367,10 +377,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
                 load_vec<T>(da + pix * ldda + cg * VE, d0);
 #pragma unroll
                 for (int i = 0; i < VE; ++i) {
-                    float xa = (z0[i] - mu[i]) * is[i];
-                    float dua = d0[i] * act_grad_t<T>(xa * ga[i] + be[i], act);
-                    s1[i] += dua;
-                    s2[i] += dua * xa;
+                    float xa, du;
+                    bn_bwd_elem<T, ACT>(z0[i], d0[i], mu[i], is[i], ga[i], be[i], A[i], Bc[i], nmi[i], xa, du);
+                    s1[i] += du;
+                    if constexpr (sizeof(T) == 2) s2[i] = __builtin_fmaf(du, xa, s2[i]);
+                    else s2[i] += du * xa;
                 }
             }
             float* row = bs + (size_t)prow * 2 * C + cg * VE;
@@ -402,17 +413,18 @@ extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const 
     unsigned grid = grid_pixels(npix, C, ve, red_iters);
     if (grid > (unsigned)red_cap) grid = (unsigned)red_cap;
     const int cg_ = C / ve, cgt_ = cg_ < 256 ? cg_ : 256, rpb_ = 256 / cgt_;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_reduce<T>, dim3(grid), dim3(256),
-                                         (size_t)rpb_ * 2 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
-                                         (long long)npix, C, save_mean, save_invstd, gamma, beta, act, sums, sum_reps);)
+    DISPATCH_T(dtype, DISPATCH_AR(act, false,
+               (void)RES; hipLaunchKernelGGL((k_bn_bwd_reduce<T, ACT>), dim3(grid), dim3(256), (size_t)rpb_ * 2 * C * sizeof(float),
+                                  (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda, (long long)npix, C, save_mean, save_invstd,
+                                  gamma, beta, sums, sum_reps);))
     AY_CHECK_LAUNCH("k_bn_bwd_reduce");
     return AYOLO_OK;
 }
 
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const T* da, int ldda, T* dz, int lddz,
                                                       long long npix, int C, const float* mean, const float* invstd,
-                                                      const float* gamma, const float* beta, int act, const float* sums,
+                                                      const float* gamma, const float* beta, const float* sums,
                                                       int reps, float* dgamma, float* dbeta, float grad_scale) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sh[];   // [6][C]: mean, invstd, gamma, beta, sum_du/n, sum_dux/n
@@ -436,29 +448,33 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
     if (prow >= RPB) return;
     for (int cg = cgl; cg < CG; cg += CGT) {
-        float mu[VE], is[VE], ga[VE], be[VE], m1[VE], m2[VE];
+        // fp16 storage: dz = du*P + (xhat*Rr + Q) with P = gamma*invstd, Q = -P*m1, Rr = -P*m2 (two fmas)
+        float mu[VE], is[VE], ga[VE], be[VE], m1[VE], m2[VE], A[VE], Bc[VE], nmi[VE], P[VE], Q[VE], Rr[VE];
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
             const int c = cg * VE + i;
             mu[i] = sh[c]; is[i] = sh[C + c]; ga[i] = sh[2 * C + c]; be[i] = sh[3 * C + c];
             m1[i] = sh[4 * C + c]; m2[i] = sh[5 * C + c];
+            A[i] = is[i] * ga[i]; Bc[i] = be[i] - mu[i] * A[i]; nmi[i] = -mu[i] * is[i];
+            P[i] = ga[i] * is[i]; Q[i] = -P[i] * m1[i]; Rr[i] = -P[i] * m2[i];
         }
         const long long stride = (long long)gridDim.x * RPB;
         long long pix = (long long)blockIdx.x * RPB + prow;
-        for (; pix + stride < npix; pix += 2 * stride) {
-            float zz[2][VE], dd[2][VE];
+        for (; pix + 3 * stride < npix; pix += 4 * stride) {
+            float zz[4][VE], dd[4][VE];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, zz[j]);
                 load_vec<T>(da + (pix + j * stride) * ldda + cg * VE, dd[j]);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int i = 0; i < VE; ++i) {
-                    const float xh = (zz[j][i] - mu[i]) * is[i];
-                    const float du = dd[j][i] * act_grad_t<T>(xh * ga[i] + be[i], act);
-                    dd[j][i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
+                    float xh, du;
+                    bn_bwd_elem<T, ACT>(zz[j][i], dd[j][i], mu[i], is[i], ga[i], be[i], A[i], Bc[i], nmi[i], xh, du);
+                    if constexpr (sizeof(T) == 2) dd[j][i] = __builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
+                    else dd[j][i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
                 }
                 store_vec<T>(dz + (pix + j * stride) * lddz + cg * VE, dd[j]);
             }
@@ -469,9 +485,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
             load_vec<T>(da + pix * ldda + cg * VE, dv);
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
-                const float xh = (zv[i] - mu[i]) * is[i];
-                const float du = dv[i] * act_grad_t<T>(xh * ga[i] + be[i], act);
-                dv[i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
+                float xh, du;
+                bn_bwd_elem<T, ACT>(zv[i], dv[i], mu[i], is[i], ga[i], be[i], A[i], Bc[i], nmi[i], xh, du);
+                if constexpr (sizeof(T) == 2) dv[i] = __builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
+                else dv[i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
             }
             store_vec<T>(dz + pix * lddz + cg * VE, dv);
         }
@@ -490,10 +507,10 @@ extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const v
     // the per-workgroup prologue stages (6 + 2*reps)*C floats in LDS: scale the elements per workgroup with C
     unsigned grid = grid_pixels(npix, C, ve, C >= 256 ? 16 : 8);
     if (grid > 2048) grid = 2048;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_apply<T>, dim3(grid), dim3(256),
-                                         6 * C * sizeof(float), (hipStream_t)s, (const T*)z, ldz, (const T*)da, ldda,
-                                         (T*)dz, lddz, (long long)npix, C, save_mean, save_invstd, gamma, beta, act,
-                                         sums, sum_reps, dgamma, dbeta, grad_scale);)
+    DISPATCH_T(dtype, DISPATCH_AR(act, false,
+               (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s,
+                                  (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,
+                                  save_invstd, gamma, beta, sums, sum_reps, dgamma, dbeta, grad_scale);))
     AY_CHECK_LAUNCH("k_bn_bwd_apply");
     return AYOLO_OK;
 }

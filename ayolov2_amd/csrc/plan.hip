@@ -99,7 +99,7 @@ extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
                                       (const float*)o.p[3], o.i[4], o.p[4], o.i[5], cs);
             break;
         case AYOLO_OP_BN_TRAIN_ACT:
-            rc = ayolo_bn_train_act(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], (const float*)o.p[2], o.i[4], o.d[0],
+            rc = ayolo_bn_train_act(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], (const float*)o.p[2], o.i[4], o.i[7], o.d[0],
                                     (const float*)o.p[3], (const float*)o.p[4], o.f[0], o.f[1], (float*)o.p[5], (float*)o.p[6],
                                     (float*)o.p[7], (float*)o.p[8], o.i[5], o.p[9], o.i[6], cs);
             break;

@@ -61,6 +61,7 @@ import os as _os
 
 OP_SIDE = 0x100
 WGRAD_SIDE_STREAM = _os.environ.get("AYOLO_WGRAD_STREAM", "1") == "1"
+MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: cv1 | cv2 as one conv
 
 
 class PlanUnsupported(Exception):
@@ -166,22 +167,45 @@ class TrainPlan:
     # ------------------------------------------------------------------ conv + BN + act
     def _conv_block(self, mod: Conv, x: Optional[Act], dst: Optional[Act], residual: Optional[Act] = None,
                     image: bool = False) -> Act:
-        conv, bn = mod.conv, getattr(mod, "batch_norm", None)
-        if not isinstance(conv, nn.Conv2d) or bn is None or conv.bias is not None or bn.momentum is None:
-            raise PlanUnsupported("non-standard Conv block")
-        if bn.running_mean is None or bn.running_mean.dtype != torch.float32 or conv.weight.dtype != torch.float32:
-            raise PlanUnsupported("needs fp32 master weights / BN buffers")
-        act = _act_code(mod.activation)
+        return self._conv_group([mod], x, [dst], residual, image)[0]
+
+    @staticmethod
+    def _mergeable(a: Conv, b: Conv) -> bool:
+        """Two Conv blocks over the SAME input can run as one conv with concatenated output channels (C3's cv1 | cv2)."""
+        ca, cb = a.conv, b.conv
+        if not (isinstance(ca, nn.Conv2d) and isinstance(cb, nn.Conv2d)):
+            return False
+        same = (ca.in_channels == cb.in_channels and ca.kernel_size == cb.kernel_size and ca.stride == cb.stride
+                and ca.padding == cb.padding and ca.weight.dtype == cb.weight.dtype)
+        k = ca.in_channels * ca.kernel_size[0] * ca.kernel_size[1]
+        # the two weight gradients must be adjacent in the gradient arena (64-element slots), outputs 8-channel aligned
+        return bool(same and MERGE_SIBLINGS and (ca.out_channels * k) % 64 == 0 and ca.out_channels % 8 == 0)
+
+    def _conv_group(self, mods: Sequence[Conv], x: Optional[Act], dsts: Sequence[Optional[Act]],
+                    residual: Optional[Act] = None, image: bool = False) -> List[Act]:
+        """One or several Conv-BN-act blocks reading the same input.  Several blocks (C3's cv1 and cv2) become ONE conv
+        whose output channels are the blocks' channels side by side: the input is read once by the forward conv and once
+        by the weight-gradient kernel, and ONE dgrad over the concatenated dz replaces a dgrad plus an accumulating
+        (read-modify-write) dgrad.  BatchNorm / activation stay per block (channel slices of the shared z / dz)."""
         dt, dev = self.dt, self.device
-        w32 = conv.weight
-        if not w32.detach().permute(0, 2, 3, 1).is_contiguous():
-            w32.data = w32.data.contiguous(memory_format=torch.channels_last)
-        Cout, Cin, kh, kw = w32.shape
+        convs = [m.conv for m in mods]
+        bns = [getattr(m, "batch_norm", None) for m in mods]
+        for conv, bn in zip(convs, bns):
+            if not isinstance(conv, nn.Conv2d) or bn is None or conv.bias is not None or bn.momentum is None:
+                raise PlanUnsupported("non-standard Conv block")
+            if bn.running_mean is None or bn.running_mean.dtype != torch.float32 or conv.weight.dtype != torch.float32:
+                raise PlanUnsupported("needs fp32 master weights / BN buffers")
+            if not conv.weight.detach().permute(0, 2, 3, 1).is_contiguous():
+                conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+        assert len(mods) == 1 or (residual is None and not image)
+        couts = [c.weight.shape[0] for c in convs]
+        Ct = sum(couts)
+        _, Cin, kh, kw = convs[0].weight.shape
         if image:
             xshape = (self.B, self.Cimg, self.H, self.W)
         else:
             xshape = tuple(x.t.shape)
-        geo = F_._Geometry(xshape, w32.shape, _pair(conv.stride), _pair(conv.padding), dt)
+        geo = F_._Geometry(xshape, (Ct, Cin, kh, kw), _pair(convs[0].stride), _pair(convs[0].padding), dt)
         if image:
             packed = ops.new_act(self.B, geo.cin_pad, self.H, self.W, dt, dev)
             self.keep.append(packed)
@@ -193,85 +217,105 @@ class TrainPlan:
                 raise PlanUnsupported("channel count not a multiple of the vector width")
             xk = x.t
         _, _, _, _, ldx = ops.nhwc_info(xk)
-        # weights: compute-dtype copy and its transpose, refreshed by a cast op at the start of every forward
-        wc = torch.empty((Cout, kh, kw, geo.cin_pad), dtype=dt, device=dev)
-        wt = torch.empty((geo.cin_pad, kh, kw, Cout), dtype=dt, device=dev)
-        self.keep += [wc, wt]
-        self.casts.append(_op(OP_CAST_WEIGHT, i=(Cout, kh, kw, Cin, Cout, geo.cin_pad, ops.dtype_code(dt)), p=(w32, wc, wt)))
-        z = self._new_act(Cout, geo.Ho, geo.Wo)
-        a = dst if dst is not None else self._new_act(Cout, geo.Ho, geo.Wo)
-        assert a.C == Cout and tuple(a.t.shape[2:]) == (geo.Ho, geo.Wo)
-        _, _, _, _, lda = ops.nhwc_info(a.t)
-        R = ops.STAT_REPS
-        st_off = self.stats.request(R * 2 * Cout)
-        sm_off = self.small.request(4 * Cout)
-        npix = self.B * geo.Ho * geo.Wo
-        d_fwd = geo.desc(dt, ldx, Cout)
         code = ops.dtype_code(dt)
-        op_conv = _op(OP_CONV_FWD, i=(EPI_NONE, R, 0), p=(xk, wc, z.t, None, None, None), conv=d_fwd)
-        res_t = residual.t if residual is not None else None
-        ldr = ops.nhwc_info(res_t)[4] if res_t is not None else 0
-        # batch statistics -> scale/shift, running-stat update and a = act(bn(z)) (+ residual) in one kernel
-        op_act = _op(OP_BN_TRAIN_ACT, i=(code, Cout, lda, Cout, R, act, ldr), l=(npix,), d=(float(npix),),
-                     f=(bn.eps, bn.momentum),
-                     p=(z.t, a.t, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, None, res_t))
-        self.fwd += [op_conv, op_act]
-
-        def bind_fwd():
-            st = self.stats.view(st_off, R * 2 * Cout)
-            sm = self.small.view(sm_off, 4 * Cout)
-            op_conv.p[5] = st.data_ptr()
-            op_act.p[2] = st.data_ptr()
-            op_act.p[7] = sm[0:Cout].data_ptr()              # save_mean
-            op_act.p[8] = sm[Cout:2 * Cout].data_ptr()       # save_invstd
-
-        self.late.append(bind_fwd)
-        if bn.num_batches_tracked is not None:
-            self.bn_counters.append(bn.num_batches_tracked)
-        # ---- parameters / gradient slots
+        # weights: compute-dtype copy and its transpose, refreshed by a cast op at the start of every forward
+        wc = torch.empty((Ct, kh, kw, geo.cin_pad), dtype=dt, device=dev)
+        wt = torch.empty((geo.cin_pad, kh, kw, Ct), dtype=dt, device=dev)
+        self.keep += [wc, wt]
+        c0s = [sum(couts[:j]) for j in range(len(couts))]
+        for conv, c0, co in zip(convs, c0s, couts):
+            self.casts.append(_op(OP_CAST_WEIGHT, i=(co, kh, kw, Cin, co, geo.cin_pad, code, Ct),
+                                  p=(conv.weight, wc[c0:c0 + co], wt[..., c0:])))
+        z = self._new_act(Ct, geo.Ho, geo.Wo)
+        R = ops.STAT_REPS
+        st_off = self.stats.request(R * 2 * Ct)
+        npix = self.B * geo.Ho * geo.Wo
+        op_conv = _op(OP_CONV_FWD, i=(EPI_NONE, R, 0), p=(xk, wc, z.t, None, None, None), conv=geo.desc(dt, ldx, Ct))
+        self.fwd.append(op_conv)
+        self.late.append(lambda: op_conv.p.__setitem__(5, self.stats.view(st_off, R * 2 * Ct).data_ptr()))
         K = geo.kdims[0] * geo.kdims[1] * geo.Cin_k
+        self.dz_elems = max(self.dz_elems, npix * Ct)
+        outs: List[Act] = []
+        per = []          # per block: (bn, act, a, zj, c0, co, sm_off, su_off, gg_off, gb_off)
+        gw_off0 = None
+        for j, (mod, conv, bn, c0, co) in enumerate(zip(mods, convs, bns, c0s, couts)):
+            act = _act_code(mod.activation)
+            dst = dsts[j]
+            a = dst if dst is not None else self._new_act(co, geo.Ho, geo.Wo)
+            assert a.C == co and tuple(a.t.shape[2:]) == (geo.Ho, geo.Wo)
+            _, _, _, _, lda = ops.nhwc_info(a.t)
+            zj = z.t[:, c0:c0 + co] if len(mods) > 1 else z.t
+            sm_off = self.small.request(4 * co)
+            res_t = residual.t if residual is not None else None
+            ldr = ops.nhwc_info(res_t)[4] if res_t is not None else 0
+            # batch statistics -> scale/shift, running-stat update and a = act(bn(z)) (+ residual) in one kernel
+            op_act = _op(OP_BN_TRAIN_ACT, i=(code, Ct, lda, co, R, act, ldr, Ct), l=(npix,), d=(float(npix),),
+                         f=(bn.eps, bn.momentum),
+                         p=(zj, a.t, None, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, None, res_t))
+            self.fwd.append(op_act)
 
-        def wview(buf, Cout=Cout, kh=kh, kw=kw, cp=geo.cin_pad, Cin=Cin):
-            g = buf.view(Cout, kh, kw, cp)[..., :Cin].permute(0, 3, 1, 2)
-            return g if cp == Cin else g.contiguous(memory_format=torch.channels_last)
+            def bind_fwd(op_act=op_act, c0=c0, co=co, sm_off=sm_off):
+                st = self.stats.view(st_off, R * 2 * Ct)
+                sm = self.small.view(sm_off, 4 * co)
+                op_act.p[2] = st.data_ptr() + 4 * c0
+                op_act.p[7] = sm[0:co].data_ptr()              # save_mean
+                op_act.p[8] = sm[co:2 * co].data_ptr()         # save_invstd
 
-        gw_off = self._register_param(conv.weight, Cout * K, wview)
-        gg_off = self._register_param(bn.weight, Cout, lambda b: b) if bn.weight is not None else None
-        gb_off = self._register_param(bn.bias, Cout, lambda b: b) if bn.bias is not None else None
-        su_off = self.sums.request(R * 2 * Cout)
-        self.dz_elems = max(self.dz_elems, npix * Cout)
+            self.late.append(bind_fwd)
+            if bn.num_batches_tracked is not None:
+                self.bn_counters.append(bn.num_batches_tracked)
+
+            # ---- parameters / gradient slots (the blocks' weight gradients are adjacent: one wgrad writes them all)
+            def wview(buf, co=co, kh=kh, kw=kw, cp=geo.cin_pad, Cin=Cin):
+                g = buf.view(co, kh, kw, cp)[..., :Cin].permute(0, 3, 1, 2)
+                return g if cp == Cin else g.contiguous(memory_format=torch.channels_last)
+
+            gw_off = self._register_param(conv.weight, co * K, wview)
+            if j == 0:
+                gw_off0 = gw_off
+            else:
+                assert gw_off == gw_off0 + c0 * K, "merged conv: weight gradients must be adjacent in the arena"
+            per.append([bn, act, a, zj, c0, co, sm_off])
+            outs.append(a)
+        for e in per:
+            bn, co = e[0], e[5]
+            e.append(self.sums.request(R * 2 * co))
+            e.append(self._register_param(bn.weight, co, lambda b: b) if bn.weight is not None else None)
+            e.append(self._register_param(bn.bias, co, lambda b: b) if bn.bias is not None else None)
         x_act = x
 
         def emit_bwd():
-            da = a.grad()
-            if not a.is_init():
-                raise RuntimeError("plan: gradient of a conv output was never produced")
-            _, _, _, _, ldda = ops.nhwc_info(da)
-            sm = self.small.view(sm_off, 4 * Cout)
-            su = self.sums.view(su_off, R * 2 * Cout)
             ga = self.gradarena
-            dgam = ga.view(gg_off, Cout) if gg_off is not None else None
-            dbet = ga.view(gb_off, Cout) if gb_off is not None else None
-            dz = self._dz(npix * Cout)
-            self.bwd.append(_op(OP_BN_BWD_REDUCE, i=(code, Cout, ldda, Cout, act, R), l=(npix,),
-                                p=(z.t, da, sm[0:Cout], sm[Cout:2 * Cout], bn.weight, bn.bias, su)))
-            self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Cout, ldda, Cout, Cout, act, R), l=(npix,), f=(1.0,),
-                                p=(z.t, da, dz, sm[0:Cout], sm[Cout:2 * Cout], bn.weight, bn.bias, su, dgam, dbet)))
-            if residual is not None:      # shortcut: d(residual) += d(a)
-                dr = residual.grad()
-                self.bwd.append(_op(OP_COPY2D, i=(code, ldda, ops.nhwc_info(dr)[4], Cout, int(residual.is_init())), l=(npix,),
-                                    p=(da, dr)))
-                residual.mark_init()
+            dz = self._dz(npix * Ct)
+            dzv = dz.view(self.B, geo.Ho, geo.Wo, Ct).permute(0, 3, 1, 2)
+            for bn, act, a, zj, c0, co, sm_off, su_off, gg_off, gb_off in per:
+                da = a.grad()
+                if not a.is_init():
+                    raise RuntimeError("plan: gradient of a conv output was never produced")
+                _, _, _, _, ldda = ops.nhwc_info(da)
+                sm = self.small.view(sm_off, 4 * co)
+                su = self.sums.view(su_off, R * 2 * co)
+                dgam = ga.view(gg_off, co) if gg_off is not None else None
+                dbet = ga.view(gb_off, co) if gb_off is not None else None
+                self.bwd.append(_op(OP_BN_BWD_REDUCE, i=(code, Ct, ldda, co, act, R), l=(npix,),
+                                    p=(zj, da, sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su)))
+                self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R), l=(npix,), f=(1.0,),
+                                    p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet)))
+                if residual is not None:      # shortcut: d(residual) += d(a)
+                    dr = residual.grad()
+                    self.bwd.append(_op(OP_COPY2D, i=(code, ldda, ops.nhwc_info(dr)[4], co, int(residual.is_init())), l=(npix,),
+                                        p=(da, dr)))
+                    residual.mark_init()
             if not image:
                 dx = x_act.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
-                                    conv=geo.desc(dt, ops.nhwc_info(dx)[4], Cout)))
+                                    conv=geo.desc(dt, ops.nhwc_info(dx)[4], Ct)))
                 x_act.mark_init()
-            self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(xk, dz, ga.view(gw_off, Cout * K)),
-                                conv=geo.desc(dt, ldx, Cout)))
+            self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(xk, dz, ga.view(gw_off0, Ct * K)),
+                                conv=geo.desc(dt, ldx, Ct)))
 
         self.bwd_emitters.append(emit_bwd)
-        return a
+        return outs
 
     def _batched_casts(self) -> List[Op]:
         """All per-layer fp32 -> compute-dtype weight casts (and transposes) as ONE launch: the job table lives in
@@ -280,10 +324,10 @@ class TrainPlan:
             return []
         import numpy as np
         job_t = np.dtype([("w32", "<u8"), ("w", "<u8"), ("wt", "<u8"), ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"),
-                          ("Cout_pad", "<i4"), ("Cin_pad", "<i4"), ("reserved", "<i4")])
+                          ("Cout_pad", "<i4"), ("Cin_pad", "<i4"), ("wt_ld", "<i4")])
         jobs = np.zeros(len(self.casts), dtype=job_t)
         for k, o in enumerate(self.casts):
-            jobs[k] = (o.p[0] or 0, o.p[1] or 0, o.p[2] or 0, o.i[0], o.i[1] * o.i[2], o.i[3], o.i[4], o.i[5], 0)
+            jobs[k] = (o.p[0] or 0, o.p[1] or 0, o.p[2] or 0, o.i[0], o.i[1] * o.i[2], o.i[3], o.i[4], o.i[5], o.i[7])
         tab = torch.from_numpy(jobs.view(np.uint8).copy()).to(self.device)
         self.keep.append(tab)
         return [_op(OP_CAST_WEIGHTS, i=(len(self.casts), self.casts[0].i[6]), p=(tab,))]
@@ -298,10 +342,15 @@ class TrainPlan:
         _, _, H, W = x.t.shape
         cat = self._new_act(2 * h, H, W)
         n = len(m.m)
-        t = self._conv_block(m.cv1, x, cat.slice(0, h) if n == 0 else None)
+        d1 = cat.slice(0, h) if n == 0 else None
+        if self._mergeable(m.cv1, m.cv2):
+            t = self._conv_group([m.cv1, m.cv2], x, [d1, cat.slice(h, 2 * h)])[0]
+        else:
+            t = self._conv_block(m.cv1, x, d1)
         for bi, b in enumerate(m.m):
             t = self._bottleneck(b, t, cat.slice(0, h) if bi == n - 1 else None)
-        self._conv_block(m.cv2, x, cat.slice(h, 2 * h))
+        if not self._mergeable(m.cv1, m.cv2):
+            self._conv_block(m.cv2, x, cat.slice(h, 2 * h))
         return self._conv_block(m.cv3, cat, dst)
 
     def _pool(self, k: int, src: Act, dst: Act) -> None:

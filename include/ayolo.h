@@ -94,7 +94,8 @@ int ayolo_ema_update(const ayolo_ema_job* jobs_dev, int njobs, float decay, ayol
  * each entry must have Cout_pad*taps*Cin_pad < 2^32). */
 typedef struct ayolo_cast_job {
     const float* w32; void* w; void* wt;      /* as ayolo_cast_weight (w / wt nullable)                           */
-    int Cout, taps, Cin, Cout_pad, Cin_pad, reserved;
+    int Cout, taps, Cin, Cout_pad, Cin_pad;
+    int wt_ld;                                /* row stride of wt in elements (0 = Cout_pad): wt may be a column slice */
 } ayolo_cast_job;
 int ayolo_cast_weights(const ayolo_cast_job* jobs_dev, int njobs, int dtype, ayolo_stream s);
 
@@ -108,9 +109,11 @@ int ayolo_bn_finalize(const float* stats, int stat_reps, int C, double count, co
                       float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                       float* save_invstd, float* scale, float* shift, ayolo_stream s);
 /* ayolo_bn_finalize + ayolo_affine_act(_res) in one pass over z: a = act(batchnorm_train(z)) (+ residual), running
- * statistics updated and save_mean / save_invstd written (all four nullable) by the kernel itself. */
+ * statistics updated and save_mean / save_invstd written (all four nullable) by the kernel itself.
+ * stats: float[stat_reps][2][stat_ld] as accumulated by ayolo_conv_fwd, pointing at this layer's first channel;
+ * stat_ld (0 = C) is the channel count of the conv that produced z when this layer is a channel slice of it. */
 int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* stats,
-                       int stat_reps, double count, const float* gamma, const float* beta, float eps, float momentum,
+                       int stat_reps, int stat_ld, double count, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
                        const void* residual, int ldr, ayolo_stream s);
 /* a = act(z*scale[c] + shift[c]); act: 0 identity, 1 SiLU.  z: npix x C (ldz), a: npix x C (lda). */
