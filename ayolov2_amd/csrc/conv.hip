@@ -195,51 +195,85 @@ __device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T,
     }
 }
 
+// fp16: the fragments of a step (2 A + 2*NI B, 16 bytes each) are fetched in one go and consumed by g_mma_frags.  Left
+// to itself hipcc reuses ONE register quad for every B fragment (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, eight times
+// per step): the wave then pays the LDS latency per MFMA instead of once per step.  The step loop issues the fetch right
+// after the barrier and puts the address arithmetic + DMA issue of step s+2 between the fetch and the MFMAs, so the LDS
+// latency is covered by that scalar / VALU work instead of being waited for.
+template <typename T, int TM, int TPX>
+struct GFrags { half8 a[BK / 16], b[BK / 16][GT<T, TM, TPX>::NI]; };
+
+template <typename T, int TM, int TPX>
+__device__ __forceinline__ void g_fetch_frags(const unsigned char* stage, int arow, int xrow, int swz, int lane,
+                                              GFrags<T, TM, TPX>& f) {
+    using G = GT<T, TM, TPX>;
+    const unsigned char* bx = stage + xrow;
+    const unsigned char* bw = stage + G::XSTAGE + arow;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+        const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
+        f.a[kk] = *reinterpret_cast<const half8*>(bw + slot);
+#pragma unroll
+        for (int ni = 0; ni < G::NI; ++ni) f.b[kk][ni] = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
+    }
+}
+
+// one 16-deep half of a step (the 256-pixel x 128-channel tile fetches and consumes a step in two halves: all of its
+// 18 fragments at once would not fit the 256-register budget of 2 waves per SIMD next to the 128 accumulators; the
+// eight MFMAs of the first half (512 cycles in the matrix pipe) cover the LDS latency of the second half's fetch)
+template <typename T, int TM, int TPX>
+struct GFragK { half8 a, b[GT<T, TM, TPX>::NI]; };
+
+template <typename T, int TM, int TPX>
+__device__ __forceinline__ void g_fetch_k(const unsigned char* stage, int arow, int xrow, int swz, int lane, int kk,
+                                          GFragK<T, TM, TPX>& f) {
+    using G = GT<T, TM, TPX>;
+    const unsigned char* bx = stage + xrow;
+    const unsigned char* bw = stage + G::XSTAGE + arow;
+    const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
+    f.a = *reinterpret_cast<const half8*>(bw + slot);
+#pragma unroll
+    for (int ni = 0; ni < G::NI; ++ni) f.b[ni] = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
+}
+
+template <typename T, int TM, int TPX>
+__device__ __forceinline__ void g_mma_k(const GFragK<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NI]) {
+#pragma unroll
+    for (int ni = 0; ni < GT<T, TM, TPX>::NI; ++ni) mma_step(f.a, f.b[ni], acc[ni]);
+}
+
+template <typename T, int TM, int TPX>
+__device__ __forceinline__ void g_mma_frags(const GFrags<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NI]) {
+    using G = GT<T, TM, TPX>;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+        for (int ni = 0; ni < G::NI; ++ni) mma_step(f.a[kk], f.b[kk][ni], acc[ni]);
+}
+
+// fp32 (exact-parity mode): fragments are fetched and consumed pair by pair
 template <typename T, int TM, int TPX>
 __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int xrow, int swz, int lane,
                                       float16v (&acc)[GT<T, TM, TPX>::NI]) {
     using G = GT<T, TM, TPX>;
     const unsigned char* bx = stage + xrow;
     const unsigned char* bw = stage + G::XSTAGE + arow;
-    if constexpr (sizeof(T) == 2) {
-        // All fragments of the step are fetched before the first MFMA.  Left to itself hipcc reuses ONE register quad for
-        // every B fragment (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, eight times per step): the wave then pays the LDS
-        // latency per MFMA instead of once per step.  The scheduling barrier keeps the two phases apart; the compiler's
-        // counted lgkmcnt waits release the MFMAs one by one as the fragments arrive.
-        half8 a[BK / 16], b[BK / 16][G::NI];
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
-            a[kk] = *reinterpret_cast<const half8*>(bw + slot);
-#pragma unroll
-            for (int ni = 0; ni < G::NI; ++ni) b[kk][ni] = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk)
-#pragma unroll
-            for (int ni = 0; ni < G::NI; ++ni) mma_step(a[kk], b[kk][ni], acc[ni]);
-        return;
-    }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-        if constexpr (sizeof(T) == 2) {
-        } else {
-            const int c0 = kk * 4 + (lane >> 5) * 2;
-            const int s0 = (c0 ^ swz) * 16, s1 = ((c0 + 1) ^ swz) * 16;
-            Tr<float>::frag a;
-            {
-                const float4v u = *reinterpret_cast<const float4v*>(bw + s0), v = *reinterpret_cast<const float4v*>(bw + s1);
-                a.v[0] = u[0]; a.v[1] = u[1]; a.v[2] = u[2]; a.v[3] = u[3]; a.v[4] = v[0]; a.v[5] = v[1]; a.v[6] = v[2]; a.v[7] = v[3];
-            }
+        const int c0 = kk * 4 + (lane >> 5) * 2;
+        const int s0 = (c0 ^ swz) * 16, s1 = ((c0 + 1) ^ swz) * 16;
+        Tr<float>::frag a;
+        {
+            const float4v u = *reinterpret_cast<const float4v*>(bw + s0), v = *reinterpret_cast<const float4v*>(bw + s1);
+            a.v[0] = u[0]; a.v[1] = u[1]; a.v[2] = u[2]; a.v[3] = u[3]; a.v[4] = v[0]; a.v[5] = v[1]; a.v[6] = v[2]; a.v[7] = v[3];
+        }
 #pragma unroll
-            for (int ni = 0; ni < G::NI; ++ni) {
-                const unsigned char* q = bx + ni * 32 * G::ROWB;
-                const float4v u = *reinterpret_cast<const float4v*>(q + s0), v = *reinterpret_cast<const float4v*>(q + s1);
-                Tr<float>::frag b;
-                b.v[0] = u[0]; b.v[1] = u[1]; b.v[2] = u[2]; b.v[3] = u[3]; b.v[4] = v[0]; b.v[5] = v[1]; b.v[6] = v[2]; b.v[7] = v[3];
-                mma_step(a, b, acc[ni]);
-            }
+        for (int ni = 0; ni < G::NI; ++ni) {
+            const unsigned char* q = bx + ni * 32 * G::ROWB;
+            const float4v u = *reinterpret_cast<const float4v*>(q + s0), v = *reinterpret_cast<const float4v*>(q + s1);
+            Tr<float>::frag b;
+            b.v[0] = u[0]; b.v[1] = u[1]; b.v[2] = u[2]; b.v[3] = u[3]; b.v[4] = v[0]; b.v[5] = v[1]; b.v[6] = v[2]; b.v[7] = v[3];
+            mma_step(a, b, acc[ni]);
         }
     }
 }
@@ -506,10 +540,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     // fill) so that every step has exactly LPS DMA instructions per thread
     unsigned ld_tile = cur_tile;
     int ld_kt = 0, ld_cls = 0, ld_nk = cur_nk;
+    // tap range of the loader's class in registers: indexing the kernarg arrays with the runtime class cost two s_load +
+    // s_waitcnt round trips in EVERY step
+    int ld_tap0 = p.ctap0[0], ld_ntap = p.cnt[0];
     bool ld_valid = true;
     g_setup_rows<T, TM, TPX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
     __syncthreads();                          // tap table visible
-#define G_ISSUE(so) g_issue<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, p.ctap0[ld_cls], p.cnt[ld_cls], sTap, lds_tiles, so, rsX, rsW, wave, kc);
+#define G_ISSUE(so) g_issue<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, lds_tiles, so, rsX, rsW, wave, kc);
 #define G_ADVANCE()                                                                           \
     {                                                                                         \
         if (++ld_kt == ld_nk) {                                                               \
@@ -521,6 +558,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
                 g_setup_rows<T, TM, TPX>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);   \
             }                                                                                 \
             ld_nk = G_NK(ld_cls);                                                             \
+            ld_tap0 = p.ctap0[ld_cls]; ld_ntap = p.cnt[ld_cls];                               \
         }                                                                                     \
     }
     unsigned so0 = 0, so1 = G::STAGE, so2 = 2 * G::STAGE;
@@ -534,9 +572,32 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
         // step s landed (this wave's part), then: everyone's part landed AND everyone finished reading step s-1
         if (after_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
         __builtin_amdgcn_s_barrier();
-        G_ISSUE(so2)                                     // step s+2 -> the stage step s-1 used
-        G_ADVANCE()
-        g_mma<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, acc);
+        if constexpr (sizeof(T) == 2 && G::NI >= 8) {
+            static_assert(BK == 32, "two 16-deep halves per step");
+            GFragK<T, TM, TPX> f0, f1;
+            g_fetch_k<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, 0, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            G_ISSUE(so2)                                 // step s+2 -> the stage step s-1 used
+            G_ADVANCE()
+            __builtin_amdgcn_sched_barrier(0);
+            g_mma_k<T, TM, TPX>(f0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            g_fetch_k<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            g_mma_k<T, TM, TPX>(f1, acc);
+        } else if constexpr (sizeof(T) == 2) {
+            GFrags<T, TM, TPX> fr;
+            g_fetch_frags<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, fr);
+            __builtin_amdgcn_sched_barrier(0);
+            G_ISSUE(so2)                                 // step s+2 -> the stage step s-1 used
+            G_ADVANCE()
+            __builtin_amdgcn_sched_barrier(0);
+            g_mma_frags<T, TM, TPX>(fr, acc);
+        } else {
+            G_ISSUE(so2)
+            G_ADVANCE()
+            g_mma<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, acc);
+        }
         // The last MFMA's result must not be read for passes+2 wait states.  hipcc (ROCm 7.2) covers that hazard inside a
         // basic block but was seen to miss it across the loop back edge (fp32 head variant: the next iteration opened
         // with v_accvgpr_read of the accumulator's last register, which came back stale) -- pad it here, explicitly.
@@ -576,22 +637,36 @@ static int num_cus() {
     return g_num_cu;
 }
 
+// workgroups per CU of one k_gconv instantiation (LDS-bound; the launch bounds give the register budget to match)
+template <typename T, int TM, int TPX>
+static constexpr int gconv_bpc() {
+    using G = GT<T, TM, TPX>;
+    int bpc = (int)(160 * 1024 / G::LDS);
+    const int bpc_max = sizeof(T) == 2 ? (G::LDS > 56 * 1024 ? 2 : (TM == 128 ? 3 : 4)) : 1;
+    return bpc > bpc_max ? bpc_max : bpc;
+}
+
+// persistent grid of one instantiation: pixel-tile slots (a multiple of the 8 XCDs) and the number of tiles the busiest
+// slot walks ("waves")
+struct GGrid { long long slots; long long waves; };
+static GGrid gconv_grid(long long Mtotal, int tp, int ntn, int bpc) {
+    const long long ntiles = (Mtotal + tp - 1) / tp;
+    long long want_slots = (long long)num_cus() * bpc / ntn;
+    if (want_slots < 8) want_slots = 8;
+    long long slots = ntiles < want_slots ? ntiles : want_slots;
+    slots = (slots + 7) / 8 * 8;
+    const long long tpx = (ntiles + 7) / 8, spx = slots / 8;         // per XCD band
+    return {slots, (tpx + spx - 1) / spx};
+}
+
 template <typename T, int TM, int EM, int TPX>
 static int launch_gconv_tp(GConvP p, hipStream_t s) {
     using G = GT<T, TM, TPX>;
     const size_t lds = G::LDS;
-    const long long ntiles = (p.Mtotal + G::TP - 1) / G::TP;
     p.ntn = (p.Nout + TM - 1) / TM;
-    // persistent grid: as many workgroups per CU as LDS / registers allow, pixel-tile slots a multiple of the 8 XCDs
     static const int bpc_env = getenv("AYOLO_GCONV_BPC") ? atoi(getenv("AYOLO_GCONV_BPC")) : 0;
-    int bpc = (int)(160 * 1024 / lds);
-    const int bpc_max = sizeof(T) == 2 ? (G::LDS > 56 * 1024 ? 2 : (TM == 128 ? 3 : 4)) : 1;
-    if (bpc > bpc_max) bpc = bpc_max;
-    if (bpc_env > 0) bpc = bpc_env;
-    long long want_slots = (long long)num_cus() * bpc / p.ntn;
-    if (want_slots < 8) want_slots = 8;
-    long long slots = ntiles < want_slots ? ntiles : want_slots;
-    slots = (slots + 7) / 8 * 8;
+    const int bpc = bpc_env > 0 ? bpc_env : gconv_bpc<T, TM, TPX>();
+    const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc).slots;
     p.nslots = (int)slots;
     dim3 grid((unsigned)(slots * p.ntn));
     static bool attr_set = false;
@@ -607,13 +682,27 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
 
 template <typename T, int TM, int EM>
 static int launch_gconv_em(const GConvP& p, hipStream_t s) {
-    // 256-pixel tiles for the narrow channel tiles when the reduction has >= 4 steps (measured: 3x3 / stem layers gain
-    // 10-15 %, one- and two-step 1x1 layers prefer the 128-pixel tile's higher occupancy)
-    if constexpr (TM < 128) {
-        static const int force = getenv("AYOLO_GCONV_TP") ? atoi(getenv("AYOLO_GCONV_TP")) : 0;
-        const bool wide = force ? force == 256 : (p.ntaps * p.C >= 128 && p.Mtotal >= 256 * 512);
-        if (wide) return launch_gconv_tp<T, TM, EM, 256>(p, s);
+    // Pixel-tile size, 128 or 256 (measured per layer on the YOLOv5s shapes at batch 64, profiles/r02_conv_tile_sweep.txt):
+    //  * one wave of 128-pixel tiles fits the chip: keep 128 (most workgroups in flight; the 20^2 maps);
+    //  * few waves (<= 3) and 256-pixel tiles need fewer: take 256.  A workgroup's step is latency-bound there, so the
+    //    number of tile "waves" is what counts: 102 400 pixels are 800 tiles of 128 on 768 slots (3 workgroups per CU)
+    //    = 2 waves, the second one 4 % full, but ONE wave of 400 tiles of 256 on 512 slots (40^2 maps: -15 %);
+    //  * many waves: the wider tile wins through fewer barriers and LDS fragment reads per MFMA when the reduction is
+    //    deep enough -- TM 64: always; TM 128: K >= 256 (3x3); TM 32: K >= 128 (stem) -- and loses a few % on one- and
+    //    two-step 1x1 layers (lower occupancy).
+    static const int force = getenv("AYOLO_GCONV_TP") ? atoi(getenv("AYOLO_GCONV_TP")) : 0;
+    bool wide;
+    if (force) wide = force == 256;
+    else {
+        const int ntn = (p.Nout + TM - 1) / TM;
+        const int K = p.ntaps * p.C;
+        const long long w128 = gconv_grid(p.Mtotal, 128, ntn, gconv_bpc<T, TM, 128>()).waves;
+        const long long w256 = gconv_grid(p.Mtotal, 256, ntn, gconv_bpc<T, TM, 256>()).waves;
+        if (w128 <= 1) wide = false;
+        else if (w128 <= 3 && w256 < w128) wide = true;
+        else wide = TM == 64 ? true : (TM == 128 ? K >= 256 : K >= 128);
     }
+    if (wide) return launch_gconv_tp<T, TM, EM, 256>(p, s);
     return launch_gconv_tp<T, TM, EM, 128>(p, s);
 }
 
@@ -926,12 +1015,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     for (int kt = 0; kt < nk; ++kt) {
         wait_vm<W::LPS>();                       // step kt landed (this wave's part) ...
         __builtin_amdgcn_s_barrier();            // ... everyone's part landed, everyone finished reading step kt-1
-        W_ISSUE(kt + 2, so2)
         const unsigned char* cX = smem_raw + so0;
         const unsigned char* cY = smem_raw + so0 + W::XSTAGE;
+        if constexpr (sizeof(T) == 4) W_ISSUE(kt + 2, so2)
         if constexpr (sizeof(T) == 2) {
-            // every fragment of the step first, then the MFMAs back to back (see g_mma: hipcc otherwise serialises
-            // ds_read -> lgkmcnt(0) -> v_mfma through one register quad)
+            // every fragment of the step first (see g_fetch_frags: hipcc otherwise serialises ds_read -> lgkmcnt(0) ->
+            // v_mfma through one register quad), then the pixel decode + DMA issue of step kt+2 while the transposing
+            // reads are in flight, then the MFMAs back to back
             half8 fa[W::BP / 16], fb[W::BP / 16][W::NI];
             const int csub = ((lane >> 4) & 1) * 16;
 #pragma unroll
@@ -942,6 +1032,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
                 for (int ni = 0; ni < W::NI; ++ni)
                     fb[kk][ni] = tr_frag_sw<W::XROWB, W::XG, W::XRPB>(cX, k0, wn * W::NI * 32 + ni * 32 + csub, lane);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            W_ISSUE(kt + 2, so2)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < W::BP / 16; ++kk)

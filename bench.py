@@ -56,8 +56,13 @@ def build_train_objects(model_name, device, world_size):
             pg_bn.append(mod.weight)
         elif hasattr(mod, "weight") and isinstance(mod.weight, nn.Parameter):
             pg_w.append(mod.weight)
-    # fused multi-tensor SGD: one launch per parameter group and, with GradScaler, no found-inf host sync
-    opt = torch.optim.SGD(pg_bn, lr=HYP["lr"], momentum=HYP["momentum"], nesterov=True, fused=True)
+    # the whole SGD-nesterov step (unscale, found-inf skip, weight decay, momentum) is ONE HIP launch (ayolo_sgd_step);
+    # AYOLO_TORCH_SGD=1 times torch's fused multi-tensor kernels instead (one launch per parameter group)
+    if os.environ.get("AYOLO_TORCH_SGD") == "1":
+        opt = torch.optim.SGD(pg_bn, lr=HYP["lr"], momentum=HYP["momentum"], nesterov=True, fused=True)
+    else:
+        from ayolov2_amd.optim import SGD
+        opt = SGD(pg_bn, lr=HYP["lr"], momentum=HYP["momentum"], nesterov=True)
     opt.add_param_group({"params": pg_w, "weight_decay": HYP["weight_decay"]})
     opt.add_param_group({"params": pg_b})
     loss_fn = ComputeLoss(model)

@@ -90,6 +90,20 @@ int ayolo_cast_weight(const float* w32, int Cout, int kh, int kw, int Cin, int C
 typedef struct ayolo_ema_job { float* ema; const float* src; int64_t n; } ayolo_ema_job;
 int ayolo_ema_update(const ayolo_ema_job* jobs_dev, int njobs, float decay, ayolo_stream s);
 
+/* Multi-tensor SGD step (torch.optim.SGD arithmetic: weight decay, momentum, dampening, nesterov) for every parameter
+ * tensor of a model in ONE launch, with torch.amp.GradScaler's contract: gradients are divided by *grad_scale
+ * (nullable) and the whole step is skipped when *found_inf != 0 (nullable).  Replaces the optimiser kernels behind
+ * `scaler.step(optimizer)` (scripts/train/yolo_trainer.py:332-338).  `jobs_dev` is a DEVICE array; hyper-parameters
+ * travel by value per parameter group (the learning rate changes every step); job.first != 0, or a NaN momentum entry,
+ * means the momentum buffer is still uninitialised (buf = g, as torch clones the gradient on the first step).
+ * One grid row per job: split multi-million-element tensors into jobs of ~32 K elements for parallelism. */
+typedef struct ayolo_sgd_job { float* p; const float* g; float* buf; int64_t n; int group; int first; } ayolo_sgd_job;
+typedef struct ayolo_sgd_group { float lr, momentum, weight_decay, dampening; int nesterov, reserved; } ayolo_sgd_group;
+#define AYOLO_SGD_MAX_GROUPS 8
+typedef struct ayolo_sgd_groups { ayolo_sgd_group g[AYOLO_SGD_MAX_GROUPS]; } ayolo_sgd_groups;
+int ayolo_sgd_step(const ayolo_sgd_job* jobs_dev, int njobs, const ayolo_sgd_groups* groups, const float* grad_scale,
+                   const float* found_inf, ayolo_stream s);
+
 /* The same cast for every layer of a model in one launch.  `jobs_dev` is a DEVICE array (written once by the caller;
  * each entry must have Cout_pad*taps*Cin_pad < 2^32). */
 typedef struct ayolo_cast_job {
