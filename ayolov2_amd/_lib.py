@@ -90,7 +90,11 @@ _SIGNATURES = {
     "ayolo_affine_act_res": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int, _P, c_int, _P],
     "ayolo_bn_eval_affine": [_P, _P, _P, _P, _P, c_float, c_int, _P, _P, _P],
     "ayolo_run_ops": [_P, c_int, _P],
+    "ayolo_run_ops_ex": [_P, c_int, _P, c_int],
+    "ayolo_side_stream_join": [_P],
+    "ayolo_run_ops_timed": [_P, c_int, _P, _P],
     "ayolo_fill_zero": [_P, c_size_t, _P],
+    "ayolo_release_thread_state": [],
 }
 
 EXPORTED = sorted(list(_SIGNATURES) + ["ayolo_version", "ayolo_last_error"])

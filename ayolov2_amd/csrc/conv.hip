@@ -626,15 +626,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     if (want_stats) g_stats_flush<T, TM>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
 }
 
-static int g_num_cu = 0;
+// compute units of the CURRENT device (cached per device ordinal: one process may drive several GPUs)
 static int num_cus() {
-    if (g_num_cu == 0) {
-        int dev = 0;
+    static int cache[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cache[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
-        if (g_num_cu <= 0) g_num_cu = 256;
+        int n = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        cache[dev] = n > 0 ? n : 256;
     }
-    return g_num_cu;
+    return cache[dev];
 }
 
 // workgroups per CU of one k_gconv instantiation (LDS-bound; the launch bounds give the register budget to match)
@@ -669,11 +672,13 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc).slots;
     p.nslots = (int)slots;
     dim3 grid((unsigned)(slots * p.ntn));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {false};      // per device: function attributes belong to the device's context
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-        attr_set = true;
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX>), grid, dim3(256), lds, s, p);
     AY_CHECK_LAUNCH("k_gconv");
@@ -1102,11 +1107,13 @@ static int launch_wgrad(WGradP p, hipStream_t s) {
     p.splits = (unsigned)splits;
     const long long blocks = tiles * ((splits + 7) / 8 * 8);
     AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)W::LDS);
-        attr_set = true;
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_wgrad<T, TM>), dim3((unsigned)blocks), dim3(256), W::LDS, s, p);
     AY_CHECK_LAUNCH("k_wgrad");

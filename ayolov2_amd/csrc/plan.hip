@@ -34,25 +34,103 @@ extern "C" int ayolo_fill_zero(void* ptr, size_t bytes, ayolo_stream s) {
     return AYOLO_OK;
 }
 
-// side stream of the executor (one per process = per GPU): created on first use
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
-static int side_fork(hipStream_t main) {
-    if (!g_side) {
-        AY_CHECK_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
-        AY_CHECK_HIP(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
-        AY_CHECK_HIP(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
+// Side stream of the executor.  No process-global state: every (host thread, device) pair gets its own side stream and
+// fork / join events on first use, so one process may drive several devices (the nn.DataParallel branch of
+// scripts/train/train_model_builder.py:132-133 runs one thread per device) and two threads may run op lists on the
+// same device without sharing events.  ayolo_release_thread_state() frees the calling thread's objects.
+#define AY_MAX_DEVICES 16
+struct SideCtx { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static thread_local SideCtx t_side[AY_MAX_DEVICES];
+
+static int side_ctx(SideCtx** out) {
+    int dev = 0;
+    AY_CHECK_HIP(hipGetDevice(&dev));
+    AY_CHECK_ARG(dev >= 0 && dev < AY_MAX_DEVICES, "run_ops: device ordinal %d unsupported", dev);
+    SideCtx& c = t_side[dev];
+    if (!c.side) {
+        AY_CHECK_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        AY_CHECK_HIP(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
+        AY_CHECK_HIP(hipEventCreateWithFlags(&c.join, hipEventDisableTiming));
     }
-    AY_CHECK_HIP(hipEventRecord(g_ev_fork, main));
-    AY_CHECK_HIP(hipStreamWaitEvent(g_side, g_ev_fork, 0));
+    *out = &c;
     return AYOLO_OK;
 }
 
-extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
+extern "C" int ayolo_release_thread_state(void) {
+    for (int d = 0; d < AY_MAX_DEVICES; ++d) {
+        SideCtx& c = t_side[d];
+        if (!c.side) continue;
+        (void)hipStreamSynchronize(c.side);
+        (void)hipStreamDestroy(c.side);
+        (void)hipEventDestroy(c.fork);
+        (void)hipEventDestroy(c.join);
+        c = SideCtx();
+    }
+    return AYOLO_OK;
+}
+
+static int side_fork(SideCtx* c, hipStream_t main) {
+    AY_CHECK_HIP(hipEventRecord(c->fork, main));
+    AY_CHECK_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+    return AYOLO_OK;
+}
+
+// the caller's stream continues only after the side stream has drained (also on the error path: work already forked
+// must not outlive the call unordered)
+static int side_join(SideCtx* c, hipStream_t main) {
+    AY_CHECK_HIP(hipEventRecord(c->join, c->side));
+    AY_CHECK_HIP(hipStreamWaitEvent(main, c->join, 0));
+    return AYOLO_OK;
+}
+
+// Make stream `waiter` wait for everything enqueued so far on the calling thread's executor side stream (a no-op when
+// this thread never used one on the current device).  With AYOLO_RUN_NO_JOIN this lets a communication stream pick up
+// finished weight-gradient buckets without stalling the compute stream (trainer.FlatGradDDP).
+extern "C" int ayolo_side_stream_join(ayolo_stream waiter) {
+    int dev = 0;
+    AY_CHECK_HIP(hipGetDevice(&dev));
+    AY_CHECK_ARG(dev >= 0 && dev < AY_MAX_DEVICES, "side_stream_join: device ordinal %d unsupported", dev);
+    SideCtx& c = t_side[dev];
+    if (!c.side) return AYOLO_OK;
+    return side_join(&c, (hipStream_t)waiter);
+}
+
+static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, hipEvent_t* ev);
+
+extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) { return run_ops_impl(ops, n, s, 0, nullptr); }
+extern "C" int ayolo_run_ops_ex(const ayolo_op* ops, int n, ayolo_stream s, int flags) { return run_ops_impl(ops, n, s, flags, nullptr); }
+
+// Measurement mode of the executor (bench.py's in-situ roofline): the same list on the same streams, with a HIP event
+// recorded before and after every op ON THE STREAM THE OP RUNS ON (side-stream weight gradients included), so ms[k] is
+// the duration of op k inside the real step -- cold caches, concurrent side-stream work and all.  Blocks until the list
+// has finished.
+extern "C" int ayolo_run_ops_timed(const ayolo_op* ops, int n, ayolo_stream s, float* ms) {
+    AY_CHECK_ARG((ops && ms) || n == 0, "run_ops_timed: null pointer");
+    if (n <= 0) return AYOLO_OK;
+    hipEvent_t* ev = (hipEvent_t*)calloc((size_t)2 * n, sizeof(hipEvent_t));
+    AY_CHECK_ARG(ev, "run_ops_timed: out of memory");
+    int rc = AYOLO_OK;
+    for (int k = 0; k < 2 * n && rc == AYOLO_OK; ++k)
+        if (hipEventCreate(&ev[k]) != hipSuccess) { ayolo_set_error("run_ops_timed: hipEventCreate failed"); rc = AYOLO_ELAUNCH; }
+    if (rc == AYOLO_OK) rc = run_ops_impl(ops, n, s, 0, ev);
+    if (rc == AYOLO_OK && hipStreamSynchronize((hipStream_t)s) != hipSuccess) { ayolo_set_error("run_ops_timed: sync failed"); rc = AYOLO_ELAUNCH; }
+    for (int k = 0; k < n && rc == AYOLO_OK; ++k) {
+        ms[k] = 0.0f;
+        if ((ops[k].kind & 0xff) == AYOLO_OP_NOP) continue;
+        if (hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) ms[k] = -1.0f;
+    }
+    for (int k = 0; k < 2 * n; ++k)
+        if (ev[k]) (void)hipEventDestroy(ev[k]);
+    free(ev);
+    return rc;
+}
+
+static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, hipEvent_t* ev) {
     AY_CHECK_ARG(ops || n == 0, "run_ops: null op list");
     static const bool debug_stall = getenv("AYOLO_DEBUG_STALL") != nullptr;
     double t_prev = debug_stall ? now_us() : 0.0;
     bool used_side = false;
+    SideCtx* sc = nullptr;
     for (int k = 0; k < n; ++k) {
         const ayolo_op& o = ops[k];
         int rc = AYOLO_OK;
@@ -60,9 +138,13 @@ extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
         // the list (weight gradients): it runs on the executor's side stream, concurrently with the ops that follow
         ayolo_stream cs = s;
         if (o.kind & AYOLO_OP_SIDE) {
-            rc = side_fork((hipStream_t)s);
-            if (rc != AYOLO_OK) return rc;
-            cs = (ayolo_stream)g_side;
+            if (!sc) rc = side_ctx(&sc);
+            if (rc == AYOLO_OK) rc = side_fork(sc, (hipStream_t)s);
+            if (rc != AYOLO_OK) {
+                if (used_side) (void)side_join(sc, (hipStream_t)s);
+                return rc;
+            }
+            cs = (ayolo_stream)sc->side;
             used_side = true;
         }
         if (debug_stall) {
@@ -70,6 +152,8 @@ extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
             if (t - t_prev > 500.0) fprintf(stderr, "[ayolo] run_ops: op %d/%d (kind %d) was blocked %.1f us in the HIP runtime\n", k - 1, n, k ? ops[k - 1].kind : 0, t - t_prev);
             t_prev = t;
         }
+        const bool timed = ev && (o.kind & 0xff) != AYOLO_OP_NOP;
+        if (timed) AY_CHECK_HIP(hipEventRecord(ev[2 * k], (hipStream_t)cs));
         switch (o.kind & 0xff) {
         case AYOLO_OP_NOP:
             break;
@@ -146,13 +230,15 @@ extern "C" int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s) {
             break;
         default:
             ayolo_set_error("run_ops: unknown op kind %d at index %d", o.kind, k);
-            return AYOLO_EINVAL;
+            rc = AYOLO_EINVAL;
         }
-        if (rc != AYOLO_OK) return rc;
+        if (rc != AYOLO_OK) {
+            if (used_side) (void)side_join(sc, (hipStream_t)s);
+            return rc;
+        }
+        if (timed) AY_CHECK_HIP(hipEventRecord(ev[2 * k + 1], (hipStream_t)cs));
     }
-    if (used_side) {                       // the caller's stream continues only after the side stream has drained
-        AY_CHECK_HIP(hipEventRecord(g_ev_join, g_side));
-        AY_CHECK_HIP(hipStreamWaitEvent((hipStream_t)s, g_ev_join, 0));
-    }
+    // AYOLO_RUN_NO_JOIN: a segment of a longer list -- side-stream work stays in flight, the caller joins later
+    if (used_side && !(flags & AYOLO_RUN_NO_JOIN)) return side_join(sc, (hipStream_t)s);
     return AYOLO_OK;
 }

@@ -239,6 +239,7 @@ class HeadConvFn(torch.autograd.Function):
                      shift=bias.float().contiguous() if bias is not None else None, head_no=no)
         raw = buf.as_strided((B, na, H, W, no), (H * W * cout_pad, no, W * cout_pad, cout_pad, 1))
         raw._ayolo_head = (cout_pad, dt)          # lets the fused loss hand its gradient over in dz layout
+        ctx.raw_ptr = buf.data_ptr()
         ctx.save_for_backward(xk, wt)
         ctx.geo, ctx.dt, ctx.ldx, ctx.cout_pad, ctx.na, ctx.no = geo, dt, ldx, cout_pad, na, no
         ctx.weight_shape = tuple(weight.shape)
@@ -251,7 +252,7 @@ class HeadConvFn(torch.autograd.Function):
         geo, dt, cout_pad = ctx.geo, ctx.dt, ctx.cout_pad
         Cout, Cin, kh, kw = ctx.weight_shape
         from .losses import take_packed_head_grad
-        pk = take_packed_head_grad(draw, cout_pad, dt)
+        pk = take_packed_head_grad(draw, cout_pad, dt, ctx.raw_ptr)
         if pk is not None:
             dz = pk[0].view(geo.B, geo.H, geo.W, cout_pad).permute(0, 3, 1, 2)     # NHWC memory, NCHW view
             dbias = pk[1]

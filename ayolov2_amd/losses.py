@@ -109,14 +109,20 @@ class _FusedLossFn(torch.autograd.Function):
         tags = [getattr(p, "_ayolo_head", None) for p in preds]
         if ctx.packed_ok and all(t is not None for t in tags) and len({t[1] for t in tags}) == 1:
             grads = []
-            for i, (p, (ldz, dt)) in enumerate(zip(preds, tags)):
+            for i, (p, tag) in enumerate(zip(preds, tags)):
+                ldz, dt = tag[0], tag[1]
                 B, na, ny, nx, no = p.shape
                 dz = torch.empty((B * ny * nx, ldz), dtype=dt, device=p.device)
-                dbias = torch.zeros(na * no, dtype=torch.float32, device=p.device)
+                # the plan executor hands over the (zeroed) slot of the head bias in its gradient arena: the bias gradient is
+                # accumulated in place, ready for the first all-reduce bucket; otherwise a fresh accumulator
+                dbias = tag[2] if len(tag) > 2 and tag[2] is not None else torch.zeros(na * no, dtype=torch.float32, device=p.device)
                 L = ctx.arr[i]
                 L.dz, L.ldz, L.dz_dtype, L.dbias = dz.data_ptr(), ldz, dtype_code(dt), dbias.data_ptr()
                 ph = torch.zeros((), dtype=torch.float32, device=p.device).expand(p.shape)
                 ph._ayolo_packed = (dz, dbias)
+                if len(_PENDING_PACKED) > 64:             # backward passes that never reached their head
+                    _PENDING_PACKED.clear()
+                _PENDING_PACKED[p.data_ptr()] = (dz, dbias)
                 grads.append(ph)
             _lib.call("ayolo_yolo_loss_bwd_packed", ctx.arr, len(grads), *ctx.consts, g.data_ptr(), _stream())
             return (None, None, None, None, None, *grads)
@@ -129,18 +135,39 @@ class _FusedLossFn(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
-def take_packed_head_grad(draw, ldz: int, dtype):
-    """For YOLOHead backward implementations: returns (dz, dbias) when `draw` is the placeholder of a packed loss
-    gradient produced for exactly this layout, else None.  A placeholder that lost its payload raises (it must never
-    be consumed as a real, all-zero gradient)."""
-    if draw is None:
+# Packed loss gradients that have been produced but not yet consumed by their YOLOHead backward, keyed by the address
+# of the head's raw-logit buffer.  The placeholder autograd carries is all zeros, so if the raw tensor has a SECOND
+# differentiable consumer (distillation / auxiliary loss) autograd hands the head `0 + other gradients` as a new dense
+# tensor that no longer carries the payload attribute: the head backward then finds the payload here and adds the two.
+_PENDING_PACKED: dict = {}
+
+
+def take_packed_head_grad(draw, ldz: int, dtype, raw_ptr: Optional[int] = None):
+    """For YOLOHead backward implementations: returns (dz, dbias) -- the head conv's backward operand (NHWC rows of
+    `ldz` channels, compute dtype) and bias gradient -- when the fused loss produced its gradient in that layout for
+    the head whose raw-logit buffer starts at `raw_ptr`, else None (`draw` is then an ordinary dense gradient).
+    Gradients of other consumers of the same logits that reached the head next to the packed one are added in."""
+    pend = _PENDING_PACKED.pop(raw_ptr, None) if raw_ptr is not None else None
+    if draw is None and pend is None:
         return None
-    pk = getattr(draw, "_ayolo_packed", None)
+    pk = getattr(draw, "_ayolo_packed", None) if draw is not None else None
     if pk is not None:
         dz, dbias = pk
         if dz.shape[1] == ldz and dz.dtype == dtype:
             return dz, dbias
         raise RuntimeError("packed head gradient has the wrong layout for this head")
+    if pend is not None:
+        dz, dbias = pend
+        if dz.shape[1] != ldz or dz.dtype != dtype:
+            raise RuntimeError("packed head gradient has the wrong layout for this head")
+        if draw is not None:
+            # the loss gradient (packed) plus what the other consumers of these logits sent (dense): rare, plain torch
+            from . import ops
+            dz2, dbias2 = ops.head_grad_pack(draw, dtype, ldz, want_bias=True)
+            B, _, H, W = dz2.shape
+            dz = dz + dz2.permute(0, 2, 3, 1).reshape(B * H * W, ldz)
+            dbias.add_(dbias2)              # in place: `dbias` may be the head bias' slot in the plan's gradient arena
+        return dz, dbias
     if draw.dim() == 5 and all(s == 0 for s in draw.stride()) and draw.numel() > 1:
         raise RuntimeError("packed head-gradient placeholder without payload reached a YOLOHead backward; "
                            "set ComputeLoss.packed_head_grad = False")
@@ -190,30 +217,46 @@ class ComputeLoss:
         ints = [c for c in tcls] + [i for idx in indices for i in idx]
         flts = [b.reshape(-1) for b in tbox] + [a.reshape(-1) for a in anch]
         ni, nf = sum(t.numel() for t in ints), sum(t.numel() for t in flts)
-        if getattr(self, "_pin_i", None) is None or self._pin_i.numel() < ni:
-            self._pin_i = torch.empty(max(ni, 1) * 2, dtype=torch.int64).pin_memory()
-        if getattr(self, "_pin_f", None) is None or self._pin_f.numel() < nf:
-            self._pin_f = torch.empty(max(nf, 1) * 2, dtype=torch.float32).pin_memory()
+        # The copies are asynchronous and the host runs about one step ahead of the GPU: a staging buffer may only be
+        # rewritten after the copy that read it has completed.  Ring of three buffer pairs, each with the event recorded
+        # behind its copies (the wait is a no-op unless the host is three steps ahead).
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None:
+            ring = self._pin_ring = [{"i": None, "f": None, "ev": None} for _ in range(3)]
+            self._pin_next = 0
+        slot = ring[self._pin_next % len(ring)]
+        self._pin_next += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        if slot["i"] is None or slot["i"].numel() < ni:
+            slot["i"] = torch.empty(max(ni, 1) * 2, dtype=torch.int64).pin_memory()
+        if slot["f"] is None or slot["f"].numel() < nf:
+            slot["f"] = torch.empty(max(nf, 1) * 2, dtype=torch.float32).pin_memory()
+        pin_i, pin_f = slot["i"], slot["f"]
         mode = getattr(self, "h2d_mode", "same")
         if mode == "pageable":
             di = torch.cat(ints).to(device) if ni else torch.empty(0, dtype=torch.int64, device=device)
             df = torch.cat(flts).to(device) if nf else torch.empty(0, device=device)
         else:
-            torch.cat(ints, out=self._pin_i[:ni]) if ni else None
-            torch.cat(flts, out=self._pin_f[:nf]) if nf else None
+            torch.cat(ints, out=pin_i[:ni]) if ni else None
+            torch.cat(flts, out=pin_f[:nf]) if nf else None
             if mode == "side":     # copy engine on its own stream; the compute stream only waits on the event
                 if getattr(self, "_copy_stream", None) is None:
                     self._copy_stream = torch.cuda.Stream(device=device)
                 cur = torch.cuda.current_stream(device)
                 with torch.cuda.stream(self._copy_stream):
-                    di = self._pin_i[:ni].to(device, non_blocking=True)
-                    df = self._pin_f[:nf].to(device, non_blocking=True)
+                    di = pin_i[:ni].to(device, non_blocking=True)
+                    df = pin_f[:nf].to(device, non_blocking=True)
+                    slot["ev"] = torch.cuda.Event()
+                    slot["ev"].record()
                 cur.wait_stream(self._copy_stream)
                 di.record_stream(cur)
                 df.record_stream(cur)
             else:
-                di = self._pin_i[:ni].to(device, non_blocking=True)
-                df = self._pin_f[:nf].to(device, non_blocking=True)
+                di = pin_i[:ni].to(device, non_blocking=True)
+                df = pin_f[:nf].to(device, non_blocking=True)
+                slot["ev"] = torch.cuda.Event()
+                slot["ev"].record()
         oi, of = 0, 0
 
         def take_i(t):

@@ -329,9 +329,13 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_
         N = pred.shape[1]
     by_seq = nms_type in ("fast_nms", "matrix_nms")           # those branches run on UNSORTED candidates
     cand = _collect_candidates(pred, conf_thres, multi_label, True, classes, None, by_seq)
-    if by_seq and (cand.counts > MAX_NMS).any():
-        raise NotImplementedError(f"{nms_type} with more than {MAX_NMS} candidates in one image")
     seg_n = np.minimum(cand.counts, MAX_NMS)
+    # metrics.py:378-379: an image with more than max_nms candidates is sorted by confidence and cut to max_nms BEFORE its
+    # branch runs, so fast_nms / matrix_nms see THAT image in confidence order (stable here; torch's argsort leaves the
+    # order of equal confidences open) and every other image in its original order
+    cand_sorted = None
+    if by_seq and (cand.counts > MAX_NMS).any():
+        cand_sorted = _collect_candidates(pred, conf_thres, multi_label, True, classes, None, False)
     empty = torch.zeros((0, 6), dtype=torch.float32, device=dev)
     output: List[torch.Tensor] = [empty] * B
 
@@ -361,8 +365,9 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_
         n = int(seg_n[b])
         if n == 0:
             continue
-        off = int(cand.offsets[b])
-        x = cand.sdet[off:off + n]
+        src = cand_sorted if (cand_sorted is not None and cand.counts[b] > MAX_NMS) else cand
+        off = int(src.offsets[b])
+        x = src.sdet[off:off + n]
         boxes = x[:, :4].contiguous()
         cls = x[:, 5].contiguous()
         colmax = torch.empty(n, dtype=torch.float32, device=dev)

@@ -61,6 +61,8 @@ import os as _os
 
 OP_SIDE = 0x100
 WGRAD_SIDE_STREAM = _os.environ.get("AYOLO_WGRAD_STREAM", "1") == "1"
+WGRAD_FIRST = _os.environ.get("AYOLO_WGRAD_FIRST", "0") == "1"
+MAX_PLANS = int(_os.environ.get("AYOLO_MAX_PLANS", "4"))                 # cached plans per model (multi-scale training)
 MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: cv1 | cv2 as one conv
 
 
@@ -137,7 +139,12 @@ class TrainPlan:
         self.dz_elems = 0
         self.late: List[Callable[[], None]] = []    # closures run after the arenas exist (pointer binding)
         self.bn_counters: List[torch.Tensor] = []
+        self.collect_times = False                          # bench.py: per-op in-situ timing (ayolo_run_ops_timed)
+        self.op_times: Dict[str, list] = {}
         self.raw_specs = []
+        self.grad_done: List[Tuple[int, int, int]] = []     # (index of the backward op that completes it, arena offset, n)
+        self.fwd_sync: list = []                            # sync_bn: (conv op, stats offset, n)
+        self.bwd_sync: list = []                            # sync_bn: (index of the reduce op, sums view)
         self.draw_ops: List[Op] = []
         self._head_dz: Dict[int, Tuple[int, int]] = {}
         self.pack_op: Optional[Op] = None
@@ -154,6 +161,11 @@ class TrainPlan:
         self.params.append(p)
         self.param_grad_view[id(p)] = (off, numel_pad, view_fn)
         return off
+
+    def _wrote(self, off: Optional[int], n: int, at: Optional[int] = None) -> None:
+        """The backward op just appended (or op index `at`) completes the gradient arena range [off, off+n)."""
+        if off is not None:
+            self.grad_done.append((len(self.bwd) - 1 if at is None else at, off, n))
 
     def _dz(self, n: int) -> torch.Tensor:
         """Backward operand dz of one layer: a slice of the shared scratch buffer, or -- when weight gradients run on the
@@ -233,6 +245,7 @@ class TrainPlan:
         op_conv = _op(OP_CONV_FWD, i=(EPI_NONE, R, 0), p=(xk, wc, z.t, None, None, None), conv=geo.desc(dt, ldx, Ct))
         self.fwd.append(op_conv)
         self.late.append(lambda: op_conv.p.__setitem__(5, self.stats.view(st_off, R * 2 * Ct).data_ptr()))
+        self.fwd_sync.append((op_conv, st_off, R * 2 * Ct))            # sync_bn: all-reduce of the batch statistics
         K = geo.kdims[0] * geo.kdims[1] * geo.Cin_k
         self.dz_elems = max(self.dz_elems, npix * Ct)
         outs: List[Act] = []
@@ -301,18 +314,28 @@ class TrainPlan:
                                     p=(zj, da, sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su)))
                 self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R), l=(npix,), f=(1.0,),
                                     p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet)))
+                self._wrote(gg_off, co)
+                self._wrote(gb_off, co)
+                self.bwd_sync.append((len(self.bwd) - 2, su))      # sync_bn: all-reduce of the sums between reduce and apply
                 if residual is not None:      # shortcut: d(residual) += d(a)
                     dr = residual.grad()
                     self.bwd.append(_op(OP_COPY2D, i=(code, ldda, ops.nhwc_info(dr)[4], co, int(residual.is_init())), l=(npix,),
                                         p=(da, dr)))
                     residual.mark_init()
+            def wgrad():
+                self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(xk, dz, ga.view(gw_off0, Ct * K)),
+                                    conv=geo.desc(dt, ldx, Ct)))
+                self._wrote(gw_off0, Ct * K)
+
+            if WGRAD_FIRST:          # fork the weight gradient before its layer's dgrad: it overlaps the dgrad, not only later layers
+                wgrad()
             if not image:
                 dx = x_act.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
                                     conv=geo.desc(dt, ops.nhwc_info(dx)[4], Ct)))
                 x_act.mark_init()
-            self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(xk, dz, ga.view(gw_off0, Ct * K)),
-                                conv=geo.desc(dt, ldx, Ct)))
+            if not WGRAD_FIRST:
+                wgrad()
 
         self.bwd_emitters.append(emit_bwd)
         return outs
@@ -412,9 +435,9 @@ class TrainPlan:
             ldx = ops.nhwc_info(x.t)[4]
             self.fwd.append(_op(OP_CONV_FWD, i=(EPI_HEAD, 1, head.no), p=(x.t, wc, buf, None, conv.bias, None),
                                 conv=geo.desc(dt, ldx, cp)))
-            self.raw_specs.append((buf, (B, head.na, H, W, head.no), (H * W * cp, head.no, W * cp, cp, 1)))
             gw_off = self._register_param(conv.weight, cp * Cin, lambda b, Cout=Cout, Cin=Cin: b.view(-1, Cin)[:Cout].view(Cout, Cin, 1, 1))
             gb_off = self._register_param(conv.bias, Cout, lambda b: b) if conv.bias is not None else None
+            self.raw_specs.append((buf, (B, head.na, H, W, head.no), (H * W * cp, head.no, W * cp, cp, 1), gb_off, Cout))
             npix = B * H * W
             self.dz_elems = max(self.dz_elems, npix * cp)
             code = ops.dtype_code(dt)
@@ -432,6 +455,8 @@ class TrainPlan:
                 x.mark_init()
                 self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(x.t, dz, ga.view(gw_off, cp * Cin)),
                                     conv=geo.desc(dt, ldx, cp, cout=cp)))
+                self._wrote(gw_off, cp * Cin)
+                self._wrote(gb_off, Cout, at=0)          # bias gradient: pack op, or the fused loss before the list runs
 
             self.bwd_emitters.append(emit)
 
@@ -516,10 +541,14 @@ class TrainPlan:
         self.dz_buf = torch.empty(max(self.dz_elems, 8), dtype=self.dt, device=dev)
         for fn in self.late:
             fn()
-        head_ops = [_op(OP_MEMSET, l=(self.stats.buf.numel() * 4,), p=(self.stats.buf,))]
-        self.fwd = head_ops + self._batched_casts() + self.fwd
-        self.bwd = [_op(OP_MEMSET, l=(self.sums.buf.numel() * 4,), p=(self.sums.buf,)),
+        # all accumulators are zeroed at the START OF THE FORWARD (one fill each): the gradient arena too, because the
+        # fused loss adds the head bias gradients into it before the backward list runs
+        head_ops = [_op(OP_MEMSET, l=(self.stats.buf.numel() * 4,), p=(self.stats.buf,)),
+                    _op(OP_MEMSET, l=(self.sums.buf.numel() * 4,), p=(self.sums.buf,)),
                     _op(OP_MEMSET, l=(self.gradarena.buf.numel() * 4,), p=(self.gradarena.buf,))]
+        nhead = len(head_ops) + (1 if self.casts else 0)
+        self.fwd = head_ops + self._batched_casts() + self.fwd
+        self.bwd = []
         for emit in reversed(self.bwd_emitters):
             emit()
         self.fwd_arr = (Op * len(self.fwd))(*self.fwd)
@@ -530,6 +559,32 @@ class TrainPlan:
         # draw ops were emitted in reverse level order
         self.draw_levels = list(reversed(range(len(self.raw_specs))))
         self.param_ptrs = tuple(p.data_ptr() for p in self.params)
+        self.fwd_sync_idx = [(next(k for k, o in enumerate(self.fwd) if o is c), off, n) for c, off, n in self.fwd_sync]
+        self.buckets = self._make_buckets()
+
+    def _make_buckets(self, target_bytes: Optional[int] = None) -> List[Tuple[int, int, int]]:
+        """Gradient buckets for data-parallel training: [(ready, lo, hi)] -- the arena range [lo, hi) is complete once
+        backward op `ready` has been ENQUEUED (weight gradients run on the side stream).  The arena is laid out in forward
+        order and backward runs in reverse, so buckets are cut from the top of the arena downwards, ~6 per model (>= 4 MB:
+        an xGMI ring all-reduce is per-link bound and latency-dominated below that)."""
+        total = self.gradarena.total
+        if target_bytes is None:
+            target_bytes = int(_os.environ.get("AYOLO_BUCKET_MB", "0")) << 20 or max(4 << 20, total * 4 // 6)
+        done = sorted(self.grad_done, key=lambda t: -t[1])            # highest arena offset (last layers) first
+        out: List[Tuple[int, int, int]] = []
+        hi, ready = total, -1
+        for k, (idx, off, n) in enumerate(done):
+            ready = max(ready, idx)
+            last = k == len(done) - 1
+            if (hi - off) * 4 >= target_bytes or last:
+                lo = 0 if last else off
+                out.append((ready, lo, hi))
+                hi = off
+        fixed, run = [], -1
+        for ready, lo, hi in out:                                      # ready indices must not decrease bucket to bucket
+            run = max(run, ready)
+            fixed.append((run, lo, hi))
+        return fixed
 
     # ------------------------------------------------------------------ execution
     def valid_for(self, params_ptrs) -> bool:
@@ -547,16 +602,87 @@ class TrainPlan:
         prev = getattr(self, "_fwd_done", None)
         if prev is not None:
             prev.synchronize()
+        self.generation = getattr(self, "generation", 0) + 1
         self.fwd_arr[self.pack_idx].p[0] = x.data_ptr()
-        _lib.check(_lib.lib().ayolo_run_ops(self.fwd_arr, len(self.fwd), torch.cuda.current_stream().cuda_stream), "ayolo_run_ops(forward)")
+        sync = getattr(self.model, "_ayolo_grad_sync", None)
+        st = torch.cuda.current_stream().cuda_stream
+        if sync is not None and getattr(sync, "sync_bn", False) and sync.active():
+            # SyncBatchNorm (train_model_builder.py:135-136): every layer's batch statistics are averaged over the ranks
+            # between its conv and its normalise pass -- the list runs in one segment per BN layer
+            a = 0
+            for k, off, n in self.fwd_sync_idx:
+                self._run(self.fwd_arr, a, k + 1, st, "forward")
+                sync.average_now(self.stats.view(off, n))
+                a = k + 1
+            self._run(self.fwd_arr, a, len(self.fwd), st, "forward")
+        else:
+            self._run(self.fwd_arr, 0, len(self.fwd), st, "forward")
         if self.bn_counters:
             torch._foreach_add_(self.bn_counters, 1)
         self._fwd_done = torch.cuda.Event()
         self._fwd_done.record()
-        raws = [buf.as_strided(shape, strides) for buf, shape, strides in self.raw_specs]
-        for r, (buf, _, _) in zip(raws, self.raw_specs):
-            r._ayolo_head = (buf.shape[-1], self.dt)      # the fused loss may hand its gradient over in dz layout
+        raws = [spec[0].as_strided(spec[1], spec[2]) for spec in self.raw_specs]
+        for r, (buf, _, _, gb_off, cout) in zip(raws, self.raw_specs):
+            # the fused loss may hand its gradient over in dz layout, adding the bias gradient straight into the arena
+            slot = self.gradarena.view(gb_off, cout) if gb_off is not None else None
+            r._ayolo_head = (buf.shape[-1], self.dt, slot)
         return raws
+
+    def _run(self, arr, a: int, b: int, stream: int, what: str, no_join: bool = False) -> None:
+        if b <= a:
+            return
+        if getattr(self, "collect_times", False) and a == 0 and b == len(arr):
+            # measurement mode (bench.py): per-op durations in situ, events on each op's own stream; synchronous
+            ms = (c_float * (b - a))()
+            _lib.check(_lib.lib().ayolo_run_ops_timed(arr, b - a, stream, ms), f"ayolo_run_ops_timed({what})")
+            self.op_times.setdefault(what, []).append(np.frombuffer(ms, dtype=np.float32).copy())
+            return
+        _lib.check(_lib.lib().ayolo_run_ops_ex(ctypes.byref(arr, a * ctypes.sizeof(Op)), b - a, stream, 1 if no_join else 0),
+                   f"ayolo_run_ops({what})")
+
+    def op_costs(self, what: str):
+        """Algorithmic cost of every op of the forward / backward list, for roofline accounting:
+        [(family, bytes, flop)] with bytes = the tensors an op must read and write once (activations in the compute dtype,
+        fp32 weight gradients), flop = 2 * MAC of the convolutions."""
+        es = 2 if self.dt == torch.float16 else 4
+        out = []
+        for o in (self.fwd if what == "forward" else self.bwd):
+            kind = o.kind & 0xff
+            d = o.conv
+            macs = d.B * d.Ho * d.Wo * d.Cout * d.kh * d.kw * d.Cin
+            xin, yout, wts = d.B * d.H * d.W * d.Cin, d.B * d.Ho * d.Wo * d.Cout, d.Cout * d.kh * d.kw * d.Cin
+            if kind == OP_CONV_FWD:
+                yes = 4 if o.i[0] == EPI_HEAD else es
+                out.append(("conv_fwd", es * (xin + wts) + yes * yout, 2.0 * macs))
+            elif kind == OP_CONV_DGRAD:
+                out.append(("conv_dgrad", es * (yout + wts + xin * (2 if o.i[0] else 1)), 2.0 * macs))
+            elif kind == OP_CONV_WGRAD:
+                out.append(("conv_wgrad", es * (xin + yout) + 4 * wts, 2.0 * macs))
+            elif kind == OP_BN_TRAIN_ACT:
+                out.append(("bn_act_fwd", es * o.l[0] * o.i[3] * (3 if o.p[9] else 2), 0.0))
+            elif kind == OP_BN_BWD_REDUCE:
+                out.append(("bn_bwd_reduce", es * o.l[0] * o.i[3] * 2, 0.0))
+            elif kind == OP_BN_BWD_APPLY:
+                out.append(("bn_bwd_apply", es * o.l[0] * o.i[4] * 3, 0.0))
+            elif kind in (OP_MAXPOOL_FWD, OP_UPSAMPLE_FWD):
+                n = o.i[3] * o.i[4] * o.i[5] * o.i[6] * (4 if kind == OP_UPSAMPLE_FWD else 1)
+                out.append(("pool_upsample", es * n * (1.25 if kind == OP_UPSAMPLE_FWD else 2) + (n if kind == OP_MAXPOOL_FWD else 0), 0.0))
+            elif kind in (OP_MAXPOOL_BWD, OP_UPSAMPLE_BWD):
+                n = o.i[3] * o.i[4] * o.i[5] * o.i[6]
+                out.append(("pool_upsample", es * n * (5 if kind == OP_UPSAMPLE_BWD else 2) + (n if kind == OP_MAXPOOL_BWD else 0), 0.0))
+            elif kind == OP_COPY2D:
+                out.append(("copy", es * o.l[0] * o.i[3] * (3 if o.i[4] else 2), 0.0))
+            elif kind == OP_PACK_INPUT:
+                n = o.i[0] * o.i[2] * o.i[3]
+                out.append(("pack_input", n * (4 * o.i[1] + es * o.i[5]), 0.0))
+            elif kind == OP_MEMSET:
+                out.append(("fill", float(o.l[0]), 0.0))
+            elif kind == OP_CAST_WEIGHTS:
+                n = sum(c.i[4] * c.i[1] * c.i[2] * c.i[5] for c in self.casts)
+                out.append(("cast_weights", n * (4 + 2 * es), 0.0))
+            else:
+                out.append(("other", 0.0, 0.0))
+        return out
 
     def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
         from .losses import take_packed_head_grad
@@ -564,19 +690,19 @@ class TrainPlan:
         late_bias = []
         for idx, lvl in zip(self.draw_idx, self.draw_levels):
             d = draws[lvl]
-            buf, shape, _ = self.raw_specs[lvl]
+            buf, shape = self.raw_specs[lvl][:2]
             op, dg, wg = self.bwd_arr[idx], self.bwd_arr[idx + 1], self.bwd_arr[idx + 2]   # pack, head dgrad, head wgrad
             if idx not in self._head_dz:
                 self._head_dz[idx] = (op.p[1], op.p[2])
             dz0, dbias0 = self._head_dz[idx]
-            pk = take_packed_head_grad(d, buf.shape[-1], self.dt)
+            pk = take_packed_head_grad(d, buf.shape[-1], self.dt, buf.data_ptr())
             if pk is not None:
                 # gradient already in the head conv's operand layout: skip the pack op, point dgrad / wgrad at it
                 op.kind = 0
                 dg.p[0] = pk[0].data_ptr()
                 wg.p[1] = pk[0].data_ptr()
                 keep += [pk[0], pk[1]]
-                if dbias0:
+                if dbias0 and pk[1].data_ptr() != dbias0:
                     late_bias.append((dbias0, pk[1]))
                 continue
             op.kind = OP_HEAD_GRAD_PACK
@@ -588,15 +714,37 @@ class TrainPlan:
                 d = d.float().contiguous()
             keep.append(d)
             op.p[0] = d.data_ptr()
-        _lib.check(_lib.lib().ayolo_run_ops(self.bwd_arr, len(self.bwd), torch.cuda.current_stream().cuda_stream), "ayolo_run_ops(backward)")
-        self._d_keep = keep
-        for ptr, dbias in late_bias:         # bias gradient of a packed head level -> its slot in the gradient arena
+        for ptr, dbias in late_bias:         # bias gradient of a packed head level that is not already in its arena slot
             off = (ptr - self.gradarena.buf.data_ptr()) // 4
-            self.gradarena.buf[off:off + dbias.numel()].copy_(dbias)
+            self.gradarena.buf[off:off + dbias.numel()].add_(dbias)
+        st = torch.cuda.current_stream().cuda_stream
         sync = getattr(self.model, "_ayolo_grad_sync", None)
-        if sync is not None:                 # FlatGradDDP: one all-reduce of the whole arena (RCCL), averaged
-            sync.reduce_flat(self.gradarena.buf)
-        # The arena is scratch that the next backward zeroes: hand out gradients that OWN their memory (autograd steals
+        active = sync is not None and sync.active()
+        # segment boundaries: after op k ... (kind, payload)
+        cuts = []
+        if active and getattr(sync, "sync_bn", False):
+            cuts += [(k, 0, su) for k, su in self.bwd_sync]
+        if active and getattr(sync, "overlap", True):
+            cuts += [(ready, 1, (lo, hi)) for ready, lo, hi in self.buckets]
+        cuts.sort(key=lambda c: (c[0], c[1]))
+        a = 0
+        for k, kind, payload in cuts:
+            # AYOLO_RUN_NO_JOIN: the compute stream does not wait for the side-stream weight gradients here; the
+            # communication stream does (sync.launch_bucket) -- the all-reduce of a bucket overlaps the rest of backward
+            self._run(self.bwd_arr, a, k + 1, st, "backward", no_join=True)
+            a = max(a, k + 1)
+            if kind == 0:
+                sync.average_now(payload)
+            else:
+                sync.launch_bucket(self.gradarena.buf[payload[0]:payload[1]])
+        self._run(self.bwd_arr, a, len(self.bwd), st, "backward")
+        self._d_keep = keep
+        if active:
+            if getattr(sync, "overlap", True):
+                sync.wait_all()                                   # compute stream waits for the bucket all-reduces
+            else:
+                sync.reduce_flat(self.gradarena.buf)              # one blocking all-reduce of the whole arena
+        # The arena is scratch that the next forward zeroes: hand out gradients that OWN their memory (autograd steals
         # them as p.grad and may keep them across steps for gradient accumulation) -- one flat copy, views into it.
         flat = self.gradarena.buf.clone()
         grads = []
@@ -611,13 +759,23 @@ class TrainPlan:
 
 
 class _PlanTrainFn(torch.autograd.Function):
+    """The plan's activations and its outputs (the raw head tensors are views of plan-owned buffers) live in STATIC
+    storage: a later training forward of the same shape overwrites them.  Forward-only calls are fine; a backward
+    through an overwritten forward (two micro-batch forwards before the first backward) is detected and raises."""
+
     @staticmethod
     def forward(ctx, plan: TrainPlan, x: torch.Tensor, *params):
         ctx.plan = plan
-        return tuple(plan.run_forward(x))
+        outs = tuple(plan.run_forward(x))
+        ctx.generation = plan.generation
+        return outs
 
     @staticmethod
     def backward(ctx, *draws):
+        if ctx.generation != ctx.plan.generation:
+            raise RuntimeError("ayolov2_amd plan: backward of a forward whose saved activations were overwritten by a later "
+                               "forward of the same shape (the plan executor keeps ONE set of static buffers per input "
+                               "shape); run backward before the next forward, or set model.use_plan = False")
         grads = ctx.plan.run_backward(draws)
         return (None, None) + tuple(grads)
 
@@ -638,5 +796,8 @@ def plan_forward_train(model, x: torch.Tensor):
         except PlanUnsupported:
             cache[key] = False
             return None
+        live = [k for k, v in cache.items() if v is not False]
+        while len(live) >= MAX_PLANS:            # a plan owns every activation of its shape (GBs): keep the newest few
+            cache.pop(live.pop(0))
         cache[key] = plan
     return list(_PlanTrainFn.apply(plan, x, *plan.params))

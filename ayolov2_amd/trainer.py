@@ -1,7 +1,8 @@
 """Data-parallel training glue with the reference's interface for this path
 (scripts/train/train_model_builder.py:75-141 ``TrainModelBuilder``, scripts/train/yolo_trainer.py:289-358
-``training_step``).  One process per GPU; gradients are all-reduced by torch DDP, whose "nccl" backend IS RCCL on
-ROCm (over xGMI inside a node), bucketed and overlapped with the HIP backward kernels.
+``training_step``).  One process per GPU; the plan executor's flat gradient arena is all-reduced over torch.distributed's
+"nccl" backend (= RCCL on ROCm, xGMI inside a node) in reverse-layer buckets launched from a communication stream while
+the remaining backward kernels run (``FlatGradDDP`` / ``_FlatSync``); non-plannable models use torch DDP.
 
 Conventions kept from the reference: the loss is multiplied by WORLD_SIZE under DDP
 (yolo_trainer.py:325-326) on top of ``loss * batch_size`` (losses.py:297-300); BatchNorm statistics stay local
@@ -88,35 +89,91 @@ class ModelEMA:
 
 
 class _FlatSync:
-    """What the plan calls at the end of backward (a plain object: it must not become a submodule of the model)."""
+    """What the plan calls during backward (a plain object: it must not become a submodule of the model).
 
-    def __init__(self, group, world: int) -> None:
-        self.group, self.world = group, world
+    Gradient exchange of the data-parallel train step (the reference wraps the model in torch DDP,
+    scripts/train/train_model_builder.py:75-78, whose reducer overlaps bucketed all-reduces with backward).  The plan
+    executor runs backward as ONE op list, so the overlap is built here: the plan cuts the list where a reverse-layer
+    bucket of its flat gradient arena is complete and calls ``launch_bucket``; the bucket's all-reduce (RCCL over xGMI
+    through torch.distributed) is enqueued from a COMMUNICATION stream that waits for the executor's side stream (weight
+    gradients) and for the compute stream (BatchNorm / bias gradients) -- the compute stream itself never waits, so the
+    collective runs under the remaining backward kernels.  ``wait_all`` joins before the optimiser."""
+
+    def __init__(self, group, world: int, sync_bn: bool = False) -> None:
+        self.group, self.world, self.sync_bn = group, world, sync_bn
+        self.overlap = os.getenv("AYOLO_DDP_OVERLAP", "1") == "1"
+        self._works = []
+        self._comm = None
+
+    def active(self) -> bool:
+        return self.world > 1 or os.getenv("AYOLO_FORCE_DDP") == "1"      # the env switch exercises the RCCL calls on one GPU
+
+    def _avg(self, t: torch.Tensor, async_op: bool):
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        w = dist.all_reduce(t, group=self.group, async_op=async_op)       # gloo has no AVG: sum, then scale
+        if w is not None:
+            w.wait()
+        if self.world > 1:
+            t.mul_(1.0 / self.world)
+        return None
 
     def reduce_flat(self, flat: torch.Tensor) -> None:
-        if self.world > 1 or os.getenv("AYOLO_FORCE_DDP") == "1":      # the env switch exercises the RCCL call on one GPU
-            dist.all_reduce(flat, group=self.group)
-            if self.world > 1:
-                flat.mul_(1.0 / self.world)
+        """One blocking averaged all-reduce of the whole arena (AYOLO_DDP_OVERLAP=0, and the reference for the buckets)."""
+        if self.active():
+            self._avg(flat, False)
+
+    def launch_bucket(self, view: torch.Tensor) -> None:
+        """Averaged all-reduce of one finished arena range, asynchronous to the compute stream."""
+        if not self.active():
+            return
+        if not view.is_cuda:
+            self._avg(view, False)
+            return
+        from . import _lib
+        cur = torch.cuda.current_stream()
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=view.device)
+        comm = self._comm
+        _lib.call("ayolo_side_stream_join", comm.cuda_stream)              # weight gradients of the bucket (side stream)
+        comm.wait_stream(cur)                                                # BatchNorm / bias gradients (compute stream)
+        with torch.cuda.stream(comm):
+            w = self._avg(view, True)
+        if w is not None:
+            self._works.append(w)
+
+    def wait_all(self) -> None:
+        for w in self._works:
+            w.wait()                                                         # current stream waits for the collective
+        self._works = []
+
+    def average_now(self, t: torch.Tensor) -> None:
+        """sync_bn: in-stream average of one layer's BatchNorm accumulators (sum, sum of squares / backward sums) over
+        the ranks.  Averaging instead of summing keeps the kernels' local pixel count valid:
+        (sum over ranks / world) / n_local = global sum / global count for equal per-rank batches."""
+        if self.active():
+            self._avg(t, False)
 
     def __getstate__(self):                       # checkpoints pickle the whole model: a process group cannot travel
-        return {"group": None, "world": 1}
+        return {"group": None, "world": 1, "sync_bn": False, "overlap": True, "_works": [], "_comm": None}
 
 
 class FlatGradDDP(nn.Module):
     """Data-parallel wrapper for models that train through the plan executor.
 
-    The plan produces every parameter gradient of a step in ONE flat fp32 arena at the end of its single autograd node,
-    so torch DDP's bucketing has nothing to overlap with and only adds per-bucket copies and hooks.  This wrapper keeps
-    DDP's contract -- parameters / buffers broadcast from rank 0 at construction, gradients averaged over the group --
-    with a single in-place ``all_reduce`` of that arena per step (one RCCL ring over xGMI, 28.9 MB for YOLOv5s).
-    BatchNorm statistics stay local, as with ``sync_bn: false`` in the reference (train_config.yaml:17)."""
+    The plan produces every parameter gradient of a step in ONE flat fp32 arena inside its single autograd node, so
+    torch DDP's per-parameter hooks have nothing to overlap with.  This wrapper keeps DDP's contract -- parameters /
+    buffers broadcast from rank 0 at construction, gradients averaged over the group -- and overlaps the exchange with
+    backward itself: the arena is all-reduced in ~5 reverse-layer buckets as they complete (see ``_FlatSync``).
+    ``sync_bn=True`` additionally averages every BatchNorm layer's batch statistics (forward) and gradient sums
+    (backward) over the ranks, i.e. torch.nn.SyncBatchNorm semantics (train_config.yaml:17 ``sync_bn``, default
+    false: statistics then stay local, as in the reference)."""
 
-    def __init__(self, module: nn.Module, process_group=None) -> None:
+    def __init__(self, module: nn.Module, process_group=None, sync_bn: bool = False) -> None:
         super().__init__()
         assert dist.is_initialized(), "init_process_group first (TrainModelBuilder.ddp_init)"
         self.module = module
-        self.sync = _FlatSync(process_group, dist.get_world_size(process_group))
+        self.sync = _FlatSync(process_group, dist.get_world_size(process_group), sync_bn)
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t, 0, group=process_group)
@@ -155,7 +212,10 @@ class TrainModelBuilder:
     def to_ddp(self) -> nn.Module:
         if self.cuda and type(self.model).__name__ == "YOLOModel" and getattr(self.model, "use_plan", True) \
                 and os.getenv("AYOLO_TORCH_DDP") != "1":
-            return FlatGradDDP(self.model)
+            return FlatGradDDP(self.model, sync_bn=bool(self.cfg.get("train", {}).get("sync_bn", False)))
+        if self.cuda and self.cfg.get("train", {}).get("sync_bn", False):
+            raise NotImplementedError("sync_bn needs the plan executor (YOLOModel with use_plan): the per-module HIP path keeps "
+                                      "BatchNorm statistics local")
         if self.cuda:
             return nn.parallel.DistributedDataParallel(self.model, device_ids=[self.local_rank], output_device=self.local_rank,
                                                        gradient_as_bucket_view=True)
@@ -165,8 +225,6 @@ class TrainModelBuilder:
         torch.manual_seed(1 + max(self.rank, 0))
         self.model.to(self.device)
         ema = ModelEMA(self.model) if self.rank in (-1, 0) else None          # train_model_builder.py:130
-        if self.cuda and self.rank != -1 and self.cfg.get("train", {}).get("sync_bn", False):
-            raise NotImplementedError("sync_bn: the HIP BatchNorm keeps statistics local (reference default)")
         if self.rank != -1:
             self.model = self.to_ddp()
         return self.model, ema, self.device

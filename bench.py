@@ -6,9 +6,12 @@ backward + SGD step, fp16 autocast with fp32 master weights) on N MI355X, one pr
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  Weak scaling: the per-GPU batch (64) is fixed as N grows; gradients are
-all-reduced by torch DDP over RCCL/xGMI, overlapped with backward.  Inputs are synthetic COCO-shape tensors that
-are resident in HBM before the timed region (no dataset, no H2D copy inside it).
+Prints ONE JSON line on rank 0.  A step is `ayolov2_amd.trainer.training_step` (the reference's
+scripts/train/yolo_trainer.py:322-338: autocast forward, ComputeLoss, x world_size, scaled backward, optimiser step, EMA on
+rank 0).  Weak scaling: the per-GPU batch (64) is fixed as N grows; the plan executor's flat gradient arena is all-reduced
+over RCCL/xGMI in reverse-layer buckets launched from a communication stream while backward is still running
+(trainer.FlatGradDDP).  Inputs are synthetic COCO-shape tensors that are resident in HBM before the timed region (no
+dataset, no image H2D copy inside it; the ~500 label rows travel from the host every step as they would from a loader).
 """
 import argparse
 import json
@@ -77,90 +80,128 @@ def build_train_objects(model_name, device, world_size):
     return model, run_model, opt, loss_fn, scaler
 
 
-def conv_kernel_roofline(model, batch, size, device, reps=5):
-    """Roofline of the dominant kernel family, k_gconv<f16>: the 57 Conv forward launches of one train step, each timed
-    live with HIP events on the launch stream.  Per launch the algorithmic cost is SURVEY.md 8d's: FLOP = 2*MAC, bytes =
-    fp16 (input + output + weights).  YOLOv5s is HBM-bound on MI355X as a whole (121 FLOP/B unfused vs a ridge of 312), so
-    the headline `achieved` is algorithmic GB/s against the 8 TB/s HBM peak; the MFMA view and the per-launch roofline
-    (sum over launches of max(FLOP/MFMA peak, bytes/HBM peak) / measured time) are reported next to it."""
-    from ayolov2_amd import ops, functional as F_
-    from ayolov2_amd.modules import Conv
-    shapes = []
-
-    def hook(mod, inp, out):
-        shapes.append((mod, tuple(inp[0].shape)))
-
-    hs = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, Conv)]
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-        model.eval()
-        model(torch.rand(1, 3, size, size, device=device))
-        model.train()
-    for h in hs:
-        h.remove()
-    total_flop = total_s = alg_bytes = roof_s = hbm_roof_s = 0.0
-    for mod, xs in shapes:
-        conv = mod.conv
-        _, cin, H, W = xs
-        dt = torch.float16
-        geo = F_._Geometry((batch, cin, H, W), conv.weight.shape, F_._pair_(conv.stride), F_._pair_(conv.padding), dt)
-        xk = torch.randn((batch, geo.Cin_k, geo.H, geo.W), device=device).to(dt).contiguous(memory_format=torch.channels_last)
-        cout = conv.weight.shape[0]
-        w, _ = mod._cache(0).get(conv.weight, dt, cout, geo.cin_pad)
-        y = ops.new_act(batch, cout, geo.Ho, geo.Wo, dt, device)
-        stats = torch.zeros((ops.STAT_REPS, 2 * cout), dtype=torch.float32, device=device)
-        d = geo.desc(dt, geo.Cin_k, cout)
-        for _ in range(2):
-            ops.conv_fwd(d, xk, w, y, 0, stats=stats)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.conv_fwd(d, xk, w, y, 0, stats=stats)
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1) / 1e3 / reps
-        kh, kw = conv.kernel_size
-        flop = 2.0 * batch * geo.Ho * geo.Wo * cout * conv.in_channels * kh * kw
-        byts = 2.0 * (xk.numel() + w.numel() + y.numel())
-        total_s += t
-        total_flop += flop
-        alg_bytes += byts
-        roof_s += max(flop / (MFMA_PEAK_TFLOPS * 1e12), byts / (HBM_PEAK_GBS * 1e9))
-        hbm_roof_s += byts / (HBM_PEAK_GBS * 1e9) if byts / (HBM_PEAK_GBS * 1e9) >= flop / (MFMA_PEAK_TFLOPS * 1e12) else 0.0
-    gbs = alg_bytes / total_s / 1e9
-    return {"bound": "hbm", "kernel": "k_gconv<f16>: the 57 Conv forward launches of one train step",
-            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            # PMC traffic covers forward AND dgrad launches of the family (same kernel); algorithmic_gb_fwd_dgrad matches it
-            "traffic": pmc_traffic(("k_gconv",), ""),
-            "traffic_unit": "GB per train step over every k_gconv launch (forward + dgrad), rocprofv3 --pmc FETCH_SIZE "
-                            "(x2 gfx950) / WRITE_SIZE passes committed under profiles/",
-            "algorithmic_gb_fwd": round(alg_bytes / 1e9, 3), "algorithmic_gb_fwd_dgrad": round(2 * alg_bytes / 1e9, 3),
-            "launch_ms_sum": round(total_s * 1e3, 3),
-            "mfma_view": {"achieved_tflops": round(total_flop / total_s / 1e12, 1), "peak_tflops": MFMA_PEAK_TFLOPS,
-                          "frac": round(total_flop / total_s / 1e12 / MFMA_PEAK_TFLOPS, 4)},
-            "per_launch_roofline_frac": round(roof_s / total_s, 4),
-            "hbm_bound_share_of_roofline_time": round(hbm_roof_s / roof_s, 3)}
-
-
-def pmc_traffic(families, suffix):
-    """HBM bytes of the roofline kernel family from the newest committed PMC summary (tools/profile_round.sh); the
-    counters need their own rocprofv3 passes, so bench.py reports the committed measurement rather than re-collecting."""
+def pmc_traffic(families):
+    """HBM bytes per step of a kernel family from the newest committed PMC summary (tools/profile_round.sh: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950).  Counters cannot be collected inside this
+    run, so the committed measurement is reported together with the file and commit it comes from."""
     import glob
+    import subprocess
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not files:
-        return None
+        return None, None
     tot = 0.0
     for k, v in json.load(open(files[-1])).items():
-        if any(f in k for f in families) and suffix in k:
+        if any(f in k for f in families):
             tot += v["fetch_GB_per_step_corrected"] + v["write_GB_per_step"]
-    return round(tot, 3) if tot else None
+    src = os.path.relpath(files[-1], ROOT)
+    try:
+        rev = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", src], capture_output=True, text=True, timeout=5).stdout.strip()
+        if rev:
+            src += "@" + rev
+    except Exception:
+        pass
+    return (round(tot, 3) if tot else None), src
 
 
-def cpu_baseline(model_name, size, batch=4, budget_s=25.0):
-    """The oracle's pure-PyTorch CPU model (kind 'port') doing the same train step on the host cores; bounded sample."""
+def in_situ_roofline(model, one_step, ms_per_step, batch):
+    """Roofline of the dominant kernel family measured INSIDE the real train step: the plan executor re-runs a few steps in
+    its measurement mode (ayolo_run_ops_timed: a HIP event before and after every op on the stream the op runs on, so cold
+    caches and the concurrent side-stream weight gradients are in the number) and the per-op times are grouped by family.
+    Per op the algorithmic cost is SURVEY.md 8d's: bytes = every tensor read / written once in the compute dtype,
+    FLOP = 2 * MAC (TrainPlan.op_costs).  Headline = k_gconv<f16>, i.e. the forward AND dgrad conv launches of the step."""
+    plans = [p for p in model.__dict__.get("_plans", {}).values() if p]
+    if not plans:
+        return None
+    plan = plans[0]
+    plan.collect_times, plan.op_times = True, {}
+    reps = 3
+    for _ in range(reps):
+        one_step()
+    torch.cuda.synchronize()
+    plan.collect_times = False
+    fam = {}
+    for what in ("forward", "backward"):
+        t = sum(plan.op_times[what]) / len(plan.op_times[what])            # ms per op, mean over the measured steps
+        for (name, byts, flop), ms in zip(plan.op_costs(what), t):
+            f = fam.setdefault(name, [0.0, 0.0, 0.0, 0])
+            f[0] += float(ms); f[1] += byts; f[2] += flop; f[3] += 1
+    plan.op_times = {}
+    # the stem runs on the image packed to 4 channels (3 real): its MACs count 3/4 (SURVEY's 49.30 GFLOP/img is on 3)
+    def view(names):
+        ms = sum(fam[n][0] for n in names if n in fam)
+        gb = sum(fam[n][1] for n in names if n in fam) / 1e9
+        tf = sum(fam[n][2] for n in names if n in fam) / 1e12
+        return ms, gb, tf
+    ms, gb, tf = view(("conv_fwd", "conv_dgrad"))
+    traffic, src = pmc_traffic(("k_gconv",))
+    fams = {n: {"launches": v[3], "ms_per_step": round(v[0], 3), "algorithmic_gb": round(v[1] / 1e9, 3),
+                "gb_per_s": round(v[1] / 1e6 / v[0], 1) if v[0] > 0 else None,
+                **({"tflops": round(v[2] / 1e9 / v[0], 1)} if v[2] else {})}
+            for n, v in sorted(fam.items(), key=lambda kv: -kv[1][0]) if v[0] > 0.0005}
+    step_gb = sum(v[1] for v in fam.values()) / 1e9
+    return {"bound": "hbm", "kernel": "k_gconv<f16>: every forward + dgrad conv launch of one train step, timed in situ",
+            "achieved": round(gb / ms * 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / ms * 1e3 / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_unit": "GB per train step over every k_gconv launch, PMC", "traffic_source": src,
+            "algorithmic_gb": round(gb, 3), "launch_ms_sum": round(ms, 3),
+            "measured": f"HIP events around each op on its own stream inside {reps} real train steps (ayolo_run_ops_timed)",
+            "mfma_view": {"achieved_tflops": round(tf / ms * 1e3, 1), "peak_tflops": MFMA_PEAK_TFLOPS,
+                          "frac": round(tf / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)},
+            "families_in_situ": fams,
+            "whole_step": {"algorithmic_gb": round(step_gb, 2), "ms_per_step": round(ms_per_step, 3),
+                           "achieved_gb_per_s": round(step_gb / ms_per_step * 1e3, 1),
+                           "frac_of_hbm_peak": round(step_gb / ms_per_step * 1e3 / HBM_PEAK_GBS, 4),
+                           "note": "sum of every op's algorithmic bytes / wall time of the step (weight gradients overlap "
+                                   "the main chain on a side stream, so family times add up to more than the step)"}}
+
+
+def host_info():
+    """Socket / model / cores of the box the CPU baseline ran on (BASELINE.md section 3 asks for lscpu's view)."""
+    info = {"threads_used": torch.get_num_threads()}
+    try:
+        import subprocess
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=5).stdout
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)"):
+                info[k] = v
+    except Exception:
+        pass
+    return info
+
+
+def _fuse_ref(r):
+    """BN folded into the conv of the oracle network (what `model.fuse()` does before validation, val.py:331)."""
+    from torch.nn.utils.fusion import fuse_conv_bn_eval
+    for mod in r.modules():
+        if hasattr(mod, "batch_norm") and isinstance(getattr(mod, "conv", None), torch.nn.Conv2d):
+            mod.conv = fuse_conv_bn_eval(mod.conv.eval(), mod.batch_norm.eval())
+            mod.batch_norm = torch.nn.Identity()
+    return r
+
+
+def _median_ms(fn, runs, warm):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline(model_name, size, batch=4, budget_s=14.0):
+    """The oracle (kind "port": pure-PyTorch CPU network + numpy / C NMS restatement, oracle/) on the host cores, bounded
+    samples of BASELINE.md section 3's three workloads.  `value` is workload C -- the headline metric's train step."""
     from ayolov2_amd.losses import ComputeLoss
+    from oracle import ops_ref
     from oracle.model_ref import RefYOLO
+    cfg = os.path.join(ROOT, "ayolov2_amd", "configs", f"{model_name}.yaml")
     torch.manual_seed(0)
-    r = RefYOLO(os.path.join(ROOT, "ayolov2_amd", "configs", f"{model_name}.yaml")).train()
+    # ---- C: train step (forward + ComputeLoss + backward + SGD), fp32
+    r = RefYOLO(cfg).train()
     r.hyp, r.gr = dict(HYP), 1.0
     loss_fn = ComputeLoss(r)
     opt = torch.optim.SGD(r.parameters(), lr=HYP["lr"], momentum=HYP["momentum"], nesterov=True)
@@ -177,9 +218,40 @@ def cpu_baseline(model_name, size, batch=4, budget_s=25.0):
         el = time.perf_counter() - t0
         if n >= 2 and el > budget_s or n >= 8:
             break
-    # first iteration includes one-off allocator/oneDNN warm-up: report the steady-state rate of the later ones
-    return {"value": round(batch * n / el, 3), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps of oracle/model_ref.py {model_name} fp32 at batch {batch}, {size}x{size}, {el:.1f} s"}
+    out = {"value": round(batch * n / el, 3), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"workload C: {n} train steps of oracle/model_ref.py {model_name} fp32 at batch {batch}, {size}x{size}, {el:.1f} s",
+           "host": host_info()}
+    # ---- A: BASELINE cfg 1 -- fuse().eval() forward + decode + NMS of 8 x 640^2, split like the reference's dt timers
+    with torch.no_grad():
+        torch.manual_seed(0)
+        rv = _fuse_ref(RefYOLO(cfg)).eval()
+        xa = torch.rand(8, 3, size, size, generator=torch.Generator().manual_seed(0))
+        t_pre = _median_ms(lambda: (xa * 255).to(torch.uint8).float() / 255.0, 5, 1)          # uint8 -> float scaling
+        pred = rv(xa)[0]
+        t_inf = _median_ms(lambda: rv(xa), 5, 2)
+        # a random-init head passes ~every anchor through conf 0.001 (30 000 candidates per image after the cap):
+        # the NMS leg of workload A is timed once; workload B below is the calibrated NMS benchmark
+        pn = pred.numpy()
+        t0 = time.perf_counter()
+        ops_ref.non_max_suppression(pn[:2], 0.001, 0.65, multi_label=True)
+        t_nms = (time.perf_counter() - t0) * 1e3 * 4
+    out["workload_a_cfg1"] = {"images": 8, "ms_per_batch": {"pre_process": round(t_pre, 2), "inference": round(t_inf, 1),
+                                                             "nms": round(t_nms, 1)},
+                              "img_per_s": round(8e3 / (t_pre + t_inf + t_nms), 2),
+                              "note": "yolov5s fuse().eval() fp32, random-init weights; NMS leg = 2 images x 4 (30 000 candidates each)"}
+    # ---- B: NMS on the calibrated synthetic predictions (8 x 25 200 x 85, ~10 % pass obj > 0.001)
+    g = torch.Generator().manual_seed(0)
+    B, N, nc = 8, 25200, 80
+    pb = torch.cat((torch.rand(B, N, 2, generator=g) * size, torch.rand(B, N, 2, generator=g) ** 3 * size / 2 + 2,
+                    torch.sigmoid(torch.randn(B, N, 1, generator=g) * 2 - 9.5),
+                    torch.sigmoid(torch.randn(B, N, nc, generator=g) * 2 - 4)), 2).numpy()
+    xc = pb[..., 4] > 0.001
+    n_cand = int(((pb[..., 5:] * pb[..., 4:5] > 0.001) & xc[..., None]).sum())
+    t_b = _median_ms(lambda: ops_ref.non_max_suppression(pb, 0.001, 0.65, multi_label=True), 5, 1)
+    out["workload_b_nms"] = {"shape": [B, N, nc + 5], "candidates": n_cand, "ms_per_batch": round(t_b, 1),
+                             "boxes_per_s": round(n_cand / t_b * 1e3, 1), "proposals_per_s": round(B * N / t_b * 1e3, 1),
+                             "note": "numpy filter + single-thread C greedy NMS (oracle/nms_oracle.c), conf 0.001 iou 0.65 multi_label"}
+    return out
 
 
 def nms_extra(device):
@@ -254,17 +326,15 @@ def main():
     head = model.model[-1]
     pred_shapes = [(args.batch, head.na, args.size // int(s), args.size // int(s), head.no) for s in head._strides_py]
 
+    from ayolov2_amd.trainer import ModelEMA, training_step
+    ema = ModelEMA(model) if rank == 0 else None                # train_model_builder.py:130: EMA lives on rank 0 only
+
     def step():
-        prep = loss_fn.prepare(targets_cpu, pred_shapes, device)   # host-side target assignment, no stream sync
-        with torch.autocast("cuda", dtype=torch.float16):
-            pred = run_model(imgs)
-            loss, _ = loss_fn(pred, targets, prepared=prep)
-        if world > 1:
-            loss = loss * world                       # yolo_trainer.py:325-326
-        scaler.scale(loss).backward()
-        scaler.step(opt)
-        scaler.update()
-        opt.zero_grad(set_to_none=True)
+        # host-side target assignment (no stream sync), then the reference's step: autocast forward, ComputeLoss,
+        # x world_size, scaled backward, optimiser step through the GradScaler, EMA
+        prep = loss_fn.prepare(targets_cpu, pred_shapes, device)
+        loss, _ = training_step(run_model, lambda pred, tg: loss_fn(pred, tg, prepared=prep), opt, scaler, imgs, targets,
+                                world_size=world, amp=True, ema=ema)
         return loss
 
     def barrier():
@@ -301,12 +371,20 @@ def main():
             "step_frac_of_mfma_peak": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / world / MFMA_PEAK_TFLOPS, 4),
         }
         if not args.no_extras and world == 1:
-            out["roofline"] = conv_kernel_roofline(model, args.batch, args.size, device)
+            out["roofline"] = in_situ_roofline(model, step, ms, args.batch)
             out["extra"] = nms_extra(device)
             out["cpu_baseline"] = cpu_baseline(args.model, args.size)
-        print(json.dumps(out), flush=True)
     if world > 1 or force_ddp:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line is the last thing this process writes to stdout (RCCL / c10d may print while shutting down)
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)          # RCCL's version banner sits in the C stdio buffer until exit otherwise
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

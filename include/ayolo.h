@@ -356,6 +356,18 @@ typedef struct ayolo_op {
     ayolo_conv_desc conv;
 } ayolo_op;
 int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s);
+/* flags: AYOLO_RUN_NO_JOIN = do not make `s` wait for the side stream at the end (the list is a segment of a longer
+ * program: the next segment's ops keep overlapping with it; the LAST segment, or ayolo_side_stream_join, joins). */
+#define AYOLO_RUN_NO_JOIN 1
+int ayolo_run_ops_ex(const ayolo_op* ops, int n, ayolo_stream s, int flags);
+/* measurement mode: the same list on the same streams with a HIP event before / after every op on the op's stream;
+ * ms[k] (host float[n]) = duration of op k in situ.  Blocks until the list has finished. */
+int ayolo_run_ops_timed(const ayolo_op* ops, int n, ayolo_stream s, float* ms);
+/* stream `waiter` waits for everything enqueued so far on the calling thread's side stream of the current device */
+int ayolo_side_stream_join(ayolo_stream waiter);
+/* The executor keeps a side stream + two events per (calling host thread, device), created on first use -- no
+ * process-global state, so several devices / threads can run op lists concurrently.  Frees the calling thread's. */
+int ayolo_release_thread_state(void);
 /* zero `bytes` bytes at a 16-byte aligned device pointer with an ordinary kernel on stream s */
 int ayolo_fill_zero(void* ptr, size_t bytes, ayolo_stream s);
 

@@ -102,6 +102,16 @@ def _flat_worker(rank, world, port, out):
     sync = net._ayolo_grad_sync
     flat = torch.arange(8, dtype=torch.float32) * (rank + 1)      # what the plan's gradient arena would hold
     sync.reduce_flat(flat)
+    # the plan's overlapped exchange: the same arena reduced bucket by bucket (reverse-layer order) must equal the single
+    # all-reduce; sync_bn's in-stream average of a statistics slice uses the same primitive
+    flat_b = torch.arange(8, dtype=torch.float32) * (rank + 1)
+    for lo, hi in ((5, 8), (2, 5), (0, 2)):
+        sync.launch_bucket(flat_b[lo:hi])
+    sync.wait_all()
+    assert torch.equal(flat_b, flat), (flat_b, flat)
+    stats = torch.tensor([2.0, 4.0]) * (rank + 1)
+    sync.average_now(stats)
+    assert torch.equal(stats, torch.tensor([3.0, 6.0]))
     import pickle
     restored = pickle.loads(pickle.dumps(sync))                    # checkpoints pickle the model: no process group inside
     assert restored.world == 1 and restored.group is None

@@ -144,3 +144,73 @@ def test_packed_head_gradient_end_to_end(use_plan):
         scale = float(g2.abs().max()) + 1e-12
         # the dense route rounds the fp32 gradient to the compute dtype in a second pass; same values, same order
         assert float((g1 - g2).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((g1 - g2).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("use_plan", [True, False])
+def test_packed_head_gradient_with_second_consumer(use_plan):
+    """The raw logits have a SECOND differentiable consumer (an auxiliary term, as a distillation loss would add): autograd
+    then hands the head `zeros placeholder + auxiliary gradient` as a new dense tensor without the payload attribute.
+    The packed loss gradient must not be dropped: parameter gradients equal the dense route's (losses.py)."""
+    import copy
+    from ayolov2_amd import YOLOModel
+    from ayolov2_amd.losses import ComputeLoss
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ayolov2_amd", "configs", "yolov5n.yaml")
+    torch.manual_seed(5)
+    m = YOLOModel(cfg).cuda().train()
+    m.hyp, m.gr, m.nc = _mini_hyp(), 1.0, 80
+    m.use_plan = use_plan
+    m2 = copy.deepcopy(m)
+    x = torch.rand(2, 3, 128, 128).cuda()
+    nt = 20
+    targets = torch.cat((torch.randint(0, 2, (nt, 1)).float(), torch.randint(0, 80, (nt, 1)).float(),
+                         torch.rand(nt, 2) * 0.9 + 0.05, torch.rand(nt, 2) * 0.3 + 0.02), 1)
+    outs = []
+    for mod, packed in ((m, True), (m2, False)):
+        cl = ComputeLoss(mod)
+        cl.packed_head_grad = packed
+        preds = mod(x)
+        prepared = cl.prepare(targets, [tuple(p.shape) for p in preds], device=x.device)
+        loss, _ = cl(preds, targets.cuda(), prepared=prepared)
+        aux = sum((p[..., :5] ** 2).mean() for p in preds)          # second consumer of the same logits
+        (loss + 3.0 * aux).backward()
+        outs.append({n: p.grad.detach().float().cpu() for n, p in mod.named_parameters()})
+    for n, g1 in outs[0].items():
+        g2 = outs[1][n]
+        scale = float(g2.abs().max()) + 1e-12
+        assert float((g1 - g2).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((g1 - g2).abs().max()) / scale)
+
+
+def test_prepare_staging_is_not_overwritten_by_the_next_step():
+    """prepare() copies the assigned targets through pinned staging asynchronously while the GPU is still busy with the
+    previous step; consecutive steps with DIFFERENT labels (different row counts per level) must each see their own
+    (a single staging buffer let step k train on step k+1's targets)."""
+    from ayolov2_amd.losses import ComputeLoss
+    torch.manual_seed(6)
+    anchors = torch.tensor([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]],
+                           dtype=torch.float32).view(3, 3, 2) / torch.tensor([8., 16., 32.]).view(3, 1, 1)
+    cl = ComputeLoss(_fake_model(_mini_hyp(), anchors.cuda()))
+    B = 4
+    shapes = [(B, 3, 32, 32, 85), (B, 3, 16, 16, 85), (B, 3, 8, 8, 85)]
+    preds = [torch.randn(s, device="cuda") for s in shapes]
+
+    def make_targets(nt):
+        return torch.cat((torch.randint(0, B, (nt, 1)).float(), torch.randint(0, 80, (nt, 1)).float(),
+                          torch.rand(nt, 2) * 0.9 + 0.05, torch.rand(nt, 2) * 0.3 + 0.02), 1)
+
+    tlist = [make_targets(n) for n in (50, 7, 90, 23, 61)]
+    tdev = [t.cuda() for t in tlist]                  # (a pageable upload inside the loop would itself synchronise)
+    want = []
+    for t, td in zip(tlist, tdev):                    # reference: one step at a time, fully synchronised
+        prep = cl.prepare(t, shapes, device="cuda")
+        torch.cuda.synchronize()
+        want.append(float(cl(preds, td, prepared=prep)[0]))
+        torch.cuda.synchronize()
+    big = torch.randn(8192, 8192, device="cuda")
+    got = []
+    for t, td in zip(tlist, tdev):                    # back to back behind a long-running kernel queue: host runs ahead
+        for _ in range(4):
+            big = big @ big * 1e-4
+        prep = cl.prepare(t, shapes, device="cuda")
+        got.append(cl(preds, td, prepared=prep)[0])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose([float(g) for g in got], want, rtol=1e-6)

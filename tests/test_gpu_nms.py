@@ -188,3 +188,21 @@ def test_candidates_staged_and_dense_chunks(monkeypatch, cpb):
         want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.65, multi_label=ml)
         got = non_max_suppression(pred.cuda(), conf_thres=0.001, iou_thres=0.65, multi_label=ml)
         _cmp(got, want, True, f"cpb={cpb} multi_label={ml}")
+
+
+@pytest.mark.parametrize("nms_type", ["fast_nms", "matrix_nms"])
+def test_fast_matrix_nms_above_the_candidate_cap(nms_type, monkeypatch):
+    """scripts/utils/metrics.py:378-379: an image with more than max_nms candidates is sorted by confidence and cut to
+    max_nms before the fast / matrix branch runs on it (:400-417), while the other images keep their original candidate
+    order.  (YoloValidator calls with multi_label and conf 0.001, where exceeding the cap is normal; round 1 raised.)
+    The cap is lowered in both the product and the oracle so that the CPU side stays an n^2 problem of seconds."""
+    from ayolov2_amd import metrics as M
+    monkeypatch.setattr(M, "MAX_NMS", 1500)
+    monkeypatch.setattr(ops_ref, "_MAX_NMS", 1500)
+    pred = synth_pred(2, 3000, 20, 640, -1.0, 11)
+    pred[1, :, 4] *= 0.003                      # image 1 stays below the cap (original order), image 0 exceeds it
+    got = M.non_max_suppression(pred.cuda(), 0.001, 0.65, multi_label=True, nms_type=nms_type)
+    want = ops_ref.non_max_suppression(pred.numpy(), 0.001, 0.65, multi_label=True, nms_type=nms_type)
+    cand = M._collect_candidates(pred.cuda().contiguous(), 0.001, True, True, None, None, True)
+    assert cand.counts[0] > 1500 > cand.counts[1] > 0, cand.counts
+    _cmp(got, want, nms_type == "fast_nms", nms_type)

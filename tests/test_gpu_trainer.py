@@ -1,0 +1,162 @@
+"""Trainer glue on the GPU: `training_step` (scripts/train/yolo_trainer.py:289-358) through the HIP plan executor with
+GradScaler, the one-launch SGD and ModelEMA, against the CPU oracle network stepped by torch's own SGD; and the
+data-parallel wrapper's overlapped bucket exchange / sync_bn code path on a single-rank RCCL group."""
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "ayolov2_amd", "configs")
+HYP = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+
+
+def _models(seed=0):
+    from ayolov2_amd import YOLOModel
+    from oracle.model_ref import RefYOLO
+    torch.manual_seed(seed)
+    cfg = os.path.join(CFG, "yolov5n.yaml")
+    m = YOLOModel(cfg)
+    r = RefYOLO(cfg)
+    r.load_state_dict(m.state_dict())
+    for mod in (m, r):
+        mod.hyp, mod.gr, mod.nc = dict(HYP), 1.0, 80
+    return m.cuda().train(), r.train()
+
+
+def _batch(seed, B=4, hw=(128, 160)):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, *hw, generator=g)
+    nt = 5 * B
+    t = torch.cat((torch.randint(0, B, (nt, 1), generator=g).float(), torch.randint(0, 80, (nt, 1), generator=g).float(),
+                   torch.rand(nt, 2, generator=g) * 0.8 + 0.1, torch.rand(nt, 2, generator=g) * 0.3 + 0.05), 1)
+    return x, t
+
+
+def _groups(model):
+    """yolo_trainer.py:149-168: BatchNorm weights / conv weights (decayed) / biases."""
+    pg_w, pg_bn, pg_b = [], [], []
+    for mod in model.modules():
+        if hasattr(mod, "bias") and isinstance(mod.bias, torch.nn.Parameter):
+            pg_b.append(mod.bias)
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            pg_bn.append(mod.weight)
+        elif hasattr(mod, "weight") and isinstance(mod.weight, torch.nn.Parameter):
+            pg_w.append(mod.weight)
+    return pg_bn, pg_w, pg_b
+
+
+def _optim(cls, model, **kw):
+    pg_bn, pg_w, pg_b = _groups(model)
+    opt = cls(pg_bn, lr=0.01, momentum=0.937, nesterov=True, **kw)
+    opt.add_param_group({"params": pg_w, "weight_decay": 5e-4})
+    opt.add_param_group({"params": pg_b})
+    return opt
+
+
+def test_training_step_matches_cpu_reference():
+    """Three `training_step`s (fp32 mode, so that the comparison is about the step logic and not fp16 rounding): forward
+    -> fused ComputeLoss -> backward through the plan -> ayolo_sgd_step -> ModelEMA, against RefYOLO + the torch-op loss +
+    torch.optim.SGD + the reference's EMA arithmetic on the CPU.  Parameters, BN running statistics and the EMA copy."""
+    import math
+    from ayolov2_amd.losses import ComputeLoss
+    from ayolov2_amd.optim import SGD
+    from ayolov2_amd.trainer import ModelEMA, training_step
+    m, r = _models(1)
+    opt_g, opt_c = _optim(SGD, m), _optim(torch.optim.SGD, r)
+    loss_g, loss_c = ComputeLoss(m), ComputeLoss(r)
+    ema = ModelEMA(m)
+    ema_ref = {k: v.detach().clone() for k, v in copy.deepcopy(r).state_dict().items()}
+    for step in range(3):
+        x, t = _batch(10 + step)
+        lg, items = training_step(m, loss_g, opt_g, None, x.cuda(), t.cuda(), world_size=1, amp=False, ema=ema)
+        lc, _ = loss_c(r(x), t)
+        opt_c.zero_grad(set_to_none=True)
+        lc.backward()
+        opt_c.step()
+        d = 0.9999 * (1 - math.exp(-(step + 1) / 2000))
+        for k, v in r.state_dict().items():
+            if v.dtype.is_floating_point:
+                ema_ref[k].mul_(d).add_((1.0 - d) * v.detach())
+            else:
+                ema_ref[k] = v.clone()
+        # step 0 starts from identical weights; later steps inherit the (BatchNorm-amplified: 80 samples per channel at
+        # stride 32) fp32 summation-order noise of the previous updates
+        np.testing.assert_allclose(float(lg), float(lc), rtol=2e-4 if step == 0 else 1e-2)
+    sd_g = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    for k, v in r.state_dict().items():
+        if v.dtype.is_floating_point:
+            err = float((sd_g[k] - v).abs().max())
+            assert err <= 2e-3 * float(v.abs().max()) + 1e-4, (k, err)
+        else:
+            assert int(sd_g[k]) == int(v), k
+    for k, v in ema.ema.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert float((v.cpu() - ema_ref[k]).abs().max()) <= 2e-3 * float(ema_ref[k].abs().max()) + 1e-4, k
+
+
+def test_training_step_amp_gradscaler_runs_and_learns():
+    """The reference's actual configuration: autocast fp16 + GradScaler (yolo_trainer.py:322-338).  The scaled loss must
+    go down over a few steps on a fixed batch and the scaler must not have skipped a step (no inf gradients)."""
+    from ayolov2_amd.losses import ComputeLoss
+    from ayolov2_amd.optim import SGD
+    from ayolov2_amd.trainer import ModelEMA, training_step
+    m, _ = _models(2)
+    opt = _optim(SGD, m)
+    loss_fn = ComputeLoss(m)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    ema = ModelEMA(m)
+    x, t = _batch(20)
+    x, t = x.cuda(), t.cuda()
+    losses = [float(training_step(m, loss_fn, opt, scaler, x, t, amp=True, ema=ema)[0]) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert float(scaler.get_scale()) == 1024.0 and ema.updates == 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_flat_grad_ddp_single_rank_rccl(sync_bn, monkeypatch):
+    """FlatGradDDP on a one-rank RCCL group with the exchange forced on: the backward list runs in bucket segments, every
+    bucket's all-reduce is enqueued from the communication stream (after the executor's side stream), the compute stream
+    joins before the gradients are handed out; with sync_bn every BN layer's statistics / gradient sums are averaged in
+    stream order.  On one rank the averages are identities, so gradients and BN buffers must equal the plain model's."""
+    import torch.distributed as dist
+    from ayolov2_amd.losses import ComputeLoss
+    from ayolov2_amd.trainer import FlatGradDDP
+    monkeypatch.setenv("AYOLO_FORCE_DDP", "1")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        m, _ = _models(3)
+        m2 = copy.deepcopy(m)
+        w = FlatGradDDP(m, sync_bn=sync_bn)
+        assert m._ayolo_grad_sync.active()
+        x, t = _batch(30)
+        outs = []
+        for mod, run in ((m, w), (m2, m2)):
+            loss, _ = ComputeLoss(mod)(run(x.cuda()), t.cuda())
+            loss.backward()
+            outs.append(({k: p.grad.detach().float().cpu() for k, p in mod.named_parameters()},
+                         {k: b.detach().float().cpu() for k, b in mod.named_buffers()}))
+        plan = next(iter(m._plans.values()))
+        assert len(plan.buckets) >= 2 and not m._ayolo_grad_sync._works       # all bucket works were waited for
+        for k, g in outs[0][0].items():
+            ref = outs[1][0][k]
+            assert float((g - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-7, k
+        for k, b in outs[0][1].items():
+            torch.testing.assert_close(b, outs[1][1][k], rtol=1e-5, atol=1e-6)
+    finally:
+        dist.destroy_process_group()

@@ -222,3 +222,30 @@ def test_tta_vs_golden(golden_dir):
     np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-6, atol=1e-5)
     np.testing.assert_allclose(tta.scale_img(x, 0.83, gs=32).numpy(), g["scaled_083"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(tta.scale_img(x, 0.5, same_shape=True, gs=32).numpy(), g["scaled_same"], rtol=1e-6, atol=1e-6)
+
+
+def test_plan_gradient_buckets_cover_the_arena():
+    """The train plan compiles on CPU tensors (no kernel runs): its reverse-layer gradient buckets must tile the flat
+    gradient arena exactly, become ready in backward order, and no bucket may be released before the last backward op
+    that writes into it (weight-gradient / BatchNorm-apply / head-bias writers recorded at emission)."""
+    import torch
+    from ayolov2_amd import YOLOModel
+    from ayolov2_amd.plan import TrainPlan
+    m = YOLOModel(os.path.join(ROOT, "ayolov2_amd", "configs", "yolov5s.yaml")).train()
+    pl = TrainPlan(m, (2, 3, 64, 64), torch.float16, torch.device("cpu"))
+    b = pl.buckets
+    assert 3 <= len(b) <= 8
+    assert b[0][2] == pl.gradarena.total and b[-1][1] == 0
+    for (r0, lo0, hi0), (r1, lo1, hi1) in zip(b, b[1:]):
+        assert lo0 == hi1 and r0 <= r1
+    for idx, off, n in pl.grad_done:
+        ready = next(r for r, lo, hi in b if lo <= off < hi)
+        assert ready >= idx and off + n <= next(hi for r, lo, hi in b if lo <= off < hi)
+    covered = sum(n for _, _, n in pl.grad_done)
+    assert covered >= sum(p.numel() for p in m.parameters())          # every parameter has a writer (slots are padded)
+    # C3's cv1 | cv2 run as one conv: 8 fewer forward / dgrad / wgrad launches than the 60 convolutions of the model
+    from collections import Counter
+    kinds = Counter(o.kind & 0xff for o in pl.bwd)
+    assert kinds[3] == 52 and kinds[2] == 51
+    # sync_bn cut points: one per conv launch (forward), one per BatchNorm layer (backward)
+    assert len(pl.fwd_sync_idx) == 49 and len(pl.bwd_sync) == 57
