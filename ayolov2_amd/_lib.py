@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AYOLO_LIB") or os.path.join(_HERE, "libayolo_hip.so")
 
 F16, F32 = 0, 1
-EPI_NONE, EPI_AFFINE, EPI_AFFINE_SILU, EPI_HEAD = 0, 1, 2, 3
+EPI_NONE, EPI_AFFINE, EPI_AFFINE_SILU, EPI_HEAD, EPI_AFFINE_RES, EPI_AFFINE_SILU_RES = 0, 1, 2, 3, 4, 5
 
 
 class ConvDesc(ctypes.Structure):

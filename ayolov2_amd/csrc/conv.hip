@@ -63,6 +63,12 @@ __device__ __forceinline__ void mma_step(const Tr<float>::frag& a, const Tr<floa
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b.v[s], acc, 0, 0, 0);
 }
+// SiLU of the inference epilogue: fp16 outputs use v_exp_f32 + v_rcp_f32 (1 ulp, far below the fp16 rounding of the
+// result; silu_f's IEEE division costs ~10 VALU ops per element), the fp32 parity mode keeps expf + true division
+template <typename T> __device__ __forceinline__ float silu_e(float u) {
+    if constexpr (sizeof(T) == 2) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+    else return silu_f(u);
+}
 __device__ __forceinline__ float cvt_round(float v, half_t*) { return (float)(half_t)v; }
 __device__ __forceinline__ float cvt_round(float v, float*) { return v; }
 
@@ -71,6 +77,7 @@ __device__ __forceinline__ float cvt_round(float v, float*) { return v; }
 //
 // EM (epilogue mode, compile time so that unused paths cost no registers):
 //   0 plain store (+ optional BN statistics)   1 accumulate into y (dgrad)   2 affine / affine+SiLU   3 YOLOHead fp32
+//   4 affine / affine+SiLU added onto y (in-place Bottleneck shortcut of the inference executor)
 //
 // A workgroup owns output-channel tile `nt` and walks the pixel tiles of its XCD's band; one "step" = (pixel tile,
 // 32-wide k slice).  The tiles of step s+2 are in flight (global -> LDS, no VGPR staging, no ds_write pass) while the
@@ -313,7 +320,8 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[g][e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
-            if constexpr (EM == 2) {
+            if constexpr (EM == 2 || EM == 4) {
+                const bool act = p.epi == AYOLO_EPI_AFFINE_SILU || p.epi == AYOLO_EPI_AFFINE_SILU_RES;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -322,7 +330,7 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
                         if (c < p.Nout) {
                             float sc = p.scale ? p.scale[c] : 1.0f, sh = p.shift ? p.shift[c] : 0.0f;
                             float u = v[g][e] * sc + sh;
-                            v[g][e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
+                            v[g][e] = act ? silu_e<T>(u) : u;
                         }
                     }
             }
@@ -351,7 +359,7 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
                 float w8[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { w8[e] = v[2 * j][e]; w8[4 + e] = v[2 * j + 1][e]; }
-                if constexpr (EM == 1) {
+                if constexpr (EM == 1 || EM == 4) {
                     const half8 o = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w8[e] += (float)o[e];
@@ -379,13 +387,14 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, f), rsY, off, 0, 0);
                 continue;
             }
-            if constexpr (EM == 2) {
+            if constexpr (EM == 2 || EM == 4) {
+                const bool act = p.epi == AYOLO_EPI_AFFINE_SILU || p.epi == AYOLO_EPI_AFFINE_SILU_RES;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (c + e < p.Nout) {
                         float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
                         float u = v[e] * sc + sh;
-                        v[e] = (p.epi == AYOLO_EPI_AFFINE_SILU) ? silu_f(u) : u;
+                        v[e] = act ? silu_e<T>(u) : u;
                     }
                 }
             }
@@ -399,7 +408,7 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
             }
             const unsigned off = (pv && c < p.Nout) ? yo + (unsigned)c * G::ES : G_OOB;   // Nout % 4 == 0 (host check)
             if constexpr (sizeof(T) == 2) {
-                if constexpr (EM == 1) {
+                if constexpr (EM == 1 || EM == 4) {
                     const half4 o = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(rsY, off, 0, 0));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += (float)o[e];
@@ -409,7 +418,7 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
                 for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, h), rsY, off, 0, 0);
             } else {
-                if constexpr (EM == 1) {
+                if constexpr (EM == 1 || EM == 4) {
                     const float4v o = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += o[e];
@@ -715,6 +724,7 @@ template <typename T, int TM>
 static int launch_gconv(const GConvP& p, hipStream_t s) {
     if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
     if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_gconv_em<T, TM, 2>(p, s);
+    if (p.epi == AYOLO_EPI_AFFINE_RES || p.epi == AYOLO_EPI_AFFINE_SILU_RES) return launch_gconv_em<T, TM, 4>(p, s);
     if (p.accumulate) return launch_gconv_em<T, TM, 1>(p, s);
     return launch_gconv_em<T, TM, 0>(p, s);
 }
@@ -788,7 +798,7 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
     int rc = check_desc(d, "conv_fwd");
     if (rc) return rc;
     AY_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
-    AY_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "conv_fwd: epilogue %d", epilogue);
+    AY_CHECK_ARG(epilogue >= 0 && epilogue <= 5, "conv_fwd: epilogue %d", epilogue);
     AY_CHECK_ARG(epilogue != AYOLO_EPI_HEAD || (head_no > 0 && d->Cout % head_no == 0), "conv_fwd: head_no=%d", head_no);
     AY_CHECK_ARG(stats == nullptr || epilogue == AYOLO_EPI_NONE, "conv_fwd: stats need EPI_NONE");
     GConvP p{};

@@ -224,6 +224,12 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
         case AYOLO_OP_MEMSET:
             rc = ayolo_fill_zero(o.p[0], (size_t)o.l[0], cs);
             break;
+        case AYOLO_OP_HEAD_DECODE: {
+            const int64_t st[4] = {o.i[5], o.i[6], o.i[7], o.i[8]};            // element strides of (b, a, y, x)
+            rc = ayolo_head_decode((const float*)o.p[0], st, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], (const float*)o.p[1], o.f[0],
+                                   (float*)o.p[2], (int64_t)o.l[0], (int64_t)o.i[9], cs);
+            break;
+        }
         case AYOLO_OP_BN_EVAL_AFFINE:
             rc = ayolo_bn_eval_affine((const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2], (const float*)o.p[3],
                                       (const float*)o.p[4], o.f[0], o.i[0], (float*)o.p[5], (float*)o.p[6], cs);

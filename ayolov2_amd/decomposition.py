@@ -200,3 +200,55 @@ def decompose_model(model: nn.Module, loss_thr: float = 0.1, prune_step: float =
             model[i] = best
         else:
             model.conv = best
+
+
+def count_param(model: nn.Module) -> int:
+    return sum(p.numel() for p in model.parameters())
+
+
+def run_decompose(model: nn.Module, validator, device, loss_thr: float = 0.1, prune_step: float = 0.01):
+    """decompose_model.py:107-152 ``run_decompose``: decompose a copy of `model` on the CPU (the SVDs are host work, as in
+    the reference), move it to `device` in eval mode and validate it with `validator` (a ``YoloValidator``; ``None`` skips
+    the validation).  Returns (decomposed_model, validation result); the eval forward of the decomposed model runs on the
+    inference executor (three launches per decomposed block, infer_plan.py)."""
+    import time
+    plans = model.__dict__.pop("_plans", None)               # cached executor plans are not part of the copy
+    try:
+        decomposed = deepcopy(model).cpu()
+    finally:
+        if plans is not None:
+            model.__dict__["_plans"] = plans
+    decompose_model(decomposed, loss_thr=loss_thr, prune_step=prune_step)
+    n0, n1 = count_param(model), count_param(decomposed)
+    decomposed.to(device).eval()
+    result = None
+    took = 0.0
+    if validator is not None:
+        validator.model = decomposed
+        t0 = time.monotonic()
+        result = validator.validation()
+        took = time.monotonic() - t0
+    decomposed.decompose_info = {"params_before": n0, "params_after": n1, "loss_thr": loss_thr, "prune_step": prune_step,
+                                 "validation_s": took, "ranks": decomposed_ranks(decomposed)}
+    return decomposed, result
+
+
+def decomposed_ranks(model: nn.Module) -> Dict[str, Tuple[int, int]]:
+    """{module name: (r_in, r_out)} of every Tucker-decomposed conv (the 3-conv Sequential of
+    tucker_decomposition_conv_layer)."""
+    out = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.Sequential) and len(mod) == 3 and all(isinstance(c, nn.Conv2d) for c in mod) \
+                and mod[0].kernel_size == (1, 1) and mod[2].kernel_size == (1, 1):
+            out[name] = (mod[0].out_channels, mod[1].out_channels)
+    return out
+
+
+def save_decomposed(model: nn.Module, path: str) -> None:
+    """decompose_model.py:293-299: the decomposed model is stored in half precision."""
+    plans = model.__dict__.pop("_plans", None)
+    try:
+        torch.save({"model": deepcopy(model).cpu().half()}, path)
+    finally:
+        if plans is not None:
+            model.__dict__["_plans"] = plans

@@ -59,7 +59,7 @@ class _WeightCache:
 class _Geometry:
     """How a conv is presented to the kernels (incl. the stem's pixel-pair packing)."""
 
-    def __init__(self, x_shape, weight_shape, stride, padding, dt):
+    def __init__(self, x_shape, weight_shape, stride, padding, dt, allow_packed_stem: bool = True):
         B, Cx, H, W = x_shape
         Cout, Cin, kh, kw = weight_shape
         sh, sw = stride
@@ -70,7 +70,7 @@ class _Geometry:
         self.B, self.Cout = B, Cout
         self.Ho = (H + 2 * ph - kh) // sh + 1
         self.Wo = (W + 2 * pw - kw) // sw + 1
-        if Cin % ce != 0 and Cin <= 4 and dt == torch.float16 and kw % 2 == 0 and sw == 2 and pw % 2 == 0 and W % 2 == 0:
+        if allow_packed_stem and Cin % ce != 0 and Cin <= 4 and dt == torch.float16 and kw % 2 == 0 and sw == 2 and pw % 2 == 0 and W % 2 == 0:
             # 4-channel NHWC image viewed as (B, H, W/2, 8): k6/s2/p2 along W becomes k3/s1/p1 over pixel pairs
             self.packed_stem = True
             self.cin_pad = 4

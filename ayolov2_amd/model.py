@@ -120,6 +120,11 @@ class YOLOModel(nn.Module):
                 raise RuntimeError("FlatGradDDP needs the plan executor (model not plannable / use_plan off): "
                                    "wrap with torch DistributedDataParallel instead")
             ops.ARENA.reset()          # one fill for all BN accumulators of this step
+        elif x.is_cuda and x.dim() == 4 and getattr(self, "use_plan", True) and not torch.is_grad_enabled():
+            from .infer_plan import plan_forward_eval
+            res = plan_forward_eval(self, x)           # static inference executor (None: unsupported structure)
+            if res is not None:
+                return res
         outs: List[Any] = []
         for i, m in enumerate(self.model):
             frm = self.routes[i]

@@ -292,6 +292,91 @@ def nms_extra(device):
             "nms_filter_hbm_gbs_lower_bound": round(B * N * (nc + 5) * 4 / dt / 1e9, 1)}
 
 
+def _timed(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def config_extras(device):
+    """BASELINE.json configurations 4 and 5 (secondary lines; the headline is configuration 2), on the inference executor:
+      cfg 4: Tucker-decomposed YOLOv5s (decompose_model defaults loss_thr 0.1 / prune_step 0.01 are kept except prune_step = 0
+             to bound the SVD count; weights carry a planted rank-1/4 structure because random-init weights have none),
+             batch 128, 640x640, fp16, eval forward + decode;
+      cfg 5: YOLOv5x 1280x1280 batch 8 fuse().eval() fp16 forward + decode, then + NMS on the synthetic-calibrated
+             (8, 100 800, 85) prediction (a random-init head passes nothing through conf 0.001)."""
+    from ayolov2_amd import YOLOModel, decomposition as D
+    from ayolov2_amd.metrics import non_max_suppression
+    from ayolov2_amd.modules import Conv
+    out = {}
+    cfgdir = os.path.join(ROOT, "ayolov2_amd", "configs")
+    # ---- cfg 4
+    torch.manual_seed(0)
+    m = YOLOModel(os.path.join(cfgdir, "yolov5s.yaml"))
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, Conv) and mod.conv.kernel_size != (1, 1):
+                w = mod.conv.weight.data
+                co, ci, kh, kw = w.shape
+                ro, ri = max(co // 4, 2), max(ci // 4, 2)
+                std = 1.0 / (ci * kh * kw) ** 0.5
+                w.copy_(torch.einsum("abhw,oa,ib->oihw", torch.randn(ro, ri, kh, kw), torch.randn(co, ro), torch.randn(ci, ri))
+                        * (std / (ro * ri) ** 0.5) + 0.05 * std * torch.randn_like(w))
+    t0 = time.perf_counter()
+    dec, _ = D.run_decompose(m, None, device, loss_thr=0.1, prune_step=0.0)
+    t_dec = time.perf_counter() - t0
+    info = dec.decompose_info
+    x4 = torch.rand(128, 3, 640, 640, device=device)
+
+    def fwd4(model):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return model(x4)[0]
+
+    t4 = _timed(lambda: fwd4(dec), 5)
+    m = m.to(device).eval()
+    t4o = _timed(lambda: fwd4(m), 5)
+    out["cfg4"] = {"workload": "Tucker-decomposed yolov5s, batch 128, 640x640, fp16 eval forward + decode",
+                   "params": info["params_after"], "params_original": info["params_before"],
+                   "decomposed_convs": len(info["ranks"]), "ranks_in_out": sorted(set(info["ranks"].values())),
+                   "decompose_s_cpu": round(t_dec, 1), "ms_per_batch": round(t4 * 1e3, 2), "img_per_s": round(128 / t4, 1),
+                   "undecomposed_ms_per_batch": round(t4o * 1e3, 2), "undecomposed_img_per_s": round(128 / t4o, 1)}
+    del dec, m, x4
+    torch.cuda.empty_cache()
+    # ---- cfg 5
+    torch.manual_seed(0)
+    mx = YOLOModel(os.path.join(cfgdir, "yolov5x.yaml")).to(device).fuse().eval()
+    x5 = torch.rand(8, 3, 1280, 1280, device=device)
+    g = torch.Generator().manual_seed(0)
+    B, N, nc, img = 8, 100800, 80, 1280
+    synth = torch.cat((torch.rand(B, N, 2, generator=g) * img, torch.rand(B, N, 2, generator=g) ** 3 * img / 2 + 2,
+                       torch.sigmoid(torch.randn(B, N, 1, generator=g) * 2 - 9.5),
+                       torch.sigmoid(torch.randn(B, N, nc, generator=g) * 2 - 4)), 2).to(device)
+
+    def fwd5():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return mx(x5)[0]
+
+    t5 = _timed(fwd5, 5)
+
+    def fwd5_nms():
+        fwd5()
+        return non_max_suppression(synth, 0.001, 0.65, multi_label=True)
+
+    t5n = _timed(fwd5_nms, 5)
+    gflop = 821.79                                              # SURVEY.md 8d: yolov5x @1280 forward conv GFLOP per image
+    out["cfg5"] = {"workload": "yolov5x 1280x1280 batch 8 fuse().eval() fp16: forward + decode (+ NMS of 8 x 100 800 x 85 synthetic)",
+                   "fwd_decode_ms": round(t5 * 1e3, 2), "fwd_decode_nms_ms": round(t5n * 1e3, 2), "img_per_s_with_nms": round(8 / t5n, 1),
+                   "fwd_conv_tflops": round(8 * gflop / t5 / 1e3, 1), "frac_of_mfma_peak": round(8 * gflop / t5 / 1e3 / MFMA_PEAK_TFLOPS, 4)}
+    del mx, x5, synth
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,6 +458,10 @@ def main():
         if not args.no_extras and world == 1:
             out["roofline"] = in_situ_roofline(model, step, ms, args.batch)
             out["extra"] = nms_extra(device)
+            try:
+                out["extra"].update(config_extras(device))
+            except Exception as e:                              # secondary lines must never cost the headline
+                out["extra"]["config_extras_error"] = repr(e)[:300]
             out["cpu_baseline"] = cpu_baseline(args.model, args.size)
     if world > 1 or force_ddp:
         torch.distributed.destroy_process_group()

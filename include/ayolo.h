@@ -60,6 +60,8 @@ typedef struct ayolo_conv_desc {
 #define AYOLO_EPI_AFFINE_SILU 2 /* y = silu(conv*scale[c] + shift[c])  (eval / fused-BN inference)     */
 #define AYOLO_EPI_HEAD 3      /* y(fp32)[pixel][ldy] = conv + shift[c] (YOLOHead logits; ldy = Cout rounded up
                                * to 8; the (B,na,ny,nx,no) tensor is a strided view: c = a*no + o)           */
+#define AYOLO_EPI_AFFINE_RES 4      /* y += conv*scale[c] + shift[c]        (in-place residual: Bottleneck shortcut)  */
+#define AYOLO_EPI_AFFINE_SILU_RES 5 /* y += silu(conv*scale[c] + shift[c])  (inference: `x + cv2(cv1(x))` over x)     */
 
 /* y = conv(x, w).  `stats` (nullable, EPI_NONE only): float[stat_reps][2*Cout] zero-initialised by the caller;
  * receives per-channel sum and sum of squares of the fp32 accumulators rounded to the output dtype (training-mode
@@ -344,7 +346,7 @@ enum {
     AYOLO_OP_CONV_FWD = 1, AYOLO_OP_CONV_DGRAD, AYOLO_OP_CONV_WGRAD, AYOLO_OP_CAST_WEIGHT, AYOLO_OP_BN_FINALIZE,
     AYOLO_OP_AFFINE_ACT, AYOLO_OP_BN_BWD_REDUCE, AYOLO_OP_BN_BWD_APPLY, AYOLO_OP_MAXPOOL_FWD, AYOLO_OP_MAXPOOL_BWD,
     AYOLO_OP_UPSAMPLE_FWD, AYOLO_OP_UPSAMPLE_BWD, AYOLO_OP_PACK_INPUT, AYOLO_OP_HEAD_GRAD_PACK, AYOLO_OP_COPY2D,
-    AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT, AYOLO_OP_CAST_WEIGHTS
+    AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT, AYOLO_OP_CAST_WEIGHTS, AYOLO_OP_HEAD_DECODE
 };
 typedef struct ayolo_op {
     int kind;
