@@ -44,6 +44,7 @@ _SIGNATURES = {
     "ayolo_ema_update": [_P, c_int, c_float, _P],
     "ayolo_cast_weights": [_P, c_int, c_int, _P],
     "ayolo_sgd_step": [_P, c_int, _P, _P, _P, _P],
+    "ayolo_coco_rows": [_P, _P, c_int64, _P, _P, c_int, _P, _P],
     "ayolo_bn_finalize": [_P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
     "ayolo_affine_act": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int, _P],
     "ayolo_bn_train_act": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P,

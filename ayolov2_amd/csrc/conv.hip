@@ -291,7 +291,7 @@ __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int 
 template <typename T, int TM, int EM, int TPX>
 __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int oah, int oaw, int wp, int lane, int cbase,
                                            bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM, TPX>::NI],
-                                           float (&ssum)[16], float (&ssq)[16]) {
+                                           float (&ssum)[16], float (&ssq)[16], const float* sAff, int cl) {
     using G = GT<T, TM, TPX>;
     constexpr int YES = (EM == 3) ? 4 : G::ES;       // bytes per output element
     const unsigned m0 = tile * G::TP;
@@ -321,18 +321,19 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[g][e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
             if constexpr (EM == 2 || EM == 4) {
+                // per-channel scale / shift of this workgroup's channel tile were staged in LDS once (sAff: a global load
+                // here would make hipcc drain the hidden DMA queue with vmcnt(0) in every epilogue)
                 const bool act = p.epi == AYOLO_EPI_AFFINE_SILU || p.epi == AYOLO_EPI_AFFINE_SILU_RES;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g) {
+                    const float4v sc = *reinterpret_cast<const float4v*>(sAff + cl + 8 * g);
+                    const float4v sh = *reinterpret_cast<const float4v*>(sAff + TM + cl + 8 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int c = cbase + 8 * g + e;
-                        if (c < p.Nout) {
-                            float sc = p.scale ? p.scale[c] : 1.0f, sh = p.shift ? p.shift[c] : 0.0f;
-                            float u = v[g][e] * sc + sh;
-                            v[g][e] = act ? silu_e<T>(u) : u;
-                        }
+                        const float u = v[g][e] * sc[e] + sh[e];
+                        v[g][e] = act ? silu_e<T>(u) : u;
                     }
+                }
             }
             if (want_stats) {
 #pragma unroll
@@ -389,13 +390,12 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
             }
             if constexpr (EM == 2 || EM == 4) {
                 const bool act = p.epi == AYOLO_EPI_AFFINE_SILU || p.epi == AYOLO_EPI_AFFINE_SILU_RES;
+                const float4v sc = *reinterpret_cast<const float4v*>(sAff + cl + 8 * g);
+                const float4v sh = *reinterpret_cast<const float4v*>(sAff + TM + cl + 8 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (c + e < p.Nout) {
-                        float sc = p.scale ? p.scale[c + e] : 1.0f, sh = p.shift ? p.shift[c + e] : 0.0f;
-                        float u = v[e] * sc + sh;
-                        v[e] = act ? silu_e<T>(u) : u;
-                    }
+                    const float u = v[e] * sc[e] + sh[e];
+                    v[e] = act ? silu_e<T>(u) : u;
                 }
             }
             if (want_stats) {
@@ -503,6 +503,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
         if (tid < p.ntaps) { e.x = (dh * p.XW + dw) * p.ldx * G::ES; e.y = dh; e.z = dw; e.w = wt * p.C * G::ES; }
         else { e.x = 0; e.y = -100000; e.z = 0; e.w = 0x40000000; }
         sTap[tid] = e;
+    }
+
+    if constexpr (EM == 2 || EM == 4) {
+        // affine epilogue constants of this channel tile -> LDS [scale | shift] (identity beyond Nout / for null pointers)
+        for (int i = tid; i < TM; i += 256) {
+            const bool in = n0 + i < p.Nout;
+            sStat[i] = (in && p.scale) ? p.scale[n0 + i] : 1.0f;
+            sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
+        }
     }
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
@@ -614,7 +623,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
         after_epi = false;
         if (cur_kt == cur_nk - 1) {
             if constexpr (sizeof(T) == 2) asm volatile("s_nop 11" ::: "memory");   // fp16: accumulators are only read here
-            g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq);
+            g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq,
+                                       sStat, cbase - n0);
             after_epi = true;
         }
         if (++cur_kt == cur_nk) {
@@ -730,7 +740,13 @@ static int launch_gconv(const GConvP& p, hipStream_t s) {
 }
 
 static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
+    // Output-channel tile: the widest that is not mostly padding.  Measured on the YOLOv5x widths (80 / 160 / 320 / 640 / 1280
+    // channels, profiles/r02_conv_tm_sweep_yolov5x.txt): 128-wide tiles beat 64- and 32-wide ones by 1.3-2.5x even where
+    // 37 % of the tile is padding (80 or 160 output channels) -- a narrow tile re-reads the pixel tile per channel tile and
+    // halves the MFMAs per barrier -- so padding waste is NOT a reason to go narrower.  AYOLO_GCONV_TM forces a tile.
+    static const int force_tm = getenv("AYOLO_GCONV_TM") ? atoi(getenv("AYOLO_GCONV_TM")) : 0;
     int tm = p.Nout <= 32 ? 32 : (p.Nout <= 64 ? 64 : 128);
+    if (force_tm == 32 || force_tm == 64 || force_tm == 128) tm = force_tm;
     if (dtype == AYOLO_F16) {
         if (tm == 32) return launch_gconv<half_t, 32>(p, s);
         if (tm == 64) return launch_gconv<half_t, 64>(p, s);

@@ -52,7 +52,7 @@ def inference_with_tta(model: nn.Module, x: torch.Tensor, s: Sequence[float], f:
     y = []
     for si, fi in zip(s, f):
         xi = scale_img(x.flip(fi) if fi else x, si, gs=int(model.stride.max()))
-        yi = model(xi)[0]
+        yi = model(xi)[0].clone()      # the inference executor returns a view of static storage; descale_pred is in place
         yi = descale_pred(yi, fi, si, img_size)
         y.append(yi)
     y = clip_augmented(model, y)

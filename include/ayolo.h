@@ -336,6 +336,15 @@ int ayolo_match_detections(const float* det, const int* det_img, int64_t N, cons
                            unsigned char* correct, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Result rows of the COCO json (scripts/utils/multi_queue.py:204-305 `_add_outputs` / `add_predicted_box`; un-letterbox =
+ * scripts/utils/general.py:324-358 `scale_coords`): det[n][6] = [x1,y1,x2,y2,conf,cls] of a whole batch, img_of_row[n] =
+ * image index of every row, letterbox[B][6] = {gain, pad_w, pad_h, w0, h0, apply (0: leave the box as it is)},
+ * cat_table[ncat] class -> category id (nullable).  out[n][6] = [x, y, width, height, score, category id].
+ * ---------------------------------------------------------------------------------------------- */
+int ayolo_coco_rows(const float* det, const int* img_of_row, int64_t n, const float* letterbox, const int* cat_table,
+                    int ncat, float* out, ayolo_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * Batched launch: a pre-compiled straight-line program of the calls above (one model forward or backward over
  * static buffers) enqueued by ONE host call.  Field use per kind: see csrc/plan.hip.
  * ---------------------------------------------------------------------------------------------- */

@@ -480,3 +480,30 @@ def batched_nms_trt(boxes, scores, top_k: int = 512, keep_top_k: int = 100, scor
         for j, (s_, c, _, i) in enumerate(kept):
             ob[b, j], osc[b, j], ocl[b, j] = boxes[b, i], s_, c
     return num, ob, osc, ocl
+
+
+# YOLO class index -> COCO category id (scripts/utils/multi_queue.py:78-159 `label_fixer`)
+COCO80_TO_91 = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 31, 32, 33, 34, 35, 36,
+                37, 38, 39, 40, 41, 42, 43, 44, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 67,
+                70, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 84, 85, 86, 87, 88, 89, 90]
+
+
+def coco_rows(names, outputs, img_size, shapes=None):
+    """scripts/utils/multi_queue.py:204-305 `_add_outputs` + `add_predicted_box` for one batch: per image
+    scale_coords(img_size, bbox, original shape) (ResultWriterTorch.scale_coords, :316-339), xyxy -> [x, y, w, h]
+    (:262-266), the json objects with the category table.  outputs: per image (n, 6) float32 or None."""
+    from pathlib import Path
+    objs = []
+    for i, name in enumerate(names):
+        if outputs[i] is None or len(outputs[i]) == 0:
+            continue
+        o = _f32(outputs[i])
+        bbox, conf = o[:, :4].copy(), o[:, 4:]
+        if shapes is not None:
+            bbox = scale_coords(img_size, bbox, shapes[i][0])
+            bbox[:, 2] = bbox[:, 2] - bbox[:, 0]
+            bbox[:, 3] = bbox[:, 3] - bbox[:, 1]
+        for row, c in zip(bbox, conf):
+            objs.append({"image_id": int(Path(name).stem), "category_id": COCO80_TO_91[int(c[1])],
+                         "bbox": [float(p) for p in row], "score": float(c[0])})
+    return objs

@@ -35,6 +35,7 @@ def main():
           if isinstance(m, Conv)]
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         model.eval()
+        model.use_plan = False          # per-module path: the forward hooks below see every Conv (the executor bypasses them)
         model(torch.rand(1, 3, size, size, device=dev))
     for h in hs:
         h.remove()
