@@ -48,7 +48,13 @@ static int side_ctx(SideCtx** out) {
     AY_CHECK_ARG(dev >= 0 && dev < AY_MAX_DEVICES, "run_ops: device ordinal %d unsupported", dev);
     SideCtx& c = t_side[dev];
     if (!c.side) {
-        AY_CHECK_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        // lowest priority: the side stream carries the weight gradients, which only have to finish by the end of the
+        // list -- the dependent chain on the caller's stream (BN passes, dgrads) should win the CUs when both have work
+        static const int prio_env = getenv("AYOLO_SIDE_PRIORITY") ? atoi(getenv("AYOLO_SIDE_PRIORITY")) : 1;
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (prio_env == 0) AY_CHECK_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        else AY_CHECK_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, prio_env > 0 ? least : greatest));
         AY_CHECK_HIP(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
         AY_CHECK_HIP(hipEventCreateWithFlags(&c.join, hipEventDisableTiming));
     }

@@ -1,13 +1,8 @@
 #!/bin/bash
-tag=${1:-r02j}
+tag=${1:-r02k}
 out=gpurun_out; mkdir -p $out
-python -m pytest tests -m gpu -x -q -s > $out/${tag}_tests.txt 2>&1; echo "tests rc=$?" | tee -a $out/${tag}_tests.txt
-grep -n "passed\|failed\|largest relative\|full-size fp16\|Error" $out/${tag}_tests.txt | cut -c1-250 | head
-python tools/eval_loop.py > /dev/null 2>&1
-python - <<'PY'
-import os, sys, time, torch
-sys.path.insert(0, os.getcwd())
-import bench
-print(bench.config_extras(torch.device("cuda"))["cfg5"])
-PY
-python bench.py --no-extras --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; print('bench', json.loads(sys.stdin.read())['ms_per_step'])"
+for rep in 1 2; do
+for v in "AYOLO_SIDE_PRIORITY=1" "AYOLO_SIDE_PRIORITY=0" "AYOLO_SIDE_PRIORITY=-1"; do
+  env $v python bench.py --no-extras --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; print('$v', json.loads(sys.stdin.read())['ms_per_step'])" | tee -a $out/${tag}_ab.txt
+done; done
+python -m pytest tests/test_gpu_infer.py -m gpu -x -q -s 2>&1 | grep -n "passed\|failed\|largest relative\|full-size fp16\|Error" | cut -c1-300
