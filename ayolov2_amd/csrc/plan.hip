@@ -230,6 +230,16 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
         case AYOLO_OP_MEMSET:
             rc = ayolo_fill_zero(o.p[0], (size_t)o.l[0], cs);
             break;
+        case AYOLO_OP_BN_BWD_FUSED:
+            // p: z, da, dz, save_mean (save_invstd follows at +C), gamma, beta, sums[2C] (the barrier word follows), dgamma, dbeta
+            rc = ayolo_bn_act_bwd_fused(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.p[2], o.i[3], o.l[0], o.i[4], (const float*)o.p[3],
+                                        (const float*)o.p[3] + o.i[4], (const float*)o.p[4], (const float*)o.p[5], o.i[5],
+                                        (float*)o.p[6], (unsigned*)((float*)o.p[6] + 2 * o.i[4]), (float*)o.p[7], (float*)o.p[8],
+                                        o.f[0], cs);
+            break;
+        case AYOLO_OP_JOIN_SIDE:
+            if (used_side) rc = side_join(sc, (hipStream_t)s);
+            break;
         case AYOLO_OP_HEAD_DECODE: {
             const int64_t st[4] = {o.i[5], o.i[6], o.i[7], o.i[8]};            // element strides of (b, a, y, x)
             rc = ayolo_head_decode((const float*)o.p[0], st, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], (const float*)o.p[1], o.f[0],
