@@ -202,7 +202,7 @@ static unsigned grid_pixels(long long npix, int C, int ve, int min_iters) {
     int cg = C / ve, cgt = cg < 256 ? cg : 256, rpb = 256 / cgt;
     long long b = npix / ((long long)rpb * min_iters);
     if (b < 1) b = 1;
-    if (b > 4096) b = 4096;
+    if (b > 16384) b = 16384;
     return (unsigned)b;
 }
 
@@ -269,8 +269,10 @@ extern "C" int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, in
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && lda % ve == 0 && (!residual || ldr % ve == 0) && C <= 2048,
                  "bn_train_act: C=%d ldz=%d lda=%d", C, ldz, lda);
     if (npix == 0) return AYOLO_OK;
-    unsigned grid = grid_pixels(npix, C, ve, 16);
-    if (grid > 1024) grid = 1024;
+    static const int act_iters = getenv("AYOLO_ACT_ITERS") ? atoi(getenv("AYOLO_ACT_ITERS")) : 16;
+    static const int act_cap = getenv("AYOLO_ACT_CAP") ? atoi(getenv("AYOLO_ACT_CAP")) : 1024;
+    unsigned grid = grid_pixels(npix, C, ve, act_iters);
+    if (grid > (unsigned)act_cap) grid = (unsigned)act_cap;
     DISPATCH_T(dtype, DISPATCH_AR(act, residual != nullptr,
                hipLaunchKernelGGL((k_bn_train_act<T, ACT, RES>), dim3(grid), dim3(256), 2 * C * sizeof(float), (hipStream_t)s,
                                   (const T*)z, ldz, (T*)a, lda, (long long)npix, C, stats, stat_reps > 0 ? stat_reps : 1,
@@ -505,8 +507,10 @@ extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const v
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && lddz % ve == 0 && C <= 2048, "bn_bwd_apply: C=%d", C);
     if (npix == 0) return AYOLO_OK;
     // the per-workgroup prologue stages (6 + 2*reps)*C floats in LDS: scale the elements per workgroup with C
-    unsigned grid = grid_pixels(npix, C, ve, C >= 256 ? 16 : 8);
-    if (grid > 2048) grid = 2048;
+    static const int app_iters = getenv("AYOLO_APP_ITERS") ? atoi(getenv("AYOLO_APP_ITERS")) : 0;
+    static const int app_cap = getenv("AYOLO_APP_CAP") ? atoi(getenv("AYOLO_APP_CAP")) : 2048;
+    unsigned grid = grid_pixels(npix, C, ve, app_iters > 0 ? app_iters : (C >= 256 ? 16 : 8));
+    if (grid > (unsigned)app_cap) grid = (unsigned)app_cap;
     DISPATCH_T(dtype, DISPATCH_AR(act, false,
                (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s,
                                   (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,

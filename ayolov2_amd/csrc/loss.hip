@@ -256,93 +256,106 @@ __global__ __launch_bounds__(256) void k_loss_rowbox(LossP P, const float* grad_
     for (int i = 0; i < 4; ++i) L.rowbox[(long long)row * 4 + i] = k * r.d[i];
 }
 
+// Packed gradient of one level, sparse form.  dz (B*ny*nx rows of ldz channels) is almost all zeros: per pixel only the na
+// objectness channels are dense, the box / class channels are non-zero only in cells that own matched rows.  Three stages:
+//   1. zero fill of dz (k_fill_zero, HBM speed)
+//   2. MODE 1: the 8-channel group holding the objectness channel of every (pixel, anchor)
+//   3. MODE 2: the other groups of every cell that owns rows (visited once, by the head row of the cell's list)
+// (the dense form walked all 32 groups of every pixel with two dependent list-head loads each: 0.28 ms for 275 MB, 1 TB/s).
+// A group's value is computed by loss_group() from the cells of BOTH anchors it may span, so every group is written whole
+// and exactly once; the bias gradient is accumulated from the same fp32 values.
 template <typename T>
+__device__ __forceinline__ void loss_group(const LossP& P, const ayolo_loss_level& L, long long pix, int cg, float k_obj, float k_cls,
+                                           float* sb) {
+    const unsigned hw = (unsigned)(L.ny * L.nx), nx = (unsigned)L.nx;
+    const int no = L.no, nc = no - 5, Cc = L.na * no, ldz = L.ldz;
+    const unsigned pu = (unsigned)pix;
+    const unsigned b = pu / hw, pp = pu - b * hw;
+    const unsigned y = pp / nx, x = pp - y * nx;
+    const int c0 = cg * 8;
+    const int a_lo = c0 / no;
+    const int a_hi = (c0 + 7 < Cc ? c0 + 7 : Cc - 1) / no;
+    const long long cell_lo = ((long long)b * L.na + a_lo) * hw + pp;
+    const int h_lo = L.head[cell_lo];
+    const int h_hi = a_hi != a_lo ? L.head[cell_lo + hw] : h_lo;
+    const float* ps0 = L.pred + (long long)b * L.sb + (long long)y * L.sy + (long long)x * L.sx;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i;
+        if (c >= Cc) continue;
+        const int a = c >= (a_lo + 1) * no ? a_hi : a_lo;
+        const int o = c - a * no;
+        if (o == 4) {
+            const long long cell = cell_lo + (long long)(a - a_lo) * hw;
+            const int ow = L.own[cell];
+            v[i] = k_obj * bce_logits_grad(ps0[(long long)a * L.sa + 4], ow ? L.score[ow - 1] : 0.0f, P.obj_pw);
+        } else {
+            const float* ps = ps0 + (long long)a * L.sa;
+            for (int h = a == a_lo ? h_lo : h_hi; h; h = L.next[h - 1]) {        // rows matched to this cell (usually none)
+                const int row = h - 1;
+                if (o < 4) v[i] += L.rowbox[(long long)row * 4 + o];
+                else if (nc > 1) v[i] += k_cls * bce_logits_grad(ps[o], (o - 5) == (int)L.tcls[row] ? P.cp : P.cn, P.cls_pw);
+            }
+        }
+        if (sb && v[i] != 0.0f) atomicAdd(&sb[c], v[i]);
+    }
+    T out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (T)v[i];
+    T* dst = reinterpret_cast<T*>(L.dz) + pix * ldz + c0;
+    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(out + 4);
+}
+
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_loss_grad_packed(LossP P, const float* grad_out) {
     const int l = blockIdx.y;
     const ayolo_loss_level& L = P.lv[l];
     const unsigned hw = (unsigned)(L.ny * L.nx);
     const long long npix = (long long)L.B * hw;
     const long long cells = npix * L.na;
-    const int no = L.no, nc = no - 5, Cc = L.na * no, ldz = L.ldz;
-    const int CG = ldz / 8, RPB = 256 / CG;
-    const int cg = threadIdx.x % CG, prow = threadIdx.x / CG;
+    const int no = L.no, nc = no - 5, Cc = L.na * no;
     const float g = grad_out[0] * (float)L.B;
     const float k_obj = g * P.h_obj * L.balance / (float)cells;
     const float k_cls = (L.n > 0 && nc > 1) ? g * P.h_cls / ((float)L.n * (float)nc) : 0.0f;
-    int aa[8], oo[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = cg * 8 + i;
-        aa[i] = c < Cc ? c / no : -1;
-        oo[i] = c < Cc ? c - aa[i] * no : 0;
+    __shared__ float sb[2048];                       // bias-gradient partials of this workgroup (ldz <= 2048)
+    if (L.dbias) {
+        for (int c = threadIdx.x; c < Cc; c += 256) sb[c] = 0.0f;
+        __syncthreads();
     }
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    T* dz = reinterpret_cast<T*>(L.dz);
-    // the group spans at most two anchors (no >= 8); only one channel in 85 is dense (objectness), rows are rare:
-    // one list-head load per anchor decides whether anything but that channel is non-zero
-    int a_lo = -1, a_hi = -1;
-    bool has_obj = false;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (aa[i] >= 0) { if (a_lo < 0) a_lo = aa[i]; a_hi = aa[i]; }
-        has_obj |= aa[i] >= 0 && oo[i] == 4;
-    }
-    const unsigned nx = (unsigned)L.nx;
-    for (long long pix = (long long)blockIdx.x * RPB + prow; prow < RPB && pix < npix; pix += (long long)gridDim.x * RPB) {
-        const unsigned pu = (unsigned)pix;
-        const unsigned b = pu / hw, pp = pu - b * hw;
-        const unsigned y = pp / nx, x = pp - y * nx;
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (a_lo >= 0) {
-            const long long cell_lo = ((long long)b * L.na + a_lo) * hw + pp;
-            const int h_lo = L.head[cell_lo];
-            const int h_hi = a_hi != a_lo ? L.head[cell_lo + hw] : h_lo;
-            if (!has_obj && !(h_lo | h_hi)) {                  // 29 of 32 groups on almost every pixel: all zero
-                const uint4 z4 = make_uint4(0, 0, 0, 0);
-                T* dst0 = dz + pix * ldz + cg * 8;
-                *reinterpret_cast<uint4*>(dst0) = z4;
-                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst0 + 4) = z4;
-                continue;
-            }
-            const float* ps0 = L.pred + (long long)b * L.sb + (long long)y * L.sy + (long long)x * L.sx;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (aa[i] < 0) continue;
-                const int o = oo[i];
-                if (o == 4) {
-                    const long long cell = cell_lo + (long long)(aa[i] - a_lo) * hw;
-                    const int ow = L.own[cell];
-                    v[i] = k_obj * bce_logits_grad(ps0[(long long)aa[i] * L.sa + 4], ow ? L.score[ow - 1] : 0.0f, P.obj_pw);
-                } else {
-                    int h = aa[i] == a_lo ? h_lo : h_hi;
-                    if (h) {
-                        const float* ps = ps0 + (long long)aa[i] * L.sa;
-                        for (; h; h = L.next[h - 1]) {                    // rows matched to this cell (usually none)
-                            const int row = h - 1;
-                            if (o < 4) v[i] += L.rowbox[(long long)row * 4 + o];
-                            else if (nc > 1) v[i] += k_cls * bce_logits_grad(ps[o], (o - 5) == (int)L.tcls[row] ? P.cp : P.cn, P.cls_pw);
-                        }
-                    }
-                }
-                acc[i] += v[i];
-            }
+    float* acc = L.dbias ? sb : nullptr;
+    if (MODE == 1) {
+        // (pixel, anchor) -> the group of that anchor's objectness channel; two anchors never share one (no >= 8)
+        const long long total = npix * L.na;
+        for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long long)gridDim.x * 256) {
+            const long long pix = w / L.na;
+            const int a = (int)(w - pix * L.na);
+            loss_group<T>(P, L, pix, (a * no + 4) / 8, k_obj, k_cls, acc);
         }
-        T out[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) out[i] = (T)v[i];
-        T* dst = dz + pix * ldz + cg * 8;
-        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
-        if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(out + 4);
+    } else {
+        // (row, k-th group of the row's anchor): only the head row of a cell's list acts, so a cell is visited once; a group
+        // shared with the neighbouring anchor belongs to the lower anchor's cell if that cell owns rows, else to the upper one
+        const int G = (no + 7) / 8 + 1;
+        const long long total = (long long)L.n * G;
+        for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long long)gridDim.x * 256) {
+            const int row = (int)(w / G), k = (int)(w - (long long)row * G);
+            const long long b = L.b[row], a = L.a[row], gj = L.gj[row], gi = L.gi[row];
+            const long long pp = gj * L.nx + gi;
+            const long long cell = (b * L.na + a) * hw + pp;
+            if (L.head[cell] - 1 != row) continue;
+            const int cg = (int)(a * no) / 8 + k;
+            const int c0 = cg * 8;
+            if (c0 >= (a + 1) * no || c0 >= Cc) continue;                          // beyond this anchor's channels
+            const int a_lo = c0 / no, a_hi = (c0 + 7 < Cc ? c0 + 7 : Cc - 1) / no;
+            bool mine = true;
+            if (a_lo != a_hi && a == a_hi) mine = L.head[cell - hw] == 0;          // the lower anchor's cell owns a shared group
+            const int obj_lo = a_lo * no + 4, obj_hi = a_hi * no + 4;
+            if ((obj_lo >= c0 && obj_lo < c0 + 8) || (obj_hi >= c0 && obj_hi < c0 + 8)) mine = false;   // stage 2 wrote it
+            if (mine) loss_group<T>(P, L, b * hw + pp, cg, k_obj, k_cls, acc);
+        }
     }
     if (L.dbias) {
-        __shared__ float sb[2048];
-        for (int c = threadIdx.x; c < ldz; c += 256) sb[c] = 0.0f;
-        __syncthreads();
-        if (prow < RPB) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (aa[i] >= 0 && acc[i] != 0.0f) atomicAdd(&sb[cg * 8 + i], acc[i]);    // all but the objectness channels are ~always 0
-        }
         __syncthreads();
         for (int c = threadIdx.x; c < Cc; c += 256)
             if (sb[c] != 0.0f) atomicAdd(&L.dbias[c], sb[c]);
@@ -427,9 +440,19 @@ extern "C" int ayolo_yolo_loss_bwd_packed(const ayolo_loss_level* lv, int nl, fl
         hipLaunchKernelGGL(k_loss_rowbox, dim3((unsigned)((max_n + 255) / 256), (unsigned)nl), dim3(256), 0, st, P, grad_out);
         AY_CHECK_LAUNCH("k_loss_rowbox");
     }
-    const long long gx = 1024;
-    if (dt == AYOLO_F16) hipLaunchKernelGGL(k_loss_grad_packed<half_t>, dim3((unsigned)gx, (unsigned)nl), dim3(256), 0, st, P, grad_out);
-    else hipLaunchKernelGGL(k_loss_grad_packed<float>, dim3((unsigned)gx, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+    const size_t es = dt == AYOLO_F16 ? 2 : 4;
+    for (int l = 0; l < nl; ++l) {
+        const ayolo_loss_level& L = lv[l];
+        rc = ayolo_fill_zero(L.dz, (size_t)L.B * L.ny * L.nx * L.ldz * es, s);
+        if (rc) return rc;
+    }
+    if (dt == AYOLO_F16) hipLaunchKernelGGL((k_loss_grad_packed<half_t, 1>), dim3(1024, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+    else hipLaunchKernelGGL((k_loss_grad_packed<float, 1>), dim3(1024, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+    if (max_n > 0) {
+        const unsigned gr_ = (unsigned)(((long long)max_n * 13 + 255) / 256);
+        if (dt == AYOLO_F16) hipLaunchKernelGGL((k_loss_grad_packed<half_t, 2>), dim3(gr_ < 2048 ? gr_ : 2048, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+        else hipLaunchKernelGGL((k_loss_grad_packed<float, 2>), dim3(gr_ < 2048 ? gr_ : 2048, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+    }
     AY_CHECK_LAUNCH("k_loss_grad_packed");
     return AYOLO_OK;
 }

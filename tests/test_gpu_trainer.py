@@ -51,9 +51,9 @@ def _groups(model):
     return pg_bn, pg_w, pg_b
 
 
-def _optim(cls, model, **kw):
+def _optim(cls, model, lr=0.01, **kw):
     pg_bn, pg_w, pg_b = _groups(model)
-    opt = cls(pg_bn, lr=0.01, momentum=0.937, nesterov=True, **kw)
+    opt = cls(pg_bn, lr=lr, momentum=0.937, nesterov=True, **kw)
     opt.add_param_group({"params": pg_w, "weight_decay": 5e-4})
     opt.add_param_group({"params": pg_b})
     return opt
@@ -68,12 +68,15 @@ def test_training_step_matches_cpu_reference():
     from ayolov2_amd.optim import SGD
     from ayolov2_amd.trainer import ModelEMA, training_step
     m, r = _models(1)
-    opt_g, opt_c = _optim(SGD, m), _optim(torch.optim.SGD, r)
+    # a small learning rate keeps the comparison about the step LOGIC: with lr 0.01 the fp32 summation-order noise of one
+    # step, amplified by the next forward's batch statistics (few samples per channel at stride 32), occasionally moved the
+    # third step's loss by > 1 % between runs
+    opt_g, opt_c = _optim(SGD, m, lr=0.002), _optim(torch.optim.SGD, r, lr=0.002)
     loss_g, loss_c = ComputeLoss(m), ComputeLoss(r)
     ema = ModelEMA(m)
     ema_ref = {k: v.detach().clone() for k, v in copy.deepcopy(r).state_dict().items()}
     for step in range(3):
-        x, t = _batch(10 + step)
+        x, t = _batch(10 + step, B=4, hw=(160, 192))
         lg, items = training_step(m, loss_g, opt_g, None, x.cuda(), t.cuda(), world_size=1, amp=False, ema=ema)
         lc, _ = loss_c(r(x), t)
         opt_c.zero_grad(set_to_none=True)
