@@ -1054,7 +1054,8 @@ __global__ __launch_bounds__(256) void k_ema_update(const ayolo_ema_job* jobs, f
 
 extern "C" int ayolo_ema_update(const ayolo_ema_job* jobs_dev, int njobs, float decay, ayolo_stream s) {
     AY_CHECK_ARG(jobs_dev && njobs > 0 && njobs <= 65535, "ema_update: njobs=%d", njobs);
-    hipLaunchKernelGGL(k_ema_update, dim3(32, (unsigned)njobs), dim3(256), 0, (hipStream_t)s, jobs_dev, decay);
+    // callers cut large tensors into jobs of a few 10^4 elements (one grid row each)
+    hipLaunchKernelGGL(k_ema_update, dim3(8, (unsigned)njobs), dim3(256), 0, (hipStream_t)s, jobs_dev, decay);
     AY_CHECK_LAUNCH("k_ema_update");
     return AYOLO_OK;
 }

@@ -60,11 +60,15 @@ class ModelEMA:
                      and v.stride() == s.stride() and dense(v) for v, s in pairs)
             tab = None
             if ok and pairs:
+                # one grid row per job: the few multi-million-element conv weights are cut into 32 K-element chunks so that
+                # they are spread over hundreds of workgroups instead of being walked by one row of the grid
+                CH = 32768
+                rows = [(v.data_ptr() + 4 * o, s_.data_ptr() + 4 * o, min(CH, v.numel() - o))
+                        for v, s_ in pairs for o in range(0, v.numel(), CH)]
                 job_t = np.dtype([("ema", "<u8"), ("src", "<u8"), ("n", "<i8")])
-                jobs = np.zeros(len(pairs), dtype=job_t)
-                for i, (v, s_) in enumerate(pairs):
-                    jobs[i] = (v.data_ptr(), s_.data_ptr(), v.numel())
+                jobs = np.array(rows, dtype=job_t)
                 tab = torch.from_numpy(jobs.view(np.uint8).copy()).to(pairs[0][0].device)
+                self._njobs = len(rows)
             self._jobs = (key, tab, pairs)
         return self._jobs
 
@@ -75,7 +79,7 @@ class ModelEMA:
             _, tab, pairs = self._job_table(model)
             if tab is not None:
                 from . import _lib
-                _lib.call("ayolo_ema_update", tab.data_ptr(), len(pairs), float(d), torch.cuda.current_stream().cuda_stream)
+                _lib.call("ayolo_ema_update", tab.data_ptr(), self._njobs, float(d), torch.cuda.current_stream().cuda_stream)
                 return
             for v, src in pairs:                             # CPU / mixed-dtype state: the reference's two in-place ops
                 v *= d
