@@ -442,6 +442,7 @@ def main():
         el = float(t.item())
     assert math.isfinite(float(loss)), "non-finite loss"
 
+    peak_train_gb = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
     if rank == 0:
         ms = el / args.steps * 1e3
         value = world * args.batch * args.steps / el
@@ -463,6 +464,9 @@ def main():
             except Exception as e:                              # secondary lines must never cost the headline
                 out["extra"]["config_extras_error"] = repr(e)[:300]
             out["cpu_baseline"] = cpu_baseline(args.model, args.size)
+        # memory budget of the step (activations kept for backward, one private dz per layer for the side-stream weight
+        # gradients, arenas, fp16 weight copies, optimiser + EMA state); measured before the secondary configurations ran
+        out["peak_memory_gb_train_step"] = peak_train_gb
     if world > 1 or force_ddp:
         torch.distributed.destroy_process_group()
     if rank == 0:
