@@ -90,6 +90,12 @@ class _Geometry:
 
 def _prepare_input(x: torch.Tensor, geo: _Geometry, dt: torch.dtype) -> torch.Tensor:
     """Returns the NHWC tensor the kernels read (logical (B, Cin_k, H, W_k))."""
+    if geo.needs_pack and (x.shape[1] > 4 or x.requires_grad):
+        # an activation whose channel count is off the vector width (the rank of a Tucker factor): zero-padded copy
+        B, C, H, W = x.shape
+        xp = torch.zeros((B, geo.cin_pad, H, W), dtype=dt, device=x.device).contiguous(memory_format=torch.channels_last)
+        xp[:, :C] = x.to(dt)
+        return xp
     if geo.needs_pack:
         xp = ops.pack_input(x, dt, geo.cin_pad)          # (B, cin_pad, H, W) NHWC
         if geo.packed_stem:
@@ -107,7 +113,8 @@ class ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, padding, eps, momentum, act, cache):
         dt = compute_dtype(weight)
-        geo = _Geometry(x.shape, weight.shape, stride, padding, dt)
+        # pixel-pair packing is for the image only: an input that wants a gradient keeps the plain (zero-padded) geometry
+        geo = _Geometry(x.shape, weight.shape, stride, padding, dt, allow_packed_stem=not x.requires_grad)
         xk = _prepare_input(x, geo, dt)
         _, _, _, _, ldx = ops.nhwc_info(xk)
         Cout = weight.shape[0]
@@ -127,7 +134,6 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.save_for_backward(xk, z, save_mean, save_invstd, g32, b32, wt)
         ctx.geo, ctx.dt, ctx.act, ctx.ldx = geo, dt, act, ldx
         ctx.weight_shape = tuple(weight.shape)
-        ctx.x_is_leaf_image = geo.needs_pack
         return a
 
     @staticmethod
@@ -140,9 +146,11 @@ class ConvBnActFn(torch.autograd.Function):
         da = ops.to_nhwc(da)
         dz, dgamma, dbeta = ops.bn_act_bwd(z, da, save_mean, save_invstd, g32, b32, act)
         dx = None
-        if ctx.needs_input_grad[0] and not ctx.x_is_leaf_image:
-            dx = ops.new_act(geo.B, Cin, geo.H, geo.W, dt, dz.device)
-            ops.conv_dgrad(geo.desc(dt, Cin, Cout), dz, wt, dx)
+        if ctx.needs_input_grad[0]:
+            dx = ops.new_act(geo.B, geo.cin_pad, geo.H, geo.W, dt, dz.device)
+            ops.conv_dgrad(geo.desc(dt, geo.cin_pad, Cout), dz, wt, dx)
+            if geo.cin_pad != Cin:
+                dx = dx[:, :Cin]
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _wgrad(geo, dt, xk, ctx.ldx, dz, Cout, Cout, Cin, kh, kw)
@@ -165,7 +173,8 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, stride, padding, cache):
         dt = compute_dtype(weight)
-        geo = _Geometry(x.shape, weight.shape, stride, padding, dt)
+        # pixel-pair packing is for the image only: an input that wants a gradient keeps the plain (zero-padded) geometry
+        geo = _Geometry(x.shape, weight.shape, stride, padding, dt, allow_packed_stem=not x.requires_grad)
         xk = _prepare_input(x, geo, dt)
         _, _, _, _, ldx = ops.nhwc_info(xk)
         Cout = weight.shape[0]
@@ -176,7 +185,6 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(xk, wt)
         ctx.geo, ctx.dt, ctx.ldx, ctx.cout_pad = geo, dt, ldx, cout_pad
         ctx.weight_shape = tuple(weight.shape)
-        ctx.x_is_leaf_image = geo.needs_pack
         return y if cout_pad == Cout else y[:, :Cout]
 
     @staticmethod
@@ -194,9 +202,11 @@ class ConvFn(torch.autograd.Function):
         dy = ops.to_nhwc(dy)
         _, _, _, _, ldy = ops.nhwc_info(dy)
         dx = None
-        if ctx.needs_input_grad[0] and not ctx.x_is_leaf_image:
-            dx = ops.new_act(geo.B, Cin, geo.H, geo.W, dt, dy.device)
-            ops.conv_dgrad(geo.desc(dt, Cin, ldy, cout=cout_pad), dy, wt, dx)
+        if ctx.needs_input_grad[0]:
+            dx = ops.new_act(geo.B, geo.cin_pad, geo.H, geo.W, dt, dy.device)
+            ops.conv_dgrad(geo.desc(dt, geo.cin_pad, ldy, cout=cout_pad), dy, wt, dx)
+            if geo.cin_pad != Cin:
+                dx = dx[:, :Cin]
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _wgrad(geo, dt, xk, ctx.ldx, dy, ldy, Cout, Cin, kh, kw, cout_pad=cout_pad)

@@ -90,7 +90,18 @@ class Conv(nn.Module):
             if last.bias is not None:
                 shift = last.bias.float() * (scale if scale is not None else 1.0) + (shift if shift is not None else 0.0)
             if self.training and bn is not None:
-                raise NotImplementedError("training a Tucker-decomposed block (batch-stat BN) is not supported yet")
+                # fine-tuning a decomposed block: the factor / core convs are plain autograd convs, the last 1x1 carries the
+                # batch-statistics BatchNorm + activation (a bias in front of a training-mode BN only shifts the mean)
+                if bn.running_mean is not None and bn.running_mean.dtype != torch.float32:
+                    raise NotImplementedError("training needs fp32 BatchNorm buffers (use autocast, not model.half())")
+                if last.bias is not None or bn.momentum is None:
+                    raise NotImplementedError("decomposed block with a biased last conv / cumulative-average BatchNorm in training")
+                y = F_.ConvBnActFn.apply(x, last.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                         _pair(last.stride), _pair(last.padding), bn.eps, bn.momentum, act,
+                                         self._cache(len(convs) - 1))
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+                return y
             return F_.conv_affine_act_eval(x, last.weight, scale, shift, _pair(last.stride), _pair(last.padding), act,
                                            self._cache(len(convs) - 1))
         if self.training and bn is not None:

@@ -499,6 +499,8 @@ class TrainPlan:
             cin = [self.Cimg if s < 0 else ch[s] for s in srcs]
             sin = [(self.H, self.W) if s < 0 else hw[s] for s in srcs]
             if isinstance(m, Conv):
+                if not isinstance(m.conv, nn.Conv2d):
+                    raise PlanUnsupported("decomposed Conv block (per-module path)")
                 s = _pair(m.conv.stride)
                 k = _pair(m.conv.kernel_size)
                 p = _pair(m.conv.padding)

@@ -28,6 +28,53 @@ SHAPES = [
 ]
 
 
+# YOLOv5l / YOLOv5s layers at the geometry of the train step (batch 16 / 64 at 640x640): every tile variant the dispatcher
+# picks at full size (128- / 256-pixel tiles, 32..128 output channels per tile, K up to 4608, two-half fragment fetch)
+FULL_SIZE = [
+    (16, 64, 128, 3, 2, 1, 320, 320),
+    (16, 64, 64, 1, 1, 0, 160, 160),
+    (16, 64, 64, 3, 1, 1, 160, 160),
+    (16, 128, 256, 3, 2, 1, 160, 160),
+    (16, 256, 256, 3, 1, 1, 40, 40),
+    (16, 512, 256, 1, 1, 0, 80, 80),
+    (16, 512, 1024, 3, 2, 1, 40, 40),
+    (16, 512, 512, 3, 1, 1, 20, 20),
+    (16, 1024, 1024, 1, 1, 0, 20, 20),
+    (16, 2048, 512, 1, 1, 0, 20, 20),
+    (64, 32, 64, 3, 2, 1, 320, 320),
+    (64, 128, 128, 3, 1, 1, 40, 40),
+    (64, 512, 256, 1, 1, 0, 20, 20),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", FULL_SIZE)
+def test_full_size_layers_fp16_vs_fp32_mode(shape):
+    """Forward, data gradient and weight gradient of one conv at full-size launch geometry: the fp16 kernels against the
+    exact-fp32 mode of the same kernels (itself held to 1e-4 of the CPU above) on operands pre-rounded to fp16, so only the
+    fp16 output rounding (2^-11 relative) and the summation order differ."""
+    from ayolov2_amd import functional as F_
+    B, Cin, Cout, k, s, p, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, device="cuda", generator=g).half().float().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5).half().float()
+    res = []
+    gy = None
+    for amp in (False, True):
+        xg = x.clone().requires_grad_(True)
+        wg = w.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            y = F_.ConvFn.apply(xg, wg, (s, s), (p, p), F_._WeightCache())
+        if gy is None:
+            gy = torch.randn(y.shape, device="cuda", generator=g).half().float()
+        y.backward(gy.to(y.dtype))
+        res.append((y.detach().float(), xg.grad.float(), wg.grad.float()))
+    for a32, a16, what, tol in zip(res[0], res[1], ("y", "dx", "dw"), (1e-3, 1e-3, 1e-4)):
+        scale = float(a32.abs().max())
+        err = float((a16 - a32).abs().max())
+        assert err <= tol * scale, (what, err, scale)
+
+
 def _tol(dt):
     return (1e-4, 1e-4) if dt == torch.float32 else (3e-3, 3e-3)   # fp16: same rounded operands, fp32 accumulate -> only the output rounding
 
