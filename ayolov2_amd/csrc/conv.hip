@@ -97,6 +97,12 @@ typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+#ifndef AYOLO_GCONV_MI2
+#define AYOLO_GCONV_MI2 1
+#endif
+#ifndef AYOLO_GCONV_MI2_64
+#define AYOLO_GCONV_MI2_64 0
+#endif
 template <typename T, int TM, int TPX = 128>
 struct GT {
     static constexpr int ES = sizeof(T);
@@ -114,8 +120,12 @@ struct GT {
     static constexpr int WR = WSTAGE / 4096;
     static constexpr int STAGE = XSTAGE + WSTAGE;
     static constexpr int LPS = XR + WR;             // DMA instructions per thread per step
-    static constexpr int WM = TM / 32, WP = 4 / WM, NI = TP / (32 * WP);
-    static constexpr int NST = NI * 4;              // store instructions per thread per epilogue
+    // wave tile: MI x NI MFMA blocks of 32 channels x 32 pixels.  The 128-channel x 256-pixel fp16 tile gives each wave
+    // 64 channels x 128 pixels (2 x 4 blocks: 6 LDS fragments per 8 MFMAs) instead of 32 x 256 (1 x 8: 9 per 8).
+    static constexpr int MI = (ES == 2 && TPX == 256 && ((TM == 128 && AYOLO_GCONV_MI2) || (TM == 64 && AYOLO_GCONV_MI2_64))) ? 2 : 1;
+    static constexpr int WM = TM / (32 * MI), WP = 4 / WM, NI = TP / (32 * WP);
+    static constexpr int NACC = MI * NI;            // accumulator blocks per wave
+    static constexpr int NST = NACC * 4;            // store instructions per thread per epilogue
     static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 2 * TM * sizeof(float);
 };
 
@@ -208,7 +218,7 @@ __device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T,
 // after the barrier and puts the address arithmetic + DMA issue of step s+2 between the fetch and the MFMAs, so the LDS
 // latency is covered by that scalar / VALU work instead of being waited for.
 template <typename T, int TM, int TPX>
-struct GFrags { half8 a[BK / 16], b[BK / 16][GT<T, TM, TPX>::NI]; };
+struct GFrags { half8 a[BK / 16][GT<T, TM, TPX>::MI], b[BK / 16][GT<T, TM, TPX>::NI]; };
 
 template <typename T, int TM, int TPX>
 __device__ __forceinline__ void g_fetch_frags(const unsigned char* stage, int arow, int xrow, int swz, int lane,
@@ -219,7 +229,8 @@ __device__ __forceinline__ void g_fetch_frags(const unsigned char* stage, int ar
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
         const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
-        f.a[kk] = *reinterpret_cast<const half8*>(bw + slot);
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi) f.a[kk][mi] = *reinterpret_cast<const half8*>(bw + mi * 32 * G::ROWB + slot);
 #pragma unroll
         for (int ni = 0; ni < G::NI; ++ni) f.b[kk][ni] = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
     }
@@ -229,7 +240,7 @@ __device__ __forceinline__ void g_fetch_frags(const unsigned char* stage, int ar
 // 18 fragments at once would not fit the 256-register budget of 2 waves per SIMD next to the 128 accumulators; the
 // eight MFMAs of the first half (512 cycles in the matrix pipe) cover the LDS latency of the second half's fetch)
 template <typename T, int TM, int TPX>
-struct GFragK { half8 a, b[GT<T, TM, TPX>::NI]; };
+struct GFragK { half8 a[GT<T, TM, TPX>::MI], b[GT<T, TM, TPX>::NI]; };
 
 template <typename T, int TM, int TPX>
 __device__ __forceinline__ void g_fetch_k(const unsigned char* stage, int arow, int xrow, int swz, int lane, int kk,
@@ -238,31 +249,38 @@ __device__ __forceinline__ void g_fetch_k(const unsigned char* stage, int arow, 
     const unsigned char* bx = stage + xrow;
     const unsigned char* bw = stage + G::XSTAGE + arow;
     const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
-    f.a = *reinterpret_cast<const half8*>(bw + slot);
+#pragma unroll
+    for (int mi = 0; mi < G::MI; ++mi) f.a[mi] = *reinterpret_cast<const half8*>(bw + mi * 32 * G::ROWB + slot);
 #pragma unroll
     for (int ni = 0; ni < G::NI; ++ni) f.b[ni] = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
 }
 
 template <typename T, int TM, int TPX>
-__device__ __forceinline__ void g_mma_k(const GFragK<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NI]) {
+__device__ __forceinline__ void g_mma_k(const GFragK<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC]) {
+    using G = GT<T, TM, TPX>;
 #pragma unroll
-    for (int ni = 0; ni < GT<T, TM, TPX>::NI; ++ni) mma_step(f.a, f.b[ni], acc[ni]);
+    for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < G::NI; ++ni) mma_step(f.a[mi], f.b[ni], acc[mi * G::NI + ni]);
 }
 
 template <typename T, int TM, int TPX>
-__device__ __forceinline__ void g_mma_frags(const GFrags<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NI]) {
+__device__ __forceinline__ void g_mma_frags(const GFrags<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC]) {
     using G = GT<T, TM, TPX>;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
-        for (int ni = 0; ni < G::NI; ++ni) mma_step(f.a[kk], f.b[kk][ni], acc[ni]);
+        for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni) mma_step(f.a[kk][mi], f.b[kk][ni], acc[mi * G::NI + ni]);
 }
 
 // fp32 (exact-parity mode): fragments are fetched and consumed pair by pair
 template <typename T, int TM, int TPX>
 __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int xrow, int swz, int lane,
-                                      float16v (&acc)[GT<T, TM, TPX>::NI]) {
+                                      float16v (&acc)[GT<T, TM, TPX>::NACC]) {
     using G = GT<T, TM, TPX>;
+    static_assert(G::MI == 1, "fp32 mode keeps the 1 x NI wave tile");
     const unsigned char* bx = stage + xrow;
     const unsigned char* bw = stage + G::XSTAGE + arow;
 #pragma unroll
@@ -290,8 +308,8 @@ __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int 
 // by the hardware), so the step loop's vmcnt arithmetic stays exact.
 template <typename T, int TM, int EM, int TPX>
 __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int oah, int oaw, int wp, int lane, int cbase,
-                                           bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM, TPX>::NI],
-                                           float (&ssum)[16], float (&ssq)[16], const float* sAff, int cl) {
+                                           bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM, TPX>::NACC],
+                                           float (&ssum)[16 * GT<T, TM, TPX>::MI], float (&ssq)[16 * GT<T, TM, TPX>::MI], const float* sAff, int cl0) {
     using G = GT<T, TM, TPX>;
     constexpr int YES = (EM == 3) ? 4 : G::ES;       // bytes per output element
     const unsigned m0 = tile * G::TP;
@@ -311,134 +329,138 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
                 yo = ((nn * (unsigned)p.YH + (unsigned)(oh * p.osh + oah)) * (unsigned)p.YW + (unsigned)(ow * p.osw + oaw)) * (unsigned)p.ldy * YES;
             }
         }
-        if constexpr (sizeof(T) == 2 && EM != 3) {
-            // fp16 outputs: lanes l and l+32 hold channels +0..3 / +4..7 of the SAME pixel for each 8-channel group.
-            // Four v_permlane32_swap per group pair give every lane 8 consecutive channels, so the tile leaves in 16-byte
-            // stores (2 per lane and pixel block instead of 4 of 8 bytes: half the requests the L2 has to take).
-            float v[4][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+        for (int mi = 0; mi < G::MI; ++mi) {
+            const int cb = cbase + mi * 32, cl = cl0 + mi * 32;
+            if constexpr (sizeof(T) == 2 && EM != 3) {
+                // fp16 outputs: lanes l and l+32 hold channels +0..3 / +4..7 of the SAME pixel for each 8-channel group.
+                // Four v_permlane32_swap per group pair give every lane 8 consecutive channels, so the tile leaves in 16-byte
+                // stores (2 per lane and pixel block instead of 4 of 8 bytes: half the requests the L2 has to take).
+                float v[4][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[g][e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
-            if constexpr (EM == 2 || EM == 4) {
-                // per-channel scale / shift of this workgroup's channel tile were staged in LDS once (sAff: a global load
-                // here would make hipcc drain the hidden DMA queue with vmcnt(0) in every epilogue)
-                const bool act = p.epi == AYOLO_EPI_AFFINE_SILU || p.epi == AYOLO_EPI_AFFINE_SILU_RES;
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                    for (int e = 0; e < 4; ++e) { v[g][e] = acc[mi * G::NI + ni][g * 4 + e]; acc[mi * G::NI + ni][g * 4 + e] = 0.0f; }
+                if constexpr (EM == 2 || EM == 4) {
+                    // per-channel scale / shift of this workgroup's channel tile were staged in LDS once (sAff: a global load
+                    // here would make hipcc drain the hidden DMA queue with vmcnt(0) in every epilogue)
+                    const bool act = p.epi == AYOLO_EPI_AFFINE_SILU || p.epi == AYOLO_EPI_AFFINE_SILU_RES;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4v sc = *reinterpret_cast<const float4v*>(sAff + cl + 8 * g);
+                        const float4v sh = *reinterpret_cast<const float4v*>(sAff + TM + cl + 8 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float u = v[g][e] * sc[e] + sh[e];
+                            v[g][e] = act ? silu_e<T>(u) : u;
+                        }
+                    }
+                }
+                if (want_stats) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float q = pv ? cvt_round(v[g][e], (T*)nullptr) : 0.0f;
+                            ssum[mi * 16 + g * 4 + e] += q;
+                            ssq[mi * 16 + g * 4 + e] += q * q;
+                        }
+                }
+                const int hsel = lane >> 5;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const v2u32 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * j][e]), __float_as_uint(v[2 * j + 1][e]),
+                                                                         false, false);
+                        v[2 * j][e] = __uint_as_float(r[0]);
+                        v[2 * j + 1][e] = __uint_as_float(r[1]);
+                    }
+                    const int c = cb - 4 * hsel + 8 * (2 * j + hsel);          // 8 channels: v[2j][0..3], v[2j+1][0..3]
+                    const unsigned off = (pv && c < p.Nout) ? yo + (unsigned)c * 2u : G_OOB;   // Nout % 8 == 0 (host check)
+                    float w8[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { w8[e] = v[2 * j][e]; w8[4 + e] = v[2 * j + 1][e]; }
+                    if constexpr (EM == 1 || EM == 4) {
+                        const half8 o = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w8[e] += (float)o[e];
+                    }
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (half_t)w8[e];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, h), rsY, off, 0, 0);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cb + 8 * g;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[mi * G::NI + ni][g * 4 + e]; acc[mi * G::NI + ni][g * 4 + e] = 0.0f; }
+                if constexpr (EM == 3) {
+                    // YOLOHead: fp32 logits + bias, NHWC [pixel][ldy] (ldy = Cout rounded up to 8), 16-byte stores;
+                    // the (B, na, ny, nx, no) tensor the loss / decode see is a strided view of this buffer
+                    const unsigned off = (pv && c < p.ldy) ? yo + (unsigned)c * 4u : G_OOB;
+                    float4v f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = v[e] + ((p.shift && c + e < p.Nout) ? p.shift[c + e] : 0.0f);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, f), rsY, off, 0, 0);
+                    continue;
+                }
+                if constexpr (EM == 2 || EM == 4) {
+                    const bool act = p.epi == AYOLO_EPI_AFFINE_SILU || p.epi == AYOLO_EPI_AFFINE_SILU_RES;
                     const float4v sc = *reinterpret_cast<const float4v*>(sAff + cl + 8 * g);
                     const float4v sh = *reinterpret_cast<const float4v*>(sAff + TM + cl + 8 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float u = v[g][e] * sc[e] + sh[e];
-                        v[g][e] = act ? silu_e<T>(u) : u;
+                        const float u = v[e] * sc[e] + sh[e];
+                        v[e] = act ? silu_e<T>(u) : u;
                     }
                 }
-            }
-            if (want_stats) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
+                if (want_stats) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float q = pv ? cvt_round(v[g][e], (T*)nullptr) : 0.0f;
-                        ssum[g * 4 + e] += q;
-                        ssq[g * 4 + e] += q * q;
+                        float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
+                        ssum[mi * 16 + g * 4 + e] += q;
+                        ssq[mi * 16 + g * 4 + e] += q * q;
                     }
-            }
-            const int hsel = lane >> 5;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const v2u32 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * j][e]), __float_as_uint(v[2 * j + 1][e]),
-                                                                     false, false);
-                    v[2 * j][e] = __uint_as_float(r[0]);
-                    v[2 * j + 1][e] = __uint_as_float(r[1]);
                 }
-                const int c = cbase - 4 * hsel + 8 * (2 * j + hsel);          // 8 channels: v[2j][0..3], v[2j+1][0..3]
-                const unsigned off = (pv && c < p.Nout) ? yo + (unsigned)c * 2u : G_OOB;   // Nout % 8 == 0 (host check)
-                float w8[8];
+                const unsigned off = (pv && c < p.Nout) ? yo + (unsigned)c * G::ES : G_OOB;   // Nout % 4 == 0 (host check)
+                if constexpr (sizeof(T) == 2) {
+                    if constexpr (EM == 1 || EM == 4) {
+                        const half4 o = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(rsY, off, 0, 0));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { w8[e] = v[2 * j][e]; w8[4 + e] = v[2 * j + 1][e]; }
-                if constexpr (EM == 1 || EM == 4) {
-                    const half8 o = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+                        for (int e = 0; e < 4; ++e) v[e] += (float)o[e];
+                    }
+                    half4 h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) w8[e] += (float)o[e];
+                    for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, h), rsY, off, 0, 0);
+                } else {
+                    if constexpr (EM == 1 || EM == 4) {
+                        const float4v o = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += o[e];
+                    }
+                    float4v f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = v[e];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, f), rsY, off, 0, 0);
                 }
-                half8 h;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) h[e] = (half_t)w8[e];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, h), rsY, off, 0, 0);
-            }
-            continue;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = cbase + 8 * g;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = acc[ni][g * 4 + e]; acc[ni][g * 4 + e] = 0.0f; }
-            if constexpr (EM == 3) {
-                // YOLOHead: fp32 logits + bias, NHWC [pixel][ldy] (ldy = Cout rounded up to 8), 16-byte stores;
-                // the (B, na, ny, nx, no) tensor the loss / decode see is a strided view of this buffer
-                const unsigned off = (pv && c < p.ldy) ? yo + (unsigned)c * 4u : G_OOB;
-                float4v f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] = v[e] + ((p.shift && c + e < p.Nout) ? p.shift[c + e] : 0.0f);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, f), rsY, off, 0, 0);
-                continue;
-            }
-            if constexpr (EM == 2 || EM == 4) {
-                const bool act = p.epi == AYOLO_EPI_AFFINE_SILU || p.epi == AYOLO_EPI_AFFINE_SILU_RES;
-                const float4v sc = *reinterpret_cast<const float4v*>(sAff + cl + 8 * g);
-                const float4v sh = *reinterpret_cast<const float4v*>(sAff + TM + cl + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u = v[e] * sc[e] + sh[e];
-                    v[e] = act ? silu_e<T>(u) : u;
-                }
-            }
-            if (want_stats) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float q = pv ? cvt_round(v[e], (T*)nullptr) : 0.0f;
-                    ssum[g * 4 + e] += q;
-                    ssq[g * 4 + e] += q * q;
-                }
-            }
-            const unsigned off = (pv && c < p.Nout) ? yo + (unsigned)c * G::ES : G_OOB;   // Nout % 4 == 0 (host check)
-            if constexpr (sizeof(T) == 2) {
-                if constexpr (EM == 1 || EM == 4) {
-                    const half4 o = __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(rsY, off, 0, 0));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)o[e];
-                }
-                half4 h;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (half_t)v[e];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, h), rsY, off, 0, 0);
-            } else {
-                if constexpr (EM == 1 || EM == 4) {
-                    const float4v o = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += o[e];
-                }
-                float4v f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] = v[e];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, f), rsY, off, 0, 0);
             }
         }
     }
 }
 
-template <typename T, int TM>
+template <typename T, int TM, int MI>
 __device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int tid, int lane, int wm, int n0, unsigned slot,
-                                              const float (&ssum)[16], const float (&ssq)[16]) {
+                                              const float (&ssum)[16 * MI], const float (&ssq)[16 * MI]) {
     for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16 * MI; ++r) {
         float a = ssum[r], b = ssq[r];
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
@@ -446,7 +468,7 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int
             b += __shfl_xor(b, off);
         }
         if ((lane & 31) == 0) {
-            int cl = wm * 32 + 4 * (lane >> 5) + 8 * (r >> 2) + (r & 3);
+            int cl = wm * 32 * MI + (r >> 4) * 32 + 4 * (lane >> 5) + 8 * ((r & 15) >> 2) + (r & 3);
             atomicAdd(&sStat[cl], a);
             atomicAdd(&sStat[TM + cl], b);
         }
@@ -466,7 +488,7 @@ template <typename T, int TM, int EM, int TPX>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && EM == 0)) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
     using G = GT<T, TM, TPX>;
     // stores per thread and epilogue (the step loop's vmcnt arithmetic): fp16 tiles leave in 16-byte stores
-    constexpr int NSTK = (sizeof(T) == 2 && EM != 3) ? G::NI * 2 : G::NST;
+    constexpr int NSTK = (sizeof(T) == 2 && EM != 3) ? G::NACC * 2 : G::NST;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     unsigned char* sTiles = smem_raw;                                             // [GNS][x tile | w tile]
     int4* sTap = reinterpret_cast<int4*>(smem_raw + GNS * G::STAGE);              // [MAX_TAPS + 1]
@@ -535,20 +557,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     }
 
     // ---- MFMA fragment geometry
-    const int arow = (wm * 32 + (lane & 31)) * G::ROWB;
+    const int arow = (wm * 32 * G::MI + (lane & 31)) * G::ROWB;
     const int xrow = (wp * G::NI * 32 + (lane & 31)) * G::ROWB;
     const int swz = ((lane & 31) / G::RPB) & (G::CPR - 1);
 
-    float16v acc[G::NI];
+    float16v acc[G::NACC];
 #pragma unroll
-    for (int i = 0; i < G::NI; ++i)
+    for (int i = 0; i < G::NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const bool want_stats = (EM == 0) && (p.stats != nullptr);
-    float ssum[16], ssq[16];
+    float ssum[16 * G::MI], ssq[16 * G::MI];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
-    const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
+    for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+    const int cbase = n0 + wm * 32 * G::MI + 4 * (lane >> 5);
 
     // steps of a class: its taps * C in 32-wide slices; a tap-less class (1x1 strided dgrad) is one all-zero step
 #define G_NK(c) ((p.cnt[c] * p.C + BK - 1) / BK < 1 ? 1 : (p.cnt[c] * p.C + BK - 1) / BK)
@@ -590,7 +612,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
         // step s landed (this wave's part), then: everyone's part landed AND everyone finished reading step s-1
         if (after_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
         __builtin_amdgcn_s_barrier();
-        if constexpr (sizeof(T) == 2 && G::NI >= 8) {
+        if constexpr (sizeof(T) == 2 && G::NACC >= 8) {
             static_assert(BK == 32, "two 16-deep halves per step");
             GFragK<T, TM, TPX> f0, f1;
             g_fetch_k<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, 0, f0);
@@ -642,7 +664,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
 #undef G_NK
 #undef G_ADVANCE
     wait_vm<0>();                             // the trailing zero-fill DMAs must land before this LDS is released
-    if (want_stats) g_stats_flush<T, TM>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
+    if (want_stats) g_stats_flush<T, TM, G::MI>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
 }
 
 // compute units of the CURRENT device (cached per device ordinal: one process may drive several GPUs)
@@ -746,6 +768,11 @@ static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
     // halves the MFMAs per barrier -- so padding waste is NOT a reason to go narrower.  AYOLO_GCONV_TM forces a tile.
     static const int force_tm = getenv("AYOLO_GCONV_TM") ? atoi(getenv("AYOLO_GCONV_TM")) : 0;
     int tm = p.Nout <= 32 ? 32 : (p.Nout <= 64 ? 64 : 128);
+    // ... except where the last 128-wide tile would be half empty (192 / 320 output channels) on a small map: there the
+    // 64-wide tiling is exact and the extra pixel-tile reads stay in L2 (YOLOv5x, batch 8 at 1280^2: 320 -> 320 3x3 on 80x80
+    // 154 vs 169 us; on the 160x160 maps the 128-wide tiles still win)
+    static const int ragged64 = getenv("AYOLO_GCONV_RAGGED64") ? atoi(getenv("AYOLO_GCONV_RAGGED64")) : 1;
+    if (ragged64 && p.Nout > 128 && p.Nout % 128 == 64 && p.Mtotal <= 65536) tm = 64;
     if (force_tm == 32 || force_tm == 64 || force_tm == 128) tm = force_tm;
     if (dtype == AYOLO_F16) {
         if (tm == 32) return launch_gconv<half_t, 32>(p, s);
