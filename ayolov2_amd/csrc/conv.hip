@@ -51,6 +51,9 @@ struct GConvP {
     // offset -- the residue classes of a strided dgrad walked back to back by the same workgroup (ncls == 1 otherwise)
     int ncls;
     int ctap0[4], cnt[4], coah[4], coaw[4];  // first tap / tap count / output offsets of each class
+    // k_gconv3 (3x3, stride 1, same-size maps): weight tap index of (dh, dw) = (g - 1, j - 1) at [g * 3 + j]
+    int row3;
+    signed char r3wt[9];
 };
 
 template <typename T> struct Tr;
@@ -667,6 +670,302 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     if (want_stats) g_stats_flush<T, TM, G::MI>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// k_gconv3: the 3x3 / stride 1 / same-size case of k_gconv (forward of the Bottleneck 3x3 convs and their dgrad), fp16.
+// In flattened (n, h, w) pixel order the input pixel of output pixel m under tap (dh, dw) is m + dh*W + dw, so the three
+// taps of one kernel ROW read the same run of input pixels shifted by one: the x rows of a (32-channel chunk, dh) pair are
+// DMA'd ONCE -- TP + 2 pixel rows -- and the three dw taps read their B fragments from LDS rows p, p + 1, p + 2 (the
+// swizzle is a function of the row, so the shifted reads stay bank-conflict free).  x DMA bytes drop 3x, all DMA bytes of
+// a 128 x 256 tile 1.75x (the step loop of these layers is bound by L2 -> LDS DMA throughput x latency).
+// What the shift cannot express is the zero padding at the left / right image border (m +- 1 is the neighbouring image
+// row there): lanes whose output pixel has w == 0 (dw = -1) or w == W - 1 (dw = +1) zero their B fragment instead.  The
+// top / bottom border is the loader's: a row whose h + dh leaves the image gets the out-of-range offset, as in k_gconv.
+// Pipeline: one iteration = one 32-channel chunk = 9 sub-steps (dh outer, dw inner), fully unrolled, so stages, tap
+// offsets and wait counts are compile-time.  W tiles run 2 sub-steps ahead (3 stages, as k_gconv); x row groups run 2
+// groups (6 sub-steps) ahead in 3 stages, each group issued in 3 parts, one per sub-step (the last part is the 2 halo rows,
+// wave 0 only; the counted waits simply do not rely on it).
+// ---------------------------------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row, left in every lane of the row (4 VALU ops, no LDS traffic)
+__device__ __forceinline__ float row16_sum(float v) {
+#define AY_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    AY_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+    AY_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+    AY_DPP_ADD(0x141);   // row_half_mirror
+    AY_DPP_ADD(0x140);   // row_mirror
+#undef AY_DPP_ADD
+    return v;
+}
+
+template <typename T, int TM, int TPX>
+struct GT3 {
+    using G = GT<T, TM, TPX>;
+    static constexpr int XROWS = G::TP + 16;                 // TP + 2 used; padded to the DMA instruction's 16 rows
+    static constexpr int XS = XROWS * G::ROWB;               // bytes per x stage
+    static constexpr int WS = G::WSTAGE;
+    static constexpr int XP = G::XR / 2;                     // DMA instructions per thread in x parts 0 and 1
+    static constexpr size_t LDS = 3 * (size_t)XS + 3 * (size_t)WS + 2 * TM * sizeof(float);
+    static_assert(G::XR % 2 == 0 && G::ES == 2, "fp16, 128- or 256-pixel tiles");
+};
+
+template <typename T, int TM, int EM, int TPX>
+__global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
+    using G = GT<T, TM, TPX>;
+    using G3 = GT3<T, TM, TPX>;
+    constexpr int NSTK = G::NACC * 2;
+    constexpr int XR = G::XR, WR = G::WR, XP = G3::XP;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    unsigned char* sX = smem_raw;                                                 // [3][XROWS][32]
+    unsigned char* sW = smem_raw + 3 * G3::XS;                                    // [3][TM][32]
+    float* sStat = reinterpret_cast<float*>(sW + 3 * G3::WS);                     // [2][TM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % G::WM, wp = wave / G::WM;
+
+    // block -> (channel tile, XCD band, slot): as k_gconv
+    const unsigned Lb = blockIdx.x;
+    const unsigned xcd = Lb & 7u, idx = Lb >> 3;
+    const unsigned nt = idx % (unsigned)p.ntn;
+    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
+    const int n0 = (int)nt * TM;
+    const unsigned ntiles_all = (unsigned)((p.Mtotal + G::TP - 1) / G::TP);
+    const unsigned tpx = (ntiles_all + 7) / 8;
+    const unsigned band_lo = xcd * tpx;
+    const unsigned ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
+    const unsigned lslot = idx / (unsigned)p.ntn;
+    const unsigned lstride = (unsigned)p.nslots / 8u;
+    unsigned cur_tile = band_lo + lslot;
+    if (cur_tile >= ntiles) return;
+
+    if constexpr (EM == 2 || EM == 4) {
+        for (int i = tid; i < TM; i += 256) {
+            const bool in = n0 + i < p.Nout;
+            sStat[i] = (in && p.scale) ? p.scale[n0 + i] : 1.0f;
+            sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
+        }
+    }
+
+    const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
+    const unsigned lds_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sX);
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sW);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    // loader lane geometry (fp16: 4 chunks per row, 16 rows per wave-instruction)
+    const int slotc = lane & (G::CPR - 1);
+    const int rowin = lane / G::CPR;
+    const int kc = slotc ^ (lane >> 4);
+    const int kcb = kc * G::CE * G::ES;                     // byte offset of this lane's chunk inside a 32-channel slice
+
+    unsigned woff[WR];
+#pragma unroll
+    for (int r = 0; r < WR; ++r) {
+        const int row = (r * 4 + wave) * G::RW + rowin;
+        const bool ok = (row < TM) & (n0 + row < p.Nout);
+        woff[r] = ok ? (unsigned)(n0 + row) * (unsigned)p.ldw * G::ES + (unsigned)kcb : G_OOB;
+    }
+    // weight column byte offsets of the nine taps (SGPRs; indices are compile-time in the unrolled body)
+    int wtap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wtap[t] = __builtin_amdgcn_readfirstlane((int)p.r3wt[t] * p.C * G::ES);
+    const int dhstep = p.XW * p.ldx * G::ES;                // bytes per input image row
+    const int nC = p.C / BK;
+
+    // x rows of the loader's tile: row j of the stage <-> flattened pixel tile * TP + j - 1
+    int xoff[XR + 1], xh0[XR + 1];
+#define G3_SETUP(tile_, valid_)                                                                            \
+    {                                                                                                      \
+        _Pragma("unroll") for (int r = 0; r <= XR; ++r) {                                                  \
+            const int j = r < XR ? (r * 4 + wave) * 16 + rowin : G::TP + rowin;                            \
+            const unsigned mu = (tile_) * G::TP + (unsigned)j - 1u;                                        \
+            const bool ok = (valid_) & (mu < (unsigned)p.Mtotal) & (r < XR || rowin < 2);                  \
+            const unsigned t_ = fdiv(mu, p.dOW);                                                           \
+            const int ow_ = (int)(mu - t_ * (unsigned)p.OW);                                               \
+            const unsigned n_ = fdiv(t_, p.dOH);                                                           \
+            const int oh_ = (int)(t_ - n_ * (unsigned)p.OH);                                               \
+            xoff[r] = (int)(((n_ * (unsigned)p.XH + (unsigned)oh_) * (unsigned)p.XW + (unsigned)ow_) * (unsigned)p.ldx * G::ES) + kcb; \
+            xh0[r] = ok ? oh_ : -100000;                                                                   \
+        }                                                                                                  \
+    }
+    // part `t_` (0, 1: XP full instructions; 2: the halo rows, wave 0) of the x row group (chunk c_, dh = g_ - 1) -> x stage g_
+#define G3_XPART(t_, g_, c_)                                                                               \
+    {                                                                                                      \
+        const int cb_ = (c_) * (BK * G::ES), dh_ = (g_) - 1;                                               \
+        if ((t_) < 2) {                                                                                    \
+            _Pragma("unroll") for (int q_ = 0; q_ < XP; ++q_) {                                            \
+                const int r = (t_) * XP + q_;                                                              \
+                const bool ok = (unsigned)(xh0[r] + dh_) < (unsigned)p.XH;                                 \
+                const unsigned off = ok ? (unsigned)(xoff[r] + dh_ * dhstep + cb_) : G_OOB;                \
+                glds16(rsX, lds_x + (g_) * G3::XS + (r * 4 + wave) * 1024, off);                           \
+            }                                                                                              \
+        } else if (wave == 0) {                                                                            \
+            const bool ok = (unsigned)(xh0[XR] + dh_) < (unsigned)p.XH;                                    \
+            const unsigned off = ok ? (unsigned)(xoff[XR] + dh_ * dhstep + cb_) : G_OOB;                   \
+            glds16(rsX, lds_x + (g_) * G3::XS + XR * 4 * 1024, off);                                       \
+        }                                                                                                  \
+    }
+    // W tile of sub-step q_ (tap q_) of chunk c_ -> W stage q_ % 3
+#define G3_W(q_, c_)                                                                                       \
+    {                                                                                                      \
+        const unsigned col_ = (unsigned)(wtap[q_] + (c_) * (BK * G::ES));                                  \
+        _Pragma("unroll") for (int r = 0; r < WR; ++r)                                                     \
+            glds16(rsW, lds_w + ((q_) % 3) * G3::WS + (r * 4 + wave) * 1024, woff[r] + col_);              \
+    }
+
+    // MFMA fragment geometry
+    const int arow = (wm * 32 * G::MI + (lane & 31)) * G::ROWB;
+    const int swzA = ((lane & 31) / G::RPB) & (G::CPR - 1);
+    int brow0 = wp * G::NI * 32 + (lane & 31) + 1;           // stage row of this lane's pixel in block ni = 0, dw = 0
+    const int hi = lane >> 5;
+
+    float16v acc[G::NACC];
+#pragma unroll
+    for (int i = 0; i < G::NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    // BN statistics: reduced per tile (DPP row sums + LDS atomics into sStat) instead of living in 64 registers across
+    // the nine unrolled sub-steps, which is what made the forward variant spill
+    const bool want_stats = (EM == 0) && (p.stats != nullptr);
+    if constexpr (EM == 0) {
+        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+    }
+    const int cbase = n0 + wm * 32 * G::MI + 4 * (lane >> 5);
+
+    // loader cursor of the x rows (two row groups ahead of the compute cursor)
+    unsigned x_tile = cur_tile;
+    bool x_valid = true;
+    G3_SETUP(x_tile, true)
+    __syncthreads();                          // sAff visible
+    // prologue: x row groups 0 and 1 of chunk 0, W tiles of sub-steps 0 and 1
+    G3_XPART(0, 0, 0) G3_XPART(1, 0, 0) G3_XPART(2, 0, 0)
+    G3_XPART(0, 1, 0) G3_XPART(1, 1, 0) G3_XPART(2, 1, 0)
+    G3_W(0, 0)
+    G3_W(1, 0)
+
+    int c = 0;
+    bool after_epi = false;
+    unsigned mleft = 0, mright = 0;           // bit ni: this lane's pixel of block ni sits in image column 0 / W - 1
+    while (true) {
+        if (c == 0) {
+            mleft = 0; mright = 0;
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni) {
+                const unsigned mu = cur_tile * G::TP + (unsigned)(wp * G::NI * 32 + ni * 32 + (lane & 31));
+                const unsigned t_ = fdiv(mu, p.dOW);
+                const int ow_ = (int)(mu - t_ * (unsigned)p.OW);
+                mleft |= (ow_ == 0 ? 1u : 0u) << ni;
+                mright |= (ow_ == p.OW - 1 ? 1u : 0u) << ni;
+            }
+        }
+        const int cn = c + 1 == nC ? 0 : c + 1;            // chunk of the next iteration (its tile may be the next one)
+        // one sub-step: wait for W(q) (and the x group, issued earlier), barrier, fetch, issue ahead, MFMA
+#define G3_SUB(q_)                                                                                         \
+        {                                                                                                  \
+            constexpr int g_ = (q_) / 3, j_ = (q_) % 3;                                                    \
+            /* keep the per-sub-step address arithmetic per sub-step: hoisted across the nine unrolled bodies it costs   \
+               ~30 VGPRs (the forward variant then spills) */                                                            \
+            _Pragma("unroll") for (int r = 0; r <= XR; ++r) asm volatile("" : "+v"(xoff[r]), "+v"(xh0[r]));  \
+            asm volatile("" : "+v"(brow0));                                                                \
+            if ((q_) == 0) { if (after_epi) wait_vm<WR + NSTK>(); else wait_vm<WR>(); }                    \
+            else if (j_ == 0) wait_vm<WR>();                                                               \
+            else wait_vm<WR + XP>();                                                                       \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            const unsigned char* stW = sW + ((q_) % 3) * G3::WS + arow;                                    \
+            const int jr = brow0 + (j_ - 1);                                                               \
+            const int swzB = (jr >> 2) & (G::CPR - 1);                                                     \
+            const unsigned char* stX = sX + g_ * G3::XS + jr * G::ROWB;                                    \
+            const unsigned zmask = j_ == 0 ? mleft : (j_ == 2 ? mright : 0u);                              \
+            half8 fa0[G::MI], fb0[G::NI], fa1[G::MI], fb1[G::NI];                                          \
+            {                                                                                              \
+                const int sa = ((0 * 2 + hi) ^ swzA) * 16, sb = ((0 * 2 + hi) ^ swzB) * 16;                \
+                _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi) fa0[mi] = *reinterpret_cast<const half8*>(stW + mi * 32 * G::ROWB + sa); \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) fb0[ni] = *reinterpret_cast<const half8*>(stX + ni * 32 * G::ROWB + sb); \
+            }                                                                                              \
+            if constexpr (G::NACC < 8) {                                                                   \
+                const int sa = ((1 * 2 + hi) ^ swzA) * 16, sb = ((1 * 2 + hi) ^ swzB) * 16;                \
+                _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi) fa1[mi] = *reinterpret_cast<const half8*>(stW + mi * 32 * G::ROWB + sa); \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) fb1[ni] = *reinterpret_cast<const half8*>(stX + ni * 32 * G::ROWB + sb); \
+            }                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            /* ahead: part j_ of the x group two groups on, the W tile two sub-steps on */                  \
+            if ((q_) == 3) {                                                                               \
+                if (c + 1 == nC) {                                                                         \
+                    x_tile += lstride;                                                                     \
+                    x_valid = x_valid && x_tile < ntiles;                                                  \
+                    G3_SETUP(x_tile, x_valid)                                                              \
+                }                                                                                          \
+            }                                                                                              \
+            if (g_ == 0) G3_XPART(j_, 2, c)                                                                \
+            else G3_XPART(j_, g_ - 1, cn)                                                                  \
+            if ((q_) + 2 < 9) G3_W(((q_) + 2) % 9, c)                                                      \
+            else G3_W(((q_) + 2) % 9, cn)                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if (zmask) {                                                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni)                                       \
+                    if ((zmask >> ni) & 1u) { _Pragma("unroll") for (int e = 0; e < 8; ++e) fb0[ni][e] = (_Float16)0.0f; } \
+            }                                                                                              \
+            _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi)                                           \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) mma_step(fa0[mi], fb0[ni], acc[mi * G::NI + ni]); \
+            if constexpr (G::NACC >= 8) {                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                const int sa = ((1 * 2 + hi) ^ swzA) * 16, sb = ((1 * 2 + hi) ^ swzB) * 16;                \
+                _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi) fa1[mi] = *reinterpret_cast<const half8*>(stW + mi * 32 * G::ROWB + sa); \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) fb1[ni] = *reinterpret_cast<const half8*>(stX + ni * 32 * G::ROWB + sb); \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (zmask) {                                                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni)                                       \
+                    if ((zmask >> ni) & 1u) { _Pragma("unroll") for (int e = 0; e < 8; ++e) fb1[ni][e] = (_Float16)0.0f; } \
+            }                                                                                              \
+            _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi)                                           \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) mma_step(fa1[mi], fb1[ni], acc[mi * G::NI + ni]); \
+        }
+        G3_SUB(0) G3_SUB(1) G3_SUB(2) G3_SUB(3) G3_SUB(4) G3_SUB(5) G3_SUB(6) G3_SUB(7) G3_SUB(8)
+        after_epi = false;
+        if (c == nC - 1) {
+            asm volatile("s_nop 11" ::: "memory");          // the accumulators are read right after the last MFMA
+            float ssum[16 * G::MI], ssq[16 * G::MI];
+#pragma unroll
+            for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+            g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, ssum, ssq, sStat, cbase - n0);
+            if (want_stats) {
+                int lq = lane;                              // opaque: keeps the LDS addresses below from being hoisted out of the
+                asm volatile("" : "+v"(lq));                // tile loop (and spilled: every reload would drain the DMA queue)
+                float* sl = sStat + wm * 32 * G::MI + 4 * (lq >> 5);
+#pragma unroll
+                for (int r = 0; r < 16 * G::MI; ++r) {
+                    const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
+                    if ((lq & 15) == 0) {
+                        const int cl = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + (r & 3);
+                        atomicAdd(&sl[cl], a);
+                        atomicAdd(&sl[TM + cl], b);
+                    }
+                }
+            }
+            after_epi = true;
+            cur_tile += lstride;
+            if (cur_tile >= ntiles) break;
+        }
+        c = cn;
+    }
+#undef G3_SUB
+#undef G3_W
+#undef G3_XPART
+#undef G3_SETUP
+    wait_vm<0>();                             // trailing DMAs must land before this LDS is released
+    if (want_stats) {
+        __syncthreads();
+        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
+        for (int i = tid; i < TM; i += 256) {
+            if (n0 + i < p.Nout) {
+                atomicAdd(&st[n0 + i], sStat[i]);
+                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
+            }
+        }
+    }
+}
+
 // compute units of the CURRENT device (cached per device ordinal: one process may drive several GPUs)
 static int num_cus() {
     static int cache[16] = {0};
@@ -709,13 +1008,29 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     const size_t lds = G::LDS;
     p.ntn = (p.Nout + TM - 1) / TM;
     static const int bpc_env = getenv("AYOLO_GCONV_BPC") ? atoi(getenv("AYOLO_GCONV_BPC")) : 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if constexpr (sizeof(T) == 2 && EM != 3) {
+        if (p.row3) {                        // 3x3 / stride 1: x rows shared by the three taps of a kernel row (k_gconv3)
+            using G3 = GT3<T, TM, TPX>;
+            const long long slots3 = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc_env > 0 ? bpc_env : 2).slots;
+            p.nslots = (int)slots3;
+            static bool attr3_set[16] = {false};
+            if (dev < 0 || dev >= 16 || !attr3_set[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv3<T, TM, EM, TPX>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3::LDS);
+                if (dev >= 0 && dev < 16) attr3_set[dev] = true;
+            }
+            hipLaunchKernelGGL((k_gconv3<T, TM, EM, TPX>), dim3((unsigned)(slots3 * p.ntn)), dim3(256), G3::LDS, s, p);
+            AY_CHECK_LAUNCH("k_gconv3");
+            return AYOLO_OK;
+        }
+    }
     const int bpc = bpc_env > 0 ? bpc_env : gconv_bpc<T, TM, TPX>();
     const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc).slots;
     p.nslots = (int)slots;
     dim3 grid((unsigned)(slots * p.ntn));
     static bool attr_set[16] = {false};      // per device: function attributes belong to the device's context
-    int dev = 0;
-    (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
@@ -742,8 +1057,8 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     else {
         const int ntn = (p.Nout + TM - 1) / TM;
         const int K = p.ntaps * p.C;
-        const long long w128 = gconv_grid(p.Mtotal, 128, ntn, gconv_bpc<T, TM, 128>()).waves;
-        const long long w256 = gconv_grid(p.Mtotal, 256, ntn, gconv_bpc<T, TM, 256>()).waves;
+        const long long w128 = gconv_grid(p.Mtotal, 128, ntn, p.row3 ? 2 : gconv_bpc<T, TM, 128>()).waves;
+        const long long w256 = gconv_grid(p.Mtotal, 256, ntn, p.row3 ? 2 : gconv_bpc<T, TM, 256>()).waves;
         if (w128 <= 1) wide = false;
         else if (w128 <= 3 && w256 < w128) wide = true;
         else wide = TM == 64 ? true : (TM == 128 ? K >= 256 : K >= 128);
@@ -817,6 +1132,20 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)(p.C > 0 ? p.C : 1));
     if (p.ncls <= 0) {                       // ordinary launch: one class = all taps
         p.ncls = 1; p.ctap0[0] = 0; p.cnt[0] = p.ntaps; p.coah[0] = p.oah; p.coaw[0] = p.oaw;
+    }
+    // 3x3, stride 1, same-size maps, whole 32-channel slices (the Bottleneck 3x3 convs and their dgrad): k_gconv3
+    static const int row3_on = getenv("AYOLO_GCONV_ROW3") ? atoi(getenv("AYOLO_GCONV_ROW3")) : 1;
+    p.row3 = 0;
+    if (row3_on && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 1 && p.isw == 1 && p.osh == 1 && p.osw == 1 &&
+        p.XH == p.OH && p.XW == p.OW && p.YH == p.OH && p.YW == p.OW && p.C % BK == 0 && p.epi != AYOLO_EPI_HEAD) {
+        int seen = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int g = p.dh[t] + 1, j = p.dw[t] + 1;
+            if (g < 0 || g > 2 || j < 0 || j > 2) { seen = -1; break; }
+            seen |= 1 << (g * 3 + j);
+            p.r3wt[g * 3 + j] = p.wt[t];
+        }
+        p.row3 = seen == 0x1ff ? 1 : 0;
     }
     return dispatch_gconv_one(dtype, p, s);
 }

@@ -1,23 +1,13 @@
 #!/bin/bash
-AYOLO_LIB=$(realpath ab/libayolo_mi2_64.so) timeout 600 python -m pytest tests/test_gpu_conv.py -m gpu -q -x 2>&1 | tail -2
-cat > /tmp/ev.py <<PY
-import os, sys, time, torch
-sys.path.insert(0, os.getcwd())
-from ayolov2_amd import YOLOModel
-torch.manual_seed(0)
-m = YOLOModel("ayolov2_amd/configs/yolov5x.yaml").cuda().fuse().eval()
-x = torch.rand(8, 3, 1280, 1280, device="cuda")
-with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-    for _ in range(3): m(x)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(10): m(x)
-    torch.cuda.synchronize(); print("cfg5 ms", (time.perf_counter() - t) * 100)
-PY
+timeout 600 python -m pytest tests/test_gpu_conv.py -m gpu -q -x 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_infer.py tests/test_gpu_model.py -m gpu -q -x 2>&1 | tail -4
 for i in 1 2; do
-echo "hip ragged64=0 $(AYOLO_GCONV_RAGGED64=0 python /tmp/ev.py 2>/dev/null | tail -1)"
-echo "hip ragged64=1 $(python /tmp/ev.py 2>/dev/null | tail -1)"
-echo "mi2_64 ragged64=1 $(AYOLO_LIB=$(realpath ab/libayolo_mi2_64.so) python /tmp/ev.py 2>/dev/null | tail -1)"
-echo "mi2_64 ragged64=0 $(AYOLO_GCONV_RAGGED64=0 AYOLO_LIB=$(realpath ab/libayolo_mi2_64.so) python /tmp/ev.py 2>/dev/null | tail -1)"
+echo "row3=0 $(AYOLO_GCONV_ROW3=0 python tools/cfg5_time.py 2>/dev/null | tail -1)"
+echo "row3=1 $(python tools/cfg5_time.py 2>/dev/null | tail -1)"
 done
-bash tools/ab_bench.sh ayolov2_amd/libayolo_hip.so ab/libayolo_mi2_64.so 2
-bash tools/ddp_timeline.sh r02 | tail -32
+for i in 1 2; do
+for r in 0 1; do
+  echo "row3=$r $(AYOLO_GCONV_ROW3=$r python bench.py --no-extras --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")"
+done; done
+python tools/conv_sweep.py yolov5s 64 640 2>/dev/null | grep -E " 3 1 |total" 
+AYOLO_GCONV_ROW3=0 python tools/conv_sweep.py yolov5s 64 640 2>/dev/null | grep -E " 3 1 |total"
