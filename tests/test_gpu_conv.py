@@ -25,6 +25,14 @@ SHAPES = [
     (2, 80, 160, 1, 1, 0, 10, 12),     # yolov5x widths
     (2, 1280, 640, 1, 1, 0, 4, 4),     # deepest 1x1 of yolov5x: K = 1280, ragged 640-wide output
     (1, 320, 320, 3, 1, 1, 8, 8),
+    # k_gconv3 (3x3 stride 1: one x row run shared by the three taps of a kernel row): maps narrower than the halo, a
+    # single column / single row (every pixel is at the left AND right border), pixel counts around the tile sizes
+    (2, 32, 32, 3, 1, 1, 7, 1),
+    (1, 64, 32, 3, 1, 1, 1, 50),
+    (3, 32, 32, 3, 1, 1, 2, 2),
+    (2, 32, 64, 3, 1, 1, 16, 16),      # 512 pixels: exactly two 256-pixel tiles, image boundary on the tile boundary
+    (1, 96, 96, 3, 1, 1, 15, 17),      # 255 pixels (one short of a tile), three 32-channel chunks
+    (1, 32, 32, 3, 1, 1, 257, 1),      # 257 pixels in one column: the halo row of tile 0 is the first pixel of tile 1
 ]
 
 
