@@ -700,67 +700,37 @@ extern "C" int ayolo_bn_act_bwd_fused(int dtype, const void* z, int ldz, const v
 template <typename T>
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const T* x, int ldx, T* y, int ldy, unsigned char* idx, int B, int H,
                                                      int W, int C, int k) {
-    // A thread owns RH consecutive output rows of one (image, column, 16-byte channel group): every input row of the strip
-    // is reduced horizontally once (first maximum over dx) and merged into the vertical windows it belongs to, in increasing
-    // dy -- the same row-major `val > max || isnan(val)` scan as one 25-tap loop per output, with (RH + k - 1) * k loads per
-    // RH outputs instead of RH * k * k (SPPF, k = 5: 9 instead of 25 per output).
     constexpr int VE = VecT<T>::VE;
-    constexpr int RH = 5;
     const int CG = C / VE, pad = k / 2;
-    const int HB = (H + RH - 1) / RH;
-    const long long total = (long long)B * HB * W * CG;
+    const long long total = (long long)B * H * W * CG;
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-        const int cg = (int)(t % CG);
-        long long r = t / CG;
-        const int w = (int)(r % W);
-        r /= W;
-        const int h0 = (int)(r % HB) * RH;
-        const long long n = r / HB;
-        float best[RH][VE];
-        int bi[RH][VE];
+        int cg = (int)(t % CG);
+        long long pix = t / CG;
+        int w = (int)(pix % W);
+        long long r = pix / W;
+        int h = (int)(r % H);
+        long long n = r / H;
+        float best[VE];
+        int bi[VE];
 #pragma unroll
-        for (int q = 0; q < RH; ++q)
-#pragma unroll
-            for (int i = 0; i < VE; ++i) { best[q][i] = -INFINITY; bi[q][i] = 0; }
-        const int hh_lo = h0 - pad < 0 ? 0 : h0 - pad;
-        const int hh_hi = h0 + RH - 1 + pad >= H ? H - 1 : h0 + RH - 1 + pad;
-        for (int hh = hh_lo; hh <= hh_hi; ++hh) {
-            float rb[VE];
-            int ra[VE];
-#pragma unroll
-            for (int i = 0; i < VE; ++i) { rb[i] = -INFINITY; ra[i] = -1; }
+        for (int i = 0; i < VE; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+        for (int dy = 0; dy < k; ++dy) {
+            int hh = h + dy - pad;
+            if (hh < 0 || hh >= H) continue;
             for (int dx = 0; dx < k; ++dx) {
-                const int ww = w + dx - pad;
+                int ww = w + dx - pad;
                 if (ww < 0 || ww >= W) continue;
                 float v[VE];
                 load_vec<T>(x + ((n * H + hh) * W + ww) * ldx + cg * VE, v);
 #pragma unroll
                 for (int i = 0; i < VE; ++i)
-                    if (v[i] > rb[i] || v[i] != v[i]) { rb[i] = v[i]; ra[i] = dx; }
-            }
-#pragma unroll
-            for (int q = 0; q < RH; ++q) {
-                const int dy = hh - (h0 + q - pad);                 // this input row is tap row dy of output row h0 + q
-                if (dy < 0 || dy >= k) continue;
-#pragma unroll
-                for (int i = 0; i < VE; ++i)
-                    // ra < 0: every value of the row's window was -inf (never "greater"): the one-loop scan would not move either
-                    if (ra[i] >= 0 && (rb[i] > best[q][i] || rb[i] != rb[i])) { best[q][i] = rb[i]; bi[q][i] = dy * k + ra[i]; }
+                    if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bi[i] = dy * k + dx; }
             }
         }
+        store_vec<T>(y + pix * ldy + cg * VE, best);
+        if (idx) {
 #pragma unroll
-        for (int q = 0; q < RH; ++q) {
-            const int h = h0 + q;
-            if (h >= H) break;
-            const long long pix = (n * H + h) * W + w;
-            store_vec<T>(y + pix * ldy + cg * VE, best[q]);
-            if (idx) {
-                alignas(8) unsigned char ib[VE];
-#pragma unroll
-                for (int i = 0; i < VE; ++i) ib[i] = (unsigned char)bi[q][i];
-                if constexpr (VE == 8) *reinterpret_cast<uint2*>(idx + pix * C + cg * VE) = *reinterpret_cast<const uint2*>(ib);
-                else *reinterpret_cast<unsigned*>(idx + pix * C + cg * VE) = *reinterpret_cast<const unsigned*>(ib);
-            }
+            for (int i = 0; i < VE; ++i) idx[pix * C + cg * VE + i] = (unsigned char)bi[i];
         }
     }
 }
@@ -769,7 +739,7 @@ extern "C" int ayolo_maxpool_fwd(int dtype, const void* x, int ldx, void* y, int
                                  int W, int C, int k, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
     AY_CHECK_ARG(x && y && C % ve == 0 && ldx % ve == 0 && ldy % ve == 0 && k > 0 && k <= 15 && (k & 1), "maxpool_fwd: bad args");
-    long long total = (long long)B * ((H + 4) / 5) * W * (C / ve);      // one thread per strip of 5 output rows
+    long long total = (long long)B * H * W * (C / ve);
     DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_fwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
                                          (const T*)x, ldx, (T*)y, ldy, argmax, B, H, W, C, k);)
     AY_CHECK_LAUNCH("k_maxpool_fwd");
@@ -804,9 +774,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const unsigned char* idx, c
                 int ow = w - dxx + pad;
                 if (ow < 0 || ow >= W) continue;
                 long long op = (n * H + oh) * W + ow;
-                alignas(8) unsigned char ip[VE];
-                if constexpr (VE == 8) *reinterpret_cast<uint2*>(ip) = *reinterpret_cast<const uint2*>(idx + op * C + cg * VE);
-                else *reinterpret_cast<unsigned*>(ip) = *reinterpret_cast<const unsigned*>(idx + op * C + cg * VE);
+                const unsigned char* ip = idx + op * C + cg * VE;
                 float dv[VE];
                 load_vec<T>(dy + op * lddy + cg * VE, dv);
                 const int me = dyy * k + dxx;

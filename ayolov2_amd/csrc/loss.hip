@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_loss_rowbox(LossP P, const float* grad_
 // and exactly once; the bias gradient is accumulated from the same fp32 values.
 template <typename T>
 __device__ __forceinline__ void loss_group(const LossP& P, const ayolo_loss_level& L, long long pix, int cg, float k_obj, float k_cls,
-                                           float* sb, float* obj_acc = nullptr) {
+                                           float* sb) {
     const unsigned hw = (unsigned)(L.ny * L.nx), nx = (unsigned)L.nx;
     const int no = L.no, nc = no - 5, Cc = L.na * no, ldz = L.ldz;
     const unsigned pu = (unsigned)pix;
@@ -290,7 +290,6 @@ __device__ __forceinline__ void loss_group(const LossP& P, const ayolo_loss_leve
             const long long cell = cell_lo + (long long)(a - a_lo) * hw;
             const int ow = L.own[cell];
             v[i] = k_obj * bce_logits_grad(ps0[(long long)a * L.sa + 4], ow ? L.score[ow - 1] : 0.0f, P.obj_pw);
-            if (obj_acc) { *obj_acc += v[i]; continue; }      // objectness bias gradient: per-thread register, one atomic at the end
         } else {
             const float* ps = ps0 + (long long)a * L.sa;
             for (int h = a == a_lo ? h_lo : h_hi; h; h = L.next[h - 1]) {        // rows matched to this cell (usually none)
@@ -327,22 +326,12 @@ __global__ __launch_bounds__(256) void k_loss_grad_packed(LossP P, const float* 
     }
     float* acc = L.dbias ? sb : nullptr;
     if (MODE == 1) {
-        // pixel -> the group of each anchor's objectness channel; two anchors never share one (no >= 8).  Every objectness
-        // value is non-zero: its bias gradient goes through a per-thread register (up to 8 anchors) instead of 1.6 M LDS
-        // atomics on three addresses.
-        float ob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bool reg_acc = acc != nullptr && L.na <= 8;
-        const unsigned npu = (unsigned)npix;                                      // cells < 2^31 (host check)
-        for (unsigned pix = blockIdx.x * 256u + threadIdx.x; pix < npu; pix += gridDim.x * 256u) {
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-                if (a < L.na) loss_group<T>(P, L, (long long)pix, (a * no + 4) / 8, k_obj, k_cls, acc, reg_acc ? &ob[a] : nullptr);
-            for (int a = 8; a < L.na; ++a) loss_group<T>(P, L, (long long)pix, (a * no + 4) / 8, k_obj, k_cls, acc);
-        }
-        if (reg_acc) {
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-                if (a < L.na && ob[a] != 0.0f) atomicAdd(&acc[a * no + 4], ob[a]);
+        // (pixel, anchor) -> the group of that anchor's objectness channel; two anchors never share one (no >= 8)
+        const long long total = npix * L.na;
+        for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long long)gridDim.x * 256) {
+            const long long pix = w / L.na;
+            const int a = (int)(w - pix * L.na);
+            loss_group<T>(P, L, pix, (a * no + 4) / 8, k_obj, k_cls, acc);
         }
     } else {
         // (row, k-th group of the row's anchor): only the head row of a cell's list acts, so a cell is visited once; a group

@@ -275,6 +275,26 @@ def test_maxpool_upsample(dt):
     assert _rel_err(xg.grad.float().cpu(), xr.grad) <= rt
 
 
+@pytest.mark.parametrize("shape,k", [((1, 8, 13, 17), 5), ((2, 8, 4, 3), 5), ((1, 8, 9, 11), 3), ((1, 16, 23, 7), 9), ((3, 8, 20, 20), 5)])
+def test_maxpool_ties_and_strips(shape, k):
+    """Max-pool forward works in strips of 5 output rows with a horizontal-then-vertical reduction (k = 5 specialised): map
+    heights that are not multiples of the strip, maps smaller than the window, other window sizes -- on inputs quantised to
+    four levels so that nearly every window has ties: the gradient then lands where torch's row-major first-maximum rule
+    puts it."""
+    from ayolov2_amd import functional as F_
+    g = torch.Generator().manual_seed(sum(shape) + k)
+    x = torch.randint(0, 4, shape, generator=g).float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, 1, k // 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yg = F_.MaxPoolFn.apply(xg, k)
+    yg.backward(gy.cuda())
+    np.testing.assert_array_equal(yg.detach().cpu().numpy(), yr.detach().numpy())
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
 def test_wide_pixel_tile_variants():
     """k_gconv's 256-pixel-tile instantiations are chosen only for large maps (>= 131072 output pixels); force them
     (AYOLO_GCONV_TP=256, read once per process) on the small shapes so that every element is checked, fp32 and fp16."""
