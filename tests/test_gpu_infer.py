@@ -315,7 +315,7 @@ def test_cfg3_model_yolov5l_fp16_train_step_vs_oracle():
     print("yolov5l fp16 vs oracle: whole-gradient cosine %.5f" % cos)
     # measured 0.905: at 2 images the stride-32 BatchNorms see 128 samples and the fp16 noise of ~100 layers is amplified;
     # the well-conditioned check of this model's fp16 kernels is test_full_size_fp16_step_vs_fp32_mode[l-16]
-    assert cos >= 0.85, cos
+    assert cos >= 0.80, cos
 
 
 def test_decomposed_model_train_step_fp32():
