@@ -770,7 +770,8 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) wtap[t] = __builtin_amdgcn_readfirstlane((int)p.r3wt[t] * p.C * G::ES);
     const int dhstep = p.XW * p.ldx * G::ES;                // bytes per input image row
-    const int nC = p.C / BK;
+    const int nC = (p.C + BK - 1) / BK;                     // the last chunk may be partly beyond C (80, 48 channels ...)
+    const int cmax = p.C - kc * G::CE;                     // chunk c holds channels of this lane's 16-byte slot iff c * BK < cmax
 
     // x rows of the loader's tile: row j of the stage <-> flattened pixel tile * TP + j - 1
     int xoff[XR + 1], xh0[XR + 1];
@@ -795,12 +796,12 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
         if ((t_) < 2) {                                                                                    \
             _Pragma("unroll") for (int q_ = 0; q_ < XP; ++q_) {                                            \
                 const int r = (t_) * XP + q_;                                                              \
-                const bool ok = (unsigned)(xh0[r] + dh_) < (unsigned)p.XH;                                 \
+                const bool ok = ((unsigned)(xh0[r] + dh_) < (unsigned)p.XH) & ((c_) * BK < cmax);          \
                 const unsigned off = ok ? (unsigned)(xoff[r] + dh_ * dhstep + cb_) : G_OOB;                \
                 glds16(rsX, lds_x + (g_) * G3::XS + (r * 4 + wave) * 1024, off);                           \
             }                                                                                              \
         } else if (wave == 0) {                                                                            \
-            const bool ok = (unsigned)(xh0[XR] + dh_) < (unsigned)p.XH;                                    \
+            const bool ok = ((unsigned)(xh0[XR] + dh_) < (unsigned)p.XH) & ((c_) * BK < cmax);             \
             const unsigned off = ok ? (unsigned)(xoff[XR] + dh_ * dhstep + cb_) : G_OOB;                   \
             glds16(rsX, lds_x + (g_) * G3::XS + XR * 4 * 1024, off);                                       \
         }                                                                                                  \
@@ -808,9 +809,9 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
     // W tile of sub-step q_ (tap q_) of chunk c_ -> W stage q_ % 3
 #define G3_W(q_, c_)                                                                                       \
     {                                                                                                      \
-        const unsigned col_ = (unsigned)(wtap[q_] + (c_) * (BK * G::ES));                                  \
+        const unsigned col_ = (unsigned)(wtap[q_] + (c_) * (BK * G::ES)) | ((c_) * BK < cmax ? 0u : G_OOB);\
         _Pragma("unroll") for (int r = 0; r < WR; ++r)                                                     \
-            glds16(rsW, lds_w + ((q_) % 3) * G3::WS + (r * 4 + wave) * 1024, woff[r] + col_);              \
+            glds16(rsW, lds_w + ((q_) % 3) * G3::WS + (r * 4 + wave) * 1024, (woff[r] + col_) | (col_ & G_OOB)); \
     }
 
     // MFMA fragment geometry
@@ -1133,11 +1134,14 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     if (p.ncls <= 0) {                       // ordinary launch: one class = all taps
         p.ncls = 1; p.ctap0[0] = 0; p.cnt[0] = p.ntaps; p.coah[0] = p.oah; p.coaw[0] = p.oaw;
     }
-    // 3x3, stride 1, same-size maps, whole 32-channel slices (the Bottleneck 3x3 convs and their dgrad): k_gconv3
+    // 3x3, stride 1, same-size maps (the Bottleneck 3x3 convs and their dgrad): k_gconv3
     static const int row3_on = getenv("AYOLO_GCONV_ROW3") ? atoi(getenv("AYOLO_GCONV_ROW3")) : 1;
+    static const int row3_ragged = getenv("AYOLO_GCONV_ROW3_RAGGED") ? atoi(getenv("AYOLO_GCONV_ROW3_RAGGED")) : 1;
     p.row3 = 0;
-    if (row3_on && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 1 && p.isw == 1 && p.osh == 1 && p.osw == 1 &&
-        p.XH == p.OH && p.XW == p.OW && p.YH == p.OH && p.YW == p.OW && p.C % BK == 0 && p.epi != AYOLO_EPI_HEAD) {
+    if (row3_on && (row3_ragged || p.C % BK == 0) && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 1 && p.isw == 1 && p.osh == 1 && p.osw == 1 &&
+        p.XH == p.OH && p.XW == p.OW && p.YH == p.OH && p.YW == p.OW && p.C >= BK && p.epi != AYOLO_EPI_HEAD &&
+        // channels beyond C in the last 32-wide chunk are fetched as zeros (x and W): at most a quarter of the MFMA work
+        ((p.C + BK - 1) / BK * BK - p.C) * 4 <= (p.C + BK - 1) / BK * BK) {
         int seen = 0;
         for (int t = 0; t < 9; ++t) {
             const int g = p.dh[t] + 1, j = p.dw[t] + 1;

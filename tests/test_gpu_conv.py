@@ -33,6 +33,8 @@ SHAPES = [
     (2, 32, 64, 3, 1, 1, 16, 16),      # 512 pixels: exactly two 256-pixel tiles, image boundary on the tile boundary
     (1, 96, 96, 3, 1, 1, 15, 17),      # 255 pixels (one short of a tile), three 32-channel chunks
     (1, 32, 32, 3, 1, 1, 257, 1),      # 257 pixels in one column: the halo row of tile 0 is the first pixel of tile 1
+    (1, 80, 160, 3, 1, 1, 20, 24),     # yolov5x: 80 channels = 2.5 chunks of 32, the last one half beyond C (zero-filled x and W)
+    (2, 72, 40, 3, 1, 1, 9, 9),
 ]
 
 
