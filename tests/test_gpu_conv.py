@@ -220,6 +220,34 @@ def test_conv_bn_silu_block_train(cfg, dt):
     assert _rel_err(m.batch_norm.bias.grad.cpu(), ref.batch_norm.bias.grad) < rt * 2
 
 
+@pytest.mark.parametrize("shape", [(4, 32, 32, 3, 1, 1, 40, 40), (4, 64, 64, 3, 1, 1, 40, 40), (2, 128, 128, 3, 1, 1, 40, 40),
+                                   (8, 128, 256, 3, 1, 1, 80, 80), (2, 80, 160, 3, 1, 1, 24, 20), (4, 128, 128, 1, 1, 0, 40, 40),
+                                   (2, 64, 128, 3, 2, 1, 40, 40)])
+def test_conv_epilogue_statistics_fp16(shape):
+    """The BatchNorm sums a conv leaves behind (sum z, sum z^2 over the rounded fp16 outputs, per channel) for every channel-tile
+    width and both conv kernels -- k_gconv keeps them in registers across tiles, k_gconv3 reduces them per tile with DPP row
+    sums + LDS atomics -- against the sums of the stored output itself (fp32 summation order is the only difference)."""
+    from ayolov2_amd import functional as F_, ops
+    B, Cin, Cout, k, s_, p_, H, W = shape
+    dt = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, device="cuda", generator=g).to(dt).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+    geo = F_._Geometry((B, Cin, H, W), wt.shape, (s_, s_), (p_, p_), dt)
+    w, _ = F_._WeightCache().get(wt.contiguous(memory_format=torch.channels_last), dt, Cout, geo.cin_pad)
+    y = ops.new_act(B, Cout, geo.Ho, geo.Wo, dt, x.device)
+    stats = torch.zeros((ops.STAT_REPS, 2 * Cout), dtype=torch.float32, device="cuda")
+    ops.conv_fwd(geo.desc(dt, geo.Cin_k, Cout), x, w, y, 0, stats=stats)
+    torch.cuda.synchronize()
+    tot = stats.double().sum(0).cpu()
+    yf = y.double()
+    P = B * geo.Ho * geo.Wo                                   # fp32 accumulation: ~1e-7 of the summed magnitudes
+    np.testing.assert_allclose(tot[:Cout].numpy(), yf.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-6 * P)
+    np.testing.assert_allclose(tot[Cout:].numpy(), (yf * yf).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-6 * P)
+    ref = F.conv2d(x.float(), wt.half().float(), None, s_, p_)
+    assert float((y.float() - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
 def test_conv_eval_and_fuse(dt):
     from ayolov2_amd.modules import Conv
