@@ -54,6 +54,10 @@ struct GConvP {
     // k_gconv3 (3x3, stride 1, same-size maps): weight tap index of (dh, dw) = (g - 1, j - 1) at [g * 3 + j]
     int row3;
     signed char r3wt[9];
+    // k_dgrad_s2 (dgrad of a 3x3 / stride 2 / pad 1 conv): weight tap of the nine (shift, class) products in the order
+    // [A: shift (0,0) classes 0,1,2,3 | B: shift (0,1) classes 1,3 | C: shift (1,0) classes 2,3 | D: shift (1,1) class 3]
+    int s2d;
+    signed char s2wt[9];
 };
 
 template <typename T> struct Tr;
@@ -967,6 +971,234 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// k_dgrad_s2: data gradient of a 3x3 / stride 2 / pad 1 conv for <= 64 input channels (the first two down-sampling convs
+// of the backbone: 420 / 210 MB of dx, the widest activations of the backward pass).
+// Output pixel (2*oh + a, 2*ow + b) of residue class (a, b) sums the taps (i, j) with a + 1 - i and b + 1 - j even, reading
+// dy at (oh + dh', ow + dw') with dh' = (a + 1 - i) / 2, dw' = (b + 1 - j) / 2: the NINE (class, tap) products of the four
+// classes read only FOUR shifts (dh', dw' in {0, 1}) of the dy tile.  k_gconv walks the classes one after the other and
+// DMAs the dy tile once per tap (nine times, 5 pieces per wave next to 4 MFMAs); here one workgroup keeps the accumulators
+// of all four classes (4 x NI blocks), a dy row group (TP + 1 pixels, one per dh') is DMA'd once per 32-channel chunk and
+// serves every product that reads it -- the k_gconv3 row-sharing idea across classes -- and the products that read the
+// same shift form ONE step (one barrier, one B-fragment fetch, up to four W tiles):
+//   A: shift (0,0) x classes 0,1,2,3   B: (0,1) x classes 1,3   C: (1,0) x classes 2,3   D: (1,1) x class 3
+// Per chunk and wave 13.5 LDS-DMA pieces and 4 barriers instead of 45 and 9.
+// The W tiles of a step land in the step's own LDS region two steps ahead.  x row groups: 3 stages,
+// the group of the NEXT chunk is issued whole at the first step (A / C) of the current chunk's same group, into the stage
+// that is neither being read nor in flight.  Right border (dw' = 1 at ow = OW - 1): the lane zeroes its B fragment; bottom
+// border (dh' = 1 at oh = OH - 1): the loader's out-of-range offset.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int TM, int EM, int TPX>
+__global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
+    using G = GT<T, TM, TPX>;
+    static_assert(sizeof(T) == 2 && G::MI == 1 && G::NI == 2 && (TM == 32 || TM == 64), "fp16, 32- or 64-channel tiles");
+    constexpr int XR = G::XR;
+    constexpr int XS = (G::TP + 16) * G::ROWB;                // TP + 1 rows used, padded to the DMA instruction's 16 rows
+    // W tiles: every step has its own region ([taps][TM rows][32]); a region is written two steps before its step reads it
+    // and read by that one step only, so no rotation is needed (A: 4 tap tiles, B: 2, C: 2, D: 1)
+    constexpr int TMB = TM * G::ROWB;
+    constexpr int WOA = 0, WOB = 4 * TMB, WOC = 6 * TMB, WOD = 8 * TMB;
+    // W pieces per wave for a step with 4 / 2 / 1 taps: rows = taps * TM, 16 rows per piece, 4 waves
+    constexpr int W4 = 4 * TM / 64, W2 = 2 * TM / 64, W1 = TM / 64 > 0 ? TM / 64 : 1;
+    constexpr int NSTK = 4 * G::NACC * 2;                     // stores per thread of the four class epilogues
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    unsigned char* sX = smem_raw;                             // [3][TP + 16][32]
+    unsigned char* sW = smem_raw + 3 * XS;                    // [9 tap tiles][TM][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % G::WM, wp = wave / G::WM;
+
+    const unsigned Lb = blockIdx.x;
+    const unsigned xcd = Lb & 7u, idx = Lb >> 3;
+    const unsigned nt = idx % (unsigned)p.ntn;
+    const int n0 = (int)nt * TM;
+    const unsigned ntiles_all = (unsigned)((p.Mtotal + G::TP - 1) / G::TP);
+    const unsigned tpx = (ntiles_all + 7) / 8;
+    const unsigned band_lo = xcd * tpx;
+    const unsigned ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
+    const unsigned lslot = idx / (unsigned)p.ntn;
+    const unsigned lstride = (unsigned)p.nslots / 8u;
+    unsigned cur_tile = band_lo + lslot;
+    if (cur_tile >= ntiles) return;
+
+    const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
+    const unsigned lds_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sX);
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sW);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    const int slotc = lane & (G::CPR - 1);
+    const int rowin = lane / G::CPR;
+    const int kc = slotc ^ (lane >> 4);
+    const int kcb = kc * G::CE * G::ES;
+    const int nC = (p.C + BK - 1) / BK;
+    const int cmax = p.C - kc * G::CE;
+    const int dhstep = p.XW * p.ldx * G::ES;
+
+    // W loader: piece r of this wave covers stage rows (r * 4 + wave) * 16 + rowin = tap t * TM + row-in-tap, with
+    // t = (r * 4 + wave) * 16 / TM and a row-in-tap that does not depend on r
+    const int wrow = ((wave * 16) % TM) + rowin;
+    const unsigned wbase = (n0 + wrow < p.Nout) ? (unsigned)(n0 + wrow) * (unsigned)p.ldw * G::ES + (unsigned)kcb : G_OOB;
+    // column byte offset of the weight tap that piece r of this wave loads in steps A / B / C / D (out of range: no tap)
+    int wcA[W4], wcB[W2], wcC[W2], wcD[W1];
+#pragma unroll
+    for (int r = 0; r < W4; ++r) wcA[r] = __builtin_amdgcn_readfirstlane((int)p.s2wt[(r * 4 + wave) * 16 / TM] * p.C * G::ES);
+#pragma unroll
+    for (int r = 0; r < W2; ++r) wcB[r] = __builtin_amdgcn_readfirstlane((int)p.s2wt[4 + (r * 4 + wave) * 16 / TM] * p.C * G::ES);
+#pragma unroll
+    for (int r = 0; r < W2; ++r) wcC[r] = __builtin_amdgcn_readfirstlane((int)p.s2wt[6 + (r * 4 + wave) * 16 / TM] * p.C * G::ES);
+#pragma unroll
+    for (int r = 0; r < W1; ++r) {
+        const int t = (r * 4 + wave) * 16 / TM;                 // TM = 32: waves 2, 3 would be tap 1 of a one-tap step
+        wcD[r] = __builtin_amdgcn_readfirstlane(t < 1 ? (int)p.s2wt[8] * p.C * G::ES : (int)G_OOB);
+    }
+
+    int xoff[XR + 1], xh0[XR + 1];
+#define S2_SETUP(tile_, valid_)                                                                            \
+    {                                                                                                      \
+        _Pragma("unroll") for (int r = 0; r <= XR; ++r) {                                                  \
+            const int j = r < XR ? (r * 4 + wave) * 16 + rowin : G::TP + rowin;                            \
+            const unsigned mu = (tile_) * G::TP + (unsigned)j;                                             \
+            const bool ok = (valid_) & (mu < (unsigned)p.Mtotal) & (r < XR || rowin < 1);                  \
+            const unsigned t_ = fdiv(mu, p.dOW);                                                           \
+            const int ow_ = (int)(mu - t_ * (unsigned)p.OW);                                               \
+            const unsigned n_ = fdiv(t_, p.dOH);                                                           \
+            const int oh_ = (int)(t_ - n_ * (unsigned)p.OH);                                               \
+            xoff[r] = (int)(((n_ * (unsigned)p.XH + (unsigned)oh_) * (unsigned)p.XW + (unsigned)ow_) * (unsigned)p.ldx * G::ES) + kcb; \
+            xh0[r] = ok ? oh_ : -100000;                                                                   \
+        }                                                                                                  \
+    }
+    // the whole x row group dh' = g_ of chunk c_ -> x stage at byte offset so_
+#define S2_X(g_, c_, so_)                                                                                  \
+    {                                                                                                      \
+        const int cb_ = (c_) * (BK * G::ES);                                                               \
+        const bool cok_ = (c_) * BK < cmax;                                                                \
+        _Pragma("unroll") for (int r = 0; r < XR; ++r) {                                                   \
+            const bool ok = ((unsigned)(xh0[r] + (g_)) < (unsigned)p.XH) & cok_;                           \
+            const unsigned off = ok ? (unsigned)(xoff[r] + (g_) * dhstep + cb_) : G_OOB;                   \
+            glds16(rsX, lds_x + (so_) + (r * 4 + wave) * 1024, off);                                       \
+        }                                                                                                  \
+        if (wave == 0) {                                                                                   \
+            const bool ok = ((unsigned)(xh0[XR] + (g_)) < (unsigned)p.XH) & cok_;                          \
+            const unsigned off = ok ? (unsigned)(xoff[XR] + (g_) * dhstep + cb_) : G_OOB;                  \
+            glds16(rsX, lds_x + (so_) + XR * 4 * 1024, off);                                               \
+        }                                                                                                  \
+    }
+    // the W tiles of a step (column offsets wc_[0 .. n_)) of chunk c_ -> the step's region at byte offset wo_
+#define S2_W(wc_, n_, c_, wo_)                                                                             \
+    {                                                                                                      \
+        const unsigned cbad_ = (c_) * BK < cmax ? 0u : G_OOB;                                              \
+        _Pragma("unroll") for (int r = 0; r < (n_); ++r) {                                                 \
+            const unsigned col_ = (unsigned)(wc_[r] + (c_) * (BK * G::ES));                                \
+            glds16(rsW, lds_w + (wo_) + (r * 4 + wave) * 1024, (wbase + col_) | ((wbase | col_ | cbad_) & G_OOB)); \
+        }                                                                                                  \
+    }
+
+    const int arow = (wm * 32 + (lane & 31)) * G::ROWB;
+    const int swzA = ((lane & 31) / G::RPB) & (G::CPR - 1);
+    int brow0 = wp * G::NI * 32 + (lane & 31);
+    const int hi = lane >> 5;
+
+    float16v acc[4][G::NACC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < G::NACC; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][i][r] = 0.0f;
+    const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
+
+    unsigned x_tile = cur_tile;
+    bool x_valid = true;
+    S2_SETUP(x_tile, true)
+    // stage byte offsets of the current chunk's two row groups; the third stage is the one to fill next
+    unsigned xg0 = 0, xg1 = XS;
+    S2_X(0, 0, xg0)
+    S2_X(1, 0, xg1)
+    S2_W(wcA, W4, 0, WOA)
+    S2_W(wcB, W2, 0, WOB)
+
+    int c = 0;
+    bool after_epi = false;
+    unsigned mright = 0;
+    while (true) {
+        if (c == 0) {
+            mright = 0;
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni) {
+                const unsigned mu = cur_tile * G::TP + (unsigned)(wp * G::NI * 32 + ni * 32 + (lane & 31));
+                const unsigned t_ = fdiv(mu, p.dOW);
+                const int ow_ = (int)(mu - t_ * (unsigned)p.OW);
+                mright |= (ow_ == p.OW - 1 ? 1u : 0u) << ni;
+            }
+        }
+        const int cn = c + 1 == nC ? 0 : c + 1;
+        const unsigned xfree = 3u * XS - xg0 - xg1;        // the stage neither group of this chunk lives in
+        // one step: NT_ products that read shift (dh', DW_) of row group at xs_, W stage ST_; class of product t = CLS_(t)
+#define S2_STEP(WO_, NT_, DW_, xs_, WAITN_, AHEAD_, C0_, C1_, C2_, C3_)                                    \
+        {                                                                                                  \
+            _Pragma("unroll") for (int r = 0; r <= XR; ++r) asm volatile("" : "+v"(xoff[r]), "+v"(xh0[r])); \
+            asm volatile("" : "+v"(brow0));                                                                \
+            WAITN_                                                                                         \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            const int jr = brow0 + (DW_);                                                                  \
+            const int swzB = (jr >> 2) & (G::CPR - 1);                                                     \
+            const unsigned char* stX = sX + (xs_) + jr * G::ROWB;                                          \
+            const unsigned char* stW = sW + (WO_) + arow;                                                  \
+            half8 fb[2][G::NI], fa[2][NT_];                                                                \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                             \
+                const int sa = ((kk * 2 + hi) ^ swzA) * 16, sb = ((kk * 2 + hi) ^ swzB) * 16;              \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) fb[kk][ni] = *reinterpret_cast<const half8*>(stX + ni * 32 * G::ROWB + sb); \
+                _Pragma("unroll") for (int t = 0; t < (NT_); ++t) fa[kk][t] = *reinterpret_cast<const half8*>(stW + t * TMB + sa); \
+            }                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            AHEAD_                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if ((DW_) && mright) {                                                                         \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni)                                       \
+                    if ((mright >> ni) & 1u) {                                                             \
+                        _Pragma("unroll") for (int e = 0; e < 8; ++e) { fb[0][ni][e] = (_Float16)0.0f; fb[1][ni][e] = (_Float16)0.0f; } \
+                    }                                                                                      \
+            }                                                                                              \
+            constexpr int cls_[4] = {C0_, C1_, C2_, C3_};                                                  \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                               \
+                _Pragma("unroll") for (int t = 0; t < (NT_); ++t)                                          \
+                    _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) mma_step(fa[kk][t], fb[kk][ni], acc[cls_[t]][ni]); \
+        }
+        // step A: rows g0 of this chunk.  Ahead: the next chunk's g0 rows into the free stage (its tile may be the next one),
+        // then the W tiles of step C
+        S2_STEP(WOA, 4, 0, xg0,
+                if (after_epi) wait_vm<W2 + NSTK>(); else wait_vm<W2>();,
+                if (c + 1 == nC) { x_tile += lstride; x_valid = x_valid && x_tile < ntiles; S2_SETUP(x_tile, x_valid) }
+                S2_X(0, cn, xfree) S2_W(wcC, W2, c, WOC),
+                0, 1, 2, 3)
+        S2_STEP(WOB, 2, 1, xg0, wait_vm<XR + W2>();, S2_W(wcD, W1, c, WOD), 1, 3, 0, 0)
+        // step C: rows g1.  Ahead: the next chunk's g1 rows into this chunk's g0 stage (read for the last time in step B)
+        S2_STEP(WOC, 2, 0, xg1, wait_vm<W1>();, S2_X(1, cn, xg0) S2_W(wcA, W4, cn, WOA), 2, 3, 0, 0)
+        S2_STEP(WOD, 1, 1, xg1, wait_vm<XR + W4>();, S2_W(wcB, W2, cn, WOB), 3, 0, 0, 0)
+        after_epi = false;
+        if (c == nC - 1) {
+            asm volatile("s_nop 11" ::: "memory");
+            float ssum[16], ssq[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                g_epilogue<T, TM, EM, TPX>(p, cur_tile, k >> 1, k & 1, wp, lane, cbase, false, rsY, acc[k], ssum, ssq, nullptr, 0);
+            after_epi = true;
+            cur_tile += lstride;
+            if (cur_tile >= ntiles) break;
+        }
+        c = cn;
+        { const unsigned t0_ = xg0; xg0 = xfree; xg1 = t0_; }
+    }
+#undef S2_STEP
+#undef S2_W
+#undef S2_X
+#undef S2_SETUP
+    wait_vm<0>();
+}
+
 // compute units of the CURRENT device (cached per device ordinal: one process may drive several GPUs)
 static int num_cus() {
     static int cache[16] = {0};
@@ -1077,7 +1309,32 @@ static int launch_gconv(const GConvP& p, hipStream_t s) {
     return launch_gconv_em<T, TM, 0>(p, s);
 }
 
+template <int TM, int EM, int TPX>
+static int launch_dgrad_s2(GConvP p, hipStream_t s) {
+    using G = GT<half_t, TM, TPX>;
+    // nine tap tiles; the one-tap step D still issues one piece per wave (4 KiB): one tile of slack behind it for TM = 32
+    const size_t lds = 3 * (size_t)(G::TP + 16) * G::ROWB + (9 + (TM == 32 ? 1 : 0)) * (size_t)TM * G::ROWB;
+    p.ntn = (p.Nout + TM - 1) / TM;
+    const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, 2).slots;
+    p.nslots = (int)slots;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad_s2<half_t, TM, EM, TPX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((k_dgrad_s2<half_t, TM, EM, TPX>), dim3((unsigned)(slots * p.ntn)), dim3(256), lds, s, p);
+    AY_CHECK_LAUNCH("k_dgrad_s2");
+    return AYOLO_OK;
+}
+
 static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
+    if (p.s2d && dtype == AYOLO_F16) {       // dgrad of a 3x3 / stride-2 conv, <= 64 input channels: all four classes at once
+        if (p.Nout <= 32) return p.accumulate ? launch_dgrad_s2<32, 1, 256>(p, s) : launch_dgrad_s2<32, 0, 256>(p, s);
+        return p.accumulate ? launch_dgrad_s2<64, 1, 128>(p, s) : launch_dgrad_s2<64, 0, 128>(p, s);
+    }
     // Output-channel tile: the widest that is not mostly padding.  Measured on the YOLOv5x widths (80 / 160 / 320 / 640 / 1280
     // channels, profiles/r02_conv_tm_sweep_yolov5x.txt): 128-wide tiles beat 64- and 32-wide ones by 1.3-2.5x even where
     // 37 % of the tile is padding (80 or 160 output channels) -- a narrow tile re-reads the pixel tile per channel tile and
@@ -1257,6 +1514,16 @@ extern "C" int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const 
         }
     if (merge) {
         m.ncls = ncls_all; m.ntaps = mt; m.K = mt * m.C;
+        // 3x3 / stride 2 / pad 1 with <= 64 input channels: the nine (class, tap) products read four shifts of the dy tile
+        // -> k_dgrad_s2 keeps all four classes' accumulators and loads every dy row group once
+        static const int s2d_on = getenv("AYOLO_DGRAD_S2") ? atoi(getenv("AYOLO_DGRAD_S2")) : 1;
+        const int cpad = (m.C + BK - 1) / BK * BK;
+        if (s2d_on && d->dtype == AYOLO_F16 && d->kh == 3 && d->kw == 3 && d->sh == 2 && d->sw == 2 && d->ph == 1 && d->pw == 1 &&
+            d->Cin <= 64 && m.C >= BK && (cpad - m.C) * 4 <= cpad) {
+            static const signed char order[9] = {4, 5, 7, 8, 3, 6, 1, 2, 0};
+            for (int t = 0; t < 9; ++t) m.s2wt[t] = order[t];
+            m.s2d = 1;
+        }
         return dispatch_gconv(d->dtype, m, (hipStream_t)s);
     }
     return AYOLO_OK;

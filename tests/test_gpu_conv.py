@@ -248,6 +248,36 @@ def test_conv_epilogue_statistics_fp16(shape):
     assert float((y.float() - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 64, 40, 40), (1, 64, 32, 8, 6), (2, 32, 80, 10, 12), (1, 48, 64, 34, 2), (3, 16, 32, 6, 6),
+                                   (2, 64, 128, 64, 48), (1, 8, 96, 18, 66), (4, 32, 64, 2, 2)])
+def test_dgrad_stride2_all_classes(shape):
+    """k_dgrad_s2 (data gradient of 3x3 / stride 2 / pad 1 convs with <= 64 input channels: the four residue classes share
+    the dy rows and their accumulators live in one workgroup) against torch's conv_transpose-style reference, fp16 with
+    pre-rounded operands; also into a pre-filled buffer (accumulate)."""
+    from ayolov2_amd import functional as F_, ops
+    B, Cin, Cout, H, W = shape
+    dt = torch.float16
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g).half().float().requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half().float()
+    y = F.conv2d(x, w, None, 2, 1)
+    gy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(gy)
+    geo = F_._Geometry((B, Cin, H, W), w.shape, (2, 2), (1, 1), dt)
+    _, wt = F_._WeightCache().get(w.cuda().contiguous(memory_format=torch.channels_last), dt, Cout, geo.cin_pad)
+    dy = gy.cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    dx = ops.new_act(B, geo.cin_pad, H, W, dt, dy.device)
+    ops.conv_dgrad(geo.desc(dt, geo.cin_pad, Cout), dy, wt, dx)
+    ref = x.grad
+    got = dx[:, :Cin].float().cpu()
+    assert float((got - ref).abs().max()) <= 3e-3 * float(ref.abs().max()), float((got - ref).abs().max())
+    base = torch.randn(dx.shape, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    dx2 = base.clone()
+    ops.conv_dgrad(geo.desc(dt, geo.cin_pad, Cout), dy, wt, dx2, accumulate=True)
+    exp = base[:, :Cin].float().cpu() + ref
+    assert float((dx2[:, :Cin].float().cpu() - exp).abs().max()) <= 4e-3 * float(exp.abs().max())
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
 def test_conv_eval_and_fuse(dt):
     from ayolov2_amd.modules import Conv
