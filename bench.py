@@ -133,13 +133,13 @@ def in_situ_roofline(model, one_step, ms_per_step, batch):
         tf = sum(fam[n][2] for n in names if n in fam) / 1e12
         return ms, gb, tf
     ms, gb, tf = view(("conv_fwd", "conv_dgrad"))
-    traffic, src = pmc_traffic(("k_gconv",))
+    traffic, src = pmc_traffic(("k_gconv", "k_dgrad_s2"))
     fams = {n: {"launches": v[3], "ms_per_step": round(v[0], 3), "algorithmic_gb": round(v[1] / 1e9, 3),
                 "gb_per_s": round(v[1] / 1e6 / v[0], 1) if v[0] > 0 else None,
                 **({"tflops": round(v[2] / 1e9 / v[0], 1)} if v[2] else {})}
             for n, v in sorted(fam.items(), key=lambda kv: -kv[1][0]) if v[0] > 0.0005}
     step_gb = sum(v[1] for v in fam.values()) / 1e9
-    return {"bound": "hbm", "kernel": "k_gconv<f16>: every forward + dgrad conv launch of one train step, timed in situ",
+    return {"bound": "hbm", "kernel": "k_gconv / k_gconv3 / k_dgrad_s2 <f16>: every forward + dgrad conv launch of one train step, timed in situ",
             "achieved": round(gb / ms * 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / ms * 1e3 / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_unit": "GB per train step over every k_gconv launch, PMC", "traffic_source": src,
             "algorithmic_gb": round(gb, 3), "launch_ms_sum": round(ms, 3),
