@@ -835,6 +835,12 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
     if constexpr (EM == 0) {
         for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
     }
+    // ... except for the narrow channel tiles (32 registers, plenty of room, and only 9-18 sub-steps per tile to amortise a
+    // per-tile reduction over): those keep them in registers across tiles like k_gconv
+    constexpr bool SREG = (EM == 0) && (TM <= 64);
+    float rsum[SREG ? 16 * G::MI : 1], rsq[SREG ? 16 * G::MI : 1];
+#pragma unroll
+    for (int r = 0; r < (SREG ? 16 * G::MI : 1); ++r) { rsum[r] = 0.0f; rsq[r] = 0.0f; }
     const int cbase = n0 + wm * 32 * G::MI + 4 * (lane >> 5);
 
     // loader cursor of the x rows (two row groups ahead of the compute cursor)
@@ -933,8 +939,9 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
             float ssum[16 * G::MI], ssq[16 * G::MI];
 #pragma unroll
             for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
-            g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, ssum, ssq, sStat, cbase - n0);
-            if (want_stats) {
+            if constexpr (SREG) g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, rsum, rsq, sStat, cbase - n0);
+            else g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, ssum, ssq, sStat, cbase - n0);
+            if (want_stats && !SREG) {
                 int lq = lane;                              // opaque: keeps the LDS addresses below from being hoisted out of the
                 asm volatile("" : "+v"(lq));                // tile loop (and spilled: every reload would drain the DMA queue)
                 float* sl = sStat + wm * 32 * G::MI + 4 * (lq >> 5);
@@ -959,6 +966,10 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
 #undef G3_XPART
 #undef G3_SETUP
     wait_vm<0>();                             // trailing DMAs must land before this LDS is released
+    if constexpr (SREG) {
+        if (want_stats) g_stats_flush<T, TM, G::MI>(p, sStat, tid, lane, wm, n0, slot, rsum, rsq);
+        return;
+    }
     if (want_stats) {
         __syncthreads();
         float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
