@@ -43,14 +43,33 @@ class ModelEMA:
             p.requires_grad_(False)
         self._jobs = None
 
+    @staticmethod
+    def _slots(module: nn.Module):
+        """{state-dict key: (owner module, '_parameters' | '_buffers', leaf name)} -- where the tensor of a key lives NOW.
+        Looking the tensor up through its owner every step follows `.data` swaps and buffer re-assignment (`model.half()`,
+        `.to(...)`) without building two ~300-entry state dicts per step (1.9 ms of host time)."""
+        out = {}
+        for name, mod in module.named_modules(remove_duplicate=False):
+            pre = name + "." if name else ""
+            for leaf, t in mod._parameters.items():
+                if t is not None:
+                    out[pre + leaf] = (mod, "_parameters", leaf)
+            for leaf, t in mod._buffers.items():
+                if t is not None and leaf not in mod._non_persistent_buffers_set:
+                    out[pre + leaf] = (mod, "_buffers", leaf)
+        return out
+
     def _job_table(self, model: nn.Module):
         import numpy as np
-        msd = model.state_dict()
-        pairs = []
-        for k, v in self.ema.state_dict().items():
-            if v.dtype.is_floating_point:
-                src = msd[k if k in msd else f"module.{k}"]
-                pairs.append((v, src))
+        refs = getattr(self, "_refs", None)
+        if refs is None or refs[0] is not model or refs[1] != sum(1 for _ in model.modules()):
+            es, ms = self._slots(self.ema), self._slots(model)
+            slots = []
+            for k, v in self.ema.state_dict().items():
+                if v.dtype.is_floating_point:
+                    slots.append((es[k], ms[k] if k in ms else ms[f"module.{k}"]))
+            self._refs = refs = (model, sum(1 for _ in model.modules()), slots)
+        pairs = [(getattr(eo, ek)[el], getattr(mo, mk)[ml]) for (eo, ek, el), (mo, mk, ml) in refs[2]]
         key = tuple((v.data_ptr(), s.data_ptr()) for v, s in pairs)
         if self._jobs is None or self._jobs[0] != key:
             def dense(t):                                   # one dense block of memory (any of the two layouts in use)

@@ -251,3 +251,37 @@ def test_plan_gradient_buckets_cover_the_arena():
     # (at this tiny size every BN backward qualifies for the one-pass fused kernel, which has no cut point; with sync_bn the
     # plan keeps the two-pass form for all 57)
     assert len(pl.fwd_sync_idx) == 49 and len(pl.bwd_sync) + pl.bn_fused == 57
+
+
+def test_model_ema_follows_reassigned_tensors_cpu():
+    """ModelEMA finds the tensors of a state-dict key through their owner module every step (no state_dict() per step):
+    in-place updates, `.data` swaps and re-assigned buffers (model.double().float()) must all be followed; arithmetic =
+    the reference's two in-place ops (scripts/utils/torch_utils.py:405-416)."""
+    import copy
+    import math
+    import os
+    from ayolov2_amd import YOLOModel
+    from ayolov2_amd.trainer import ModelEMA
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.manual_seed(5)
+    m = YOLOModel(os.path.join(root, "ayolov2_amd", "configs", "yolov5n.yaml"), verbose=False)
+    ema = ModelEMA(m)
+    ref = copy.deepcopy(m).eval()
+    with torch.no_grad():
+        for step in range(3):
+            for p in m.parameters():
+                p.add_(0.01 * torch.randn_like(p))
+            for b in m.buffers():
+                if b.dtype.is_floating_point:
+                    b.add_(0.01)
+            if step == 1:
+                m = m.double().float()
+            ema.update(m)
+            d = 0.9999 * (1 - math.exp(-(step + 1) / 2000))
+            msd = m.state_dict()
+            for k, v in ref.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v *= d
+                    v += (1 - d) * msd[k].detach()
+    for (k, a), b in zip(ema.ema.state_dict().items(), ref.state_dict().values()):
+        assert torch.equal(a, b), k
