@@ -21,6 +21,12 @@ class ConvDesc(ctypes.Structure):
                                      "ph", "pw", "Ho", "Wo")]
 
 
+class BnSeg(ctypes.Structure):
+    """ayolo_bn_seg (include/ayolo.h): one Conv-BN-act block whose BatchNorm-backward sums a dgrad epilogue accumulates."""
+    _fields_ = [("z", c_void_p), ("mean_invstd", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("sums", c_void_p),
+                ("ldz", c_int), ("c0", c_int), ("C", c_int), ("reserved", c_int)]
+
+
 class LossLevel(ctypes.Structure):
     _fields_ = ([("pred", c_void_p)] + [(n, c_int64) for n in ("sb", "sa", "sy", "sx")]
                 + [(n, c_int) for n in ("B", "na", "ny", "nx", "no", "n")]
@@ -39,6 +45,7 @@ _P = c_void_p
 _SIGNATURES = {
     "ayolo_conv_fwd": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, _P],
     "ayolo_conv_dgrad": [POINTER(ConvDesc), _P, _P, _P, c_int, _P],
+    "ayolo_conv_dgrad_bn": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P],
     "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P],
     "ayolo_cast_weight": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "ayolo_ema_update": [_P, c_int, c_float, _P],
@@ -132,3 +139,16 @@ def check(rc: int, what: str) -> None:
 
 def call(name: str, *args) -> None:
     check(getattr(lib(), name)(*args), name)
+
+
+def bump_versions(tensors) -> None:
+    """Kernels write parameters / buffers through raw pointers, which autograd's version counters do not see.  Everything
+    that caches derived data keyed on ``tensor._version`` (the inference executor's folded BatchNorm + fp16 weight copies,
+    functional._WeightCache) relies on the writers calling this after such a write (optim.SGD.step, ModelEMA.update, the
+    BatchNorm running statistics of a training forward)."""
+    import torch
+    ts = [t for t in tensors if t is not None]
+    if ts:
+        with torch.no_grad():
+            torch._C._increment_version(ts)
+

@@ -58,6 +58,15 @@ struct GConvP {
     // [A: shift (0,0) classes 0,1,2,3 | B: shift (0,1) classes 1,3 | C: shift (1,0) classes 2,3 | D: shift (1,1) class 3]
     int s2d;
     signed char s2wt[9];
+    // k_gconv_s2f (forward 3x3 / stride 2 / pad 1): weight tap of (dh, dw) = (g - 1, j - 1) at [g * 3 + j]
+    int s2f;
+    signed char f2wt[9];
+    // BN-backward statistics in the epilogue (BNR kernels, fp16 dgrad): the output y is the gradient da of up to two
+    // Conv-BN-act blocks side by side in channels (a concat buffer); for each, z / saved statistics / affine parameters and
+    // the [reps][2][C] accumulators of sum(du), sum(du * xhat) that ayolo_bn_act_bwd_reduce would fill
+    int bnr, bnr_act, bnr_reps;
+    ayolo_bn_seg bseg[2];
+    unsigned z_bytes[2];
 };
 
 template <typename T> struct Tr;
@@ -97,6 +106,17 @@ __device__ __forceinline__ float cvt_round(float v, float*) { return v; }
 // fragment reads bank-conflict free without padding.
 // BN statistics are accumulated in registers across all tiles of the workgroup and reduced once at the end.
 // ---------------------------------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row, left in every lane of the row (4 VALU ops, no LDS traffic)
+__device__ __forceinline__ float row16_sum(float v) {
+#define AY_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    AY_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+    AY_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+    AY_DPP_ADD(0x141);   // row_half_mirror
+    AY_DPP_ADD(0x140);   // row_mirror
+#undef AY_DPP_ADD
+    return v;
+}
+
 #define GNS 3                      // LDS stages
 #define G_OOB 0x80000000u          // buffer offset beyond any descriptor (tensors are < 2 GiB, checked on the host)
 
@@ -133,7 +153,7 @@ struct GT {
     static constexpr int WM = TM / (32 * MI), WP = 4 / WM, NI = TP / (32 * WP);
     static constexpr int NACC = MI * NI;            // accumulator blocks per wave
     static constexpr int NST = NACC * 4;            // store instructions per thread per epilogue
-    static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 2 * TM * sizeof(float);
+    static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 6 * TM * sizeof(float);   // stats [2][TM] + BNR constants [4][TM]
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -313,28 +333,110 @@ __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int 
 // tile finished: acc[ni][r] holds channel = cbase + 8*(r>>2) + (r&3), pixel = m0 + wp*NI*32 + ni*32 + (lane&31).
 // Exactly NST buffer stores per thread (invalid pixels / channel groups use the out-of-range offset and are dropped
 // by the hardware), so the step loop's vmcnt arithmetic stays exact.
-template <typename T, int TM, int EM, int TPX>
+// BNR kernels (fp16 dgrad, see ayolo_conv_dgrad_bn): what the epilogue needs to form du = da * act'(bn(z)) and xhat for the
+// values it stores.  The segment of a 32-channel block is uniform per (wave, mi) -- the host checks that the segment
+// boundary is a multiple of 32 -- so each wave picks the z descriptor of its MI blocks ONCE, into SGPRs (a per-store
+// select between two descriptors ends in a v_cndmask + readfirstlane waterfall loop around every load).
+template <int MI>
+struct BnrCtx {
+    __amdgpu_buffer_rsrc_t rsZ[MI];
+    unsigned ldzb[MI];         // bytes per pixel of the block's z buffer
+    int c0[MI];                // first output channel of the block's segment
+    const float* sBn;          // LDS [4][TM]: invstd | -mean * invstd | invstd * gamma | beta - mean * invstd * gamma
+    int act;
+};
+
+// per-channel constants of this workgroup's channel tile [n0, n0 + TM) -> LDS (zeros beyond a segment / Nout, which keeps
+// du = 0 there: the accumulators of padding channels are exact zeros)
+template <int TM>
+__device__ __forceinline__ void g_bnr_setup(const GConvP& p, float* sBn, int n0, int tid) {
+    for (int i = tid; i < TM; i += 256) {
+        const int c = n0 + i;
+        const int sg = (p.bnr > 1 && c >= p.bseg[1].c0) ? 1 : 0;
+        const int cl = c - p.bseg[sg].c0;
+        float is = 0.0f, nmi = 0.0f, A = 0.0f, Bc = 0.0f;
+        if (c < p.Nout && cl >= 0 && cl < p.bseg[sg].C) {
+            const float mu = p.bseg[sg].mean_invstd[cl];
+            is = p.bseg[sg].mean_invstd[p.bseg[sg].C + cl];
+            const float ga = p.bseg[sg].gamma ? p.bseg[sg].gamma[cl] : 1.0f, be = p.bseg[sg].beta ? p.bseg[sg].beta[cl] : 0.0f;
+            A = is * ga; Bc = be - mu * A; nmi = -mu * is;
+        }
+        sBn[i] = is; sBn[TM + i] = nmi; sBn[2 * TM + i] = A; sBn[3 * TM + i] = Bc;
+    }
+}
+
+// cblk0: first output channel of this wave's first 32-channel block (wave-uniform)
+template <int MI>
+__device__ __forceinline__ BnrCtx<MI> g_bnr_ctx(const GConvP& p, const float* sBn, int cblk0) {
+    BnrCtx<MI> b;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int cblk = __builtin_amdgcn_readfirstlane(cblk0 + mi * 32);
+        const int sg = (p.bnr > 1 && cblk >= p.bseg[1].c0) ? 1 : 0;
+        b.rsZ[mi] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg ? p.bseg[1].z : p.bseg[0].z), 0, sg ? p.z_bytes[1] : p.z_bytes[0], 0x00020000);
+        b.ldzb[mi] = (unsigned)(sg ? p.bseg[1].ldz : p.bseg[0].ldz) * 2u;
+        b.c0[mi] = sg ? p.bseg[1].c0 : p.bseg[0].c0;
+    }
+    b.sBn = sBn;
+    b.act = p.bnr_act;
+    return b;
+}
+
+template <typename T, int TM, int EM, int TPX, bool BNR = false>
 __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int oah, int oaw, int wp, int lane, int cbase,
                                            bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM, TPX>::NACC],
-                                           float (&ssum)[16 * GT<T, TM, TPX>::MI], float (&ssq)[16 * GT<T, TM, TPX>::MI], const float* sAff, int cl0) {
+                                           float (&ssum)[16 * GT<T, TM, TPX>::MI], float (&ssq)[16 * GT<T, TM, TPX>::MI], const float* sAff, int cl0,
+                                           const BnrCtx<GT<T, TM, TPX>::MI> bc = BnrCtx<GT<T, TM, TPX>::MI>{}) {
     using G = GT<T, TM, TPX>;
     constexpr int YES = (EM == 3) ? 4 : G::ES;       // bytes per output element
+    static_assert(!BNR || (sizeof(T) == 2 && (EM == 0 || EM == 1)), "BN-backward statistics: fp16 dgrad epilogues only");
     const unsigned m0 = tile * G::TP;
+    // pixel of this lane in pixel block ni: valid?, index in the y tensor
+    auto pixel_of = [&](int ni, bool& pv_, unsigned& ypix_) {
+        const unsigned m = m0 + wp * G::NI * 32 + ni * 32 + (lane & 31);
+        pv_ = m < (unsigned)p.Mtotal;
+        const unsigned mu = pv_ ? m : 0u;
+        if (p.y_linear) ypix_ = mu;
+        else {
+            const unsigned t = fdiv(mu, p.dOW);
+            const int ow = (int)(mu - t * (unsigned)p.OW);
+            const unsigned nn = fdiv(t, p.dOH);
+            const int oh = (int)(t - nn * (unsigned)p.OH);
+            ypix_ = (nn * (unsigned)p.YH + (unsigned)(oh * p.osh + oah)) * (unsigned)p.YW + (unsigned)(ow * p.osw + oaw);
+        }
+    };
+    // BNR: the z vectors of a pixel block are requested ONE BLOCK AHEAD of their use (2 * MI loads of 16 bytes per lane):
+    // fetched where they are consumed, every (pixel block, channel group) would wait out a full HBM round trip
+    half8 znext[BNR ? G::MI : 1][2];
+    bool pv_n = false;
+    unsigned ypix_n = 0;
+    auto z_request = [&](bool pv_, unsigned ypix_) {
+        if constexpr (BNR) {
+#pragma unroll
+            for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = cbase + mi * 32 - 4 * (lane >> 5) + 8 * (2 * j + (lane >> 5));
+                    const unsigned zoff = (pv_ && c < p.Nout) ? ypix_ * bc.ldzb[mi] + (unsigned)(c - bc.c0[mi]) * 2u : G_OOB;
+                    znext[mi][j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(bc.rsZ[mi], zoff, 0, 0));
+                }
+        }
+    };
+    pixel_of(0, pv_n, ypix_n);
+    z_request(pv_n, ypix_n);
 #pragma unroll
     for (int ni = 0; ni < G::NI; ++ni) {
-        const unsigned m = m0 + wp * G::NI * 32 + ni * 32 + (lane & 31);
-        const bool pv = m < (unsigned)p.Mtotal;
-        unsigned yo = 0;
-        {
-            const unsigned mu = pv ? m : 0u;
-            if (p.y_linear) yo = mu * (unsigned)p.ldy * YES;
-            else {
-                const unsigned t = fdiv(mu, p.dOW);
-                const int ow = (int)(mu - t * (unsigned)p.OW);
-                const unsigned nn = fdiv(t, p.dOH);
-                const int oh = (int)(t - nn * (unsigned)p.OH);
-                yo = ((nn * (unsigned)p.YH + (unsigned)(oh * p.osh + oah)) * (unsigned)p.YW + (unsigned)(ow * p.osw + oaw)) * (unsigned)p.ldy * YES;
-            }
+        const bool pv = pv_n;
+        const unsigned ypix = ypix_n;
+        const unsigned yo = ypix * (unsigned)p.ldy * YES;
+        half8 zcur[BNR ? G::MI : 1][2];
+        if constexpr (BNR) {
+#pragma unroll
+            for (int mi = 0; mi < G::MI; ++mi) { zcur[mi][0] = znext[mi][0]; zcur[mi][1] = znext[mi][1]; }
+        }
+        if (ni + 1 < G::NI) {
+            pixel_of(ni + 1, pv_n, ypix_n);
+            z_request(pv_n, ypix_n);
         }
 #pragma unroll
         for (int mi = 0; mi < G::MI; ++mi) {
@@ -397,6 +499,39 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
 #pragma unroll
                     for (int e = 0; e < 8; ++e) h[e] = (half_t)w8[e];
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, h), rsY, off, 0, 0);
+                    if constexpr (BNR) {
+                        // du = da * act'(z*A + Bc), xhat = z*invstd + nmi for the 8 channels c .. c+7 of this lane's pixel, from
+                        // the ROUNDED gradient just stored (what a separate pass would read back); sums stay in registers
+                        const half8 zz = zcur[mi][j];
+                        // opaque index: the constants are re-read from LDS for every pixel block -- left visible, the reads of all
+                        // (mi, j) pairs are merged across the unrolled ni loop and 64-128 registers of constants stay live
+                        int kqo = cl - 4 * hsel + 8 * (2 * j + hsel);
+                        asm volatile("" : "+v"(kqo));
+                        const float* kq = bc.sBn + kqo;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float4v kis = *reinterpret_cast<const float4v*>(kq + 4 * q);
+                            const float4v knm = *reinterpret_cast<const float4v*>(kq + TM + 4 * q);
+                            const float4v kA = *reinterpret_cast<const float4v*>(kq + 2 * TM + 4 * q);
+                            const float4v kB = *reinterpret_cast<const float4v*>(kq + 3 * TM + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float zf = (float)zz[4 * q + e], da = (float)h[4 * q + e];
+                                const float xh = __builtin_fmaf(zf, kis[e], knm[e]);
+                                const float u = __builtin_fmaf(zf, kA[e], kB[e]);
+                                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+                                const float gg = sg * __builtin_fmaf(u, 1.0f - sg, 1.0f);
+                                const float du = bc.act ? da * gg : da;
+                                ssum[mi * 16 + j * 8 + 4 * q + e] += du;
+                                ssq[mi * 16 + j * 8 + 4 * q + e] = __builtin_fmaf(du, xh, ssq[mi * 16 + j * 8 + 4 * q + e]);
+                            }
+                        }
+                        // pin the arithmetic HERE: its only consumers are the reductions after the last tile, and left alone the
+                        // compiler sinks all of it there, keeping every z vector, every stored value and every constant of the
+                        // epilogue alive in scratch (1.7 KB per lane) until then
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(ssum[mi * 16 + j * 8 + e]), "+v"(ssq[mi * 16 + j * 8 + e]));
+                    }
                 }
                 continue;
             }
@@ -461,7 +596,42 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
     }
 }
 
-template <typename T, int TM, int MI>
+// channel (relative to the wave's first channel wm * 32 * MI) of statistics register r.  Forward statistics are taken
+// before the epilogue's lane swap (4-channel runs of the MFMA layout), BNR sums after it (8 consecutive channels)
+template <bool POST>
+__device__ __forceinline__ int g_stat_chan(int r, int hsel) {
+    if constexpr (POST) return (r >> 4) * 32 + 8 * (2 * ((r >> 3) & 1) + hsel) + (r & 7);
+    else return (r >> 4) * 32 + 4 * hsel + 8 * ((r & 15) >> 2) + (r & 3);
+}
+
+// workgroup totals in sStat [2][TM] -> global accumulators: forward statistics [reps][2][Nout], or (BNR) the
+// [reps][2][C] accumulators of the segment each channel belongs to
+template <int TM, bool BNR>
+__device__ __forceinline__ void g_stats_to_global(const GConvP& p, const float* sStat, int tid, int n0, unsigned slot) {
+    if constexpr (BNR) {
+        for (int i = tid; i < TM; i += 256) {
+            const int c = n0 + i;
+            const int sg = (p.bnr > 1 && c >= p.bseg[1].c0) ? 1 : 0;
+            const int cl = c - p.bseg[sg].c0, C = p.bseg[sg].C;
+            if (c < p.Nout && cl >= 0 && cl < C) {
+                float* st = p.bseg[sg].sums + (size_t)(slot % (unsigned)p.bnr_reps) * 2 * C;
+                atomicAdd(&st[cl], sStat[i]);
+                atomicAdd(&st[C + cl], sStat[TM + i]);
+            }
+        }
+    } else {
+        // replicated accumulators: workgroups spread over stat_reps copies so L2 atomics do not serialise
+        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
+        for (int i = tid; i < TM; i += 256) {
+            if (n0 + i < p.Nout) {
+                atomicAdd(&st[n0 + i], sStat[i]);
+                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
+            }
+        }
+    }
+}
+
+template <typename T, int TM, int MI, bool BNR = false>
 __device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int tid, int lane, int wm, int n0, unsigned slot,
                                               const float (&ssum)[16 * MI], const float (&ssq)[16 * MI]) {
     for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
@@ -475,31 +645,24 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int
             b += __shfl_xor(b, off);
         }
         if ((lane & 31) == 0) {
-            int cl = wm * 32 * MI + (r >> 4) * 32 + 4 * (lane >> 5) + 8 * ((r & 15) >> 2) + (r & 3);
+            const int cl = wm * 32 * MI + g_stat_chan<BNR>(r, lane >> 5);
             atomicAdd(&sStat[cl], a);
             atomicAdd(&sStat[TM + cl], b);
         }
     }
     __syncthreads();
-    // replicated accumulators: workgroups spread over stat_reps copies so L2 atomics do not serialise
-    float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
-    for (int i = tid; i < TM; i += 256) {
-        if (n0 + i < p.Nout) {
-            atomicAdd(&st[n0 + i], sStat[i]);
-            atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
-        }
-    }
+    g_stats_to_global<TM, BNR>(p, sStat, tid, n0, slot);
 }
 
-template <typename T, int TM, int EM, int TPX>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && EM == 0)) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
+template <typename T, int TM, int EM, int TPX, bool BNR = false>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
     using G = GT<T, TM, TPX>;
     // stores per thread and epilogue (the step loop's vmcnt arithmetic): fp16 tiles leave in 16-byte stores
     constexpr int NSTK = (sizeof(T) == 2 && EM != 3) ? G::NACC * 2 : G::NST;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     unsigned char* sTiles = smem_raw;                                             // [GNS][x tile | w tile]
     int4* sTap = reinterpret_cast<int4*>(smem_raw + GNS * G::STAGE);              // [MAX_TAPS + 1]
-    float* sStat = reinterpret_cast<float*>(sTap + MAX_TAPS + 1);                 // [2][TM]
+    float* sStat = reinterpret_cast<float*>(sTap + MAX_TAPS + 1);                 // [2][TM] (+ [4][TM] BNR constants)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -542,6 +705,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
             sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
         }
     }
+    constexpr bool TILE_RED = BNR && TM == 128;
+    if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 2 * TM, n0, tid);
+    if constexpr (TILE_RED) {
+        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+    }
+    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 2 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
     const unsigned lds_tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sTiles);
@@ -652,8 +821,25 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
         after_epi = false;
         if (cur_kt == cur_nk - 1) {
             if constexpr (sizeof(T) == 2) asm volatile("s_nop 11" ::: "memory");   // fp16: accumulators are only read here
-            g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq,
-                                       sStat, cbase - n0);
+            g_epilogue<T, TM, EM, TPX, BNR>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq,
+                                            sStat, cbase - n0, bctx);
+            if constexpr (TILE_RED) {
+                // 128-channel tiles: the BNR sums are reduced per tile (DPP row sums + LDS atomics, as k_gconv3) instead of
+                // living in 32-64 registers across the step loop next to the accumulators and the fragments
+                int lq = lane;
+                asm volatile("" : "+v"(lq));
+                float* sl = sStat + wm * 32 * G::MI;
+#pragma unroll
+                for (int r = 0; r < 16 * G::MI; ++r) {
+                    const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
+                    ssum[r] = 0.0f; ssq[r] = 0.0f;
+                    if ((lq & 15) == 0) {
+                        const int cl = g_stat_chan<true>(r, lq >> 5);
+                        atomicAdd(&sl[cl], a);
+                        atomicAdd(&sl[TM + cl], b);
+                    }
+                }
+            }
             after_epi = true;
         }
         if (++cur_kt == cur_nk) {
@@ -671,7 +857,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
 #undef G_NK
 #undef G_ADVANCE
     wait_vm<0>();                             // the trailing zero-fill DMAs must land before this LDS is released
-    if (want_stats) g_stats_flush<T, TM, G::MI>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
+    if constexpr (TILE_RED) {
+        __syncthreads();
+        g_stats_to_global<TM, true>(p, sStat, tid, n0, slot);
+    } else if constexpr (BNR) g_stats_flush<T, TM, G::MI, true>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
+    else if (want_stats) g_stats_flush<T, TM, G::MI>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
 }
 
 
@@ -690,17 +880,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
 // groups (6 sub-steps) ahead in 3 stages, each group issued in 3 parts, one per sub-step (the last part is the 2 halo rows,
 // wave 0 only; the counted waits simply do not rely on it).
 // ---------------------------------------------------------------------------------------------------
-// sum over the 16 lanes of a DPP row, left in every lane of the row (4 VALU ops, no LDS traffic)
-__device__ __forceinline__ float row16_sum(float v) {
-#define AY_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
-    AY_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
-    AY_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
-    AY_DPP_ADD(0x141);   // row_half_mirror
-    AY_DPP_ADD(0x140);   // row_mirror
-#undef AY_DPP_ADD
-    return v;
-}
-
 template <typename T, int TM, int TPX>
 struct GT3 {
     using G = GT<T, TM, TPX>;
@@ -708,11 +887,11 @@ struct GT3 {
     static constexpr int XS = XROWS * G::ROWB;               // bytes per x stage
     static constexpr int WS = G::WSTAGE;
     static constexpr int XP = G::XR / 2;                     // DMA instructions per thread in x parts 0 and 1
-    static constexpr size_t LDS = 3 * (size_t)XS + 3 * (size_t)WS + 2 * TM * sizeof(float);
+    static constexpr size_t LDS = 3 * (size_t)XS + 3 * (size_t)WS + 6 * TM * sizeof(float);
     static_assert(G::XR % 2 == 0 && G::ES == 2, "fp16, 128- or 256-pixel tiles");
 };
 
-template <typename T, int TM, int EM, int TPX>
+template <typename T, int TM, int EM, int TPX, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
     using G = GT<T, TM, TPX>;
     using G3 = GT3<T, TM, TPX>;
@@ -750,6 +929,8 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
             sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
         }
     }
+    if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 2 * TM, n0, tid);
+    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 2 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
     const unsigned lds_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sX);
@@ -831,13 +1012,14 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     // BN statistics: reduced per tile (DPP row sums + LDS atomics into sStat) instead of living in 64 registers across
     // the nine unrolled sub-steps, which is what made the forward variant spill
-    const bool want_stats = (EM == 0) && (p.stats != nullptr);
-    if constexpr (EM == 0) {
+    const bool want_stats = !BNR && (EM == 0) && (p.stats != nullptr);
+    const bool any_stats = BNR || want_stats;
+    if constexpr (EM == 0 || BNR) {
         for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
     }
     // ... except for the narrow channel tiles (32 registers, plenty of room, and only 9-18 sub-steps per tile to amortise a
     // per-tile reduction over): those keep them in registers across tiles like k_gconv
-    constexpr bool SREG = (EM == 0) && (TM <= 64);
+    constexpr bool SREG = (EM == 0 || BNR) && (TM <= 64);
     float rsum[SREG ? 16 * G::MI : 1], rsq[SREG ? 16 * G::MI : 1];
 #pragma unroll
     for (int r = 0; r < (SREG ? 16 * G::MI : 1); ++r) { rsum[r] = 0.0f; rsq[r] = 0.0f; }
@@ -939,17 +1121,17 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
             float ssum[16 * G::MI], ssq[16 * G::MI];
 #pragma unroll
             for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
-            if constexpr (SREG) g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, rsum, rsq, sStat, cbase - n0);
-            else g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, ssum, ssq, sStat, cbase - n0);
-            if (want_stats && !SREG) {
+            if constexpr (SREG) g_epilogue<T, TM, EM, TPX, BNR>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, rsum, rsq, sStat, cbase - n0, bctx);
+            else g_epilogue<T, TM, EM, TPX, BNR>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, ssum, ssq, sStat, cbase - n0, bctx);
+            if (any_stats && !SREG) {
                 int lq = lane;                              // opaque: keeps the LDS addresses below from being hoisted out of the
                 asm volatile("" : "+v"(lq));                // tile loop (and spilled: every reload would drain the DMA queue)
-                float* sl = sStat + wm * 32 * G::MI + 4 * (lq >> 5);
+                float* sl = sStat + wm * 32 * G::MI;
 #pragma unroll
                 for (int r = 0; r < 16 * G::MI; ++r) {
                     const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
                     if ((lq & 15) == 0) {
-                        const int cl = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + (r & 3);
+                        const int cl = g_stat_chan<BNR>(r, lq >> 5);
                         atomicAdd(&sl[cl], a);
                         atomicAdd(&sl[TM + cl], b);
                     }
@@ -967,18 +1149,12 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
 #undef G3_SETUP
     wait_vm<0>();                             // trailing DMAs must land before this LDS is released
     if constexpr (SREG) {
-        if (want_stats) g_stats_flush<T, TM, G::MI>(p, sStat, tid, lane, wm, n0, slot, rsum, rsq);
+        if (any_stats) g_stats_flush<T, TM, G::MI, BNR>(p, sStat, tid, lane, wm, n0, slot, rsum, rsq);
         return;
     }
-    if (want_stats) {
+    if (any_stats) {
         __syncthreads();
-        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
-        for (int i = tid; i < TM; i += 256) {
-            if (n0 + i < p.Nout) {
-                atomicAdd(&st[n0 + i], sStat[i]);
-                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
-            }
-        }
+        g_stats_to_global<TM, BNR>(p, sStat, tid, n0, slot);
     }
 }
 
@@ -1000,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
 // that is neither being read nor in flight.  Right border (dw' = 1 at ow = OW - 1): the lane zeroes its B fragment; bottom
 // border (dh' = 1 at oh = OH - 1): the loader's out-of-range offset.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int TM, int EM, int TPX>
+template <typename T, int TM, int EM, int TPX, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
     using G = GT<T, TM, TPX>;
     static_assert(sizeof(T) == 2 && G::MI == 1 && G::NI == 2 && (TM == 32 || TM == 64), "fp16, 32- or 64-channel tiles");
@@ -1016,6 +1192,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     unsigned char* sX = smem_raw;                             // [3][TP + 16][32]
     unsigned char* sW = smem_raw + 3 * XS;                    // [9 tap tiles][TM][32]
+    float* sStat = reinterpret_cast<float*>(sW + (9 + (TM == 32 ? 1 : 0)) * TMB);   // BNR: sums [2][TM] + constants [4][TM]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1025,6 +1202,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
     const unsigned Lb = blockIdx.x;
     const unsigned xcd = Lb & 7u, idx = Lb >> 3;
     const unsigned nt = idx % (unsigned)p.ntn;
+    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
     const int n0 = (int)nt * TM;
     const unsigned ntiles_all = (unsigned)((p.Mtotal + G::TP - 1) / G::TP);
     const unsigned tpx = (ntiles_all + 7) / 8;
@@ -1039,6 +1217,12 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
     const unsigned lds_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sX);
     const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sW);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    if constexpr (BNR) {
+        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+        g_bnr_setup<TM>(p, sStat + 2 * TM, n0, tid);
+        __syncthreads();
+    }
+    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 2 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
 
     const int slotc = lane & (G::CPR - 1);
     const int rowin = lane / G::CPR;
@@ -1193,9 +1377,29 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
         if (c == nC - 1) {
             asm volatile("s_nop 11" ::: "memory");
             float ssum[16], ssq[16];
+            if constexpr (BNR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                g_epilogue<T, TM, EM, TPX>(p, cur_tile, k >> 1, k & 1, wp, lane, cbase, false, rsY, acc[k], ssum, ssq, nullptr, 0);
+                g_epilogue<T, TM, EM, TPX, BNR>(p, cur_tile, k >> 1, k & 1, wp, lane, cbase, false, rsY, acc[k], ssum, ssq, nullptr, cbase - n0, bctx);
+            if constexpr (BNR) {
+                // the four classes' pixels of this tile: reduced per tile (DPP row sums + LDS atomics), as k_gconv3 does --
+                // 32 more registers living across the step loop do not fit next to the 128 accumulators
+                int lq = lane;
+                asm volatile("" : "+v"(lq));
+                float* sl = sStat + wm * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
+                    if ((lq & 15) == 0) {
+                        const int cl = g_stat_chan<true>(r, lq >> 5);
+                        atomicAdd(&sl[cl], a);
+                        atomicAdd(&sl[TM + cl], b);
+                    }
+                }
+            }
             after_epi = true;
             cur_tile += lstride;
             if (cur_tile >= ntiles) break;
@@ -1208,6 +1412,267 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
 #undef S2_X
 #undef S2_SETUP
     wait_vm<0>();
+    if constexpr (BNR) {
+        __syncthreads();
+        g_stats_to_global<TM, true>(p, sStat, tid, n0, slot);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// k_gconv_s2f: forward 3x3 / stride 2 / pad 1 on an
+// even-sized map.  Output pixel (oh, ow) reads input row 2*oh + dh and columns 2*ow - 1, 2*ow, 2*ow + 1.  For one dh the taps
+// dw = -1 / +1 read the ODD input columns: in flattened output order one run of odd columns (stage row j <-> output-aligned
+// pixel m0 + j - 1, input column 2*ow' + 1) serves both -- dw = +1 reads row p + 1, dw = -1 reads row p, the lane with ow == 0
+// zeroes that fragment (column -1 is padding; row p is the previous image row's last odd column) -- and the tap dw = 0 reads
+// the even columns (same row geometry, column 2*ow').  Six row-group loads and six barriers per 32-channel chunk instead of
+// nine tap loads and nine barriers (tools/experiments/next_round_math.py checks the identity on the CPU).
+// Step s = 0..5 of a chunk: dh = s / 2 - 1, odd columns for even s (two taps), even columns for odd s (one tap).  x row
+// groups: 3 stages, the group of step s + 2 is issued whole at step s; W: 3 stages of two tap tiles, two steps ahead.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int TM, int EM, int TPX>
+__global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
+    using G = GT<T, TM, TPX>;
+    static_assert(sizeof(T) == 2, "fp16");
+    constexpr int XR = G::XR;
+    constexpr int XS = (G::TP + 16) * G::ROWB;
+    constexpr int TMB = TM * G::ROWB;
+    constexpr int WSB = 2 * TMB < 4096 ? 4096 : 2 * TMB;      // W stage: two tap tiles
+    constexpr int W2 = WSB / 4096, W1 = TMB / 4096 > 0 ? TMB / 4096 : 1;   // pieces per wave for two / one tap tiles
+    constexpr int NSTK = G::NACC * 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    unsigned char* sX = smem_raw;                             // [3][TP + 16][32]
+    unsigned char* sW = smem_raw + 3 * XS;                    // [3][2][TM][32]
+    float* sStat = reinterpret_cast<float*>(sW + 3 * WSB);    // [2][TM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % G::WM, wp = wave / G::WM;
+
+    const unsigned Lb = blockIdx.x;
+    const unsigned xcd = Lb & 7u, idx = Lb >> 3;
+    const unsigned nt = idx % (unsigned)p.ntn;
+    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
+    const int n0 = (int)nt * TM;
+    const unsigned ntiles_all = (unsigned)((p.Mtotal + G::TP - 1) / G::TP);
+    const unsigned tpx = (ntiles_all + 7) / 8;
+    const unsigned band_lo = xcd * tpx;
+    const unsigned ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
+    const unsigned lslot = idx / (unsigned)p.ntn;
+    const unsigned lstride = (unsigned)p.nslots / 8u;
+    unsigned cur_tile = band_lo + lslot;
+    if (cur_tile >= ntiles) return;
+
+    if constexpr (EM == 2 || EM == 4) {
+        for (int i = tid; i < TM; i += 256) {
+            const bool in = n0 + i < p.Nout;
+            sStat[i] = (in && p.scale) ? p.scale[n0 + i] : 1.0f;
+            sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
+        }
+    }
+    const bool want_stats = (EM == 0) && (p.stats != nullptr);
+    if constexpr (EM == 0) {
+        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+    }
+
+    const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
+    const unsigned lds_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sX);
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sW);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    const int slotc = lane & (G::CPR - 1);
+    const int rowin = lane / G::CPR;
+    const int kc = slotc ^ (lane >> 4);
+    const int kcb = kc * G::CE * G::ES;
+    const int nC = (p.C + BK - 1) / BK;
+    const int cmax = p.C - kc * G::CE;
+    const int dhstep = p.XW * p.ldx * G::ES;                  // bytes per input image row
+    const int colstep = p.ldx * G::ES;                        // bytes per input pixel
+
+    // W loader: a stage holds two tap tiles; piece r of this wave covers stage rows (r * 4 + wave) * 16 + rowin
+    unsigned woff[W2];
+    int wtile[W2];                                            // 0 / 1: which of the two tap tiles the piece belongs to (>= 2: none)
+#pragma unroll
+    for (int r = 0; r < W2; ++r) {
+        const int row = (r * 4 + wave) * 16 + rowin;
+        const int t = row / TM, rt = row - t * TM;
+        wtile[r] = __builtin_amdgcn_readfirstlane(((r * 4 + wave) * 16) / TM);
+        woff[r] = (t < 2 && n0 + rt < p.Nout) ? (unsigned)(n0 + rt) * (unsigned)p.ldw * G::ES + (unsigned)kcb : G_OOB;
+    }
+    int wtap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wtap[t] = __builtin_amdgcn_readfirstlane((int)p.f2wt[t] * p.C * G::ES);
+
+    // x rows of the loader's tile: stage row j <-> output-aligned pixel tile * TP + j - 1, input pixel (n, 2*oh, 2*ow)
+    int xoff[XR + 1], xh0[XR + 1];
+#define F2_SETUP(tile_, valid_)                                                                            \
+    {                                                                                                      \
+        _Pragma("unroll") for (int r = 0; r <= XR; ++r) {                                                  \
+            const int j = r < XR ? (r * 4 + wave) * 16 + rowin : G::TP + rowin;                            \
+            const unsigned mu = (tile_) * G::TP + (unsigned)j - 1u;                                        \
+            const bool ok = (valid_) & (mu < (unsigned)p.Mtotal) & (r < XR || rowin < 1);                  \
+            const unsigned t_ = fdiv(mu, p.dOW);                                                           \
+            const int ow_ = (int)(mu - t_ * (unsigned)p.OW);                                               \
+            const unsigned n_ = fdiv(t_, p.dOH);                                                           \
+            const int oh_ = (int)(t_ - n_ * (unsigned)p.OH);                                               \
+            xoff[r] = (int)(((n_ * (unsigned)p.XH + (unsigned)(2 * oh_)) * (unsigned)p.XW + (unsigned)(2 * ow_)) * (unsigned)p.ldx * G::ES) + kcb; \
+            xh0[r] = ok ? 2 * oh_ : -100000;                                                               \
+        }                                                                                                  \
+    }
+    // the row group of step s_ (dh = s_ / 2 - 1, odd columns for even s_) of chunk c_ -> x stage s_ % 3
+#define F2_X(s_, c_)                                                                                       \
+    {                                                                                                      \
+        constexpr int dh_ = (s_) / 2 - 1, odd_ = 1 - ((s_) & 1);                                           \
+        const int cb_ = (c_) * (BK * G::ES) + odd_ * colstep;                                              \
+        const bool cok_ = (c_) * BK < cmax;                                                                \
+        _Pragma("unroll") for (int r = 0; r < XR; ++r) {                                                   \
+            const bool ok = ((unsigned)(xh0[r] + dh_) < (unsigned)p.XH) & cok_;                            \
+            const unsigned off = ok ? (unsigned)(xoff[r] + dh_ * dhstep + cb_) : G_OOB;                    \
+            glds16(rsX, lds_x + ((s_) % 3) * XS + (r * 4 + wave) * 1024, off);                             \
+        }                                                                                                  \
+        if (wave == 0) {                                                                                   \
+            const bool ok = ((unsigned)(xh0[XR] + dh_) < (unsigned)p.XH) & cok_;                           \
+            const unsigned off = ok ? (unsigned)(xoff[XR] + dh_ * dhstep + cb_) : G_OOB;                   \
+            glds16(rsX, lds_x + ((s_) % 3) * XS + XR * 4 * 1024, off);                                     \
+        }                                                                                                  \
+    }
+    // the W tiles of step s_ of chunk c_ -> W stage s_ % 3: odd-column steps carry taps dw = +1 (tile 0) and dw = -1 (tile 1),
+    // even-column steps the tap dw = 0 (tile 0)
+#define F2_W(s_, c_)                                                                                       \
+    {                                                                                                      \
+        constexpr int g_ = (s_) / 2, odd_ = 1 - ((s_) & 1);                                                \
+        const unsigned cbad_ = (c_) * BK < cmax ? 0u : G_OOB;                                              \
+        _Pragma("unroll") for (int r = 0; r < (odd_ ? W2 : W1); ++r) {                                     \
+            const int tap_ = odd_ ? (wtile[r] == 0 ? g_ * 3 + 2 : g_ * 3 + 0) : g_ * 3 + 1;                \
+            const unsigned none_ = (wtile[r] < (odd_ ? 2 : 1)) ? 0u : G_OOB;                              \
+            const unsigned col_ = (unsigned)(wtap[tap_] + (c_) * (BK * G::ES));                            \
+            glds16(rsW, lds_w + ((s_) % 3) * WSB + (r * 4 + wave) * 1024, (woff[r] + col_) | ((woff[r] | cbad_ | none_) & G_OOB)); \
+        }                                                                                                  \
+    }
+
+    const int arow = (wm * 32 * G::MI + (lane & 31)) * G::ROWB;
+    const int swzA = ((lane & 31) / G::RPB) & (G::CPR - 1);
+    int brow0 = wp * G::NI * 32 + (lane & 31);               // stage row p of this lane's pixel in block ni = 0 (own row: p + 1)
+    const int hi = lane >> 5;
+
+    float16v acc[G::NACC];
+#pragma unroll
+    for (int i = 0; i < G::NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const int cbase = n0 + wm * 32 * G::MI + 4 * (lane >> 5);
+
+    unsigned x_tile = cur_tile;
+    bool x_valid = true;
+    F2_SETUP(x_tile, true)
+    __syncthreads();
+    F2_X(0, 0) F2_W(0, 0)
+    F2_X(1, 0) F2_W(1, 0)
+
+    int c = 0;
+    bool after_epi = false;
+    unsigned mleft = 0;
+    while (true) {
+        if (c == 0) {
+            mleft = 0;
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni) {
+                const unsigned mu = cur_tile * G::TP + (unsigned)(wp * G::NI * 32 + ni * 32 + (lane & 31));
+                const unsigned t_ = fdiv(mu, p.dOW);
+                mleft |= ((int)(mu - t_ * (unsigned)p.OW) == 0 ? 1u : 0u) << ni;
+            }
+        }
+        const int cn = c + 1 == nC ? 0 : c + 1;
+        // pieces issued per step and wave: XR (+1 halo, wave 0: the waits do not count on it) + W2 / W1
+#define F2_STEP(s_)                                                                                        \
+        {                                                                                                  \
+            constexpr int odd_ = 1 - ((s_) & 1);                                                           \
+            _Pragma("unroll") for (int r = 0; r <= XR; ++r) asm volatile("" : "+v"(xoff[r]), "+v"(xh0[r])); \
+            asm volatile("" : "+v"(brow0));                                                                \
+            /* after W(s): everything step s - 1 issued = x group of s + 1 and the W tiles of s + 1 */     \
+            if ((s_) == 0) { if (after_epi) wait_vm<XR + W1 + NSTK>(); else wait_vm<XR + W1>(); }          \
+            else if (odd_) wait_vm<XR + W1>();                                                             \
+            else wait_vm<XR + W2>();                                                                       \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            const unsigned char* stW = sW + ((s_) % 3) * WSB + arow;                                       \
+            const unsigned char* stX = sX + ((s_) % 3) * XS;                                               \
+            const int j1 = brow0 + 1, j0 = brow0;                                                          \
+            half8 fa[2][2][G::MI], fb[2][2][G::NI];                /* [kk][tap tile][..] */                  \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                             \
+                const int sa = ((kk * 2 + hi) ^ swzA) * 16;                                                \
+                const int sb1 = ((kk * 2 + hi) ^ ((j1 >> 2) & (G::CPR - 1))) * 16;                         \
+                const int sb0 = ((kk * 2 + hi) ^ ((j0 >> 2) & (G::CPR - 1))) * 16;                         \
+                _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi) {                                     \
+                    fa[kk][0][mi] = *reinterpret_cast<const half8*>(stW + mi * 32 * G::ROWB + sa);         \
+                    if (odd_) fa[kk][1][mi] = *reinterpret_cast<const half8*>(stW + TMB + mi * 32 * G::ROWB + sa); \
+                }                                                                                          \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) {                                     \
+                    fb[kk][0][ni] = *reinterpret_cast<const half8*>(stX + (j1 + ni * 32) * G::ROWB + sb1); \
+                    if (odd_) fb[kk][1][ni] = *reinterpret_cast<const half8*>(stX + (j0 + ni * 32) * G::ROWB + sb0); \
+                }                                                                                          \
+            }                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if ((s_) == 4) {                                                                               \
+                if (c + 1 == nC) { x_tile += lstride; x_valid = x_valid && x_tile < ntiles; F2_SETUP(x_tile, x_valid) } \
+            }                                                                                              \
+            if ((s_) + 2 < 6) { F2_X((s_) + 2, c) F2_W((s_) + 2, c) }                                      \
+            else { F2_X(((s_) + 2) % 6, cn) F2_W(((s_) + 2) % 6, cn) }                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if (odd_ && mleft) {                                                                           \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni)                                       \
+                    if ((mleft >> ni) & 1u) {                                                              \
+                        _Pragma("unroll") for (int e = 0; e < 8; ++e) { fb[0][1][ni][e] = (_Float16)0.0f; fb[1][1][ni][e] = (_Float16)0.0f; } \
+                    }                                                                                      \
+            }                                                                                              \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                               \
+                _Pragma("unroll") for (int t = 0; t < (odd_ ? 2 : 1); ++t)                                 \
+                    _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi)                                   \
+                        _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) mma_step(fa[kk][t][mi], fb[kk][t][ni], acc[mi * G::NI + ni]); \
+        }
+        F2_STEP(0) F2_STEP(1) F2_STEP(2) F2_STEP(3) F2_STEP(4) F2_STEP(5)
+        after_epi = false;
+        if (c == nC - 1) {
+            asm volatile("s_nop 11" ::: "memory");
+            float ssum[16 * G::MI], ssq[16 * G::MI];
+#pragma unroll
+            for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+            g_epilogue<T, TM, EM, TPX>(p, cur_tile, p.oah, p.oaw, wp, lane, cbase, want_stats, rsY, acc, ssum, ssq, sStat, cbase - n0);
+            if (want_stats) {
+                int lq = lane;
+                asm volatile("" : "+v"(lq));
+                float* sl = sStat + wm * 32 * G::MI + 4 * (lq >> 5);
+#pragma unroll
+                for (int r = 0; r < 16 * G::MI; ++r) {
+                    const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
+                    if ((lq & 15) == 0) {
+                        const int cl = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + (r & 3);
+                        atomicAdd(&sl[cl], a);
+                        atomicAdd(&sl[TM + cl], b);
+                    }
+                }
+            }
+            after_epi = true;
+            cur_tile += lstride;
+            if (cur_tile >= ntiles) break;
+        }
+        c = cn;
+    }
+#undef F2_STEP
+#undef F2_W
+#undef F2_X
+#undef F2_SETUP
+    wait_vm<0>();
+    if (want_stats) {
+        __syncthreads();
+        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
+        for (int i = tid; i < TM; i += 256) {
+            if (n0 + i < p.Nout) {
+                atomicAdd(&st[n0 + i], sStat[i]);
+                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
+            }
+        }
+    }
 }
 
 // compute units of the CURRENT device (cached per device ordinal: one process may drive several GPUs)
@@ -1246,7 +1711,7 @@ static GGrid gconv_grid(long long Mtotal, int tp, int ntn, int bpc) {
     return {slots, (tpx + spx - 1) / spx};
 }
 
-template <typename T, int TM, int EM, int TPX>
+template <typename T, int TM, int EM, int TPX, bool BNR = false>
 static int launch_gconv_tp(GConvP p, hipStream_t s) {
     using G = GT<T, TM, TPX>;
     const size_t lds = G::LDS;
@@ -1254,6 +1719,23 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     static const int bpc_env = getenv("AYOLO_GCONV_BPC") ? atoi(getenv("AYOLO_GCONV_BPC")) : 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    if constexpr (sizeof(T) == 2 && EM != 3 && EM != 1) {
+        if (p.s2f) {                         // forward 3x3 / stride 2 with the odd-column taps sharing one row run
+            constexpr size_t lds2 = 3 * (size_t)(G::TP + 16) * G::ROWB + 3 * (size_t)(2 * TM * G::ROWB < 4096 ? 4096 : 2 * TM * G::ROWB) +
+                                    2 * TM * sizeof(float);
+            const long long slots2 = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc_env > 0 ? bpc_env : 2).slots;
+            p.nslots = (int)slots2;
+            static bool attr2_set[16] = {false};
+            if (dev < 0 || dev >= 16 || !attr2_set[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv_s2f<T, TM, EM, TPX>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                if (dev >= 0 && dev < 16) attr2_set[dev] = true;
+            }
+            hipLaunchKernelGGL((k_gconv_s2f<T, TM, EM, TPX>), dim3((unsigned)(slots2 * p.ntn)), dim3(256), lds2, s, p);
+            AY_CHECK_LAUNCH("k_gconv_s2f");
+            return AYOLO_OK;
+        }
+    }
     if constexpr (sizeof(T) == 2 && EM != 3) {
         if (p.row3) {                        // 3x3 / stride 1: x rows shared by the three taps of a kernel row (k_gconv3)
             using G3 = GT3<T, TM, TPX>;
@@ -1261,11 +1743,11 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
             p.nslots = (int)slots3;
             static bool attr3_set[16] = {false};
             if (dev < 0 || dev >= 16 || !attr3_set[dev]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv3<T, TM, EM, TPX>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv3<T, TM, EM, TPX, BNR>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3::LDS);
                 if (dev >= 0 && dev < 16) attr3_set[dev] = true;
             }
-            hipLaunchKernelGGL((k_gconv3<T, TM, EM, TPX>), dim3((unsigned)(slots3 * p.ntn)), dim3(256), G3::LDS, s, p);
+            hipLaunchKernelGGL((k_gconv3<T, TM, EM, TPX, BNR>), dim3((unsigned)(slots3 * p.ntn)), dim3(256), G3::LDS, s, p);
             AY_CHECK_LAUNCH("k_gconv3");
             return AYOLO_OK;
         }
@@ -1276,16 +1758,16 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     dim3 grid((unsigned)(slots * p.ntn));
     static bool attr_set[16] = {false};      // per device: function attributes belong to the device's context
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX, BNR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR>), grid, dim3(256), lds, s, p);
     AY_CHECK_LAUNCH("k_gconv");
     return AYOLO_OK;
 }
 
-template <typename T, int TM, int EM>
+template <typename T, int TM, int EM, bool BNR = false>
 static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     // Pixel-tile size, 128 or 256 (measured per layer on the YOLOv5s shapes at batch 64, profiles/r02_conv_tile_sweep.txt):
     //  * one wave of 128-pixel tiles fits the chip: keep 128 (most workgroups in flight; the 20^2 maps);
@@ -1307,8 +1789,9 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
         else if (w128 <= 3 && w256 < w128) wide = true;
         else wide = TM == 64 ? true : (TM == 128 ? K >= 256 : K >= 128);
     }
-    if (wide) return launch_gconv_tp<T, TM, EM, 256>(p, s);
-    return launch_gconv_tp<T, TM, EM, 128>(p, s);
+    if (p.s2f && TM == 128) wide = false;          // k_gconv_s2f: the 128 x 256 tile would spill (all four fragment sets live)
+    if (wide) return launch_gconv_tp<T, TM, EM, 256, BNR>(p, s);
+    return launch_gconv_tp<T, TM, EM, 128, BNR>(p, s);
 }
 
 template <typename T, int TM>
@@ -1316,15 +1799,18 @@ static int launch_gconv(const GConvP& p, hipStream_t s) {
     if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
     if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_gconv_em<T, TM, 2>(p, s);
     if (p.epi == AYOLO_EPI_AFFINE_RES || p.epi == AYOLO_EPI_AFFINE_SILU_RES) return launch_gconv_em<T, TM, 4>(p, s);
+    if constexpr (sizeof(T) == 2) {
+        if (p.bnr) return p.accumulate ? launch_gconv_em<T, TM, 1, true>(p, s) : launch_gconv_em<T, TM, 0, true>(p, s);
+    }
     if (p.accumulate) return launch_gconv_em<T, TM, 1>(p, s);
     return launch_gconv_em<T, TM, 0>(p, s);
 }
 
-template <int TM, int EM, int TPX>
+template <int TM, int EM, int TPX, bool BNR = false>
 static int launch_dgrad_s2(GConvP p, hipStream_t s) {
     using G = GT<half_t, TM, TPX>;
     // nine tap tiles; the one-tap step D still issues one piece per wave (4 KiB): one tile of slack behind it for TM = 32
-    const size_t lds = 3 * (size_t)(G::TP + 16) * G::ROWB + (9 + (TM == 32 ? 1 : 0)) * (size_t)TM * G::ROWB;
+    const size_t lds = 3 * (size_t)(G::TP + 16) * G::ROWB + (9 + (TM == 32 ? 1 : 0)) * (size_t)TM * G::ROWB + 6 * TM * sizeof(float);
     p.ntn = (p.Nout + TM - 1) / TM;
     const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, 2).slots;
     p.nslots = (int)slots;
@@ -1332,17 +1818,21 @@ static int launch_dgrad_s2(GConvP p, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad_s2<half_t, TM, EM, TPX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad_s2<half_t, TM, EM, TPX, BNR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_dgrad_s2<half_t, TM, EM, TPX>), dim3((unsigned)(slots * p.ntn)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_dgrad_s2<half_t, TM, EM, TPX, BNR>), dim3((unsigned)(slots * p.ntn)), dim3(256), lds, s, p);
     AY_CHECK_LAUNCH("k_dgrad_s2");
     return AYOLO_OK;
 }
 
 static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
     if (p.s2d && dtype == AYOLO_F16) {       // dgrad of a 3x3 / stride-2 conv, <= 64 input channels: all four classes at once
+        if (p.bnr) {
+            if (p.Nout <= 32) return p.accumulate ? launch_dgrad_s2<32, 1, 256, true>(p, s) : launch_dgrad_s2<32, 0, 256, true>(p, s);
+            return p.accumulate ? launch_dgrad_s2<64, 1, 128, true>(p, s) : launch_dgrad_s2<64, 0, 128, true>(p, s);
+        }
         if (p.Nout <= 32) return p.accumulate ? launch_dgrad_s2<32, 1, 256>(p, s) : launch_dgrad_s2<32, 0, 256>(p, s);
         return p.accumulate ? launch_dgrad_s2<64, 1, 128>(p, s) : launch_dgrad_s2<64, 0, 128>(p, s);
     }
@@ -1387,6 +1877,11 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
         a.Mtotal = (long long)a.B * p.OH * p.OW; b.Mtotal = (long long)b.B * p.OH * p.OW;
         b.x = (const char*)p.x + x_img * a.B;
         b.y = (char*)p.y + y_img * a.B;
+        for (int k = 0; k < p.bnr; ++k) {        // BNR: z has y's pixels
+            const long long z_img = (long long)p.YH * p.YW * p.bseg[k].ldz * 2;
+            b.bseg[k].z = (const char*)p.bseg[k].z + z_img * a.B;
+            a.z_bytes[k] = (unsigned)(z_img * a.B); b.z_bytes[k] = (unsigned)(z_img * b.B);
+        }
         int rc = dispatch_gconv(dtype, a, s);
         return rc ? rc : dispatch_gconv(dtype, b, s);
     }
@@ -1418,6 +1913,23 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
             p.r3wt[g * 3 + j] = p.wt[t];
         }
         p.row3 = seen == 0x1ff ? 1 : 0;
+    }
+    // forward 3x3 / stride 2 / pad 1 on even maps -> k_gconv_s2f.  Measured on MI355X (profiles/r03_conv_layer_sweep*.txt):
+    // 32 -> 64 @ 320^2 177 -> 160 us; the wider layers move by -4 .. +4 us (their step is bound by the W tiles, not by x), so
+    // it is the default for <= 32 input channels only (AYOLO_GCONV_S2F=1: every eligible layer, =0: none)
+    static const int s2f_on = getenv("AYOLO_GCONV_S2F") ? atoi(getenv("AYOLO_GCONV_S2F")) : -1;
+    p.s2f = 0;
+    if ((s2f_on > 0 || (s2f_on < 0 && p.C <= 32)) && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 2 && p.isw == 2 && p.osh == 1 && p.osw == 1 &&
+        !p.accumulate && p.XH == 2 * p.OH && p.XW == 2 * p.OW && p.YH == p.OH && p.YW == p.OW && p.C >= BK && p.epi != AYOLO_EPI_HEAD &&
+        ((p.C + BK - 1) / BK * BK - p.C) * 4 <= (p.C + BK - 1) / BK * BK && p.Nout <= 128 * 1024) {
+        int seen = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int g = p.dh[t] + 1, j = p.dw[t] + 1;
+            if (g < 0 || g > 2 || j < 0 || j > 2) { seen = -1; break; }
+            seen |= 1 << (g * 3 + j);
+            p.f2wt[g * 3 + j] = p.wt[t];
+        }
+        p.s2f = seen == 0x1ff ? 1 : 0;
     }
     return dispatch_gconv_one(dtype, p, s);
 }
@@ -1467,8 +1979,33 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
 // dgrad: dx[n,h,w,ci] = sum_{kh,kw,co} dy[n,(h+ph-kh)/sh,(w+pw-kw)/sw,co] * w[co,kh,kw,ci] over exact divisions.
 // Each (h mod sh, w mod sw) residue class is a stride-1 gather conv over dy with its own tap subset, so no
 // MFMA work is spent on structural zeros.
+static int conv_dgrad_impl(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
+                           const ayolo_bn_seg* segs, int nseg, int act, int sum_reps, ayolo_stream s);
+
 extern "C" int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
                                 ayolo_stream s) {
+    return conv_dgrad_impl(d, dy, wt, dx, accumulate, nullptr, 0, 0, 1, s);
+}
+
+extern "C" int ayolo_conv_dgrad_bn(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
+                                   const ayolo_bn_seg* segs, int nseg, int act, int sum_reps, ayolo_stream s) {
+    AY_CHECK_ARG(d && d->dtype == AYOLO_F16, "conv_dgrad_bn: fp16 only");
+    AY_CHECK_ARG(segs && (nseg == 1 || nseg == 2) && sum_reps >= 1, "conv_dgrad_bn: nseg=%d sum_reps=%d", nseg, sum_reps);
+    for (int k = 0; k < nseg; ++k) {
+        const ayolo_bn_seg& g = segs[k];
+        AY_CHECK_ARG(g.z && g.mean_invstd && g.sums, "conv_dgrad_bn: null pointer in segment %d", k);
+        AY_CHECK_ARG(g.C > 0 && g.C % 8 == 0 && g.c0 >= 0 && g.c0 % 8 == 0 && g.ldz % 8 == 0 && g.ldz >= g.C && g.c0 + g.C <= d->Cin,
+                     "conv_dgrad_bn: segment %d: c0=%d C=%d ldz=%d", k, g.c0, g.C, g.ldz);
+        AY_CHECK_ARG((long long)d->B * d->H * d->W * g.ldz * 2 < (1ll << 31) - 4096, "conv_dgrad_bn: z of segment %d exceeds 2 GiB", k);
+    }
+    // a 32-channel block of dx belongs to ONE segment (wave-uniform descriptor choice in the epilogue)
+    AY_CHECK_ARG(nseg == 1 || (segs[1].c0 % 32 == 0 && segs[0].c0 + segs[0].C <= segs[1].c0),
+                 "conv_dgrad_bn: second segment must start on a 32-channel boundary after the first");
+    return conv_dgrad_impl(d, dy, wt, dx, accumulate, segs, nseg, act, sum_reps, s);
+}
+
+static int conv_dgrad_impl(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
+                           const ayolo_bn_seg* segs, int nseg, int act, int sum_reps, ayolo_stream s) {
     int rc = check_desc(d, "conv_dgrad");
     if (rc) return rc;
     AY_CHECK_ARG(dy && wt && dx, "conv_dgrad: null pointer");
@@ -1495,6 +2032,11 @@ extern "C" int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const 
             p.YH = d->H; p.YW = d->W; p.ldy = d->ldx; p.osh = d->sh; p.osw = d->sw; p.oah = a; p.oaw = b;
             p.C = d->Cout; p.ldw = d->kh * d->kw * d->Cout; p.Nout = d->Cin;
             p.epi = AYOLO_EPI_NONE; p.accumulate = accumulate; p.stat_reps = 1;
+            p.bnr = nseg; p.bnr_act = act; p.bnr_reps = sum_reps;
+            for (int k = 0; k < nseg; ++k) {
+                p.bseg[k] = segs[k];
+                p.z_bytes[k] = (unsigned)((long long)d->B * d->H * d->W * segs[k].ldz * 2);
+            }
             p.y_linear = (d->sh == 1 && d->sw == 1) ? 1 : 0;
             p.x_linear = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0) ? 1 : 0;
             p.Mtotal = (long long)d->B * p.OH * p.OW;

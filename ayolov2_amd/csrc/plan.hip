@@ -58,9 +58,21 @@ static int side_ctx(SideCtx** out) {
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         static const int nside_env = getenv("AYOLO_SIDE_STREAMS") ? atoi(getenv("AYOLO_SIDE_STREAMS")) : 1;
         c.nside = nside_env < 1 ? 1 : (nside_env > AY_MAX_SIDE ? AY_MAX_SIDE : nside_env);
+        // AYOLO_SIDE_CUS = n: the side stream may only use n of the device's compute units (CU mask), so the weight
+        // gradients cannot take slots / bandwidth from the dependent chain on more than that part of the chip
+        static const int side_cus = getenv("AYOLO_SIDE_CUS") ? atoi(getenv("AYOLO_SIDE_CUS")) : 0;
         for (int k = 0; k < c.nside; ++k) {
             hipStream_t* st = k == 0 ? &c.side : &c.more[k - 1];
-            if (prio_env == 0) AY_CHECK_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+            if (side_cus > 0) {
+                hipDeviceProp_t prop;
+                AY_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+                uint32_t mask[32] = {0};
+                const int total = prop.multiProcessorCount > 1024 ? 1024 : prop.multiProcessorCount;
+                const int ncu = side_cus > total ? total : side_cus;
+                for (int b = 0; b < ncu; ++b) mask[b >> 5] |= 1u << (b & 31);
+                AY_CHECK_HIP(hipExtStreamCreateWithCUMask(st, (uint32_t)((total + 31) / 32), mask));
+            }
+            else if (prio_env == 0) AY_CHECK_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
             else AY_CHECK_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_env > 0 ? least : greatest));
         }
         AY_CHECK_HIP(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
@@ -186,7 +198,10 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
                                 (float*)o.p[5], o.i[1], o.i[2], cs);
             break;
         case AYOLO_OP_CONV_DGRAD:
-            rc = ayolo_conv_dgrad(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], cs);
+            // i[1] > 0: the BatchNorm-backward sums of the i[1] block(s) that produced dx ride in the epilogue
+            // (p[3]: host array of ayolo_bn_seg, i[2]: activation, i[3]: accumulator replicas)
+            if (o.i[1] > 0) rc = ayolo_conv_dgrad_bn(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const ayolo_bn_seg*)o.p[3], o.i[1], o.i[2], o.i[3], cs);
+            else rc = ayolo_conv_dgrad(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], cs);
             break;
         case AYOLO_OP_CONV_WGRAD:
             rc = ayolo_conv_wgrad(&o.conv, o.p[0], o.p[1], (float*)o.p[2], o.f[0], cs);

@@ -45,41 +45,30 @@ def EVBsigma2(sigma2: float, L: int, M: int, s: np.ndarray, residual: float, xub
 
 
 def EVBMF(Y, sigma2: Optional[float] = None, H: Optional[int] = None):
-    """Analytic empirical variational Bayes matrix factorisation (Nakajima et al. 2013).  Y: (L, M), L <= M.
-    Returns (U, diag(d), V, post); callers only use the shapes (= estimated rank)."""
+    """Analytic empirical variational Bayes matrix factorisation (Nakajima et al. 2013) of Y (L x M, L <= M): the rank is
+    the number of singular values above sqrt(M * sigma2 * (1 + tau_bar) * (1 + alpha / tau_bar)), tau_bar = 2.5129 sqrt(alpha),
+    with the noise variance sigma2 found by a bounded scalar minimisation of the free energy when it is not given.
+    Returns (U, diag(d), V, info) like the reference (decomposition.py:25-206); its callers only use diag's shape
+    (estimate_ranks, decomposition.py:357-359), so the posterior moments the reference also fills in are not computed."""
     Y = Y.detach().cpu().numpy() if isinstance(Y, torch.Tensor) else np.asarray(Y)
     L, M = Y.shape
-    if H is None:
-        H = L
+    H = L if H is None else H
     alpha = L / M
-    tauubar = 2.5129 * np.sqrt(alpha)
+    tau_bar = 2.5129 * np.sqrt(alpha)
     U, s, Vt = np.linalg.svd(Y, full_matrices=False)
     U, s, V = U[:, :H], s[:H], Vt[:H].T
-    residual = 0.0
-    if H < L:
-        residual = float(np.sum(Y ** 2) - np.sum(s ** 2))
+    residual = float(np.sum(Y ** 2) - np.sum(s ** 2)) if H < L else 0.0
     if sigma2 is None:
-        xubar = (1 + tauubar) * (1 + alpha / tauubar)
-        eH_ub = int(np.min([np.ceil(L / (1 + alpha)) - 1, H]))
-        upper = (np.sum(s ** 2) + residual) / (L * M)
-        lower = np.max([s[eH_ub] ** 2 / (M * xubar), np.mean(s[eH_ub:] ** 2) / M])
-        sigma2 = minimize_scalar(EVBsigma2, args=(L, M, s, residual, xubar), bounds=[lower, upper], method="Bounded").x
-    threshold = np.sqrt(M * sigma2 * (1 + tauubar) * (1 + alpha / tauubar))
-    pos = int(np.sum(s > threshold))
-    sp = s[:pos]
-    d = sp / 2 * (1 - (L + M) * sigma2 / sp ** 2 + np.sqrt((1 - (L + M) * sigma2 / sp ** 2) ** 2 - 4 * L * M * sigma2 ** 2 / sp ** 4))
-    post: Dict[str, Union[np.ndarray, float]] = {k: np.zeros(H) for k in ("ma", "mb", "sa2", "sb2", "cacb")}
-    t = d * sp / (M * sigma2)
-    delta = np.sqrt(M * d / (L * sp)) * (1 + alpha / t)
-    post["ma"][:pos] = np.sqrt(d * delta)
-    post["mb"][:pos] = np.sqrt(d / delta)
-    post["sa2"][:pos] = sigma2 * delta / sp
-    post["sb2"][:pos] = sigma2 / (delta * sp)
-    post["cacb"][:pos] = np.sqrt(d * sp / (L * M))
-    post["sigma2"] = sigma2
-    post["F"] = 0.5 * (L * M * np.log(2 * np.pi * sigma2) + (residual + np.sum(s ** 2)) / sigma2
-                       + np.sum(M * np.log(t + 1) + L * np.log(t / alpha + 1) - M * t))
-    return U[:, :pos], np.diag(d), V[:, :pos], post
+        x_bar = (1 + tau_bar) * (1 + alpha / tau_bar)
+        h_ub = int(min(np.ceil(L / (1 + alpha)) - 1, H))
+        hi = (np.sum(s ** 2) + residual) / (L * M)
+        lo = max(s[h_ub] ** 2 / (M * x_bar), np.mean(s[h_ub:] ** 2) / M)
+        sigma2 = minimize_scalar(EVBsigma2, args=(L, M, s, residual, x_bar), bounds=[lo, hi], method="Bounded").x
+    rank = int(np.sum(s > np.sqrt(M * sigma2 * (1 + tau_bar) * (1 + alpha / tau_bar))))
+    sp = s[:rank]
+    shrink = 1 - (L + M) * sigma2 / sp ** 2
+    d = sp / 2 * (shrink + np.sqrt(shrink ** 2 - 4 * L * M * sigma2 ** 2 / sp ** 4))        # EVB-shrunk singular values
+    return U[:, :rank], np.diag(d), V[:, :rank], {"sigma2": float(sigma2)}
 
 
 # --------------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 glue -- plain torch/numpy ops on whatever device the boxes live on."""
 from __future__ import annotations
 
-from typing import Optional, Tuple, Union
+from typing import Tuple
 
 import numpy as np
 import torch
@@ -33,28 +33,6 @@ def xywh2xyxy(x, ratio=(1.0, 1.0), wh=(1.0, 1.0), pad=(0.0, 0.0)):
     y[:, 1] = ratio[1] * wh[1] * (x[:, 1] - hh) + pad[1]
     y[:, 2] = ratio[0] * wh[0] * (x[:, 0] + hw) + pad[0]
     y[:, 3] = ratio[1] * wh[1] * (x[:, 1] + hh) + pad[1]
-    return y
-
-
-def xyxy2xywh(x, wh=(1.0, 1.0), clip_eps: Optional[float] = None, check_validity: bool = True):
-    """[x1, y1, x2, y2] -> [cx, cy, w, h] / wh (general.py:252-294)."""
-    y = x.clone() if isinstance(x, torch.Tensor) else np.copy(x)
-    if clip_eps is not None:
-        y = clip_coords(y, (wh[0] - clip_eps, wh[1] - clip_eps))
-    y[:, 0] = ((x[:, 0] + x[:, 2]) / 2) / wh[0]
-    y[:, 1] = ((x[:, 1] + x[:, 3]) / 2) / wh[1]
-    y[:, 2] = (x[:, 2] - x[:, 0]) / wh[0]
-    y[:, 3] = (x[:, 3] - x[:, 1]) / wh[1]
-    if check_validity:
-        mn = torch.minimum if isinstance(y, torch.Tensor) else np.minimum
-        mx = torch.maximum if isinstance(y, torch.Tensor) else np.maximum
-        zero = torch.zeros_like(y[:, 0]) if isinstance(y, torch.Tensor) else 0
-        one = torch.ones_like(y[:, 0]) if isinstance(y, torch.Tensor) else 1
-        y[:, 2] = y[:, 2] + (mn((y[:, 0] - (y[:, 2] / 2)), zero) * 2)
-        y[:, 2] = y[:, 2] - ((mx((y[:, 0] + (y[:, 2] / 2)), one) - 1) * 2)
-        y[:, 3] = y[:, 3] + (mn((y[:, 1] - (y[:, 3] / 2)), zero) * 2)
-        y[:, 3] = y[:, 3] - ((mx((y[:, 1] + (y[:, 3] / 2)), one) - 1) * 2)
-        y = y.clip(1e-12, 1)
     return y
 
 

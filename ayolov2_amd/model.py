@@ -108,6 +108,14 @@ class YOLOModel(nn.Module):
             print(f"YOLOModel: {len(layers)} layers, {n_param:,d} parameters")
 
     # ------------------------------------------------------------------------------------------
+    def __getstate__(self):
+        """copy.deepcopy / pickle / torch.save of the module (yolo_trainer.py:379-386 deep-copies the EMA model into every
+        checkpoint): the cached executor plans are derived data -- GBs of static activations and ctypes op arrays that
+        cannot be pickled -- and are rebuilt on the copy's first forward."""
+        state = self.__dict__.copy()
+        state.pop("_plans", None)
+        return state
+
     def forward(self, x: torch.Tensor):
         if self.training:
             from . import ops

@@ -126,6 +126,22 @@ def conv_dgrad(desc: ConvDesc, dy, wt, dx, accumulate=False):
     call("ayolo_conv_dgrad", desc, _ptr(dy), _ptr(wt), _ptr(dx), int(accumulate), _stream())
 
 
+def conv_dgrad_bn(desc: ConvDesc, dy, wt, dx, segs, act: int, accumulate=False):
+    """dgrad with the BatchNorm-backward sums of the block(s) that produced x in its epilogue (ayolo_conv_dgrad_bn).
+    segs: [(z, save_mean|save_invstd [2C], gamma, beta, sums [reps][2C], c0)] -- channels [c0, c0 + C) of dx."""
+    from ._lib import BnSeg
+    arr = (BnSeg * len(segs))()
+    reps = None
+    for k, (z, mi, gamma, beta, sums, c0) in enumerate(segs):
+        _, C, _, _, ldz = nhwc_info(z)
+        arr[k].z, arr[k].mean_invstd, arr[k].gamma, arr[k].beta, arr[k].sums = _ptr(z), _ptr(mi), _ptr(gamma), _ptr(beta), _ptr(sums)
+        arr[k].ldz, arr[k].c0, arr[k].C = ldz, int(c0), C
+        r = sums.shape[0] if sums.dim() == 2 else 1
+        assert reps in (None, r)
+        reps = r
+    call("ayolo_conv_dgrad_bn", desc, _ptr(dy), _ptr(wt), _ptr(dx), int(accumulate), arr, len(segs), int(act), reps, _stream())
+
+
 def conv_wgrad(desc: ConvDesc, x, dy, dw, alpha=1.0):
     call("ayolo_conv_wgrad", desc, _ptr(x), _ptr(dy), _ptr(dw), float(alpha), _stream())
 
@@ -150,6 +166,8 @@ def bn_finalize(stats, C, count, gamma, beta, eps, momentum, running_mean, runni
     reps = stats.shape[0] if stats.dim() == 2 else 1
     call("ayolo_bn_finalize", _ptr(stats), reps, C, float(count), _ptr(gamma), _ptr(beta), float(eps), float(momentum),
          _ptr(running_mean), _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), _ptr(scale), _ptr(shift), _stream())
+    from ._lib import bump_versions
+    bump_versions((running_mean, running_var))
     return save_mean, save_invstd, scale, shift
 
 

@@ -68,7 +68,9 @@ class SGD(torch.optim.SGD):
                 raise _lib.AyoloError("ayolov2_amd.optim.SGD: parameter is not a dense block of memory")
             dev = p.device
             gr = self._dense_like(p, g)
-            keep.append(gr)
+            if gr is not g:
+                keep.append(gr)            # a re-laid-out copy lives as long as the table; the caller's own gradient
+                                           # tensors are NOT retained (the key validates their addresses)
             buf = None
             if float(self.param_groups[gi]["momentum"]) != 0.0:
                 st = self.state[p]
@@ -92,8 +94,8 @@ class SGD(torch.optim.SGD):
         # pinned staging + asynchronous copy: a pageable .to(device) would block the host until the stream has drained
         host = torch.from_numpy(jobs.view(np.uint8).copy()).pin_memory()
         tab = host.to(dev, non_blocking=True)
+        copied = len(keep) > 0
         keep.append(host)
-        copied = any(k is not g for k, g in zip(keep, [g for g in grads if g is not None]))
         return tab, len(rows), keep, copied
 
     @torch.no_grad()
@@ -142,4 +144,5 @@ class SGD(torch.optim.SGD):
         _lib.call("ayolo_sgd_step", tab.data_ptr(), n, ctypes.byref(groups),
                   scale.data_ptr() if scale is not None else None, found.data_ptr() if found is not None else None,
                   torch.cuda.current_stream().cuda_stream)
+        _lib.bump_versions(p for (_, p), g in zip(plist, grads) if g is not None)     # written through raw pointers
         return loss

@@ -73,6 +73,9 @@ WGRAD_PAIRED = _os.environ.get("AYOLO_WGRAD_PAIRED", "0") == "1"
 FUSE_BN_BWD = _os.environ.get("AYOLO_FUSE_BN_BWD", "0") == "1"
 MAX_PLANS = int(_os.environ.get("AYOLO_MAX_PLANS", "4"))                 # cached plans per model (multi-scale training)
 MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: cv1 | cv2 as one conv
+# BatchNorm-backward sums (the first of the two backward passes of a Conv-BN-act block) computed in the epilogue of the
+# dgrad that produces the block's output gradient, instead of a pass of its own over da and z (ayolo_conv_dgrad_bn)
+BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
 
 
 class PlanUnsupported(Exception):
@@ -148,7 +151,11 @@ class TrainPlan:
         self.dz_elems = 0
         self.late: List[Callable[[], None]] = []    # closures run after the arenas exist (pointer binding)
         self.bn_counters: List[torch.Tensor] = []
+        self.bn_buffers: List[torch.Tensor] = []            # running statistics the forward kernels update in place
         self.bn_fused = 0                                   # BN layers whose backward runs as the one-pass fused kernel
+        self.bn_in_dgrad = 0                                # BN layers whose backward sums ride in a dgrad epilogue
+        self._gwrites: List[tuple] = []                     # (backward op index, root Act id, c_lo, c_hi, is_dgrad)
+        self._bn_layers: List[dict] = []                    # two-pass BN backward layers (candidates for the dgrad epilogue)
         self.collect_times = False                          # bench.py: per-op in-situ timing (ayolo_run_ops_timed)
         self.op_times: Dict[str, list] = {}
         self.raw_specs = []
@@ -176,6 +183,10 @@ class TrainPlan:
         """The backward op just appended (or op index `at`) completes the gradient arena range [off, off+n)."""
         if off is not None:
             self.grad_done.append((len(self.bwd) - 1 if at is None else at, off, n))
+
+    def _gw(self, act: "Act", is_dgrad: bool) -> None:
+        """The backward op just appended writes (or accumulates into) the gradient of `act`."""
+        self._gwrites.append((len(self.bwd) - 1, id(act.root), act.c0, act.c0 + act.C, is_dgrad))
 
     def _dz(self, n: int) -> torch.Tensor:
         """Backward operand dz of one layer: a slice of the shared scratch buffer, or -- when weight gradients run on the
@@ -287,6 +298,7 @@ class TrainPlan:
             self.late.append(bind_fwd)
             if bn.num_batches_tracked is not None:
                 self.bn_counters.append(bn.num_batches_tracked)
+            self.bn_buffers += [bn.running_mean, bn.running_var]
 
             # ---- parameters / gradient slots (the blocks' weight gradients are adjacent: one wgrad writes them all)
             def wview(buf, co=co, kh=kh, kw=kw, cp=geo.cin_pad, Cin=Cin):
@@ -338,10 +350,13 @@ class TrainPlan:
                     self._wrote(gg_off, co)
                     self._wrote(gb_off, co)
                     self.bwd_sync.append((len(self.bwd) - 2, su))  # sync_bn: all-reduce of the sums between reduce and apply
+                    self._bn_layers.append(dict(reduce=len(self.bwd) - 2, a=a, z=zj, ldz=Ct, sm=sm[0:2 * co], gamma=bn.weight,
+                                                beta=bn.bias, sums=su, C=co, act=act, R=R))
                 if residual is not None:      # shortcut: d(residual) += d(a)
                     dr = residual.grad()
                     self.bwd.append(_op(OP_COPY2D, i=(code, ldda, ops.nhwc_info(dr)[4], co, int(residual.is_init())), l=(npix,),
                                         p=(da, dr)))
+                    self._gw(residual, False)
                     residual.mark_init()
             def wgrad():
                 self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(xk, dz, ga.view(gw_off0, Ct * K)),
@@ -354,6 +369,7 @@ class TrainPlan:
                 dx = x_act.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
                                     conv=geo.desc(dt, ops.nhwc_info(dx)[4], Ct)))
+                self._gw(x_act, True)
                 x_act.mark_init()
             if WGRAD_PAIRED and WGRAD_SIDE_STREAM:
                 self.bwd.append(_op(OP_JOIN_SIDE))
@@ -411,6 +427,7 @@ class TrainPlan:
             dy, dx = dst.grad(), src.grad()
             self.bwd.append(_op(OP_MAXPOOL_BWD, i=(code, ops.nhwc_info(dy)[4], ops.nhwc_info(dx)[4], B, H, W, C, k, int(src.is_init())),
                                 p=(arg, dy, dx)))
+            self._gw(src, False)
             src.mark_init()
 
         self.bwd_emitters.append(emit)
@@ -435,6 +452,7 @@ class TrainPlan:
             dy, dx = out.grad(), x.grad()
             self.bwd.append(_op(OP_UPSAMPLE_BWD, i=(code, ops.nhwc_info(dy)[4], ops.nhwc_info(dx)[4], B, H, W, C, int(x.is_init())),
                                 p=(dy, dx)))
+            self._gw(x, False)
             x.mark_init()
 
         self.bwd_emitters.append(emit)
@@ -475,6 +493,7 @@ class TrainPlan:
                 dx = x.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x.is_init()),), p=(dz, wt, dx),
                                     conv=geo.desc(dt, ops.nhwc_info(dx)[4], cp, cout=cp)))
+                self._gw(x, True)
                 x.mark_init()
                 self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(x.t, dz, ga.view(gw_off, cp * Cin)),
                                     conv=geo.desc(dt, ldx, cp, cout=cp)))
@@ -576,6 +595,7 @@ class TrainPlan:
         self.bwd = []
         for emit in reversed(self.bwd_emitters):
             emit()
+        self._fold_bn_reduce()
         self.fwd_arr = (Op * len(self.fwd))(*self.fwd)
         self.bwd_arr = (Op * len(self.bwd))(*self.bwd)
         # pointer-patch slots inside the arrays (ctypes copies structs into the array)
@@ -586,6 +606,51 @@ class TrainPlan:
         self.param_ptrs = tuple(p.data_ptr() for p in self.params)
         self.fwd_sync_idx = [(next(k for k, o in enumerate(self.fwd) if o is c), off, n) for c, off, n in self.fwd_sync]
         self.buckets = self._make_buckets()
+
+    def _fold_bn_reduce(self) -> None:
+        """Move the first pass of the BatchNorm + activation backward (sum du, sum du * xhat over all pixels) into the
+        epilogue of the dgrad that PRODUCES the layer's output gradient: that kernel has every value of da in registers, so
+        instead of a pass that re-reads da and z from HBM it reads z once and the sums cost no launch of their own.  Valid
+        when the LAST writer of the layer's da (backward order; fan-out tensors are accumulated by several ops) is a conv
+        dgrad whose dx covers the layer's channels -- it then holds the TOTAL gradient, and the sums are what the separate
+        pass would compute from the same rounded values.  A dgrad serves up to two layers side by side in its dx (C3's
+        concat buffer: the last Bottleneck's output and the cv2 half).  Layers fed by pool / upsample / shortcut-copy
+        backward ops keep the separate pass; so do fp32 plans (the exact-parity mode)."""
+        if not BN_REDUCE_IN_DGRAD or self.dt != torch.float16:
+            return
+        from ._lib import BnSeg
+        by_op: Dict[int, list] = {}
+        for L in self._bn_layers:
+            a = L["a"]
+            root, lo, hi = id(a.root), a.c0, a.c0 + L["C"]
+            ws = [w for w in self._gwrites if w[1] == root and w[2] < hi and w[3] > lo and w[0] < L["reduce"]]
+            if not ws:
+                continue
+            last = max(ws, key=lambda w: w[0])
+            if not last[4] or not (last[2] <= lo and hi <= last[3]):
+                continue
+            by_op.setdefault(last[0], []).append((lo - last[2], L))
+        for idx, items in by_op.items():
+            items.sort(key=lambda t: t[0])
+            op = self.bwd[idx]
+            segs = [(c0, L) for c0, L in items]
+            ok = (len(segs) <= 2 and all(c0 % 8 == 0 and L["C"] % 8 == 0 for c0, L in segs)
+                  and len({L["act"] for _, L in segs}) == 1 and len({L["R"] for _, L in segs}) == 1
+                  and (len(segs) == 1 or (segs[1][0] % 32 == 0 and segs[0][0] + segs[0][1]["C"] <= segs[1][0])))
+            if not ok:
+                continue
+            arr = (BnSeg * len(segs))()
+            for k, (c0, L) in enumerate(segs):
+                arr[k].z, arr[k].mean_invstd = L["z"].data_ptr(), L["sm"].data_ptr()
+                arr[k].gamma = L["gamma"].data_ptr() if L["gamma"] is not None else None
+                arr[k].beta = L["beta"].data_ptr() if L["beta"] is not None else None
+                arr[k].sums = L["sums"].data_ptr()
+                arr[k].ldz, arr[k].c0, arr[k].C = L["ldz"], c0, L["C"]
+                self.bwd[L["reduce"]].kind = 0                       # the separate reduce pass is not needed
+                self.bn_in_dgrad += 1
+            self.keep.append(arr)
+            op.p[3] = ctypes.addressof(arr)
+            op.i[1], op.i[2], op.i[3] = len(segs), segs[0][1]["act"], segs[0][1]["R"]
 
     def _make_buckets(self, target_bytes: Optional[int] = None) -> List[Tuple[int, int, int]]:
         """Gradient buckets for data-parallel training: [(ready, lo, hi)] -- the arena range [lo, hi) is complete once
@@ -644,6 +709,7 @@ class TrainPlan:
             self._run(self.fwd_arr, 0, len(self.fwd), st, "forward")
         if self.bn_counters:
             torch._foreach_add_(self.bn_counters, 1)
+        _lib.bump_versions(self.bn_buffers)                     # written through raw pointers by k_bn_train_act
         self._fwd_done = torch.cuda.Event()
         self._fwd_done.record()
         raws = [spec[0].as_strided(spec[1], spec[2]) for spec in self.raw_specs]
@@ -680,7 +746,12 @@ class TrainPlan:
                 yes = 4 if o.i[0] == EPI_HEAD else es
                 out.append(("conv_fwd", es * (xin + wts) + yes * yout, 2.0 * macs))
             elif kind == OP_CONV_DGRAD:
-                out.append(("conv_dgrad", es * (yout + wts + xin * (2 if o.i[0] else 1)), 2.0 * macs))
+                zb = 0
+                if o.i[1] > 0:                      # BatchNorm-backward sums in the epilogue: z of the served layers read once
+                    from ._lib import BnSeg
+                    segs = ctypes.cast(o.p[3], ctypes.POINTER(BnSeg))
+                    zb = es * d.B * d.H * d.W * sum(segs[k].C for k in range(o.i[1]))
+                out.append(("conv_dgrad", es * (yout + wts + xin * (2 if o.i[0] else 1)) + zb, 2.0 * macs))
             elif kind == OP_CONV_WGRAD:
                 out.append(("conv_wgrad", es * (xin + yout) + 4 * wts, 2.0 * macs))
             elif kind == OP_BN_TRAIN_ACT:
@@ -710,6 +781,22 @@ class TrainPlan:
             else:
                 out.append(("other", 0.0, 0.0))
         return out
+
+    def _grad_out_buffer(self) -> torch.Tensor:
+        """The flat buffer this step's gradients are handed out in.  A pool of two persistent buffers, reused whenever no
+        parameter's .grad still lives in them (zero_grad(set_to_none=True) after every step, yolo_trainer.py:336): the
+        gradient addresses then repeat from step to step, which is what lets optim.SGD keep its job table instead of
+        rebuilding and re-uploading it every step.  A buffer still referenced by a .grad (gradient accumulation over
+        several backward passes) is never overwritten -- a fresh one is allocated instead."""
+        pool = self.__dict__.setdefault("_flat_pool", [])
+        live = {p.grad.untyped_storage().data_ptr() for p in self.params if p.grad is not None}
+        for b in pool:
+            if b.untyped_storage().data_ptr() not in live:
+                return b
+        b = torch.empty_like(self.gradarena.buf)
+        if len(pool) < 2:
+            pool.append(b)
+        return b
 
     def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
         from .losses import take_packed_head_grad
@@ -773,7 +860,8 @@ class TrainPlan:
                 sync.reduce_flat(self.gradarena.buf)              # one blocking all-reduce of the whole arena
         # The arena is scratch that the next forward zeroes: hand out gradients that OWN their memory (autograd steals
         # them as p.grad and may keep them across steps for gradient accumulation) -- one flat copy, views into it.
-        flat = self.gradarena.buf.clone()
+        flat = self._grad_out_buffer()
+        flat.copy_(self.gradarena.buf)
         grads = []
         for p in self.params:
             off, n, view_fn = self.param_grad_view[id(p)]

@@ -99,6 +99,7 @@ class ModelEMA:
             if tab is not None:
                 from . import _lib
                 _lib.call("ayolo_ema_update", tab.data_ptr(), self._njobs, float(d), torch.cuda.current_stream().cuda_stream)
+                _lib.bump_versions(v for v, _ in pairs)          # raw-pointer writes: caches keyed on _version must see them
                 return
             for v, src in pairs:                             # CPU / mixed-dtype state: the reference's two in-place ops
                 v *= d

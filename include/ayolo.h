@@ -77,6 +77,27 @@ int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void*
 int ayolo_conv_dgrad(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
                      ayolo_stream s);
 
+/* The same dgrad with the FIRST pass of the BatchNorm + activation backward of the layer(s) that produced x folded into
+ * its epilogue (autograd's native_batch_norm_backward + silu_backward of scripts/train/yolo_trainer.py:329; what
+ * ayolo_bn_act_bwd_reduce computes in a pass of its own): dx is the gradient `da` of up to two Conv-BN-act blocks that
+ * lie side by side in dx's channels (a concat buffer).  For block k (channels [c0, c0 + C) of dx) the kernel reads z at
+ * the pixel it has just produced (z: the block's pre-BatchNorm conv output, channel stride ldz), forms
+ * du = da * act'(bn(z)) from the rounded value it stores (for accumulate != 0: the total), and adds sum(du) and
+ * sum(du * xhat) into sums[replica][0..C) / [C..2C) exactly as the separate pass would (replicas as for `stats` of
+ * ayolo_conv_fwd; zeroed by the caller).  dx is written unchanged, so ayolo_bn_act_bwd_apply and any other reader of da
+ * are unaffected.  Only valid when this call is the LAST writer of those channels of dx.
+ * fp16 only; c0 and C multiples of 8 and every 32-channel block of dx inside one segment; nseg in {1, 2}. */
+typedef struct ayolo_bn_seg {
+    const void* z;            /* conv output the BatchNorm normalised, NHWC, same pixels as dx        */
+    const float* mean_invstd; /* float[2*C]: save_mean | save_invstd of the forward pass               */
+    const float* gamma;       /* float[C] or NULL (= 1)                                                */
+    const float* beta;        /* float[C] or NULL (= 0)                                                */
+    float* sums;              /* float[reps][2*C] accumulators                                         */
+    int ldz, c0, C, reserved;
+} ayolo_bn_seg;
+int ayolo_conv_dgrad_bn(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
+                        const ayolo_bn_seg* segs, int nseg, int act, int sum_reps, ayolo_stream s);
+
 /* dw[Cout][kh][kw][Cin] (fp32, must be zeroed by the caller) += sum_pixels dy (x) x ; alpha scales the result. */
 int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha,
                      ayolo_stream s);

@@ -417,3 +417,72 @@ def test_bn_bwd_fused_equals_two_pass(C, H, B, ld_extra, act):
     assert float((d > 0).float().mean()) < 0.02
     if ld_extra:
         assert float(dz[:, C:].abs().max()) == 0.0
+
+
+# (B, Cin, Cout, k, s, p, H, W, segments as (c0, C) of dx's channels): every dgrad kernel that carries the BN-backward sums
+BNR_CASES = [
+    ((2, 64, 32, 1, 1, 0, 20, 24), [(0, 64)]),                 # k_gconv, 64-channel tile
+    ((2, 64, 64, 1, 1, 0, 40, 40), [(0, 32), (32, 32)]),       # two segments (C3 concat buffer), one per wave
+    ((2, 128, 64, 1, 1, 0, 24, 24), [(0, 64), (64, 64)]),      # 128-channel tile: per-tile reduction, segment per (wave, mi)
+    ((2, 256, 128, 1, 1, 0, 16, 16), [(0, 128), (128, 128)]),  # two channel tiles, one segment each
+    ((2, 32, 64, 1, 1, 0, 33, 17), [(0, 32)]),                 # 32-channel tile, ragged pixel tiles
+    ((3, 32, 32, 3, 1, 1, 13, 17), [(0, 32)]),                 # k_gconv3, registers across tiles
+    ((2, 128, 128, 3, 1, 1, 20, 20), [(0, 128)]),              # k_gconv3, 128-channel tile (per-tile reduction)
+    ((2, 32, 64, 3, 2, 1, 40, 40), [(0, 32)]),                 # k_dgrad_s2, 32-channel tile (the stem's output gradient)
+    ((2, 64, 128, 3, 2, 1, 24, 24), [(0, 64)]),                # k_dgrad_s2, 64-channel tile
+    ((1, 128, 256, 3, 2, 1, 16, 16), [(0, 128)]),              # k_gconv walking the four residue classes
+    ((2, 64, 64, 3, 2, 1, 13, 17), [(0, 64)]),                 # odd map: one launch per residue class
+    ((2, 96, 48, 1, 1, 0, 12, 12), [(8, 80)]),                 # a segment that is a strict sub-range of dx's channels
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", BNR_CASES)
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_dgrad_with_bn_backward_sums(case, accumulate):
+    """ayolo_conv_dgrad_bn: dx is bit-identical to the plain dgrad, and the sums it leaves in the accumulators equal what
+    ayolo_bn_act_bwd_reduce computes from that dx (same rounded values; only the fp32 summation order differs)."""
+    from ayolov2_amd import functional as F_, ops
+    from ayolov2_amd._lib import call
+    shape, segs = case
+    B, Cin, Cout, k, s, p, H, W = shape
+    dt = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + len(segs))
+    geo = F_._Geometry((B, Cin, H, W), (Cout, Cin, k, k), (s, s), (p, p), dt)
+    w32 = (torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    _, wt = F_._WeightCache().get(w32, dt, Cout, geo.cin_pad)
+    dy = ops.new_act(B, Cout, geo.Ho, geo.Wo, dt, "cuda")
+    dy.copy_(torch.randn(dy.shape, device="cuda", generator=g))
+    base = ops.new_act(B, Cin, H, W, dt, "cuda")
+    base.copy_(torch.randn(base.shape, device="cuda", generator=g))
+    d = geo.desc(dt, Cin, Cout)
+    # reference: plain dgrad, then the separate reduce pass per segment
+    dx_ref = base.clone(memory_format=torch.preserve_format) if accumulate else ops.new_act(B, Cin, H, W, dt, "cuda")
+    ops.conv_dgrad(d, dy, wt, dx_ref, accumulate=accumulate)
+    dx = base.clone(memory_format=torch.preserve_format) if accumulate else ops.new_act(B, Cin, H, W, dt, "cuda")
+    seg_args, refs = [], []
+    for c0, C in segs:
+        z = ops.new_act(B, C, H, W, dt, "cuda")
+        z.copy_(torch.randn(z.shape, device="cuda", generator=g) * 1.5 + 0.3)
+        mean = torch.randn(C, device="cuda", generator=g) * 0.3
+        invstd = torch.rand(C, device="cuda", generator=g) + 0.5
+        gamma = torch.randn(C, device="cuda", generator=g)
+        beta = torch.randn(C, device="cuda", generator=g) * 0.5
+        mi = torch.cat((mean, invstd)).contiguous()
+        sums = torch.zeros((ops.STAT_REPS, 2 * C), device="cuda")
+        seg_args.append((z, mi, gamma, beta, sums, c0))
+        ref = torch.zeros((ops.STAT_REPS, 2 * C), device="cuda")
+        da = dx_ref[:, c0:c0 + C]
+        call("ayolo_bn_act_bwd_reduce", ops.dtype_code(dt), z.data_ptr(), C, da.data_ptr(), Cin, B * H * W, C, mean.data_ptr(),
+             invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, ref.data_ptr(), ops.STAT_REPS, torch.cuda.current_stream().cuda_stream)
+        refs.append(ref)
+    ops.conv_dgrad_bn(d, dy, wt, dx, seg_args, act=1, accumulate=accumulate)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    for (z, mi, gamma, beta, sums, c0), ref in zip(seg_args, refs):
+        got, want = sums.sum(0).double().cpu(), ref.sum(0).double().cpu()
+        C = z.shape[1]
+        # scale: the L1 mass of the summands is ~ npix * |du|; compare against the largest channel total and that mass
+        mass = float(dx_ref[:, c0:c0 + C].float().abs().sum() / C)
+        err = float((got - want).abs().max())
+        assert err <= 2e-5 * mass + 1e-6, (err, mass, float(want.abs().max()))

@@ -158,6 +158,24 @@ def test_cfg5_forward_leg_yolov5x_1280_fp16():
     assert float((z16[..., 4:] - z32[..., 4:]).abs().max()) < 0.02          # objectness / class probabilities
 
 
+def test_cfg5_yolov5x_fp16_eval_vs_oracle():
+    """BASELINE cfg 5's model and dtype against the ORACLE (not only against its own fp32 mode): YOLOv5x, fuse().eval(),
+    fp16, one 640 x 640 image (the CPU oracle needs ~10 s for it; the 1280^2 launch geometry is the test above).
+    Raw logits within 2 % of the logit range per level (the fp16 bar of every other model), decoded scores within 0.02."""
+    m, r = _pair("x", seed=35)
+    m, r = m.cuda().eval().fuse(), r.eval()
+    x = torch.rand(1, 3, 640, 640)
+    with torch.no_grad():
+        zr, raws_r = r(x)
+        with torch.autocast("cuda", dtype=torch.float16):
+            zg, raws_g = m(x.cuda())
+    assert _has_plan(m, "eval")
+    for a, b in zip(raws_g, raws_r):
+        err = float((a.cpu() - b).abs().max())
+        assert err <= 0.02 * float(b.max() - b.min()), (err, float(b.max() - b.min()))
+    assert float((zg[..., 4:].cpu() - zr[..., 4:]).abs().max()) < 0.02
+
+
 def _train_step(m, x, t, amp):
     """One forward + loss + backward.  The fp16 mode scales the loss as the reference's GradScaler does
     (yolo_trainer.py:329; a fixed 2^12 here) -- unscaled fp16 gradients of the early layers sit in the subnormal range --
@@ -227,7 +245,12 @@ def test_yolov5s_train_step_fp32_and_fp16_vs_oracle():
     # the per-parameter worst-element statistic is an extreme value of noise (3-4 sigma of a parameter's elements) and moves a
     # lot between runs; it is bounded loosely, the gradient's direction is what is held tight
     assert np.median(e) <= 0.35 and e[int(0.9 * len(e))] <= 0.6, (np.median(e), e[int(0.9 * len(e))], e[-1], top)
-    assert glob >= 0.97, glob                     # measured 0.986 .. 0.994 over repeated runs
+    # measured 0.968 .. 0.994 over repeated runs.  The spread is NOT the kernels (tools/race_screen.py: forward and dgrad
+    # are bit-reproducible) and not only conditioning: two IDENTICAL fp16 steps agree to cosine 0.993-0.998 with each other
+    # (tools/cond_explore.py; two fp32-mode steps: 1.000000) -- the BatchNorm statistics are accumulated with fp32 atomics in
+    # launch order, their last bits move the fp16 rounding of a few % of the activations, and that is the run-to-run floor of
+    # any whole-gradient comparison in fp16.  A wrong tile / channel chunk moves the cosine below 0.9.
+    assert glob >= 0.95, glob
 
 
 @pytest.mark.parametrize("name,batch,thr", [("s", 64, (0.975, 0.96, 0.93)), ("l", 16, None)])

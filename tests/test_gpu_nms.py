@@ -77,11 +77,13 @@ def test_batched_nms_golden(golden_dir, nms_type):
             _cmp(got, want, exact, f"{nms_type} a{agn} n{nb}")
 
 
-@pytest.mark.parametrize("B,N,mu,ml", [(2, 25200, -9.5, True), (1, 25200, -6.0, True), (3, 6000, -7.0, False)])
+@pytest.mark.parametrize("B,N,mu,ml", [(2, 25200, -9.5, True), (1, 25200, -6.0, True), (3, 6000, -7.0, False),
+                                        (2, 100800, -9.5, True)])
 def test_nms_vs_oracle_large(B, N, mu, ml):
-    """COCO-shape proposal counts (BASELINE.json config 1 shape), compared with the CPU oracle row for row."""
+    """COCO-shape proposal counts (BASELINE.json config 1 shape: 25 200 at 640^2; config 5 shape: 100 800 proposals per
+    image at 1280^2, ~10 % of them candidates), compared with the CPU oracle row for row."""
     from ayolov2_amd.metrics import non_max_suppression
-    pred = synth_pred(B, N, 80, 640, mu, seed=11)
+    pred = synth_pred(B, N, 80, 1280 if N > 50000 else 640, mu, seed=11)
     want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.65, multi_label=ml)
     got = non_max_suppression(pred.cuda(), conf_thres=0.001, iou_thres=0.65, multi_label=ml)
     _cmp(got, want, True, "large")

@@ -156,6 +156,43 @@ def test_tucker_product_vs_golden(golden_dir):
     assert abs(float(loss) - float(g["conv_loss"])) < 1e-4
 
 
+def test_decompose_model_prune_bisection_vs_golden(golden_dir):
+    """G7b: the reference's DEFAULT decompose_model path -- loss_thr 0.1, prune_step 0.01, i.e. the L1-unstructured prune
+    bisection of decomposition.py:296-323 (decompose_model.py:63-74) -- on a seeded two-block net: same accepted ranks, the
+    same pruned-then-decomposed kernels (compared as ONE dense 3x3 kernel, which is free of the factors' sign / rotation
+    ambiguity) and the same network output as the reference driver run by tools/make_golden.py."""
+    from torch import nn
+    from ayolov2_amd import decomposition as D
+    g = np.load(os.path.join(golden_dir, "g7b_decompose_model.npz"))
+
+    class Blk(nn.Module):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.conv = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+
+        def forward(self, x):
+            return self.conv(x)
+
+    net = nn.Sequential(Blk(16, 24), Blk(24, 16))
+    for blk, k in zip(net, ("w0", "w1")):
+        blk.conv.weight.data = torch.from_numpy(g[k].copy())
+    torch.manual_seed(int(g["probe_seed"]))          # the probe inputs come from the global generator, as in the reference
+    D.decompose_model(net, loss_thr=0.1, prune_step=0.01)
+    for i, blk in enumerate(net):
+        seq = blk.conv
+        assert isinstance(seq, nn.Sequential)
+        assert [list(m.weight.shape) for m in seq] == g[f"shapes{i}"].tolist()
+        assert (seq.in_channels, seq.out_channels, tuple(seq.kernel_size)) == (g[f"w{i}"].shape[1], g[f"w{i}"].shape[0], (3, 3))
+        first, core, last = (m.weight.detach().double() for m in seq)
+        dense = torch.einsum("oa,abhw,bi->oihw", last[:, :, 0, 0], core, first[:, :, 0, 0]).float().numpy()
+        # a different prune ratio (one bisection step is 1 / 128 of the weights) moves the kernel by ~1e-2; HOOI by < 1e-4
+        np.testing.assert_allclose(dense, g[f"dense{i}"], atol=2e-4, rtol=0)
+    x = torch.rand((2, 16, 12, 12), generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    with torch.no_grad():
+        y = net(x)
+    np.testing.assert_allclose(y.numpy(), g["y"], atol=1e-3, rtol=1e-3)
+
+
 def test_decompose_model_surface():
     """decompose_model swaps `.conv` for a 3-conv Sequential carrying in/out_channels/kernel_size attrs and lowers
     the parameter count (decomposition.py:325-335)."""

@@ -127,6 +127,47 @@ def g8_validator():
     np.savez_compressed(os.path.join(OUT, "g8_validator.npz"), **g8)
 
 
+def g7b_net(weights=None):
+    """Two Conv blocks (`.conv` children, as kindle's Conv exposes them) with planted low-rank 3x3 weights + noise."""
+    class Blk(torch.nn.Module):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+
+        def forward(self, x):
+            return self.conv(x)
+
+    net = torch.nn.Sequential(Blk(16, 24), Blk(24, 16))
+    if weights is None:
+        rs = np.random.default_rng(17)
+        weights = []
+        for (co, ci, ro, ri) in ((24, 16, 6, 5), (16, 24, 5, 6)):
+            core = rs.standard_normal((ro, ri, 3, 3))
+            w = np.einsum("abhw,oa,ib->oihw", core, rs.standard_normal((co, ro)), rs.standard_normal((ci, ri))) / 12
+            weights.append((w + 0.01 * rs.standard_normal(w.shape)).astype(np.float32))
+    for blk, w in zip(net, weights):
+        blk.conv.weight.data = torch.from_numpy(np.ascontiguousarray(w))
+    return net, weights
+
+
+def g7b_prune_bisection(rd):
+    net, weights = g7b_net()
+    torch.manual_seed(123)                       # decompose_model draws its probe inputs from the global generator
+    rd.decompose_model(net, loss_thr=0.1, prune_step=0.01)
+    x = torch.rand((2, 16, 12, 12), generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        y = net(x)
+    out = {"w0": weights[0], "w1": weights[1], "y": y.numpy().astype(np.float32), "x_seed": 9, "probe_seed": 123}
+    for i, blk in enumerate(net):
+        seq = blk.conv
+        assert isinstance(seq, torch.nn.Sequential), "the fixture must exercise a successful decomposition"
+        out[f"shapes{i}"] = np.array([list(m.weight.shape) for m in seq])
+        # the pruned-then-decomposed kernel the bisection settled on, as ONE dense 3x3 kernel (sign / rotation free)
+        first, core, last = (m.weight.detach().double() for m in seq)
+        out[f"dense{i}"] = torch.einsum("oa,abhw,bi->oihw", last[:, :, 0, 0], core, first[:, :, 0, 0]).float().numpy()
+    return out
+
+
 def g9_tta():
     """G9: inference_with_tta / scale_img / descale_pred / clip_augmented (tta_utils.py:15-86, torch_utils.py:305-331)
     around a deterministic stand-in model (a YOLO-shaped function of the input), the reference's own code run here."""
@@ -180,6 +221,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         g9_tta()
         print("g9 written")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g7b":
+        from scripts.tensor_decomposition import decomposition as rd
+        np.savez_compressed(os.path.join(OUT, "g7b_decompose_model.npz"), **g7b_prune_bisection(rd))
+        print("g7b written")
         return
     from scripts.utils import general as rg
     from scripts.utils import metrics as rm
@@ -359,6 +405,11 @@ def main():
     g7["conv_loss"] = float(loss)
     g7["conv_shapes"] = np.array([list(m.weight.shape) for m in seq])
     np.savez_compressed(os.path.join(OUT, "g7_tucker.npz"), **g7)
+
+    # ---- G7b: the reference's decompose_model() driver on its DEFAULT path (decompose_model.py:63-74: loss_thr 0.1,
+    # prune_step 0.01 -> the L1-prune bisection of decomposition.py:296-323) over a seeded two-block net
+    g7b = g7b_prune_bisection(rd)
+    np.savez_compressed(os.path.join(OUT, "g7b_decompose_model.npz"), **g7b)
 
     g8_validator()
     g9_tta()
