@@ -156,6 +156,17 @@ struct GT {
     static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 6 * TM * sizeof(float);   // stats [2][TM] + BNR constants [4][TM]
 };
 
+// Explicit MFMA-result hazard pad (see the comment in k_gconv's step loop).  The pad only works if the MFMAs stay in front of
+// it: an asm statement -- even volatile with a memory clobber -- does not order register-only instructions, and hipcc was seen
+// to schedule the last MFMAs of a step BEHIND the pad after an unrelated edit of the epilogue (test_head_conv then failed with
+// one stale accumulator register per tile).  sched_barrier(0) on both sides pins it.
+#define AY_MFMA_PAD(asm_nops)                          \
+    do {                                               \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile(asm_nops ::: "memory");           \
+        __builtin_amdgcn_sched_barrier(0);             \
+    } while (0)
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Buffer descriptor (raw, stride 0, `bytes` records) held in 4 SGPRs, and the LDS-DMA load itself.  The DMA is issued
@@ -817,10 +828,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
         // The last MFMA's result must not be read for passes+2 wait states.  hipcc (ROCm 7.2) covers that hazard inside a
         // basic block but was seen to miss it across the loop back edge (fp32 head variant: the next iteration opened
         // with v_accvgpr_read of the accumulator's last register, which came back stale) -- pad it here, explicitly.
-        if constexpr (sizeof(T) == 4) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        if constexpr (sizeof(T) == 4) AY_MFMA_PAD("s_nop 15\n\ts_nop 3");
         after_epi = false;
         if (cur_kt == cur_nk - 1) {
-            if constexpr (sizeof(T) == 2) asm volatile("s_nop 11" ::: "memory");   // fp16: accumulators are only read here
+            if constexpr (sizeof(T) == 2) AY_MFMA_PAD("s_nop 11");   // fp16: accumulators are only read here
             g_epilogue<T, TM, EM, TPX, BNR>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq,
                                             sStat, cbase - n0, bctx);
             if constexpr (TILE_RED) {
@@ -1117,7 +1128,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
         G3_SUB(0) G3_SUB(1) G3_SUB(2) G3_SUB(3) G3_SUB(4) G3_SUB(5) G3_SUB(6) G3_SUB(7) G3_SUB(8)
         after_epi = false;
         if (c == nC - 1) {
-            asm volatile("s_nop 11" ::: "memory");          // the accumulators are read right after the last MFMA
+            AY_MFMA_PAD("s_nop 11");          // the accumulators are read right after the last MFMA
             float ssum[16 * G::MI], ssq[16 * G::MI];
 #pragma unroll
             for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
@@ -1375,7 +1386,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
         S2_STEP(WOD, 1, 1, xg1, wait_vm<XR + W4>();, S2_W(wcB, W2, cn, WOB), 3, 0, 0, 0)
         after_epi = false;
         if (c == nC - 1) {
-            asm volatile("s_nop 11" ::: "memory");
+            AY_MFMA_PAD("s_nop 11");
             float ssum[16], ssq[16];
             if constexpr (BNR) {
 #pragma unroll
@@ -1633,7 +1644,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
         F2_STEP(0) F2_STEP(1) F2_STEP(2) F2_STEP(3) F2_STEP(4) F2_STEP(5)
         after_epi = false;
         if (c == nC - 1) {
-            asm volatile("s_nop 11" ::: "memory");
+            AY_MFMA_PAD("s_nop 11");
             float ssum[16 * G::MI], ssq[16 * G::MI];
 #pragma unroll
             for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
@@ -2269,7 +2280,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
                 }
             }
         }
-        if constexpr (sizeof(T) == 4) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // see k_gconv: MFMA result hazard across the back edge
+        if constexpr (sizeof(T) == 4) AY_MFMA_PAD("s_nop 15\n\ts_nop 3");   // see k_gconv: MFMA result hazard across the back edge
         const unsigned t = so0; so0 = so1; so1 = so2; so2 = t;
     }
 #undef W_ISSUE

@@ -152,6 +152,7 @@ class TrainPlan:
         self.late: List[Callable[[], None]] = []    # closures run after the arenas exist (pointer binding)
         self.bn_counters: List[torch.Tensor] = []
         self.bn_buffers: List[torch.Tensor] = []            # running statistics the forward kernels update in place
+        self.bn_sync_fix: list = []                         # sync_bn: (bn, small-arena offset, C, local count) per layer
         self.bn_fused = 0                                   # BN layers whose backward runs as the one-pass fused kernel
         self.bn_in_dgrad = 0                                # BN layers whose backward sums ride in a dgrad epilogue
         self._gwrites: List[tuple] = []                     # (backward op index, root Act id, c_lo, c_hi, is_dgrad)
@@ -299,6 +300,7 @@ class TrainPlan:
             if bn.num_batches_tracked is not None:
                 self.bn_counters.append(bn.num_batches_tracked)
             self.bn_buffers += [bn.running_mean, bn.running_var]
+            self.bn_sync_fix.append((bn, sm_off, co, npix))
 
             # ---- parameters / gradient slots (the blocks' weight gradients are adjacent: one wgrad writes them all)
             def wview(buf, co=co, kh=kh, kw=kw, cp=geo.cin_pad, Cin=Cin):
@@ -670,6 +672,22 @@ class TrainPlan:
                 lo = 0 if last else off
                 out.append((ready, lo, hi))
                 hi = off
+        # The LAST bucket ends with the first layer, whose gradients are the last thing backward produces (the stem's weight
+        # gradient runs at the very end of the list on the largest activations of the net): as one bucket its all-reduce can
+        # only start after the backward window has closed (round 2: bucket 5 at +10.02 ms of a 9.98 ms window).  Split it: the
+        # part that is complete BEFORE the first layer's own ops leaves early, what remains exposed is the first layer's few
+        # KB (a latency-bound collective either way).
+        if out:
+            ready_l, lo_l, hi_l = out[-1]
+            inside = [(idx, off, n) for idx, off, n in done if lo_l <= off < hi_l]
+            first_ops = max(idx for idx, _, _ in inside)                        # the op that completes the bucket
+            early = [(idx, off, n) for idx, off, n in inside if idx < first_ops - 2]   # not the first layer's wgrad / BN apply
+            if early and len(early) < len(inside):
+                cut = min(off for _, off, _ in early)
+                late_hi = max(off + n for idx, off, n in inside if idx >= first_ops - 2)
+                if late_hi <= cut and (hi_l - cut) * 4 >= 64 << 10:
+                    out[-1] = (max(idx for idx, _, _ in early), cut, hi_l)
+                    out.append((ready_l, lo_l, cut))
         fixed, run = [], -1
         for ready, lo, hi in out:                                      # ready indices must not decrease bucket to bucket
             run = max(run, ready)
@@ -705,6 +723,19 @@ class TrainPlan:
                 sync.average_now(self.stats.view(off, n))
                 a = k + 1
             self._run(self.fwd_arr, a, len(self.fwd), st, "forward")
+            # The kernels scale the running variance by n / (n - 1) with the LOCAL sample count n; torch's SyncBatchNorm uses
+            # the global count N = world * n.  Add the difference momentum * var * (N/(N-1) - n/(n-1)) (var from the saved
+            # inverse standard deviation) -- a handful of tiny ops per layer, on a path that already runs ~100 blocking
+            # collectives per step.
+            world = sync.world
+            if world > 1:
+                with torch.no_grad():
+                    for bn, sm_off, co, n in self.bn_sync_fix:
+                        if bn.running_var is None or n < 2:
+                            continue
+                        inv = self.small.view(sm_off, 4 * co)[co:2 * co]
+                        N = world * n
+                        bn.running_var.add_((inv.pow(-2) - bn.eps) * (bn.momentum * (N / (N - 1) - n / (n - 1))))
         else:
             self._run(self.fwd_arr, 0, len(self.fwd), st, "forward")
         if self.bn_counters:
@@ -790,13 +821,13 @@ class TrainPlan:
         several backward passes) is never overwritten -- a fresh one is allocated instead."""
         pool = self.__dict__.setdefault("_flat_pool", [])
         live = {p.grad.untyped_storage().data_ptr() for p in self.params if p.grad is not None}
-        for b in pool:
-            if b.untyped_storage().data_ptr() not in live:
-                return b
-        b = torch.empty_like(self.gradarena.buf)
+        for b, extra in pool:
+            if b.untyped_storage().data_ptr() not in live and not any(e.untyped_storage().data_ptr() in live for e in extra.values()):
+                return b, extra
+        b, extra = torch.empty_like(self.gradarena.buf), {}
         if len(pool) < 2:
-            pool.append(b)
-        return b
+            pool.append((b, extra))
+        return b, extra
 
     def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
         from .losses import take_packed_head_grad
@@ -860,12 +891,22 @@ class TrainPlan:
                 sync.reduce_flat(self.gradarena.buf)              # one blocking all-reduce of the whole arena
         # The arena is scratch that the next forward zeroes: hand out gradients that OWN their memory (autograd steals
         # them as p.grad and may keep them across steps for gradient accumulation) -- one flat copy, views into it.
-        flat = self._grad_out_buffer()
+        flat, extra = self._grad_out_buffer()
         flat.copy_(self.gradarena.buf)
+        lo_, hi_ = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
         grads = []
         for p in self.params:
             off, n, view_fn = self.param_grad_view[id(p)]
             g = view_fn(flat[off:off + n])
+            if not (lo_ <= g.data_ptr() < hi_):
+                # not a view (the stem: 3 of its 4 packed input channels are compacted): the copy lives in a persistent
+                # buffer of the pool entry too, so that EVERY gradient address repeats from step to step
+                keep = extra.get(id(p))
+                if keep is None or keep.shape != g.shape or keep.stride() != g.stride():
+                    keep = extra[id(p)] = torch.empty_like(g)
+                keep.copy_(g)
+                g = keep.as_strided(keep.shape, keep.stride())      # a fresh view object: autograd only adopts a gradient
+                                                                    # tensor nobody else references (it would clone `keep`)
             if g.stride() != p.stride() and g.is_contiguous(memory_format=torch.channels_last) and p.dim() == 4 \
                     and p.shape[2] == 1 and p.shape[3] == 1:
                 g = g.as_strided(p.shape, p.stride())                # 1x1 kernels: same memory, the parameter's strides
@@ -891,6 +932,13 @@ class _PlanTrainFn(torch.autograd.Function):
             raise RuntimeError("ayolov2_amd plan: backward of a forward whose saved activations were overwritten by a later "
                                "forward of the same shape (the plan executor keeps ONE set of static buffers per input "
                                "shape); run backward before the next forward, or set model.use_plan = False")
+        if getattr(ctx.plan, "_bwd_generation", None) == ctx.generation:
+            # the BatchNorm sums, the gradient arena and the head bias gradients the fused loss adds into it are zeroed once
+            # per FORWARD: a second backward through the same forward would accumulate on top of the first
+            raise RuntimeError("ayolov2_amd plan: second backward through the same forward (retain_graph / two losses "
+                               "back-propagated separately): sum the losses and call backward once, or set "
+                               "model.use_plan = False")
+        ctx.plan._bwd_generation = ctx.generation
         grads = ctx.plan.run_backward(draws)
         return (None, None) + tuple(grads)
 

@@ -123,9 +123,16 @@ class _FlatSync:
     gradients) and for the compute stream (BatchNorm / bias gradients) -- the compute stream itself never waits, so the
     collective runs under the remaining backward kernels.  ``wait_all`` joins before the optimiser."""
 
-    def __init__(self, group, world: int, sync_bn: bool = False) -> None:
+    def __init__(self, group, world: int, sync_bn: bool = False, compress: Optional[str] = None) -> None:
         self.group, self.world, self.sync_bn = group, world, sync_bn
         self.overlap = os.getenv("AYOLO_DDP_OVERLAP", "1") == "1"
+        # gradient compression of the bucket exchange (SURVEY.md 8e "fp16/bf16 gradient compression optional"): the bucket is
+        # cast to a 16-bit buffer, averaged over the ranks in that type and written back into the fp32 arena -- half the
+        # bytes on the xGMI links (YOLOv5l at 4 images per GPU is the exchange-bound case: 186 MB of fp32 gradients against
+        # a short backward).  "bf16" keeps fp32's range (gradients still carry the GradScaler's factor here); "fp16" has
+        # three more mantissa bits and overflows above 65504.  Off by default: the reference exchanges fp32.
+        self.compress = compress if compress is not None else (os.getenv("AYOLO_DDP_COMPRESS") or None)
+        assert self.compress in (None, "fp16", "bf16"), self.compress
         self._works = []
         self._comm = None
 
@@ -147,12 +154,23 @@ class _FlatSync:
         if self.active():
             self._avg(flat, False)
 
+    def _exchange(self, view: torch.Tensor, async_op: bool):
+        """Average `view` over the ranks in place, through a 16-bit buffer when compression is on.  Returns
+        (work handle or None, finish() or None): finish copies the reduced 16-bit buffer back and must run after the work."""
+        if self.compress is None:
+            return self._avg(view, async_op), None
+        half = view.to(torch.bfloat16 if self.compress == "bf16" else torch.float16)
+        w = self._avg(half, async_op)
+        return w, (lambda: view.copy_(half))
+
     def launch_bucket(self, view: torch.Tensor) -> None:
         """Averaged all-reduce of one finished arena range, asynchronous to the compute stream."""
         if not self.active():
             return
         if not view.is_cuda:
-            self._avg(view, False)
+            w, fin = self._exchange(view, False)
+            if fin is not None:
+                fin()
             return
         from . import _lib
         cur = torch.cuda.current_stream()
@@ -162,13 +180,26 @@ class _FlatSync:
         _lib.call("ayolo_side_stream_join", comm.cuda_stream)              # weight gradients of the bucket (side stream)
         comm.wait_stream(cur)                                                # BatchNorm / bias gradients (compute stream)
         with torch.cuda.stream(comm):
-            w = self._avg(view, True)
-        if w is not None:
-            self._works.append(w)
+            w, fin = self._exchange(view, True)
+            if fin is not None:
+                if w is not None:
+                    w.wait()                                                 # the communication stream waits for the collective
+                fin()
+                w = None
+            # whatever the backend did (NCCL: the collective runs on its own stream behind `w`; gloo / compression: the work
+            # was waited for and the scaling / write-back was enqueued on the communication stream), an event on the
+            # communication stream marks the point the compute stream must wait for
+            ev = torch.cuda.Event()
+            ev.record(comm)
+        self._works.append((w, ev))
 
     def wait_all(self) -> None:
-        for w in self._works:
-            w.wait()                                                         # current stream waits for the collective
+        cur = torch.cuda.current_stream() if self._works and torch.cuda.is_available() else None
+        for w, ev in self._works:
+            if w is not None:
+                w.wait()                                                     # current stream waits for the collective
+            if cur is not None:
+                cur.wait_event(ev)                                           # ... and for what the communication stream did after it
         self._works = []
 
     def average_now(self, t: torch.Tensor) -> None:
@@ -179,7 +210,7 @@ class _FlatSync:
             self._avg(t, False)
 
     def __getstate__(self):                       # checkpoints pickle the whole model: a process group cannot travel
-        return {"group": None, "world": 1, "sync_bn": False, "overlap": True, "_works": [], "_comm": None}
+        return {"group": None, "world": 1, "sync_bn": False, "overlap": True, "compress": None, "_works": [], "_comm": None}
 
 
 class FlatGradDDP(nn.Module):
@@ -193,11 +224,11 @@ class FlatGradDDP(nn.Module):
     (backward) over the ranks, i.e. torch.nn.SyncBatchNorm semantics (train_config.yaml:17 ``sync_bn``, default
     false: statistics then stay local, as in the reference)."""
 
-    def __init__(self, module: nn.Module, process_group=None, sync_bn: bool = False) -> None:
+    def __init__(self, module: nn.Module, process_group=None, sync_bn: bool = False, compress: Optional[str] = None) -> None:
         super().__init__()
         assert dist.is_initialized(), "init_process_group first (TrainModelBuilder.ddp_init)"
         self.module = module
-        self.sync = _FlatSync(process_group, dist.get_world_size(process_group), sync_bn)
+        self.sync = _FlatSync(process_group, dist.get_world_size(process_group), sync_bn, compress)
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t, 0, group=process_group)

@@ -131,3 +131,67 @@ def test_flat_grad_ddp_two_ranks_gloo(tmp_path):
         assert torch.equal(a["state"][k], b["state"][k]), f"not broadcast: {k}"
     want = torch.arange(8, dtype=torch.float32) * 1.5               # mean of x1 and x2
     assert torch.equal(a["flat"], want) and torch.equal(b["flat"], want)
+
+
+def _plan_bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from ayolov2_amd import YOLOModel
+    from ayolov2_amd.plan import TrainPlan
+    from ayolov2_amd.trainer import _FlatSync
+    dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    model = YOLOModel(os.path.join(ROOT, "ayolov2_amd", "configs", "yolov5s.yaml")).train()
+    # the REAL plan of the benchmark model (op lists and arenas are built without launching anything: the CPU will do)
+    plan = TrainPlan(model, (2, 3, 64, 64), torch.float16, torch.device("cpu"))
+    total = plan.gradarena.total
+    buckets = plan.buckets
+    # structure: the buckets tile the arena from the top down, ready indices never decrease, and a bucket is only handed
+    # over after the last backward op that writes into its range has been enqueued
+    assert buckets[0][2] == total and buckets[-1][1] == 0
+    for (r0, lo0, hi0), (r1, lo1, hi1) in zip(buckets, buckets[1:]):
+        assert lo0 == hi1 and r1 >= r0
+    for ready, lo, hi in buckets:
+        last_writer = max(idx for idx, off, n in plan.grad_done if off < hi and off + n > lo)
+        assert ready >= last_writer, (ready, last_writer, lo, hi)
+    assert (buckets[-1][2] - buckets[-1][1]) * 4 < 256 << 10, "the bucket that can only leave after backward must be small"
+    g = torch.Generator().manual_seed(1000 + rank)
+    arena = torch.randn(total, generator=g) * (rank + 1)                   # what this rank's backward would leave in the arena
+    sync = _FlatSync(None, world)
+    flat = arena.clone()
+    sync.reduce_flat(flat)                                                 # reference: ONE averaged all-reduce
+    bucketed = arena.clone()
+    for ready, lo, hi in buckets:                                          # the overlapped exchange, in hand-over order
+        sync.launch_bucket(bucketed[lo:hi])
+    sync.wait_all()
+    assert torch.equal(bucketed, flat)
+    # 16-bit compression of the exchange: the mean of the ROUNDED per-rank buckets, written back into the fp32 arena
+    for kind, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        csync = _FlatSync(None, world, compress=kind)
+        small = (arena * 1e-2).clone()                                     # inside fp16's range
+        comp = small.clone()
+        for ready, lo, hi in buckets:
+            csync.launch_bucket(comp[lo:hi])
+        csync.wait_all()
+        gathered = [torch.empty_like(small) for _ in range(world)]
+        dist.all_gather(gathered, small)
+        want = sum(t.to(dt) for t in gathered)                             # gloo: sum in the 16-bit type, then scale
+        want = (want * (1.0 / world)).float()
+        assert torch.allclose(comp, want, rtol=2 ** -7, atol=1e-6), kind
+        exact = sum(gathered) / world
+        assert float((comp - exact).abs().max()) <= 2 ** (-7 if kind == "bf16" else -10) * float(exact.abs().max()) + 1e-6
+    torch.save({"flat": flat[:64].clone(), "n": len(buckets)}, os.path.join(out, f"pb{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_real_plan_buckets_two_ranks_gloo(tmp_path):
+    """The bucket table of a compiled YOLOv5s TrainPlan (plan.buckets: ranges + hand-over points of the real backward op
+    list) driven through _FlatSync on two gloo ranks: bucket by bucket == one flat all-reduce, with and without 16-bit
+    compression of the exchange."""
+    port = _free_port()
+    mp.spawn(_plan_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "pb0.pt"))
+    b = torch.load(os.path.join(tmp_path, "pb1.pt"))
+    assert torch.equal(a["flat"], b["flat"]) and a["n"] == b["n"] >= 5

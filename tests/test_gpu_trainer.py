@@ -169,3 +169,89 @@ def test_flat_grad_ddp_single_rank_rccl(sync_bn, monkeypatch):
             torch.testing.assert_close(b, outs[1][1][k], rtol=1e-5, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_eval_after_raw_pointer_updates_sees_new_weights():
+    """the inference executor and the per-module weight cache key their folded BatchNorm vectors / fp16
+    weight copies on tensor._version, while ayolo_sgd_step, ayolo_ema_update and the BatchNorm running-statistic update of a
+    training forward write through raw pointers.  The reference validates the SAME ema.ema object after every epoch
+    (yolo_trainer.py:120): validate once (plan built), train, validate again -- the second validation must see the new
+    weights.  Checked against the CPU oracle loaded with the EMA state dict."""
+    from oracle.model_ref import RefYOLO
+    from ayolov2_amd.losses import ComputeLoss
+    from ayolov2_amd.optim import SGD
+    from ayolov2_amd.trainer import ModelEMA, training_step
+    m, _ = _models(5)
+    opt = _optim(SGD, m, lr=0.05)
+    loss_fn = ComputeLoss(m)
+    ema = ModelEMA(m)
+    ema.decay = lambda x: 0.5                                   # make the EMA move visibly in a few steps
+    xv = torch.rand(2, 3, 128, 160, generator=torch.Generator().manual_seed(7)).cuda()
+    with torch.no_grad():
+        z0 = ema.ema(xv)[0].clone()                             # first validation: builds (and caches) the inference plan
+    for step in range(3):
+        x, t = _batch(30 + step)
+        training_step(m, loss_fn, opt, None, x.cuda(), t.cuda(), amp=False, ema=ema)
+    with torch.no_grad():
+        z1 = ema.ema(xv)[0].clone()                             # second validation through the SAME cached plan
+    r = RefYOLO(os.path.join(CFG, "yolov5n.yaml")).eval()
+    r.load_state_dict({k: v.cpu() for k, v in ema.ema.state_dict().items()})
+    with torch.no_grad():
+        zr = r(xv.cpu())[0]
+    assert float((z1 - z0).abs().max()) > 1e-3, "the EMA model did not change: the test would prove nothing"
+    np.testing.assert_allclose(z1.cpu().numpy(), zr.numpy(), rtol=1e-4, atol=2e-3)
+    # the per-module path (use_plan off: fine-tuning of decomposed blocks) stepped by the one-launch SGD: its fp16 weight
+    # cache must follow the update too
+    m.use_plan = False
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a0 = m(xv)[0].float().clone()
+    m.train()
+    x, t = _batch(40)
+    training_step(m, loss_fn, opt, None, x.cuda(), t.cuda(), amp=True, ema=None)
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a1 = m(xv)[0].float().clone()
+    r.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        ar = r(xv.cpu())[0]
+    assert float((a1 - a0).abs().max()) > 1e-3
+    assert float((a1[..., 4:].cpu() - ar[..., 4:]).abs().max()) < 0.02
+
+
+def test_model_copies_after_forwards_and_repeated_backward():
+    """(medium) deepcopy / torch.save of a model that has cached executor plans (the reference deep-copies the EMA
+    model into every checkpoint, yolo_trainer.py:379-386); (medium) the one-launch SGD reuses its job table from step to step
+    (the plan hands out gradients at repeating addresses); (low) a second backward through one forward raises instead of
+    double-accumulating the BatchNorm sums."""
+    import io
+    from ayolov2_amd.losses import ComputeLoss
+    from ayolov2_amd.optim import SGD
+    from ayolov2_amd.trainer import training_step
+    m, _ = _models(6)
+    x, t = _batch(50)
+    x, t = x.cuda(), t.cuda()
+    opt = _optim(SGD, m)
+    loss_fn = ComputeLoss(m)
+    builds = []
+    orig = opt._build_table
+    opt._build_table = lambda *a, **k: (builds.append(1), orig(*a, **k))[1]
+    for _ in range(6):
+        training_step(m, loss_fn, opt, None, x, t, amp=True)
+    assert len(builds) <= 2, f"the SGD job table was rebuilt {len(builds)} times in 6 steps"
+    m.eval()
+    with torch.no_grad():
+        m(x)
+    assert m.__dict__.get("_plans"), "both executors should have cached plans by now"
+    c = copy.deepcopy(m)
+    assert not c.__dict__.get("_plans")
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    with torch.no_grad():
+        np.testing.assert_allclose(c(x)[0].cpu().numpy(), m(x)[0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    m.train()
+    raws = m(x)
+    loss = sum(r.float().square().mean() for r in raws)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss.backward()
