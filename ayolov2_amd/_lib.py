@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+from typing import Optional
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -151,4 +152,47 @@ def bump_versions(tensors) -> None:
     if ts:
         with torch.no_grad():
             torch._C._increment_version(ts)
+
+
+class _Roctx:
+    """roctx ranges (rocprofv3 --marker-trace) around the stages of the train / validation step: the reference's `dt`
+    stage timers and logger lines (scripts/utils/train_utils.py:420-470) as profiler markers.  A no-op
+    when libroctx64 is not on the loader path."""
+
+    def __init__(self) -> None:
+        self._lib = None
+        for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+            try:
+                self._lib = ctypes.CDLL(name)
+                self._lib.roctxRangePushA.argtypes = [c_char_p]
+                break
+            except OSError:
+                continue
+
+    def push(self, name: str) -> None:
+        if self._lib is not None:
+            self._lib.roctxRangePushA(name.encode())
+
+    def pop(self) -> None:
+        if self._lib is not None:
+            self._lib.roctxRangePop()
+
+
+_roctx: Optional[_Roctx] = None
+
+
+class roctx_range:
+    def __init__(self, name: str) -> None:
+        self.name = name
+
+    def __enter__(self):
+        global _roctx
+        if _roctx is None:
+            _roctx = _Roctx()
+        _roctx.push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _roctx.pop()
+        return False
 

@@ -350,6 +350,7 @@ class InferPlan:
         self.cast_arr = (Op * 1)(_op(OP_CAST_WEIGHTS, i=(len(self.casts), ops.dtype_code(self.dt)), p=(tab,)))
         self.fwd_arr = (Op * len(self.fwd))(*self.fwd)
         self.pack_idx = next(k for k, o in enumerate(self.fwd) if o is self.pack_op)
+        self.decode_idx = [k for k, o in enumerate(self.fwd) if (o.kind & 0xff) == OP_HEAD_DECODE]
         self._tracked = [t for f, _ in self.folds for t in f.tensors()]
         self._ptrs = tuple(t.data_ptr() for t in self._tracked)
 
@@ -370,15 +371,23 @@ class InferPlan:
             self._versions = vers
         self._x_keep = x
         self.fwd_arr[self.pack_idx].p[0] = x.data_ptr()
+        # The decoded prediction -- what val.py keeps, post-processes and may hold across batches (`out, train_out =
+        # model(img)`, train_utils.py:441-444) -- is written into a tensor that belongs to THIS call: the decode ops are
+        # pointed at a fresh allocation (caching allocator: no device malloc, no extra copy).  model.static_outputs = True
+        # keeps the round-2 behaviour (one static buffer, overwritten by the next forward of the same shape).
+        out = self.out if getattr(self.model, "static_outputs", False) else torch.empty_like(self.out)
+        for k in self.decode_idx:
+            self.fwd_arr[k].p[2] = out.data_ptr()
         _lib.check(_lib.lib().ayolo_run_ops(self.fwd_arr, len(self.fwd), st), "ayolo_run_ops(inference)")
+        # the raw per-level logits stay views of the executor's static buffers (valid until the next forward of this shape)
         raws = [buf.as_strided(shape, strides) for buf, shape, strides in self.raw_specs]
-        return self.out, raws
+        return out, raws
 
 
 def plan_forward_eval(model, x: torch.Tensor):
     """Eval forward through the cached inference plan; returns (decoded, raws) or None if the structure is unsupported.
-    The returned tensors are views of plan-owned static buffers: the next forward of the same shape overwrites them
-    (clone what must survive, as with any cudagraph-style static executor)."""
+    `decoded` is a tensor of its own (the decode kernels write into a fresh allocation per call); the raw per-level logits
+    are views of plan-owned static buffers that the next forward of the same shape overwrites."""
     w = next((p for p in model.parameters()), None)
     dt = torch.float16 if (torch.is_autocast_enabled() or (w is not None and w.dtype == torch.float16)) else torch.float32
     key = ("eval", tuple(x.shape), dt, x.device)

@@ -289,19 +289,24 @@ def training_step(model: nn.Module, loss_fn, optimizer: torch.optim.Optimizer, s
                   targets: torch.Tensor, world_size: int = 1, amp: bool = True, ema: Optional["ModelEMA"] = None):
     """autocast forward -> ComputeLoss -> (x world_size under DDP) -> scaled backward -> step (accumulate = 1) -> EMA
     (yolo_trainer.py:322-338)."""
-    with torch.autocast(imgs.device.type, dtype=torch.float16, enabled=amp and imgs.is_cuda):
+    from ._lib import roctx_range
+    with roctx_range("train.forward+loss"), torch.autocast(imgs.device.type, dtype=torch.float16, enabled=amp and imgs.is_cuda):
         pred = model(imgs)
         loss, items = loss_fn(pred, targets)
     if world_size > 1:
         loss = loss * world_size
-    if scaler is not None:
-        scaler.scale(loss).backward()
-        scaler.step(optimizer)
-        scaler.update()
-    else:
-        loss.backward()
-        optimizer.step()
-    optimizer.zero_grad(set_to_none=True)
-    if ema is not None:
-        ema.update(model)
+    with roctx_range("train.backward"):
+        if scaler is not None:
+            scaler.scale(loss).backward()
+        else:
+            loss.backward()
+    with roctx_range("train.optimizer"):
+        if scaler is not None:
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+        if ema is not None:
+            ema.update(model)
     return loss.detach(), items

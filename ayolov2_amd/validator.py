@@ -119,7 +119,32 @@ class YoloValidator:
     def init_statistics(self) -> None:
         self.seen = 0
         self.loss = torch.zeros(3, device=self.device)
-        self.statistics: Dict[str, Any] = {"stats": []}
+        # dt: seconds spent in pre-process / inference / NMS over the run (train_utils.py:420-470).  On the GPU the stages are
+        # asynchronous, so they are bracketed by events on the stream and summed when the statistics are read -- the
+        # reference's host clocks around un-synchronised launches would time the enqueue, and a synchronise per stage would
+        # serialise the loop
+        self.statistics: Dict[str, Any] = {"stats": [], "dt": [0.0, 0.0, 0.0]}
+        self._dt_events: list = []
+
+    def _mark(self):
+        if self.device.type != "cuda":
+            import time
+            return time.perf_counter()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stage_times(self) -> List[float]:
+        """[pre-process, inference, NMS] seconds so far; resolves the pending events (one synchronise)."""
+        for marks in self._dt_events:
+            for k, (a, b) in enumerate(marks):
+                if isinstance(a, float):
+                    self.statistics["dt"][k] += b - a
+                else:
+                    b.synchronize()
+                    self.statistics["dt"][k] += a.elapsed_time(b) * 1e-3
+        self._dt_events = []
+        return self.statistics["dt"]
 
     @staticmethod
     def convert_target(targets: torch.Tensor, width: int, height: int, n_batch: int = 0) -> torch.Tensor:
@@ -138,19 +163,25 @@ class YoloValidator:
 
     @torch.no_grad()
     def validation_step(self, val_batch, batch_idx: int = 0) -> None:
+        from ._lib import roctx_range
         imgs, targets, paths, shapes = val_batch
         targets_cpu = targets.detach().float().cpu()                 # labels come from the host loader: no sync needed later
-        imgs = imgs.to(self.device, non_blocking=True)
-        if imgs.dtype == torch.uint8:                                # prepare_img (train_utils.py:256-261)
-            imgs = imgs.float() / 255.0
-        imgs = imgs.half() if self.half else imgs.float()
-        targets = targets.to(self.device, non_blocking=True)
+        t0 = self._mark()
+        with roctx_range("val.pre_process"):
+            imgs = imgs.to(self.device, non_blocking=True)
+            if imgs.dtype == torch.uint8:                            # prepare_img (train_utils.py:256-261)
+                imgs = imgs.float() / 255.0
+            imgs = imgs.half() if self.half else imgs.float()
+            targets = targets.to(self.device, non_blocking=True)
         _, _, height, width = imgs.shape
-        if self.tta:                                                 # train_utils.py:425-433
-            from .tta import inference_with_tta
-            outs = inference_with_tta(self.model, imgs, self.tta_scales, self.tta_flips)
-        else:
-            outs = self.model(imgs)
+        t1 = self._mark()
+        with roctx_range("val.inference"):
+            if self.tta:                                             # train_utils.py:425-433
+                from .tta import inference_with_tta
+                outs = inference_with_tta(self.model, imgs, self.tta_scales, self.tta_flips)
+            else:
+                outs = self.model(imgs)
+        t2 = self._mark()
         out, train_out = (outs[0], outs[1]) if isinstance(outs, (tuple, list)) and len(outs) == 2 else (outs, None)
         trt_case = isinstance(train_out, torch.Tensor)               # engine with the NMS plugin appended (train_utils.py:456-457)
         if self.loss_fn is not None and train_out is not None and not trt_case:
@@ -158,11 +189,15 @@ class YoloValidator:
         targets = self.convert_target(targets, width, height)
         targets_cpu = self.convert_target(targets_cpu, width, height)
         lb = [targets[targets[:, 0] == i, 1:] for i in range(imgs.shape[0])] if self.hybrid_label else None
-        if trt_case:
-            out = self.convert_trt_out(out, train_out)
-        else:
-            out = non_max_suppression(out, self.cfg_hyp["conf_t"], self.cfg_hyp["iou_t"], multi_label=True, labels=lb or (),
-                                      agnostic=self.single_cls, nms_type=self.nms_type)
+        t3 = self._mark()
+        with roctx_range("val.nms"):
+            if trt_case:
+                out = self.convert_trt_out(out, train_out)
+            else:
+                out = non_max_suppression(out, self.cfg_hyp["conf_t"], self.cfg_hyp["iou_t"], multi_label=True, labels=lb or (),
+                                          agnostic=self.single_cls, nms_type=self.nms_type)
+        t4 = self._mark()
+        self._dt_events.append(((t0, t1), (t1, t2), (t3, t4)))
         self.statistics_per_image(imgs, out, targets, shapes, paths, targets_cpu=targets_cpu)
 
     def statistics_per_image(self, img: torch.Tensor, out: List[torch.Tensor], targets: torch.Tensor, shapes, paths=None,
@@ -213,7 +248,7 @@ class YoloValidator:
     def compute_statistics(self) -> Dict[str, Any]:
         """train_utils.py:474-520: (mp, mr, map50, map) + per-class arrays."""
         stats = [np.concatenate(x, 0) for x in zip(*self.statistics["stats"])] if self.statistics["stats"] else []
-        res: Dict[str, Any] = {"mp": 0.0, "mr": 0.0, "map50": 0.0, "map": 0.0, "seen": self.seen}
+        res: Dict[str, Any] = {"mp": 0.0, "mr": 0.0, "map50": 0.0, "map": 0.0, "seen": self.seen, "dt": list(self.stage_times())}
         if len(stats) and stats[0].any():
             p, r, ap, f1, ap_class = ap_per_class(*stats)
             ap50, ap_m = ap[:, 0], ap.mean(1)

@@ -78,6 +78,24 @@ def test_infer_plan_tracks_weight_updates():
     np.testing.assert_allclose(zg.cpu().numpy(), zr.numpy(), rtol=1e-4, atol=2e-3)
 
 
+def test_eval_prediction_survives_the_next_forward():
+    """A val.py-style loop may keep `out` of batch i while batch i + 1 runs: the decoded prediction belongs to the call
+    that produced it; only with model.static_outputs = True is it the executor's static buffer."""
+    m, _ = _pair("n", seed=36)
+    m = m.cuda().eval()
+    x0, x1 = torch.rand(2, 3, 64, 96).cuda(), torch.rand(2, 3, 64, 96).cuda()
+    with torch.no_grad():
+        out0, _ = m(x0)
+        keep = out0.clone()
+        out1, _ = m(x1)
+        assert out1.data_ptr() != out0.data_ptr() and torch.equal(out0, keep) and not torch.equal(out1, keep)
+        m.static_outputs = True
+        s0, _ = m(x0)
+        s1, _ = m(x1)
+        assert s0.data_ptr() == s1.data_ptr()
+        assert torch.equal(s1, out1)
+
+
 def test_infer_plan_fp16_yolov5s():
     """The dtype validation runs in (`half` models / autocast): fp16 storage, fp32 accumulation.  Tolerance: 2 % of the
     logit range (same bar as the fp16 train-step tests)."""

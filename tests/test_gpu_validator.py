@@ -83,3 +83,6 @@ def test_validator_end_to_end_matches_host_replay():
     np.testing.assert_allclose(res["map50"], ap[:, 0].mean(), rtol=1e-12)
     np.testing.assert_allclose(res["map"], ap.mean(1).mean(), rtol=1e-12)
     np.testing.assert_allclose(res["mp"], p.mean(), rtol=1e-12)
+    # the reference's stage timers (train_utils.py:420-470): pre-process / inference / NMS seconds, event-timed on the stream
+    dt = res["dt"]
+    assert len(dt) == 3 and all(t > 0 for t in dt) and val.statistics["dt"] == dt
