@@ -1727,7 +1727,7 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     using G = GT<T, TM, TPX>;
     const size_t lds = G::LDS;
     p.ntn = (p.Nout + TM - 1) / TM;
-    static const int bpc_env = getenv("AYOLO_GCONV_BPC") ? atoi(getenv("AYOLO_GCONV_BPC")) : 0;
+    constexpr int bpc_env = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if constexpr (sizeof(T) == 2 && EM != 3 && EM != 1) {
@@ -1856,8 +1856,7 @@ static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
     // ... except where the last 128-wide tile would be half empty (192 / 320 output channels) on a small map: there the
     // 64-wide tiling is exact and the extra pixel-tile reads stay in L2 (YOLOv5x, batch 8 at 1280^2: 320 -> 320 3x3 on 80x80
     // 154 vs 169 us; on the 160x160 maps the 128-wide tiles still win)
-    static const int ragged64 = getenv("AYOLO_GCONV_RAGGED64") ? atoi(getenv("AYOLO_GCONV_RAGGED64")) : 1;
-    if (ragged64 && p.Nout > 128 && p.Nout % 128 == 64 && p.Mtotal <= 65536) tm = 64;
+    if (p.Nout > 128 && p.Nout % 128 == 64 && p.Mtotal <= 65536) tm = 64;
     if (force_tm == 32 || force_tm == 64 || force_tm == 128) tm = force_tm;
     if (dtype == AYOLO_F16) {
         if (tm == 32) return launch_gconv<half_t, 32>(p, s);
@@ -1910,9 +1909,8 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     }
     // 3x3, stride 1, same-size maps (the Bottleneck 3x3 convs and their dgrad): k_gconv3
     static const int row3_on = getenv("AYOLO_GCONV_ROW3") ? atoi(getenv("AYOLO_GCONV_ROW3")) : 1;
-    static const int row3_ragged = getenv("AYOLO_GCONV_ROW3_RAGGED") ? atoi(getenv("AYOLO_GCONV_ROW3_RAGGED")) : 1;
     p.row3 = 0;
-    if (row3_on && (row3_ragged || p.C % BK == 0) && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 1 && p.isw == 1 && p.osh == 1 && p.osw == 1 &&
+    if (row3_on && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 1 && p.isw == 1 && p.osh == 1 && p.osw == 1 &&
         p.XH == p.OH && p.XW == p.OW && p.YH == p.OH && p.YW == p.OW && p.C >= BK && p.epi != AYOLO_EPI_HEAD &&
         // channels beyond C in the last 32-wide chunk are fetched as zeros (x and W): at most a quarter of the MFMA work
         ((p.C + BK - 1) / BK * BK - p.C) * 4 <= (p.C + BK - 1) / BK * BK) {
@@ -2026,9 +2024,8 @@ static int conv_dgrad_impl(const ayolo_conv_desc* d, const void* dy, const void*
     // Residue classes (a, b) = (h mod sh, w mod sw).  When every class has the same output grid (H % sh == W % sw == 0)
     // ONE launch walks all of them per dy tile: dy is read from HBM once instead of once per class (the later classes
     // hit L2) and the classes' interleaved half-line writes of dx meet in L2.  Otherwise one launch per class.
-    static const bool no_merge = getenv("AYOLO_NO_DGRAD_MERGE") != nullptr;
     const int ncls_all = d->sh * d->sw;
-    const bool merge = !no_merge && ncls_all > 1 && ncls_all <= 4 && d->H % d->sh == 0 && d->W % d->sw == 0 &&
+    const bool merge = ncls_all > 1 && ncls_all <= 4 && d->H % d->sh == 0 && d->W % d->sw == 0 &&
                        d->kh * d->kw <= MAX_TAPS;
     GConvP m{};
     int mt = 0;
@@ -2307,9 +2304,8 @@ static int launch_wgrad(WGradP p, hipStream_t s) {
     // Split the pixel reduction.  More splits = more workgroups in flight but N*K fp32 atomics per split: with a step
     // time t_step per workgroup and an L2 atomic rate R the cost A*s + B/(tiles*s) is minimal at
     // s* = sqrt(steps_per_tile * t_step * R / (N*K))  (measured: t_step*R ~ 1.5e5), capped by ~3 workgroups per CU.
-    static const double ka = getenv("AYOLO_WGRAD_KA") ? atof(getenv("AYOLO_WGRAD_KA")) : 1.5e5;
-    static const int bpc_env = getenv("AYOLO_WGRAD_BPC") ? atoi(getenv("AYOLO_WGRAD_BPC")) : 0;
-    const int bpc = bpc_env > 0 ? bpc_env : (sizeof(T) == 2 ? 3 : 1);
+    const double ka = 1.5e5;
+    const int bpc = sizeof(T) == 2 ? 3 : 1;
     long long cap = ((long long)num_cus() * bpc + tiles - 1) / tiles;
     const double steps_per_tile = (double)p.P / W::BP;
     long long want = (long long)(sqrt(steps_per_tile * ka / ((double)p.N * (double)p.K)) + 0.5);

@@ -269,10 +269,9 @@ extern "C" int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, in
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && lda % ve == 0 && (!residual || ldr % ve == 0) && C <= 2048,
                  "bn_train_act: C=%d ldz=%d lda=%d", C, ldz, lda);
     if (npix == 0) return AYOLO_OK;
-    static const int act_iters = getenv("AYOLO_ACT_ITERS") ? atoi(getenv("AYOLO_ACT_ITERS")) : 16;
-    static const int act_cap = getenv("AYOLO_ACT_CAP") ? atoi(getenv("AYOLO_ACT_CAP")) : 1024;
-    unsigned grid = grid_pixels(npix, C, ve, act_iters);
-    if (grid > (unsigned)act_cap) grid = (unsigned)act_cap;
+    // >= 16 pixels per thread, at most 4 workgroups per CU: measured best on every YOLOv5s layer (profiles/r03_bn_grid_sweep.txt)
+    unsigned grid = grid_pixels(npix, C, ve, 16);
+    if (grid > 1024u) grid = 1024u;
     DISPATCH_T(dtype, DISPATCH_AR(act, residual != nullptr,
                hipLaunchKernelGGL((k_bn_train_act<T, ACT, RES>), dim3(grid), dim3(256), 2 * C * sizeof(float), (hipStream_t)s,
                                   (const T*)z, ldz, (T*)a, lda, (long long)npix, C, stats, stat_reps > 0 ? stat_reps : 1,
@@ -410,10 +409,8 @@ extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const 
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && C <= 2048, "bn_bwd_reduce: C=%d", C);
     if (npix == 0) return AYOLO_OK;
     // >= 16 pixels per thread, at most 4 workgroups per CU (measured best): the per-workgroup tail (2*C atomics) stays small
-    static const int red_iters = getenv("AYOLO_RED_ITERS") ? atoi(getenv("AYOLO_RED_ITERS")) : 16;
-    static const int red_cap = getenv("AYOLO_RED_CAP") ? atoi(getenv("AYOLO_RED_CAP")) : 1024;
-    unsigned grid = grid_pixels(npix, C, ve, red_iters);
-    if (grid > (unsigned)red_cap) grid = (unsigned)red_cap;
+    unsigned grid = grid_pixels(npix, C, ve, 16);
+    if (grid > 1024u) grid = 1024u;
     const int cg_ = C / ve, cgt_ = cg_ < 256 ? cg_ : 256, rpb_ = 256 / cgt_;
     DISPATCH_T(dtype, DISPATCH_AR(act, false,
                (void)RES; hipLaunchKernelGGL((k_bn_bwd_reduce<T, ACT>), dim3(grid), dim3(256), (size_t)rpb_ * 2 * C * sizeof(float),
@@ -507,189 +504,13 @@ extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const v
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && lddz % ve == 0 && C <= 2048, "bn_bwd_apply: C=%d", C);
     if (npix == 0) return AYOLO_OK;
     // the per-workgroup prologue stages (6 + 2*reps)*C floats in LDS: scale the elements per workgroup with C
-    static const int app_iters = getenv("AYOLO_APP_ITERS") ? atoi(getenv("AYOLO_APP_ITERS")) : 0;
-    static const int app_cap = getenv("AYOLO_APP_CAP") ? atoi(getenv("AYOLO_APP_CAP")) : 2048;
-    unsigned grid = grid_pixels(npix, C, ve, app_iters > 0 ? app_iters : (C >= 256 ? 16 : 8));
-    if (grid > (unsigned)app_cap) grid = (unsigned)app_cap;
+    unsigned grid = grid_pixels(npix, C, ve, C >= 256 ? 16 : 8);
+    if (grid > 2048u) grid = 2048u;
     DISPATCH_T(dtype, DISPATCH_AR(act, false,
                (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s,
                                   (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,
                                   save_invstd, gamma, beta, sums, sum_reps, dgamma, dbeta, grad_scale);))
     AY_CHECK_LAUNCH("k_bn_bwd_apply");
-    return AYOLO_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// BN + activation backward in ONE pass for layers small enough to live in the register file of the resident grid
-// (the 20^2 / 40^2 maps of a batch-64 step: <= 16.7 M elements).  Every thread keeps its <= FE (z, da) 16-byte vectors in
-// registers: phase 1 accumulates sum(du), sum(du*xhat) (row partials in LDS, one global atomic per channel sum and
-// workgroup); a grid-wide barrier (one arrival counter per launch, zeroed by the caller) makes the totals visible; phase 2
-// computes dz from the SAME registers.  z and da are read once instead of twice and the layer is one launch instead of two
-// (on these latency-bound layers the two-kernel form cost 35-60 us in situ).  Same arithmetic per element as
-// k_bn_bwd_reduce + k_bn_bwd_apply (du is recomputed in phase 2, not rounded to fp16 in between).
-//
-// Residency: the barrier needs every workgroup of the grid resident at once.  The host sizes the grid to 2 workgroups per
-// CU (launch bounds 256 x 2 -> 256 VGPRs each).  Kernels of OTHER streams may hold CU slots when this one starts (the
-// executor's side-stream weight gradients): they never wait for this kernel, so they drain and the late workgroups of this
-// grid get their slots -- the barrier only takes longer.  The spin is bounded and traps instead of hanging.
-// ---------------------------------------------------------------------------------------------------
-#define BN_FUSED_FE 16
-template <typename T, int ACT>
-__global__ __launch_bounds__(256, 2) void k_bn_bwd_fused(const T* z, int ldz, const T* da, int ldda, T* dz, int lddz,
-                                                         long long npix, int C, const float* mean, const float* invstd,
-                                                         const float* gamma, const float* beta, float* sums,
-                                                         unsigned* barrier, float* dgamma, float* dbeta, float grad_scale) {
-    static_assert(sizeof(T) == 2, "fp16 storage only (the fp32 parity mode keeps the two-pass kernels)");
-    constexpr int VE = 8;
-    extern __shared__ float bs[];   // phase 1: [RPB][2*C] row partials; phase 2: [2][C] totals / n
-    const int CG = C / VE;          // host: CG is a power of two <= 256, so RPB * CG == 256 and every thread owns a column
-    const int RPB = 256 / CG;
-    const int cg = threadIdx.x % CG, prow = threadIdx.x / CG;
-    constexpr bool live = true;
-    const long long stride = (long long)gridDim.x * RPB;
-    const long long pix0 = (long long)blockIdx.x * RPB + prow;
-    float is[VE], A[VE], Bc[VE], nmi[VE], P[VE];
-#pragma unroll
-    for (int i = 0; i < VE; ++i) {
-        const int c = cg * VE + i;
-        const float mu = mean[c], ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
-        is[i] = invstd[c];
-        A[i] = is[i] * ga; Bc[i] = be - mu * A[i]; nmi[i] = -mu * is[i]; P[i] = ga * is[i];
-    }
-    // branch-free loads / stores through buffer descriptors: a slot beyond the tensor (or an idle thread) uses an offset
-    // outside the descriptor -> the hardware returns zeros / drops the store (the host checks the extents are < 2 GiB)
-    typedef unsigned int bv4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc((void*)z, 0, (int)(((npix - 1) * ldz + C) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)da, 0, (int)(((npix - 1) * ldda + C) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)dz, 0, (int)(((npix - 1) * lddz + C) * 2), 0x00020000);
-    bv4 rz[BN_FUSED_FE], rd[BN_FUSED_FE];
-#pragma unroll
-    for (int j = 0; j < BN_FUSED_FE; ++j) {
-        const long long pix = pix0 + j * stride;
-        const bool ok = live && pix < npix;
-        rz[j] = __builtin_amdgcn_raw_buffer_load_b128(rZ, ok ? (unsigned)((pix * ldz + cg * VE) * 2) : 0x80000000u, 0, 0);
-        rd[j] = __builtin_amdgcn_raw_buffer_load_b128(rD, ok ? (unsigned)((pix * ldda + cg * VE) * 2) : 0x80000000u, 0, 0);
-    }
-    float s1[VE], s2[VE];
-#pragma unroll
-    for (int i = 0; i < VE; ++i) { s1[i] = 0.0f; s2[i] = 0.0f; }
-#pragma unroll
-    for (int j = 0; j < BN_FUSED_FE; ++j) {
-        const T* zh = reinterpret_cast<const T*>(&rz[j]);
-        const T* dh = reinterpret_cast<const T*>(&rd[j]);
-#pragma unroll
-        for (int i = 0; i < VE; ++i) {
-            float xh, du;
-            bn_bwd_elem<T, ACT>((float)zh[i], (float)dh[i], 0.0f, is[i], 0.0f, 0.0f, A[i], Bc[i], nmi[i], xh, du);
-            s1[i] += du;                                   // padded slots hold da = 0 -> du = 0: they add nothing
-            s2[i] = __builtin_fmaf(du, xh, s2[i]);
-        }
-        __builtin_amdgcn_sched_barrier(0);                 // one vector at a time: keep the other 30 packed (register budget)
-    }
-    {
-        float* row = bs + (size_t)prow * 2 * C + cg * VE;
-#pragma unroll
-        for (int i = 0; i < VE; ++i) { row[i] = s1[i]; row[C + i] = s2[i]; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) {
-        float t = 0.0f;
-        for (int r = 0; r < RPB; ++r) t += bs[(size_t)r * 2 * C + i];
-        atomicAdd(&sums[i], t);
-    }
-    // ---- grid barrier: all partial sums are in L2 before anyone reads the totals
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 26)) __builtin_trap();   // ~10 s: a grid that can never be co-resident must not hang the box
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
-    __syncthreads();
-    const float invn = 1.0f / (float)npix;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) {
-        const float t = __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not a stale L1 line
-        bs[i] = t * invn;
-        if (blockIdx.x == 0) {
-            if (i < C) { if (dbeta) dbeta[i] = t * grad_scale; }
-            else if (dgamma) dgamma[i - C] = t * grad_scale;
-        }
-    }
-    __syncthreads();
-    // Phase 2 recomputes xhat / du from the packed registers.  Without this, the compiler keeps all 256 phase-1 results
-    // alive across the barrier instead (common subexpressions) and spills them: make the registers opaque.
-#pragma unroll
-    for (int j = 0; j < BN_FUSED_FE; ++j) asm volatile("" : "+v"(rz[j]), "+v"(rd[j]));
-    float Q[VE], Rr[VE];
-#pragma unroll
-    for (int i = 0; i < VE; ++i) { Q[i] = -P[i] * bs[cg * VE + i]; Rr[i] = -P[i] * bs[C + cg * VE + i]; }
-#pragma unroll
-    for (int j = 0; j < BN_FUSED_FE; ++j) {
-        const long long pix = pix0 + j * stride;
-        const T* zh = reinterpret_cast<const T*>(&rz[j]);
-        const T* dh = reinterpret_cast<const T*>(&rd[j]);
-        half8 o;
-#pragma unroll
-        for (int i = 0; i < VE; ++i) {
-            float xh, du;
-            bn_bwd_elem<T, ACT>((float)zh[i], (float)dh[i], 0.0f, is[i], 0.0f, 0.0f, A[i], Bc[i], nmi[i], xh, du);
-            o[i] = (half_t)__builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bv4, o), rO, pix < npix ? (unsigned)((pix * lddz + cg * VE) * 2) : 0x80000000u, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// 0 when the fused kernel can take this layer (fp16, channel groups divide a workgroup, every element fits the resident
-// grid's registers); the caller then zeroes sums[2*C] and *barrier and calls ayolo_bn_act_bwd_fused
-extern "C" int ayolo_bn_act_bwd_fused_ok(int dtype, int64_t npix, int C) {
-    if (dtype != AYOLO_F16 || C <= 0 || C % 8 != 0 || C > 2048) return 0;
-    const int cg = C / 8;
-    if (cg > 256 || (cg & (cg - 1)) != 0) return 0;         // channel groups must tile the 256-thread workgroup exactly
-    const int rpb = 256 / cg;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
-    const long long grid = 2ll * cus;
-    return npix <= grid * rpb * BN_FUSED_FE ? 1 : 0;
-}
-
-extern "C" int ayolo_bn_act_bwd_fused(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
-                                      int64_t npix, int C, const float* save_mean, const float* save_invstd, const float* gamma,
-                                      const float* beta, int act, float* sums, unsigned* barrier, float* dgamma, float* dbeta,
-                                      float grad_scale, ayolo_stream s) {
-    AY_CHECK_ARG(z && da && dz && sums && barrier && save_mean && save_invstd, "bn_bwd_fused: null pointer");
-    AY_CHECK_ARG(ldz % 8 == 0 && ldda % 8 == 0 && lddz % 8 == 0, "bn_bwd_fused: channel strides must be multiples of 8");
-    AY_CHECK_ARG(ayolo_bn_act_bwd_fused_ok(dtype, npix, C), "bn_bwd_fused: layer of %lld x %d does not fit the resident grid", (long long)npix, C);
-    AY_CHECK_ARG(npix * (int64_t)(ldz > ldda ? (ldz > lddz ? ldz : lddz) : (ldda > lddz ? ldda : lddz)) * 2 < (1ll << 31), "bn_bwd_fused: tensor extent >= 2 GiB");
-    if (npix == 0) return AYOLO_OK;
-    const int cg = C / 8, rpb = 256 / cg;
-    static int cus_cache[16] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int cus = (dev >= 0 && dev < 16) ? cus_cache[dev] : 0;
-    if (cus == 0) {
-        hipDeviceProp_t prop;
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        if (dev >= 0 && dev < 16) cus_cache[dev] = cus;
-    }
-    // as few workgroups as hold the layer (every one must be resident), at least enough to spread over the CUs
-    long long need = (npix + (long long)rpb * BN_FUSED_FE - 1) / ((long long)rpb * BN_FUSED_FE);
-    long long grid = need < cus ? (npix + rpb - 1) / rpb < cus ? (npix + rpb - 1) / rpb : cus : need;
-    if (grid > 2ll * cus) grid = 2ll * cus;
-    const size_t lds = (size_t)rpb * 2 * C * sizeof(float);
-    if (act) hipLaunchKernelGGL((k_bn_bwd_fused<half_t, 1>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)s, (const half_t*)z, ldz,
-                                (const half_t*)da, ldda, (half_t*)dz, lddz, (long long)npix, C, save_mean, save_invstd, gamma, beta, sums,
-                                barrier, dgamma, dbeta, grad_scale);
-    else hipLaunchKernelGGL((k_bn_bwd_fused<half_t, 0>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)s, (const half_t*)z, ldz,
-                            (const half_t*)da, ldda, (half_t*)dz, lddz, (long long)npix, C, save_mean, save_invstd, gamma, beta, sums,
-                            barrier, dgamma, dbeta, grad_scale);
-    AY_CHECK_LAUNCH("k_bn_bwd_fused");
     return AYOLO_OK;
 }
 

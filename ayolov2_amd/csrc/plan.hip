@@ -3,14 +3,7 @@
 // static buffers, so a training step costs two host calls instead of ~1600 Python-level launches, and the
 // list is a straight-line HIP stream program (graph-capturable).
 #include "common.h"
-#include <time.h>
 #include <stdlib.h>
-
-static inline double now_us() {
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
-}
 
 // Zero fill as an ordinary kernel on the caller's stream.  hipMemsetAsync was observed (ROCm 7.2, null stream) to
 // complete AFTER kernels enqueued behind it when the GPU was idle, wiping partially accumulated BN sums.
@@ -52,29 +45,15 @@ static int side_ctx(SideCtx** out) {
     SideCtx& c = t_side[dev];
     if (!c.side) {
         // lowest priority: the side stream carries the weight gradients, which only have to finish by the end of the
-        // list -- the dependent chain on the caller's stream (BN passes, dgrads) should win the CUs when both have work
-        static const int prio_env = getenv("AYOLO_SIDE_PRIORITY") ? atoi(getenv("AYOLO_SIDE_PRIORITY")) : 1;
+        // list -- the dependent chain on the caller's stream (BN passes, dgrads) should win the CUs when both have work.
+        // Measured alternatives, none kept: highest / default priority (+0.8 % / +0.3 %), several side streams, a CU mask
+        // (hipExtStreamCreateWithCUMask, 64 / 128 CUs for the side stream: 24.0 / 21.4 ms per step against 15.1 --
+        // profiles/r03_scheduling_ab.txt: the weight gradients are latency-bound per workgroup, so confining them to a
+        // quarter of the chip stretches them far beyond the backward window)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        static const int nside_env = getenv("AYOLO_SIDE_STREAMS") ? atoi(getenv("AYOLO_SIDE_STREAMS")) : 1;
-        c.nside = nside_env < 1 ? 1 : (nside_env > AY_MAX_SIDE ? AY_MAX_SIDE : nside_env);
-        // AYOLO_SIDE_CUS = n: the side stream may only use n of the device's compute units (CU mask), so the weight
-        // gradients cannot take slots / bandwidth from the dependent chain on more than that part of the chip
-        static const int side_cus = getenv("AYOLO_SIDE_CUS") ? atoi(getenv("AYOLO_SIDE_CUS")) : 0;
-        for (int k = 0; k < c.nside; ++k) {
-            hipStream_t* st = k == 0 ? &c.side : &c.more[k - 1];
-            if (side_cus > 0) {
-                hipDeviceProp_t prop;
-                AY_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-                uint32_t mask[32] = {0};
-                const int total = prop.multiProcessorCount > 1024 ? 1024 : prop.multiProcessorCount;
-                const int ncu = side_cus > total ? total : side_cus;
-                for (int b = 0; b < ncu; ++b) mask[b >> 5] |= 1u << (b & 31);
-                AY_CHECK_HIP(hipExtStreamCreateWithCUMask(st, (uint32_t)((total + 31) / 32), mask));
-            }
-            else if (prio_env == 0) AY_CHECK_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-            else AY_CHECK_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_env > 0 ? least : greatest));
-        }
+        c.nside = 1;
+        AY_CHECK_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, least));
         AY_CHECK_HIP(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
         AY_CHECK_HIP(hipEventCreateWithFlags(&c.join, hipEventDisableTiming));
     }
@@ -162,8 +141,6 @@ extern "C" int ayolo_run_ops_timed(const ayolo_op* ops, int n, ayolo_stream s, f
 
 static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, hipEvent_t* ev) {
     AY_CHECK_ARG(ops || n == 0, "run_ops: null op list");
-    static const bool debug_stall = getenv("AYOLO_DEBUG_STALL") != nullptr;
-    double t_prev = debug_stall ? now_us() : 0.0;
     bool used_side = false;
     SideCtx* sc = nullptr;
     for (int k = 0; k < n; ++k) {
@@ -182,11 +159,6 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
             }
             cs = (ayolo_stream)forked;
             used_side = true;
-        }
-        if (debug_stall) {
-            double t = now_us();
-            if (t - t_prev > 500.0) fprintf(stderr, "[ayolo] run_ops: op %d/%d (kind %d) was blocked %.1f us in the HIP runtime\n", k - 1, n, k ? ops[k - 1].kind : 0, t - t_prev);
-            t_prev = t;
         }
         const bool timed = ev && (o.kind & 0xff) != AYOLO_OP_NOP;
         if (timed) AY_CHECK_HIP(hipEventRecord(ev[2 * k], (hipStream_t)cs));
@@ -262,13 +234,6 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
             break;
         case AYOLO_OP_MEMSET:
             rc = ayolo_fill_zero(o.p[0], (size_t)o.l[0], cs);
-            break;
-        case AYOLO_OP_BN_BWD_FUSED:
-            // p: z, da, dz, save_mean (save_invstd follows at +C), gamma, beta, sums[2C] (the barrier word follows), dgamma, dbeta
-            rc = ayolo_bn_act_bwd_fused(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.p[2], o.i[3], o.l[0], o.i[4], (const float*)o.p[3],
-                                        (const float*)o.p[3] + o.i[4], (const float*)o.p[4], (const float*)o.p[5], o.i[5],
-                                        (float*)o.p[6], (unsigned*)((float*)o.p[6] + 2 * o.i[4]), (float*)o.p[7], (float*)o.p[8],
-                                        o.f[0], cs);
             break;
         case AYOLO_OP_JOIN_SIDE:
             if (used_side) rc = side_join(sc, (hipStream_t)s);

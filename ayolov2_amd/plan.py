@@ -33,7 +33,6 @@ from .modules import C3, SPPF, Bottleneck, Concat, Conv, UpSample, YOLOHead, _ac
  OP_BN_BWD_APPLY, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_PACK_INPUT, OP_HEAD_GRAD_PACK,
  OP_COPY2D, OP_MEMSET, OP_BN_EVAL_AFFINE, OP_BN_TRAIN_ACT, OP_CAST_WEIGHTS) = range(1, 20)
 OP_JOIN_SIDE = 21
-OP_BN_BWD_FUSED = 22
 
 
 class Op(ctypes.Structure):
@@ -63,14 +62,6 @@ import os as _os
 
 OP_SIDE = 0x100
 WGRAD_SIDE_STREAM = _os.environ.get("AYOLO_WGRAD_STREAM", "1") == "1"
-WGRAD_FIRST = _os.environ.get("AYOLO_WGRAD_FIRST", "0") == "1"
-# 1: a layer's weight gradient (side stream) runs next to ITS OWN dgrad only -- forked before the dgrad, joined after it --
-# so the HBM-bound BatchNorm passes of the following layers have the chip to themselves
-WGRAD_PAIRED = _os.environ.get("AYOLO_WGRAD_PAIRED", "0") == "1"
-# BN + activation backward of the small layers (20^2 / 40^2 maps) as one register-resident pass with a grid barrier.
-# OFF by default: correct (tests/test_gpu_conv.py) and 2x faster than the two-pass pair in isolation, but inside the step its
-# grid barrier waits for the side-stream weight-gradient kernels to give up CU slots: 16.8 vs 15.0 ms/step (r02m)
-FUSE_BN_BWD = _os.environ.get("AYOLO_FUSE_BN_BWD", "0") == "1"
 MAX_PLANS = int(_os.environ.get("AYOLO_MAX_PLANS", "4"))                 # cached plans per model (multi-scale training)
 MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: cv1 | cv2 as one conv
 # BatchNorm-backward sums (the first of the two backward passes of a Conv-BN-act block) computed in the epilogue of the
@@ -153,7 +144,6 @@ class TrainPlan:
         self.bn_counters: List[torch.Tensor] = []
         self.bn_buffers: List[torch.Tensor] = []            # running statistics the forward kernels update in place
         self.bn_sync_fix: list = []                         # sync_bn: (bn, small-arena offset, C, local count) per layer
-        self.bn_fused = 0                                   # BN layers whose backward runs as the one-pass fused kernel
         self.bn_in_dgrad = 0                                # BN layers whose backward sums ride in a dgrad epilogue
         self._gwrites: List[tuple] = []                     # (backward op index, root Act id, c_lo, c_hi, is_dgrad)
         self._bn_layers: List[dict] = []                    # two-pass BN backward layers (candidates for the dgrad epilogue)
@@ -334,26 +324,15 @@ class TrainPlan:
                 su = self.sums.view(su_off, R * 2 * co)
                 dgam = ga.view(gg_off, co) if gg_off is not None else None
                 dbet = ga.view(gb_off, co) if gb_off is not None else None
-                sync = getattr(self.model, "_ayolo_grad_sync", None)
-                if (FUSE_BN_BWD and R >= 2 and not (sync is not None and getattr(sync, "sync_bn", False))
-                        and _lib.lib().ayolo_bn_act_bwd_fused_ok(code, npix, co)):
-                    # one pass, one launch: z / da stay in registers across a grid barrier (the second replica of `su` holds
-                    # the barrier word; sm = [mean | invstd] is one contiguous slot)
-                    self.bwd.append(_op(OP_BN_BWD_FUSED, i=(code, Ct, ldda, Ct, co, act), l=(npix,), f=(1.0,),
-                                        p=(zj, da, dzv[:, c0:c0 + co], sm[0:2 * co], bn.weight, bn.bias, su, dgam, dbet)))
-                    self._wrote(gg_off, co)
-                    self._wrote(gb_off, co)
-                    self.bn_fused += 1
-                else:
-                    self.bwd.append(_op(OP_BN_BWD_REDUCE, i=(code, Ct, ldda, co, act, R), l=(npix,),
-                                        p=(zj, da, sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su)))
-                    self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R), l=(npix,), f=(1.0,),
-                                        p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet)))
-                    self._wrote(gg_off, co)
-                    self._wrote(gb_off, co)
-                    self.bwd_sync.append((len(self.bwd) - 2, su))  # sync_bn: all-reduce of the sums between reduce and apply
-                    self._bn_layers.append(dict(reduce=len(self.bwd) - 2, a=a, z=zj, ldz=Ct, sm=sm[0:2 * co], gamma=bn.weight,
-                                                beta=bn.bias, sums=su, C=co, act=act, R=R))
+                self.bwd.append(_op(OP_BN_BWD_REDUCE, i=(code, Ct, ldda, co, act, R), l=(npix,),
+                                    p=(zj, da, sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su)))
+                self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R), l=(npix,), f=(1.0,),
+                                    p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet)))
+                self._wrote(gg_off, co)
+                self._wrote(gb_off, co)
+                self.bwd_sync.append((len(self.bwd) - 2, su))  # sync_bn: all-reduce of the sums between reduce and apply
+                self._bn_layers.append(dict(reduce=len(self.bwd) - 2, a=a, z=zj, ldz=Ct, sm=sm[0:2 * co], gamma=bn.weight,
+                                            beta=bn.bias, sums=su, C=co, act=act, R=R))
                 if residual is not None:      # shortcut: d(residual) += d(a)
                     dr = residual.grad()
                     self.bwd.append(_op(OP_COPY2D, i=(code, ldda, ops.nhwc_info(dr)[4], co, int(residual.is_init())), l=(npix,),
@@ -365,18 +344,13 @@ class TrainPlan:
                                     conv=geo.desc(dt, ldx, Ct)))
                 self._wrote(gw_off0, Ct * K)
 
-            if WGRAD_FIRST or WGRAD_PAIRED:   # fork the weight gradient before its layer's dgrad: it overlaps the dgrad
-                wgrad()
             if not image:
                 dx = x_act.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
                                     conv=geo.desc(dt, ops.nhwc_info(dx)[4], Ct)))
                 self._gw(x_act, True)
                 x_act.mark_init()
-            if WGRAD_PAIRED and WGRAD_SIDE_STREAM:
-                self.bwd.append(_op(OP_JOIN_SIDE))
-            if not (WGRAD_FIRST or WGRAD_PAIRED):
-                wgrad()
+            wgrad()
 
         self.bwd_emitters.append(emit_bwd)
         return outs
@@ -791,8 +765,6 @@ class TrainPlan:
                 out.append(("bn_bwd_reduce", es * o.l[0] * o.i[3] * 2, 0.0))
             elif kind == OP_BN_BWD_APPLY:
                 out.append(("bn_bwd_apply", es * o.l[0] * o.i[4] * 3, 0.0))
-            elif kind == OP_BN_BWD_FUSED:
-                out.append(("bn_bwd_fused", es * o.l[0] * o.i[4] * 3, 0.0))
             elif kind in (OP_MAXPOOL_FWD, OP_UPSAMPLE_FWD):
                 n = o.i[3] * o.i[4] * o.i[5] * o.i[6] * (4 if kind == OP_UPSAMPLE_FWD else 1)
                 out.append(("pool_upsample", es * n * (1.25 if kind == OP_UPSAMPLE_FWD else 2) + (n if kind == OP_MAXPOOL_FWD else 0), 0.0))

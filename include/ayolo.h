@@ -166,17 +166,6 @@ int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, in
                            const float* gamma, const float* beta, int act, const float* sums, int sum_reps,
                            float* dgamma, float* dbeta, float grad_scale, ayolo_stream s);
 
-/* The same backward in ONE pass and one launch for layers that fit the register file of the resident grid (fp16, the
- * 20^2 / 40^2 maps of a batch-64 step): every thread keeps its z / da vectors in registers across a grid-wide barrier, so z
- * and da are read once.  ayolo_bn_act_bwd_fused_ok tells whether a layer qualifies (fp16, C/8 a power of two <= 256,
- * npix*C within the grid's capacity).  sums: float[2*C] and barrier: one uint32, both ZEROED by the caller before the launch.
- * Same arithmetic per element as the two-pass pair. */
-int ayolo_bn_act_bwd_fused_ok(int dtype, int64_t npix, int C);
-int ayolo_bn_act_bwd_fused(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz, int64_t npix,
-                           int C, const float* save_mean, const float* save_invstd, const float* gamma, const float* beta,
-                           int act, float* sums, unsigned* barrier, float* dgamma, float* dbeta, float grad_scale,
-                           ayolo_stream s);
-
 /* ------------------------------------------------------------------------------------------------
  * Small NHWC ops: kindle SPPF's MaxPool2d(5,1,2), UpSample(None,2) nearest, input packing, bias grad.
  * ---------------------------------------------------------------------------------------------- */
@@ -388,8 +377,7 @@ enum {
     AYOLO_OP_AFFINE_ACT, AYOLO_OP_BN_BWD_REDUCE, AYOLO_OP_BN_BWD_APPLY, AYOLO_OP_MAXPOOL_FWD, AYOLO_OP_MAXPOOL_BWD,
     AYOLO_OP_UPSAMPLE_FWD, AYOLO_OP_UPSAMPLE_BWD, AYOLO_OP_PACK_INPUT, AYOLO_OP_HEAD_GRAD_PACK, AYOLO_OP_COPY2D,
     AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT, AYOLO_OP_CAST_WEIGHTS, AYOLO_OP_HEAD_DECODE,
-    AYOLO_OP_JOIN_SIDE,         /* the caller's stream waits for everything enqueued so far on the side stream */
-    AYOLO_OP_BN_BWD_FUSED
+    AYOLO_OP_JOIN_SIDE          /* the caller's stream waits for everything enqueued so far on the side stream */
 };
 typedef struct ayolo_op {
     int kind;

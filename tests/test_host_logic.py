@@ -285,9 +285,10 @@ def test_plan_gradient_buckets_cover_the_arena():
     kinds = Counter(o.kind & 0xff for o in pl.bwd)
     assert kinds[3] == 52 and kinds[2] == 51
     # sync_bn cut points: one per conv launch (forward), one per BatchNorm layer (backward)
-    # (at this tiny size every BN backward qualifies for the one-pass fused kernel, which has no cut point; with sync_bn the
-    # plan keeps the two-pass form for all 57)
-    assert len(pl.fwd_sync_idx) == 49 and len(pl.bwd_sync) + pl.bn_fused == 57
+    assert len(pl.fwd_sync_idx) == 49 and len(pl.bwd_sync) == 57
+    # fp16 plans fold the BatchNorm-backward sums of every layer whose output gradient is last written by a conv dgrad into
+    # that dgrad's epilogue (all but the three fed by pool / upsample backward ops): the separate reduce op becomes a no-op
+    assert pl.bn_in_dgrad == 54 and kinds[0] >= 54 and kinds[7] == 3
 
 
 def test_model_ema_follows_reassigned_tensors_cpu():

@@ -60,7 +60,7 @@ def main():
                 shape = f"{d.Cin:4d}->{d.Cout:4d} k{d.kh} s{d.sh} {d.H:3d}->{d.Ho:3d}"
             elif kind in (P.OP_BN_TRAIN_ACT, P.OP_BN_BWD_REDUCE):
                 shape = f"C={o.i[3]:4d} npix={o.l[0]}"
-            elif kind in (P.OP_BN_BWD_APPLY, P.OP_BN_BWD_FUSED):
+            elif kind == P.OP_BN_BWD_APPLY:
                 shape = f"C={o.i[4]:4d} npix={o.l[0]}"
             gbs = byts / ms / 1e6 if ms > 0 else 0.0
             tfs = flop / ms / 1e9 if ms > 0 else 0.0
