@@ -86,6 +86,7 @@ _SIGNATURES = {
     "ayolo_nms_class_layout": [_P, c_uint32, c_int, _P, _P, _P, _P, _P],
     "ayolo_nms_class_merge": [_P, _P, _P, _P, _P, c_int, c_uint32, _P, c_int, c_uint32, c_uint32, _P, _P, _P, _P, _P,
                               POINTER(c_size_t), _P],
+    "ayolo_nms_class_fast": [_P, c_int, c_int, c_int, c_float, c_int, _P, c_float, c_uint32, c_uint32, c_uint32, _P, POINTER(c_size_t), _P, _P, _P],
     "ayolo_trt_nms_key_bits": [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)],
     "ayolo_trt_nms_candidates": [_P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, c_uint32, _P],
     "ayolo_trt_nms_layout": [_P, c_uint32, c_int, c_int, c_int, c_uint32, _P, _P, _P, _P],

@@ -7,6 +7,8 @@
 // division) so kept indices are bit-identical to the oracle.
 #include "common.h"
 #include <hipcub/hipcub.hpp>
+#include <string.h>
+#include <math.h>
 
 #define CAND_ROWS 64
 
@@ -1165,5 +1167,854 @@ extern "C" int ayolo_match_detections(const float* det, const int* det_img, int6
     hipLaunchKernelGGL(k_match_correct, dim3((unsigned)cdiv64(N * niou, 256)), dim3(256), 0, st, best_l, best_iou, owner, N, iouv_dev,
                        niou, correct);
     AY_CHECK_LAUNCH("k_match_correct");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One-call class-aware NMS of the `nms` branch (metrics.py:313-388 with the boxes offset by cls * 4096), no library sorts
+// and no host read-back until the result:
+//   k_candidates (conf filter, 340 B per raw proposal)            -> candidate rows + keys (image | ~conf | seq)
+//   k_seg_hist     per (image, class) counts, coordinate span      -> nseg counters
+//   k_seg_scan     exclusive scan, limits checked on the device    -> segment offsets, fallback flags
+//   k_seg_scatter  candidates grouped by segment (any order)       -> 24 B per candidate
+//   k_seg_nms      ONE workgroup per segment: bitonic sort by key in LDS, greedy NMS on the offset boxes in LDS
+//                  (64-box blocks resolved by one wavefront, later boxes checked against the block's kept boxes by all),
+//                  kept rows appended to the image's list
+//   k_img_topk     ONE workgroup per image: bitonic sort of the kept keys, first max_det rows emitted
+// The offset makes boxes of different classes disjoint whenever the candidates' coordinates span less than 4096 (checked
+// on the device), so the global greedy scan in confidence order equals independent per-class scans merged in confidence
+// order -- ~nc times fewer box pairs, and segments small enough (<= SEG_CAP) to live in LDS.  Arithmetic that decides
+// an index is the CPU sequence (offset add, area, IoU with a true division, strict >).  Whenever a limit does not hold
+// (span, a segment above SEG_CAP, more than IMG_CAP kept boxes or more than max_nms candidates in an image, candidate
+// buffer too small) a status flag is set and the caller takes the general path instead.
+// ---------------------------------------------------------------------------------------------------
+#define SEG_CAP 2048
+#define IMG_CAP 8192
+#define NMSF_OVERFLOW 1u      // candidate buffer too small (status[0] > capacity)
+#define NMSF_SPAN 2u          // coordinates span >= 4096: classes not separable by the offset
+#define NMSF_SEGCAP 4u        // a (image, class) segment has more than SEG_CAP candidates
+#define NMSF_IMGCAP 8u        // an image kept more than IMG_CAP boxes before the max_det cut
+#define NMSF_MAXNMS 16u       // an image has more than max_nms candidates (the reference truncates before NMS)
+
+struct SegNmsP {
+    const float* det; const uint64_t* keys; const uint32_t* counters;   // k_candidates outputs (counters[0] = total)
+    uint32_t capacity; int B, nc, img_shift;                            // image = key >> img_shift
+    uint32_t* seg_cnt; uint32_t* seg_off; uint32_t* seg_fill;           // [nseg], [nseg + 1], [nseg]
+    uint32_t* span; uint32_t* flags;                                    // [2], [1]
+    uint64_t* gkey; float* gbox;                                        // [capacity], [capacity][4]
+    uint64_t* kkey; float* kbox; uint32_t* kcls; uint32_t* kcnt;        // per image kept lists [B][IMG_CAP] (+ [B])
+    // max_nms truncation (metrics.py:378-379: an image with more candidates keeps its max_nms most confident ones):
+    uint32_t* thist; uint32_t* tpick; uint64_t* tlist; uint32_t* tfill; uint64_t* tkey; uint32_t* preflags;   // [B][TR_BINS], [B][2], [B][IMG_CAP], [B], [B], [1]
+    float thr; double thr_mid; int thr_odd; uint32_t max_det, max_nms;
+    float* out; uint32_t* out_cnt;                                      // [B][max_det][6], [B]
+};
+
+// ---- max_nms truncation: the max_nms smallest keys (= most confident candidates) of an over-full image, exactly, as a
+// radix select: two histogram levels of TR_BITS bits over the confidence field (workgroup-private in LDS) narrow the
+// max_nms-th key down to one bucket of both levels, the (few) keys of that bucket are sorted by one workgroup, and the
+// resulting threshold key selects the candidates.  Every kernel returns at once when no image is over-full.
+#define TR_BITS 11
+#define TR_BINS (1 << TR_BITS)
+#define TR_LDS_IMGS 8          // images whose histograms fit one workgroup's LDS (64 KiB)
+// Bucket of a key at a select level.  conf = obj * cls <= 1 puts float(conf) below 0x40000000, so the two leading bits of the
+// ~conf field are 11 for every candidate: the buckets start BELOW them (level 0: exponent low 6 bits + 5 mantissa bits = 32
+// buckets per octave; with the leading bits included all confidences of a typical batch fell into ~30 buckets and the LDS
+// histogram atomics serialised).  A key whose leading bits are not 11 (conf >= 2: not a probability) is smaller than all
+// others and goes to bucket 0 of both levels, which keeps the map monotone.
+__device__ __forceinline__ uint32_t tr_bin(uint64_t key, int img_shift, int level = 0) {
+    const uint32_t f = (uint32_t)(key >> (img_shift - 32));            // the ~conf field
+    return (f >> 30) != 3u ? 0u : (f >> (30 - TR_BITS * (level + 1))) & (TR_BINS - 1);
+}
+
+__device__ __forceinline__ bool any_image_over(const SegNmsP& p) {
+    bool over = false;
+    for (int b = 0; b < p.B; ++b) over |= p.counters[1 + b] > p.max_nms;     // uniform, B scalar loads
+    return over;
+}
+
+// tpick[img]: {bucket level 0, keys of it still wanted, bucket level 1, keys of it still wanted}
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_trunc_hist(SegNmsP p) {
+    extern __shared__ uint32_t s_th[];                     // [min(B, TR_LDS_IMGS)][TR_BINS]
+    if (!any_image_over(p)) return;
+    const bool in_lds = p.B <= TR_LDS_IMGS;
+    uint32_t* gh = p.thist + (size_t)LEVEL * p.B * TR_BINS;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < p.B * TR_BINS; i += 256) s_th[i] = 0;
+        __syncthreads();
+    }
+    const uint32_t total = min(p.counters[0], p.capacity);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const uint64_t key = p.keys[i];
+        const int img = (int)(key >> p.img_shift);
+        bool in = p.counters[1 + img] > p.max_nms;
+        if (LEVEL == 1) in = in && p.tpick[4 * img] == tr_bin(key, p.img_shift, 0);
+        if (in) {
+            const uint32_t bin = (uint32_t)img * TR_BINS + tr_bin(key, p.img_shift, LEVEL);
+            if (in_lds) atomicAdd(&s_th[bin], 1u); else atomicAdd(&gh[bin], 1u);
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.B * TR_BINS; i += 256)
+            if (s_th[i]) atomicAdd(&gh[i], s_th[i]);
+    }
+}
+
+// one workgroup per image: the bucket of this level in which the cumulative count crosses the wanted number
+template <int LEVEL>
+__global__ __launch_bounds__(1024) void k_trunc_pick(SegNmsP p) {
+    __shared__ uint32_t s_scan[1024];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    if (p.counters[1 + img] <= p.max_nms) {
+        if (tid == 0 && LEVEL == 0) { p.tkey[img] = ~0ull; p.tpick[4 * img] = 0xffffffffu; p.tpick[4 * img + 1] = 0; p.tpick[4 * img + 2] = 0xffffffffu; p.tpick[4 * img + 3] = 0; }
+        return;
+    }
+    const uint32_t want = LEVEL == 0 ? p.max_nms : p.tpick[4 * img + 1];
+    const uint32_t* gh = p.thist + ((size_t)LEVEL * p.B + img) * TR_BINS;
+    constexpr int PER = TR_BINS / 1024;
+    static_assert(PER >= 1, "one or more bins per thread");
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { c[k] = gh[tid * PER + k]; sum += c[k]; }
+    s_scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
+    }
+    uint32_t below = s_scan[tid] - sum;                    // keys in the buckets before this thread's first one
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (below < want && below + c[k] >= want) {        // exactly one (thread, k) satisfies this
+            p.tpick[4 * img + 2 * LEVEL] = (uint32_t)(tid * PER + k);
+            p.tpick[4 * img + 2 * LEVEL + 1] = want - below;           // keys of this bucket that are still wanted (>= 1)
+        }
+        below += c[k];
+    }
+}
+
+// keys of the deciding bucket (both levels) -> the image's list.  Workgroup-level aggregation: all hits of an image share
+// ONE global counter, and same-address atomics serialise in L2 (~12 ns each)
+__global__ __launch_bounds__(256) void k_trunc_collect(SegNmsP p) {
+    __shared__ uint32_t s_cnt[TR_LDS_IMGS], s_base[TR_LDS_IMGS];
+    if (!any_image_over(p)) return;
+    const bool agg = p.B <= TR_LDS_IMGS;
+    const uint32_t total = min(p.counters[0], p.capacity);
+    const uint32_t per = (total + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per, hi = min(total, lo + per);
+    if (threadIdx.x < TR_LDS_IMGS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // pass 1: count this workgroup's hits per image; pass 2: write them behind ONE reservation per image
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const uint64_t key = p.keys[i];
+            const int img = (int)(key >> p.img_shift);
+            if (p.tpick[4 * img] == tr_bin(key, p.img_shift, 0) && p.tpick[4 * img + 2] == tr_bin(key, p.img_shift, 1)) {
+                if (!agg) {
+                    if (pass == 0) continue;
+                    const uint32_t slot = atomicAdd(&p.tfill[img], 1u);
+                    if (slot < IMG_CAP) p.tlist[(size_t)img * IMG_CAP + slot] = key;
+                } else if (pass == 0) atomicAdd(&s_cnt[img], 1u);
+                else {
+                    const uint32_t slot = s_base[img] + atomicAdd(&s_cnt[img], 1u);
+                    if (slot < IMG_CAP) p.tlist[(size_t)img * IMG_CAP + slot] = key;
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0 && agg && threadIdx.x < p.B) {
+            s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&p.tfill[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+            s_cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+template <int NT> __device__ __forceinline__ void lds_bitonic(uint64_t* key, uint32_t* val, int N2, int tid);
+
+__global__ __launch_bounds__(1024) void k_trunc_thr(SegNmsP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char thr_lds[];
+    uint64_t* skey = reinterpret_cast<uint64_t*>(thr_lds);
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(thr_lds + (size_t)IMG_CAP * 8);
+    const int img = blockIdx.x, tid = threadIdx.x;
+    if (p.tpick[4 * img] == 0xffffffffu) return;           // image not truncated: tkey = ~0 (k_trunc_pick)
+    const uint32_t n = p.tfill[img];
+    if (n > IMG_CAP) { if (tid == 0) { atomicOr(p.preflags, NMSF_SEGCAP); p.tkey[img] = ~0ull; } return; }
+    int N2 = 64;
+    while (N2 < (int)n) N2 <<= 1;
+    for (int i = tid; i < N2; i += 1024) { skey[i] = i < (int)n ? p.tlist[(size_t)img * IMG_CAP + i] : ~0ull; sidx[i] = 0; }
+    __syncthreads();
+    lds_bitonic<1024>(skey, sidx, N2, tid);
+    if (tid == 0) p.tkey[img] = skey[p.tpick[4 * img + 3] - 1];
+}
+
+__global__ __launch_bounds__(256) void k_seg_hist(SegNmsP p) {
+    extern __shared__ uint32_t s_hist[];        // [nseg]
+    __shared__ uint32_t s_hi[4], s_lo[4];
+    const int nseg = p.B * p.nc;
+    for (int i = threadIdx.x; i < nseg; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t total = min(p.counters[0], p.capacity);
+    uint32_t hi = 0, lo = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const float2* src = reinterpret_cast<const float2*>(p.det + (size_t)i * 6);
+        const float2 a = src[0], c = src[1], d = src[2];
+        const uint64_t key = p.keys[i];
+        const int img = (int)(key >> p.img_shift);
+        if (key > p.tkey[img]) continue;                   // beyond the image's max_nms most confident candidates
+        atomicAdd(&s_hist[img * p.nc + (int)d.y], 1u);
+        hi = max(max(hi, float_order(a.x)), max(float_order(a.y), max(float_order(c.x), float_order(c.y))));
+        lo = max(max(lo, float_order(-a.x)), max(float_order(-a.y), max(float_order(-c.x), float_order(-c.y))));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+        lo = max(lo, (uint32_t)__shfl_xor((int)lo, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_hi[threadIdx.x >> 6] = hi; s_lo[threadIdx.x >> 6] = lo; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nseg; i += 256)
+        if (s_hist[i]) atomicAdd(&p.seg_cnt[i], s_hist[i]);
+    if (threadIdx.x == 0) {
+        hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        lo = max(max(s_lo[0], s_lo[1]), max(s_lo[2], s_lo[3]));
+        if (hi > __hip_atomic_load(&p.span[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.span[0], hi);
+        if (lo > __hip_atomic_load(&p.span[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&p.span[1], lo);
+    }
+}
+
+__device__ __forceinline__ float order_float(uint32_t code) {      // inverse of float_order
+    return __uint_as_float((code & 0x80000000u) ? (code & 0x7fffffffu) : ~code);
+}
+
+// one workgroup: exclusive scan of the segment counts; every limit of the fast path is checked here, on the device
+__global__ __launch_bounds__(1024) void k_seg_scan(SegNmsP p) {
+    __shared__ uint32_t s_scan[1024];
+    __shared__ uint32_t s_carry, s_flags;
+    const int tid = threadIdx.x, nseg = p.B * p.nc;
+    if (tid == 0) { s_carry = 0; s_flags = 0; }
+    __syncthreads();
+    for (int base = 0; base < nseg; base += 1024) {
+        const int sg = base + tid;
+        const uint32_t n = sg < nseg ? p.seg_cnt[sg] : 0u;
+        if (n > SEG_CAP) atomicOr(&s_flags, NMSF_SEGCAP);
+        s_scan[tid] = n;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t add = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        const uint32_t carry = s_carry;
+        if (sg < nseg) p.seg_off[sg] = carry + s_scan[tid] - n;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + s_scan[1023];
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        p.seg_off[nseg] = s_carry;
+        uint32_t f = s_flags | p.preflags[0];              // raised by the truncation kernels before this one
+        if (p.counters[0] > p.capacity) f |= NMSF_OVERFLOW;
+        if (p.counters[0] > 0) {
+            const float hi = order_float(p.span[0]), lo = order_float(p.span[1]);     // max(coord), max(-coord)
+            if (!(hi + lo < 4096.0f)) f |= NMSF_SPAN;
+        }
+        p.flags[0] = f;
+    }
+}
+
+// each workgroup owns a contiguous range of candidates: local rank per segment by LDS atomics, ONE global reservation per
+// (workgroup, segment), then the rows are written to seg_off[segment] + reservation + local rank
+#define SCAT_PER 8             // candidates per thread
+__global__ __launch_bounds__(256) void k_seg_scatter(SegNmsP p) {
+    extern __shared__ uint32_t s_sc[];                     // [nseg] counts, then [nseg] global bases
+    if (p.flags[0]) return;
+    const int nseg = p.B * p.nc;
+    uint32_t* s_cnt = s_sc;
+    uint32_t* s_base = s_sc + nseg;
+    for (int i = threadIdx.x; i < nseg; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    const uint32_t total = min(p.counters[0], p.capacity);
+    const uint32_t lo = blockIdx.x * (256 * SCAT_PER);
+    uint32_t rank[SCAT_PER];
+    int sgs[SCAT_PER];
+#pragma unroll
+    for (int k = 0; k < SCAT_PER; ++k) {
+        const uint32_t i = lo + k * 256 + threadIdx.x;
+        sgs[k] = -1;
+        if (i < total) {
+            const uint64_t key = p.keys[i];
+            const int img = (int)(key >> p.img_shift);
+            if (key <= p.tkey[img]) {
+                sgs[k] = img * p.nc + (int)p.det[(size_t)i * 6 + 5];
+                rank[k] = atomicAdd(&s_cnt[sgs[k]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nseg; i += 256)
+        if (s_cnt[i]) s_base[i] = atomicAdd(&p.seg_fill[i], s_cnt[i]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAT_PER; ++k) {
+        if (sgs[k] < 0) continue;
+        const uint32_t i = lo + k * 256 + threadIdx.x;
+        const float2* src = reinterpret_cast<const float2*>(p.det + (size_t)i * 6);
+        const float2 a = src[0], c = src[1];
+        const uint32_t slot = p.seg_off[sgs[k]] + s_base[sgs[k]] + rank[k];
+        p.gkey[slot] = p.keys[i];
+        reinterpret_cast<float4*>(p.gbox)[slot] = make_float4(a.x, a.y, c.x, c.y);
+    }
+}
+
+// ascending bitonic sort of n (key, payload) pairs in LDS; N2 = power of two >= n, slots [n, N2) hold ~0 keys
+template <int NT>
+__device__ __forceinline__ void lds_bitonic(uint64_t* key, uint32_t* val, int N2, int tid) {
+    for (int k = 2; k <= N2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < N2 / 2; t += NT) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // lower index of pair t at distance j
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const uint64_t a = key[i], b = key[l];
+                if ((a > b) == up) {
+                    key[i] = b; key[l] = a;
+                    const uint32_t va = val[i]; val[i] = val[l]; val[l] = va;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// Segments of at most MAT_CAP candidates (the common case: ~nc segments share an image's candidates): rank sort instead of
+// a bitonic network (no barrier per stage), the whole suppression bit matrix of the segment in LDS -- every 64 x 64 tile by
+// one wavefront, the row word straight from a ballot, all tiles in parallel -- and then ONE wavefront walks the matrix
+// (k_nms_reduce's scan).  The blockwise k_seg_nms below serialises (resolve block, test later boxes) per 64-box block.
+// `inter / u > thr` for the correctly rounded float quotient WITHOUT the division (an IEEE division is ~40 VALU operations,
+// more than the rest of a box-pair test): RN(x) > thr  <=>  x > m or (x == m and the float above thr has an even mantissa),
+// m = thr + ulp(thr) / 2 being the round-to-nearest boundary.  m has 25 significant bits and u 24, so u * m is EXACT in
+// double and the comparison decides the real inequality exactly.  u <= 0 (degenerate boxes) follows the quotient's sign /
+// infinity: u < 0 gives a negative quotient (never above thr >= 0), u == 0 gives +inf.
+__device__ __forceinline__ bool iou_above(float inter, float u, double thr_mid, int thr_odd) {
+    const double di = (double)inter, prod = (double)u * thr_mid;
+    const bool pos = (di > prod) | ((di == prod) & (thr_odd != 0));
+    return u > 0.0f ? pos : (u == 0.0f);
+}
+
+#define MAT_CAP 512
+__global__ __launch_bounds__(256) void k_seg_nms_small(SegNmsP p) {
+    __shared__ uint64_t skin[MAT_CAP], skey[MAT_CAP];          // keys as loaded / sorted
+    __shared__ float4 sbox[MAT_CAP];                           // sorted boxes + class offset
+    __shared__ uint16_t sidx[MAT_CAP], skl[MAT_CAP];           // sorted position -> position in the segment; kept list
+    __shared__ uint64_t smat[MAT_CAP * (MAT_CAP / 64)];        // row i, word w: later boxes 64w .. 64w+63 that box i suppresses
+    __shared__ uint64_t srem[MAT_CAP / 64];
+    __shared__ uint32_t s_kept, s_base;
+    if (p.flags[0]) return;
+    const int sg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = (int)p.seg_cnt[sg];
+    if (n == 0 || n > MAT_CAP) return;
+    const uint32_t off = p.seg_off[sg];
+    const int img = sg / p.nc, cls = sg - img * p.nc;
+    for (int i = tid; i < n; i += 256) skin[i] = p.gkey[off + i];
+    __syncthreads();
+    // rank sort: keys are unique, so the ranks are a permutation
+    {
+        const uint64_t k0 = tid < n ? skin[tid] : 0ull, k1 = tid + 256 < n ? skin[tid + 256] : 0ull;
+        int r0 = 0, r1 = 0;
+        const int n8 = n & ~7;
+        for (int j = 0; j < n8; j += 8) {                      // eight independent broadcast reads in flight per step
+            uint64_t kj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kj[u] = skin[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { r0 += kj[u] < k0; r1 += kj[u] < k1; }
+        }
+        for (int j = n8; j < n; ++j) {
+            const uint64_t kj = skin[j];
+            r0 += kj < k0; r1 += kj < k1;
+        }
+        if (tid < n) { skey[r0] = k0; sidx[r0] = (uint16_t)tid; }
+        if (tid + 256 < n) { skey[r1] = k1; sidx[r1] = (uint16_t)(tid + 256); }
+    }
+    __syncthreads();
+    const float o = (float)cls * 4096.0f;                      // metrics.py:383: boxes + cls * max_wh, in float32
+    for (int i = tid; i < n; i += 256) {
+        const float4 b = reinterpret_cast<const float4*>(p.gbox)[off + sidx[i]];
+        sbox[i] = make_float4(b.x + o, b.y + o, b.z + o, b.w + o);
+    }
+    __syncthreads();
+    const int nb = (n + 63) >> 6;
+    // ---- suppression matrix in two passes.  Only a few % of the box pairs of a class overlap at all, and the IoU test with
+    // its exact threshold comparison is ~4x the instructions of an overlap test, so:
+    //   pass 1: OVERLAP bits of every pair of the upper triangle -- 64 x 64 tiles, lane = column box, row boxes broadcast
+    //           from LDS, the row word straight from a ballot (4 compares per pair; a superset of `inter > 0`);
+    //   pass 2: every thread walks the set bits of its share of the words and keeps those whose IoU is above the threshold.
+    for (int t = wave; t < nb * nb; t += 4) {
+        const int rb = t / nb, cb = t - rb * nb;
+        if (cb < rb) continue;
+        const int j = cb * 64 + lane;
+        const bool cvalid = j < n;
+        const float4 bj = sbox[cvalid ? j : 0];
+        const int rows = min(64, n - rb * 64);
+        for (int i0 = 0; i0 < rows; i0 += 4) {                 // four row boxes fetched per step (independent broadcast reads)
+            float4 bi4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bi4[u] = sbox[min(rb * 64 + i0 + u, n - 1)];
+            uint64_t myword = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ri = rb * 64 + i0 + u;
+                const float4 bi = bi4[u];
+                const bool ov = cvalid && j > ri && i0 + u < rows && bi.x < bj.z && bj.x < bi.z && bi.y < bj.w && bj.y < bi.w;
+                const uint64_t word = __ballot(ov);
+                if (lane == u) myword = word;
+            }
+            if (lane < 4 && i0 + lane < rows) smat[(rb * 64 + i0 + lane) * (MAT_CAP / 64) + cb] = myword;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * nb; idx += 256) {
+        const int ri = idx / nb, cb = idx - ri * nb;
+        if (cb < (ri >> 6)) continue;
+        uint64_t word = smat[ri * (MAT_CAP / 64) + cb], out = 0;
+        if (word == 0) continue;
+        const float4 bi = sbox[ri];
+        const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+        while (word != 0) {
+            const int t = __ffsll((unsigned long long)word) - 1;
+            word &= word - 1;
+            const float4 bj = sbox[cb * 64 + t];
+            const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+            const float inter = w * h;                         // torchvision nms: pairs without overlap skipped, strict >
+            if (inter > 0.0f && iou_above(inter, ai + aj - inter, p.thr_mid, p.thr_odd)) out |= 1ull << t;
+        }
+        smat[ri * (MAT_CAP / 64) + cb] = out;
+    }
+    if (tid < MAT_CAP / 64) srem[tid] = 0;
+    if (tid == 0) s_kept = 0;
+    __syncthreads();
+    // ---- greedy scan by wavefront 0
+    if (wave == 0) {
+        uint32_t kept = 0;
+        for (int blk = 0; blk < nb && kept < p.max_det; ++blk) {
+            const int i = blk * 64 + lane;
+            const uint64_t d = i < n ? smat[i * (MAT_CAP / 64) + blk] : 0ull;
+            const uint64_t valid = (blk * 64 + 64 <= n) ? ~0ull : ((1ull << (n - blk * 64)) - 1ull);
+            uint64_t alive = ~srem[blk] & valid;               // uniform (LDS broadcast)
+            uint64_t keep = 0;
+            uint32_t k2 = kept;
+            while (alive != 0 && k2 < p.max_det) {
+                const int t = __ffsll((unsigned long long)alive) - 1;
+                keep |= 1ull << t;
+                ++k2;
+                alive &= ~(rl64(d, t) | (1ull << t));
+            }
+            if ((keep >> lane) & 1ull) skl[kept + __popcll(keep & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            kept = k2;
+            // OR the rows of this block's kept boxes into the removed set of the later blocks: lane = kept box, one wave
+            // reduction per later word (a loop over the kept boxes by the few "word" lanes was 64 dependent LDS reads)
+            const bool mine = ((keep >> lane) & 1ull) != 0;
+            for (int w = blk + 1; w < nb; ++w) {
+                uint64_t v = mine ? smat[i * (MAT_CAP / 64) + w] : 0ull;
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o2), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o2);
+                    v |= ((uint64_t)hi << 32) | lo;
+                }
+                if (lane == 0) srem[w] |= v;
+            }
+        }
+        if (lane == 0) s_kept = kept;
+    }
+    __syncthreads();
+    const uint32_t kept = s_kept;
+    if (tid == 0) s_base = atomicAdd(&p.kcnt[img], kept);
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t r = tid; r < kept; r += 256) {
+        const uint32_t j = skl[r];
+        const size_t dst = (size_t)img * ((size_t)p.nc * p.max_det) + base + r;
+        p.kkey[dst] = skey[j];
+        reinterpret_cast<float4*>(p.kbox)[dst] = reinterpret_cast<const float4*>(p.gbox)[off + sidx[j]];
+        p.kcls[dst] = (uint32_t)cls;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seg_nms(SegNmsP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char seg_lds[];
+    uint64_t* skey = reinterpret_cast<uint64_t*>(seg_lds);                       // [SEG_CAP]
+    float4* sbox = reinterpret_cast<float4*>(seg_lds + (size_t)SEG_CAP * 8);     // [SEG_CAP] boxes + class offset, SORTED order
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(seg_lds + (size_t)SEG_CAP * 24);// [SEG_CAP] sort payload: position in the segment
+    uint16_t* skl = reinterpret_cast<uint16_t*>(seg_lds + (size_t)SEG_CAP * 28); // [SEG_CAP] kept boxes (sorted positions)
+    __shared__ uint64_t s_keep;
+    __shared__ uint32_t s_kept, s_base;
+    if (p.flags[0]) return;
+    const int sg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = p.seg_cnt[sg];
+    if (n <= MAT_CAP) return;                              // k_seg_nms_small's
+    const uint32_t off = p.seg_off[sg];
+    const int img = sg / p.nc, cls = sg - img * p.nc;
+    int N2 = 64;
+    while (N2 < (int)n) N2 <<= 1;
+    for (int i = tid; i < N2; i += 256) {
+        skey[i] = i < (int)n ? p.gkey[off + i] : ~0ull;
+        sidx[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    lds_bitonic<256>(skey, sidx, N2, tid);
+    // boxes in sorted order, with the reference's class offset applied (metrics.py:383: boxes + cls * max_wh, in float32)
+    const float o = (float)cls * 4096.0f;
+    for (int i = tid; i < (int)n; i += 256) {
+        const float4 b = reinterpret_cast<const float4*>(p.gbox)[off + sidx[i]];
+        sbox[i] = make_float4(b.x + o, b.y + o, b.z + o, b.w + o);
+    }
+    if (tid == 0) s_kept = 0;
+    __syncthreads();
+    // greedy scan over blocks of 64 sorted boxes: wavefront 0 resolves a block (intra-block suppression words, then the
+    // sequential scan in SGPRs), then all four wavefronts test every later, still alive box against the block's kept boxes
+    unsigned char* salive = reinterpret_cast<unsigned char*>(skl + SEG_CAP);       // [SEG_CAP]
+    for (int i = tid; i < (int)n; i += 256) salive[i] = 1;
+    __syncthreads();
+    // suppressed(i -> j): torchvision nms on the offset boxes (pairs without overlap skipped, strict >)
+    // `on`: this lane has a pair to test.  The IEEE division runs only where some lane of the wavefront sees an overlap
+    // (wave-uniform branch): most box pairs are disjoint
+    auto sup = [&](bool on, const float4 bi, float ai, const float4 bj, float aj) -> bool {
+        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+        const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+        const float inter = w * h;
+        return on && inter > 0.0f && iou_above(inter, ai + aj - inter, p.thr_mid, p.thr_odd);
+    };
+    constexpr int SLOTS = SEG_CAP / 256;
+    const int nblk = ((int)n + 63) >> 6;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (wave == 0) {
+            const int j = blk * 64 + lane;
+            const bool valid = j < (int)n;
+            const float4 bj = sbox[valid ? j : 0];
+            const float aj = (bj.z - bj.x) * (bj.w - bj.y);
+            uint64_t m = 0;                               // bit i: box blk*64 + i (i < lane) would suppress this lane's box
+            const int lim = min(63, (int)n - blk * 64);
+            for (int i = 0; i < lim; ++i) {
+                const float4 bi = sbox[blk * 64 + i];
+                const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+                if (sup(i < lane && valid, bi, ai, bj, aj)) m |= 1ull << i;
+            }
+            uint64_t rem = __ballot(valid && salive[valid ? j : 0] != 0);
+            uint64_t keep = 0;
+            const uint32_t kept0 = s_kept;
+            uint32_t kept = kept0;
+            while (rem != 0 && kept < p.max_det) {
+                const int t = __ffsll((unsigned long long)rem) - 1;
+                keep |= 1ull << t;
+                ++kept;
+                rem &= ~(__ballot((m >> t) & 1ull) | (1ull << t));
+            }
+            if ((keep >> lane) & 1ull) skl[kept0 + __popcll(keep & ((1ull << lane) - 1ull))] = (uint16_t)j;
+            if (lane == 0) { s_keep = keep; s_kept = kept; }
+        }
+        __syncthreads();
+        const uint64_t keep = s_keep;
+        if (s_kept >= p.max_det || blk + 1 == nblk) break;   // uniform
+        const int nslots = ((int)n - (blk + 1) * 64 + 255) >> 8;      // slots of 256 later boxes that exist (uniform)
+        float4 mine[SLOTS];
+        float marea[SLOTS];
+        bool live[SLOTS];
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            live[q] = false;
+            if (q < nslots) {
+                const int j = (blk + 1) * 64 + q * 256 + tid;
+                live[q] = j < (int)n && salive[j < (int)n ? j : 0] != 0;
+                mine[q] = sbox[j < (int)n ? j : 0];
+                marea[q] = (mine[q].z - mine[q].x) * (mine[q].w - mine[q].y);
+            }
+        }
+        uint64_t km = keep;
+        while (km != 0) {
+            const int t = __ffsll((unsigned long long)km) - 1;
+            km &= km - 1;
+            const float4 bi = sbox[blk * 64 + t];
+            const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q)
+                if (q < nslots) { if (sup(live[q], bi, ai, mine[q], marea[q])) live[q] = false; }
+        }
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+            if (q < nslots) {
+                const int j = (blk + 1) * 64 + q * 256 + tid;
+                if (j < (int)n && !live[q]) salive[j] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // kept boxes (sorted positions skl[0 .. kept)) -> the image's list, with their ORIGINAL coordinates
+    const uint32_t kept = s_kept;
+    if (tid == 0) s_base = atomicAdd(&p.kcnt[img], kept);
+    __syncthreads();
+    const uint32_t base = s_base;                          // < nc * max_det: every segment keeps at most max_det boxes
+    for (uint32_t r = tid; r < kept; r += 256) {
+        const uint32_t j = skl[r];
+        const size_t dst = (size_t)img * ((size_t)p.nc * p.max_det) + base + r;
+        p.kkey[dst] = skey[j];
+        reinterpret_cast<float4*>(p.kbox)[dst] = reinterpret_cast<const float4*>(p.gbox)[off + sidx[j]];
+        p.kcls[dst] = (uint32_t)cls;
+    }
+}
+
+// one workgroup per image: the max_det most confident kept boxes of all its classes, emitted in confidence order as
+// [x1, y1, x2, y2, conf, cls] rows (conf recovered from the key: ~conf bits above the seq field).  Up to nc * max_det boxes
+// arrive (random boxes hardly overlap: every class keeps its first max_det), so the cut is a SELECTION, not a sort of all of
+// them: an LDS histogram over the leading confidence bits finds the bucket that holds the max_det-th key, the keys below it
+// are taken, the bucket's own keys are sorted and contribute the rest; only the <= max_det winners are sorted for output.
+#define TOPK_OUT 1024          // max_det supported by this path
+#define TOPK_BND 4096          // keys in the deciding bucket
+#define TOPK_KPT 32            // kept keys per thread (registers): nc * max_det <= 32 768
+__global__ __launch_bounds__(1024) void k_img_topk(SegNmsP p, int seq_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char img_lds[];
+    uint64_t* okey = reinterpret_cast<uint64_t*>(img_lds);                                   // [TOPK_OUT]
+    uint64_t* bkey = okey + TOPK_OUT;                                                          // [TOPK_BND]
+    uint32_t* oidx = reinterpret_cast<uint32_t*>(bkey + TOPK_BND);                             // [TOPK_OUT]
+    uint32_t* bidx = oidx + TOPK_OUT;                                                          // [TOPK_BND]
+    uint32_t* hist = bidx + TOPK_BND;                                                          // [TR_BINS]
+    __shared__ uint32_t s_scan[1024];
+    __shared__ uint32_t s_no, s_nb, s_bstar, s_r;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    if (p.flags[0]) { if (tid == 0) p.out_cnt[img] = 0; return; }
+    const uint32_t kcap = (uint32_t)p.nc * p.max_det;
+    const uint32_t K = min(p.kcnt[img], kcap);
+    const uint32_t want = min(K, p.max_det);
+    const uint64_t* kk = p.kkey + (size_t)img * kcap;
+    if (tid == 0) { s_no = 0; s_nb = 0; s_bstar = 0xffffffffu; s_r = 0; }
+    // this thread's keys, fetched ONCE with independent loads (a load per loop iteration in front of an LDS atomic was a
+    // chain of ~1 us round trips: 24 per pass)
+    uint64_t kreg[TOPK_KPT];
+#pragma unroll
+    for (int k = 0; k < TOPK_KPT; ++k) {
+        const uint32_t i = (uint32_t)k * 1024u + tid;
+        kreg[k] = i < K ? kk[i] : ~0ull;
+    }
+    if (K > TOPK_OUT) {
+        for (int i = tid; i < TR_BINS; i += 1024) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TOPK_KPT; ++k)
+            if ((uint32_t)k * 1024u + tid < K) atomicAdd(&hist[tr_bin(kreg[k], p.img_shift)], 1u);
+        __syncthreads();
+        constexpr int PER = TR_BINS / 1024;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { c[k] = hist[tid * PER + k]; sum += c[k]; }
+        s_scan[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t add = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        uint32_t below = s_scan[tid] - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (below < want && below + c[k] >= want) { s_bstar = (uint32_t)(tid * PER + k); s_r = want - below; }
+            below += c[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t bstar = s_bstar;
+#pragma unroll
+    for (int k = 0; k < TOPK_KPT; ++k) {
+        const uint32_t i = (uint32_t)k * 1024u + tid;
+        if (i < K) {
+            const uint64_t key = kreg[k];
+            const uint32_t bin = K > TOPK_OUT ? tr_bin(key, p.img_shift) : 0u;
+            if (K <= TOPK_OUT || bin < bstar) {
+                const uint32_t slot = atomicAdd(&s_no, 1u);
+                okey[slot] = key; oidx[slot] = i;
+            } else if (bin == bstar) {
+                const uint32_t slot = atomicAdd(&s_nb, 1u);
+                if (slot < TOPK_BND) { bkey[slot] = key; bidx[slot] = i; }
+            }
+        }
+    }
+    __syncthreads();
+    if (K > TOPK_OUT) {
+        const uint32_t nb = s_nb;
+        if (nb > TOPK_BND) { if (tid == 0) { atomicOr(&p.flags[0], NMSF_IMGCAP); p.out_cnt[img] = 0; } return; }
+        // the r smallest keys of the deciding bucket join the winners: rank of every bucket key among the bucket's keys
+        // (unique keys: ranks are a permutation; batched broadcast reads, no barrier per stage as a sorting network has)
+        const uint32_t no = s_no, r = s_r;
+        uint64_t mk[TOPK_BND / 1024];
+        uint32_t rk[TOPK_BND / 1024];
+#pragma unroll
+        for (int q = 0; q < TOPK_BND / 1024; ++q) { mk[q] = (uint32_t)q * 1024u + tid < nb ? bkey[q * 1024 + tid] : ~0ull; rk[q] = 0; }
+        const int nb8 = (int)nb & ~7;
+        for (int j = 0; j < nb8; j += 8) {
+            uint64_t kj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kj[u] = bkey[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < TOPK_BND / 1024; ++q) rk[q] += kj[u] < mk[q];
+        }
+        for (int j = nb8; j < (int)nb; ++j) {
+            const uint64_t kj = bkey[j];
+#pragma unroll
+            for (int q = 0; q < TOPK_BND / 1024; ++q) rk[q] += kj < mk[q];
+        }
+#pragma unroll
+        for (int q = 0; q < TOPK_BND / 1024; ++q)
+            if ((uint32_t)q * 1024u + tid < nb && rk[q] < r) { okey[no + rk[q]] = mk[q]; oidx[no + rk[q]] = bidx[q * 1024 + tid]; }
+        __syncthreads();
+    }
+    // okey / oidx hold the winners in any order (K <= TOPK_OUT: all K kept boxes): rank them, emit the first `want`
+    const int cnt = K > TOPK_OUT ? (int)want : (int)K;
+    {
+        const uint64_t mkey = tid < cnt ? okey[tid] : ~0ull;
+        const uint32_t midx = tid < cnt ? oidx[tid] : 0u;
+        uint32_t rank = 0;
+        const int c8 = cnt & ~7;
+        for (int j = 0; j < c8; j += 8) {
+            uint64_t kj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kj[u] = okey[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += kj[u] < mkey;
+        }
+        for (int j = c8; j < cnt; ++j) rank += okey[j] < mkey;
+        if (tid < cnt) { bkey[rank] = mkey; bidx[rank] = midx; }       // sorted winners (the bucket buffers are free now)
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < want; r += 1024) {
+        const size_t src = (size_t)img * kcap + bidx[r];
+        const float4 b = reinterpret_cast<const float4*>(p.kbox)[src];
+        const float conf = __uint_as_float(~(uint32_t)(bkey[r] >> seq_bits));
+        float* d = p.out + ((size_t)img * p.max_det + r) * 6;
+        d[0] = b.x; d[1] = b.y; d[2] = b.z; d[3] = b.w; d[4] = conf; d[5] = (float)p.kcls[src];
+    }
+    if (tid == 0) p.out_cnt[img] = want;
+}
+
+// status (device, uint32): [0] flags (NMSF_*: non-zero = take the general path), [1] candidates, [2 .. 2 + B) rows per image
+// in `out`, [2 + B .. 2 + 2B) candidates per image.  ws == NULL: *ws_bytes receives the workspace size for `capacity`.
+extern "C" int ayolo_nms_class_fast(const float* pred, int B, int N, int no, float conf_thres, int multi_label,
+                                    const uint64_t* class_mask, float iou_thres_f, uint32_t max_det, uint32_t max_nms,
+                                    uint32_t capacity, void* ws, size_t* ws_bytes, float* out, uint32_t* status,
+                                    ayolo_stream s) {
+    AY_CHECK_ARG(ws_bytes, "nms_class_fast: ws_bytes null");
+    AY_CHECK_ARG(B > 0 && N > 0 && no > 6 && max_det > 0 && max_det <= TOPK_OUT && capacity > 0, "nms_class_fast: bad sizes");
+    AY_CHECK_ARG((uint64_t)(no - 5) * max_det <= (uint64_t)TOPK_KPT * 1024, "nms_class_fast: nc * max_det = %llu kept boxes per image unsupported", (unsigned long long)(no - 5) * max_det);
+    const int nc = no - 5, nseg = B * nc;
+    AY_CHECK_ARG(B <= 1024 && (size_t)nseg * 4 <= 48 * 1024, "nms_class_fast: B * nc = %d segments unsupported", nseg);
+    int seq_bits, total_bits;
+    if (ayolo_nms_key_bits(B, N, multi_label ? nc : 1, 0, &seq_bits, &total_bits) != AYOLO_OK) {
+        ayolo_set_error("nms_class_fast: key needs %d bits", total_bits);
+        return AYOLO_EINVAL;
+    }
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    size_t o = 0;
+    const size_t o_det = o; o += al((size_t)capacity * 24);
+    const size_t o_keys = o; o += al((size_t)capacity * 8);
+    const size_t o_gkey = o; o += al((size_t)capacity * 8);
+    const size_t o_gbox = o; o += al((size_t)capacity * 16);
+    const size_t kimg = (size_t)nc * max_det;               // kept boxes of an image before the max_det cut: exact bound
+    const size_t o_kkey = o; o += al((size_t)B * kimg * 8);
+    const size_t o_kbox = o; o += al((size_t)B * kimg * 16);
+    const size_t o_kcls = o; o += al((size_t)B * kimg * 4);
+    const size_t o_tlist = o; o += al((size_t)B * IMG_CAP * 8);
+    const size_t o_tkey = o; o += al((size_t)B * 8);
+    const size_t o_tpick = o; o += al((size_t)B * 16);
+    const size_t o_zero = o;       // zeroed every call: counters | seg_cnt | seg_fill | span | kcnt | tfill | preflags | thist
+    const size_t n_zero = (size_t)(1 + B) + 2 * (size_t)nseg + 2 + 2 * (size_t)B + 1 + 2 * (size_t)B * TR_BINS;
+    o += al(n_zero * 4);
+    const size_t o_segoff = o; o += al((size_t)(nseg + 1) * 4);
+    if (ws == nullptr) { *ws_bytes = o; return AYOLO_OK; }
+    if (*ws_bytes < o) { ayolo_set_error("nms_class_fast: workspace %zu < %zu", *ws_bytes, o); return AYOLO_ENOSPC; }
+    AY_CHECK_ARG(pred && out && status && ((uintptr_t)ws % 256) == 0, "nms_class_fast: null / misaligned pointer");
+    unsigned char* w = (unsigned char*)ws;
+    uint32_t* z = (uint32_t*)(w + o_zero);
+    int rc = ayolo_fill_zero(z, n_zero * 4, s);
+    if (rc) return rc;
+    SegNmsP p{};
+    p.det = (float*)(w + o_det); p.keys = (uint64_t*)(w + o_keys); p.counters = z;
+    p.capacity = capacity; p.B = B; p.nc = nc; p.img_shift = 32 + seq_bits;
+    p.seg_cnt = z + (1 + B); p.seg_fill = p.seg_cnt + nseg; p.span = p.seg_fill + nseg; p.kcnt = p.span + 2;
+    p.tfill = p.kcnt + B; p.preflags = p.tfill + B; p.thist = p.preflags + 1;
+    p.tlist = (uint64_t*)(w + o_tlist); p.tkey = (uint64_t*)(w + o_tkey); p.tpick = (uint32_t*)(w + o_tpick);
+    p.seg_off = (uint32_t*)(w + o_segoff);
+    p.flags = status;
+    p.gkey = (uint64_t*)(w + o_gkey); p.gbox = (float*)(w + o_gbox);
+    p.kkey = (uint64_t*)(w + o_kkey); p.kbox = (float*)(w + o_kbox); p.kcls = (uint32_t*)(w + o_kcls);
+    p.thr = iou_thres_f; p.max_det = max_det; p.max_nms = max_nms;
+    {   // round-to-nearest boundary above thr: the quotient test of the segment kernels (iou_above)
+        AY_CHECK_ARG(iou_thres_f >= 0.0f && iou_thres_f < 3.0e38f, "nms_class_fast: iou threshold %g", (double)iou_thres_f);
+        const float next = nextafterf(iou_thres_f, INFINITY);
+        p.thr_mid = ((double)iou_thres_f + (double)next) * 0.5;
+        uint32_t bits;
+        memcpy(&bits, &iou_thres_f, 4);
+        p.thr_odd = (int)(bits & 1u);
+    }
+    p.out = out; p.out_cnt = status + 2;
+    CandParams cp{pred, B, N, no, conf_thres, multi_label, 1, class_mask, nullptr, N,
+                  (float*)(w + o_det), (uint64_t*)(w + o_keys), z, capacity, seq_bits, 0, 0, 0, 0, 0, 0};
+    rc = run_candidates(cp, no, s);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)s;
+    const unsigned gridc = (unsigned)std::min<uint64_t>(((uint64_t)capacity + 255) / 256, 1024);
+    static bool attr_t[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t img_lds = (size_t)IMG_CAP * 12;
+    if (dev < 0 || dev >= 16 || !attr_t[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunc_thr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunc_hist<0>), hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS_IMGS * TR_BINS * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunc_hist<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS_IMGS * TR_BINS * 4);
+        if (dev >= 0 && dev < 16) attr_t[dev] = true;
+    }
+    const size_t th_lds = (size_t)(B <= TR_LDS_IMGS ? B : 0) * TR_BINS * 4;
+    hipLaunchKernelGGL(k_trunc_hist<0>, dim3(256), dim3(256), th_lds, st, p);
+    AY_CHECK_LAUNCH("k_trunc_hist");
+    hipLaunchKernelGGL(k_trunc_pick<0>, dim3((unsigned)B), dim3(1024), 0, st, p);
+    AY_CHECK_LAUNCH("k_trunc_pick");
+    hipLaunchKernelGGL(k_trunc_hist<1>, dim3(256), dim3(256), th_lds, st, p);
+    AY_CHECK_LAUNCH("k_trunc_hist");
+    hipLaunchKernelGGL(k_trunc_pick<1>, dim3((unsigned)B), dim3(1024), 0, st, p);
+    AY_CHECK_LAUNCH("k_trunc_pick");
+    hipLaunchKernelGGL(k_trunc_collect, dim3(256), dim3(256), 0, st, p);
+    AY_CHECK_LAUNCH("k_trunc_collect");
+    hipLaunchKernelGGL(k_trunc_thr, dim3((unsigned)B), dim3(1024), img_lds, st, p);
+    AY_CHECK_LAUNCH("k_trunc_thr");
+    hipLaunchKernelGGL(k_seg_hist, dim3(256), dim3(256), (size_t)nseg * 4, st, p);
+    AY_CHECK_LAUNCH("k_seg_hist");
+    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, p);
+    AY_CHECK_LAUNCH("k_seg_scan");
+    hipLaunchKernelGGL(k_seg_scatter, dim3((unsigned)(((uint64_t)capacity + 256 * SCAT_PER - 1) / (256 * SCAT_PER))), dim3(256), (size_t)nseg * 8, st, p);
+    AY_CHECK_LAUNCH("k_seg_scatter");
+    static bool attr_set[16] = {false};
+    const size_t seg_lds = (size_t)SEG_CAP * 31, topk_lds = (size_t)(TOPK_OUT + TOPK_BND) * 12 + (size_t)TR_BINS * 4;
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_nms), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_img_topk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)topk_lds);
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(k_seg_nms_small, dim3((unsigned)nseg), dim3(256), 0, st, p);
+    AY_CHECK_LAUNCH("k_seg_nms_small");
+    hipLaunchKernelGGL(k_seg_nms, dim3((unsigned)nseg), dim3(256), seg_lds, st, p);
+    AY_CHECK_LAUNCH("k_seg_nms");
+    hipLaunchKernelGGL(k_img_topk, dim3((unsigned)B), dim3(1024), topk_lds, st, p, seq_bits);
+    AY_CHECK_LAUNCH("k_img_topk");
+    // status[1] = total, status[2 + B ..] = candidates per image: copied from the counters (device to device, 4 * (1 + B) bytes)
+    AY_CHECK_HIP(hipMemcpyAsync(status + 1, z, 4, hipMemcpyDeviceToDevice, st));
+    AY_CHECK_HIP(hipMemcpyAsync(status + 2 + B, z + 1, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     return AYOLO_OK;
 }

@@ -274,6 +274,66 @@ def _greedy_nms_by_class(cand: _Candidates, seg_n: np.ndarray, iou_thres: float,
     return True
 
 
+_FAST_STATE: dict = {}       # (device, B, N, no, multi_label) -> [capacity, workspace, pinned status copy]
+NMS_FAST = os.environ.get("AYOLO_NMS_FAST", "1") != "0"           # the one-call LDS-resident route of the `nms` branch
+
+
+def _nms_class_fast(pred: torch.Tensor, conf_thres: float, iou_thres: float, multi_label: bool,
+                    classes: Optional[Sequence[int]], max_det: int, output: List[torch.Tensor]) -> bool:
+    """The class-aware `nms` branch in ONE library call (ayolo_nms_class_fast: no library sorts, no intermediate host
+    read).  The work buffers are sized from the previous call of the same shape; the single host read at the end returns
+    the per-image counts together with the status flags.  Returns False when a limit of that path did not hold (the
+    general path then recomputes everything); a candidate-buffer overflow is retried once with the reported size."""
+    B, N, no = pred.shape
+    nc = no - 5
+    dev = pred.device
+    class_mask = None
+    if classes is not None:
+        words = np.zeros((nc + 63) // 64, dtype=np.uint64)
+        for c in classes:
+            c = int(c)
+            if 0 <= c < nc:
+                words[c >> 6] |= np.uint64(1) << np.uint64(c & 63)
+        class_mask = torch.from_numpy(words.view(np.int64)).to(dev)
+    key = (dev, B, N, no, multi_label)
+    st = _FAST_STATE.get(key)
+    worst = B * N * (nc if multi_label else 1)
+    if st is None:
+        st = _FAST_STATE[key] = [min(worst, max(1 << 16, B * N * 2)), None, torch.empty(2 + 2 * B, dtype=torch.int32).pin_memory()]
+        while len(_FAST_STATE) > 8:
+            _FAST_STATE.pop(next(iter(_FAST_STATE)))
+    thr_f = thr_as_float_for_double_compare(iou_thres)
+    stream = torch.cuda.current_stream()
+    for _ in range(2):
+        capacity = int(st[0])
+        need = _lib.c_size_t(0)
+        args = (pred.data_ptr(), B, N, no, float(np.float32(conf_thres)), int(multi_label), ops._ptr(class_mask), thr_f, int(max_det),
+                MAX_NMS, capacity)
+        call("ayolo_nms_class_fast", *args, None, need, None, None, stream.cuda_stream)
+        if st[1] is None or st[1].numel() < int(need.value):
+            st[1] = torch.empty(int(need.value), dtype=torch.uint8, device=dev)
+        need = _lib.c_size_t(st[1].numel())
+        out = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
+        status = torch.empty(2 + 2 * B, dtype=torch.int32, device=dev)
+        call("ayolo_nms_class_fast", *args, st[1].data_ptr(), need, out.data_ptr(), status.data_ptr(), stream.cuda_stream)
+        st[2].copy_(status, non_blocking=True)
+        stream.synchronize()                                                   # the one host read of this path
+        host = st[2].numpy()
+        flags, total = int(host[0]), int(np.uint32(host[1]))
+        if flags & 1:                                                          # candidate buffer too small: resize, once
+            st[0] = min(worst, total + total // 4 + 1024)
+            continue
+        if flags:
+            return False
+        st[0] = max(min(worst, total + total // 2 + 1024), 1 << 14)            # next call: 1.5x what this one needed
+        for b in range(B):
+            k = int(host[2 + b])
+            if k:
+                output[b] = out[b, :k]
+        return True
+    return False
+
+
 def _tv_batched_strategy(cand: _Candidates, seg_n: np.ndarray, class_agnostic: bool):
     """torchvision 0.10.1 ops.boxes.batched_nms: per-class NMS when boxes.numel() > 4000, else the coordinate
     trick offset = idx * (boxes.max() + 1).  Returns (scales tensor, modes array)."""
@@ -327,6 +387,11 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_
                 extra[i, torch.arange(len(l), device=dev), l[:, 0].long() + 5] = 1.0
         pred = torch.cat((pred, extra), 1).contiguous()
         N = pred.shape[1]
+    if (nms_type == "nms" and not agnostic and nc > 1 and NMS_BY_CLASS and NMS_FAST and B <= 1024 and B * nc <= 12288
+            and max_det <= 1024 and nc * max_det <= 32768):
+        fast_out: List[torch.Tensor] = [torch.zeros((0, 6), dtype=torch.float32, device=dev)] * B
+        if _nms_class_fast(pred, conf_thres, iou_thres, multi_label, classes, max_det, fast_out):
+            return fast_out
     by_seq = nms_type in ("fast_nms", "matrix_nms")           # those branches run on UNSORTED candidates
     cand = _collect_candidates(pred, conf_thres, multi_label, True, classes, None, by_seq)
     seg_n = np.minimum(cand.counts, MAX_NMS)
@@ -344,7 +409,7 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_
             scales, modes = _tv_batched_strategy(cand, seg_n, agnostic)
         else:
             scales, modes = (0.0 if agnostic else float(MAX_WH)), np.zeros(B, dtype=np.int64)
-        if nms_type == "nms" and not agnostic and nc > 1 and NMS_BY_CLASS and int(seg_n.max()) > 512:
+        if nms_type == "nms" and not agnostic and nc > 1 and NMS_BY_CLASS and int(seg_n.max()) > 512:   # (general path)
             if _greedy_nms_by_class(cand, seg_n, iou_thres, nc, max_det, output):
                 return output
         out, out_idx, kept = _greedy_nms(cand, seg_n, iou_thres, scales, modes, max_det)

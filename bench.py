@@ -139,6 +139,15 @@ def in_situ_roofline(model, one_step, ms_per_step, batch):
                 **({"tflops": round(v[2] / 1e9 / v[0], 1)} if v[2] else {})}
             for n, v in sorted(fam.items(), key=lambda kv: -kv[1][0]) if v[0] > 0.0005}
     step_gb = sum(v[1] for v in fam.values()) / 1e9
+    # SURVEY.md 8d's model of the step: every conv reads its input, writes its output and reads the weights ONCE; BatchNorm /
+    # activation passes are "fused away" and count nothing.  forward + dgrad + wgrad conv ops of the plan:
+    conv_only_gb = sum(fam[n][1] for n in ("conv_fwd", "conv_dgrad", "conv_wgrad") if n in fam) / 1e9
+    if plan.bn_in_dgrad:      # the z reads of the BN sums folded into dgrad epilogues are not conv traffic in 8d's sense
+        from ayolov2_amd.plan import OP_CONV_DGRAD
+        conv_only_gb -= sum(2 * o.conv.B * o.conv.H * o.conv.W * sum(_seg_c(o)) for o in plan.bwd
+                            if (o.kind & 0xff) == OP_CONV_DGRAD and o.i[1] > 0) / 1e9
+    img_s = batch / (ms_per_step * 1e-3)
+    step_tf = img_s * FWD_BWD_GFLOP_PER_IMG / 1e3
     return {"bound": "hbm", "kernel": "k_gconv / k_gconv3 / k_dgrad_s2 <f16>: every forward + dgrad conv launch of one train step, timed in situ",
             "achieved": round(gb / ms * 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / ms * 1e3 / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_unit": "GB per train step over every k_gconv launch, PMC", "traffic_source": src,
@@ -146,12 +155,30 @@ def in_situ_roofline(model, one_step, ms_per_step, batch):
             "measured": f"HIP events around each op on its own stream inside {reps} real train steps (ayolo_run_ops_timed)",
             "mfma_view": {"achieved_tflops": round(tf / ms * 1e3, 1), "peak_tflops": MFMA_PEAK_TFLOPS,
                           "frac": round(tf / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)},
+            # SURVEY.md 8d's headline: (49.30 GFLOP x img/s) / dense fp16 MFMA peak, over the WHOLE step
+            "mfma": {"bound": "mfma", "achieved": round(step_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
+                     "basis": f"{FWD_BWD_GFLOP_PER_IMG} GFLOP per image (conv MACs fwd + bwd, SURVEY.md 8d) x {img_s:.0f} img/s, wall time of the step"},
+            "bn_layers_folded_into_dgrad": plan.bn_in_dgrad,
             "families_in_situ": fams,
             "whole_step": {"algorithmic_gb": round(step_gb, 2), "ms_per_step": round(ms_per_step, 3),
                            "achieved_gb_per_s": round(step_gb / ms_per_step * 1e3, 1),
                            "frac_of_hbm_peak": round(step_gb / ms_per_step * 1e3 / HBM_PEAK_GBS, 4),
                            "note": "sum of every op's algorithmic bytes / wall time of the step (weight gradients overlap "
-                                   "the main chain on a side stream, so family times add up to more than the step)"}}
+                                   "the main chain on a side stream, so family times add up to more than the step)",
+                           "conv_only_8d": {"algorithmic_gb": round(conv_only_gb, 2),
+                                            "achieved_gb_per_s": round(conv_only_gb / ms_per_step * 1e3, 1),
+                                            "frac_of_hbm_peak": round(conv_only_gb / ms_per_step * 1e3 / HBM_PEAK_GBS, 4),
+                                            "note": "SURVEY.md 8d's model: conv in / out / weights once, every BatchNorm / "
+                                                    "activation pass counted as fused away"}}}
+
+
+def _seg_c(op):
+    """channel counts of the BatchNorm segments a dgrad op carries (plan._fold_bn_reduce)"""
+    import ctypes
+    from ayolov2_amd._lib import BnSeg
+    segs = ctypes.cast(op.p[3], ctypes.POINTER(BnSeg))
+    return [segs[k].C for k in range(op.i[1])]
 
 
 def host_info():
@@ -192,7 +219,7 @@ def _median_ms(fn, runs, warm):
     return ts[len(ts) // 2]
 
 
-def cpu_baseline(model_name, size, batch=4, budget_s=14.0):
+def cpu_baseline(model_name, size, batch=8, budget_s=14.0):
     """The oracle (kind "port": pure-PyTorch CPU network + numpy / C NMS restatement, oracle/) on the host cores, bounded
     samples of BASELINE.md section 3's three workloads.  `value` is workload C -- the headline metric's train step."""
     from ayolov2_amd.losses import ComputeLoss
@@ -216,7 +243,7 @@ def cpu_baseline(model_name, size, batch=4, budget_s=14.0):
         opt.step()
         n += 1
         el = time.perf_counter() - t0
-        if n >= 2 and el > budget_s or n >= 8:
+        if n >= 2 and el > budget_s or n >= 6:
             break
     out = {"value": round(batch * n / el, 3), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"workload C: {n} train steps of oracle/model_ref.py {model_name} fp32 at batch {batch}, {size}x{size}, {el:.1f} s",
@@ -233,12 +260,12 @@ def cpu_baseline(model_name, size, batch=4, budget_s=14.0):
         # the NMS leg of workload A is timed once; workload B below is the calibrated NMS benchmark
         pn = pred.numpy()
         t0 = time.perf_counter()
-        ops_ref.non_max_suppression(pn[:2], 0.001, 0.65, multi_label=True)
-        t_nms = (time.perf_counter() - t0) * 1e3 * 4
+        ops_ref.non_max_suppression(pn, 0.001, 0.65, multi_label=True)
+        t_nms = (time.perf_counter() - t0) * 1e3
     out["workload_a_cfg1"] = {"images": 8, "ms_per_batch": {"pre_process": round(t_pre, 2), "inference": round(t_inf, 1),
                                                              "nms": round(t_nms, 1)},
                               "img_per_s": round(8e3 / (t_pre + t_inf + t_nms), 2),
-                              "note": "yolov5s fuse().eval() fp32, random-init weights; NMS leg = 2 images x 4 (30 000 candidates each)"}
+                              "note": "yolov5s fuse().eval() fp32, random-init weights; NMS leg timed once over all 8 images (30 000 candidates each)"}
     # ---- B: NMS on the calibrated synthetic predictions (8 x 25 200 x 85, ~10 % pass obj > 0.001)
     g = torch.Generator().manual_seed(0)
     B, N, nc = 8, 25200, 80

@@ -302,6 +302,21 @@ int ayolo_nms_class_merge(const float* rows1, const int32_t* out_idx, const uint
                           const uint32_t* seg_off2, const uint32_t* perm, int nseg, uint32_t max_out,
                           const uint32_t* sel_off, int B, uint32_t tot, uint32_t max_det, uint32_t* flags,
                           uint32_t* scan, float* out, uint32_t* kept, void* ws, size_t* ws_bytes, ayolo_stream s);
+
+/* The whole class-aware `nms` branch of non_max_suppression (scripts/utils/metrics.py:313-388: confidence filter, multi-label
+ * expansion, boxes offset by cls * 4096, torchvision.ops.nms, max_det) in ONE call without library sorts or intermediate host
+ * reads: candidates -> per (image, class) grouping -> one workgroup per segment sorts and scans its candidates in LDS -> one
+ * workgroup per image merges the kept boxes in confidence order.  pred: (B, N, no) fp32 xywh + obj + nc class scores;
+ * out: (B, max_det, 6) rows [x1, y1, x2, y2, conf, cls]; status (device uint32[2 + 2B]): [0] flags -- non-zero means a limit of
+ * this path did not hold (bit 0: `capacity` candidates were not enough, [1] holds the number needed; bit 1: coordinates span
+ * >= 4096 so classes are not separable by the offset; bit 2: a segment above 2048 candidates, or more than 8192 keys in the
+ * histogram bucket that decides the max_nms cut; bit 3: an image kept more than 8192 boxes) and the caller takes the general
+ * path (ayolo_nms_candidates ... ayolo_nms_reduce).  An image with more than max_nms candidates keeps its max_nms most
+ * confident ones before NMS (metrics.py:378-379), selected exactly on the device; [2 .. 2 + B) rows per image in `out`; [2 + B ..) candidates per image.
+ * ws == NULL: *ws_bytes receives the workspace size for `capacity`.  iou_thres_f as for ayolo_nms_mask. */
+int ayolo_nms_class_fast(const float* pred, int B, int N, int no, float conf_thres, int multi_label,
+                         const uint64_t* class_mask, float iou_thres_f, uint32_t max_det, uint32_t max_nms,
+                         uint32_t capacity, void* ws, size_t* ws_bytes, float* out, uint32_t* status, ayolo_stream s);
 /* Fixed-shape batched NMS with the TensorRT BatchedNMS_TRT contract of the reference's engines
  * (scripts/model_converter/model_converter.py:268-388; outputs read by train_utils.py:262-283): per (image, class)
  * the topK boxes with score = obj*cls > scoreThreshold, greedy NMS with the plugin's jaccard (isNormalized = 0: +1 on

@@ -145,34 +145,70 @@ def test_head_decode_vs_oracle():
 
 def test_nms_per_class_segments_equal_all_pairs(monkeypatch):
     """The class-aware `nms` branch runs per (image, class) segment when the candidates' coordinates span < 4096 (the
-    reference's class offset).  Both routes must give the oracle's rows: (a) ordinary boxes -> segmented route,
-    (b) a few boxes wider than the offset -> the all-pairs route is taken, (c) the segmented route switched off."""
+    reference's class offset).  Every route must give the oracle's rows: (a) ordinary boxes -> the one-call LDS-resident route
+    (ayolo_nms_class_fast); (b) the same with that route switched off -> the segmented route over library sorts; (c) a few
+    boxes wider than the offset -> both decline (span check, on the device / on the host) and the all-pairs route is taken;
+    (d) the segmented routes switched off."""
     from ayolov2_amd import metrics as M
     pred = synth_pred(2, 20000, 80, 640, -7.0, seed=5)
     pred[:, :64, 4] = 0.9                      # equal confidences across classes: tie order = candidate order
     pred[:, :64, 5:] = 0.0
     pred[:, :64, 5 + (torch.arange(64) % 7)] = 0.8
     want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.6, multi_label=True)
-    calls = []
-    orig = M._greedy_nms_by_class
+    calls, fast_calls = [], []
+    orig, orig_fast = M._greedy_nms_by_class, M._nms_class_fast
 
     def spy(*a, **k):
         r = orig(*a, **k)
         calls.append(r)
         return r
 
+    def spy_fast(*a, **k):
+        r = orig_fast(*a, **k)
+        fast_calls.append(r)
+        return r
+
     monkeypatch.setattr(M, "_greedy_nms_by_class", spy)
+    monkeypatch.setattr(M, "_nms_class_fast", spy_fast)
+    _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.6, multi_label=True), want, True, "one-call route")
+    assert fast_calls == [True] and calls == []
+    monkeypatch.setattr(M, "NMS_FAST", False)
     _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.6, multi_label=True), want, True, "segmented")
     assert calls == [True]
+    monkeypatch.setattr(M, "NMS_FAST", True)
     wide = pred.clone()
     wide[0, 100:104, 2:4] = 9000.0             # boxes wider than the class offset: classes are no longer disjoint
     wide[0, 100:104, 4] = 0.95
     want_w = ops_ref.non_max_suppression(wide.numpy(), conf_thres=0.001, iou_thres=0.6, multi_label=True)
-    _cmp(M.non_max_suppression(wide.cuda(), 0.001, 0.6, multi_label=True), want_w, True, "wide boxes")
-    assert calls == [True, False]
+    _cmp(M.non_max_suppression(wide.cuda(), 0.001, 0.6, multi_label=True), want_w, True, "all pairs (span)")
+    assert fast_calls == [True, False] and calls == [True, False]
     monkeypatch.setattr(M, "NMS_BY_CLASS", False)
-    _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.6, multi_label=True), want, True, "all pairs")
-    assert len(calls) == 2
+    _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.6, multi_label=True), want, True, "all pairs (switch)")
+    assert fast_calls == [True, False] and calls == [True, False]
+
+
+def test_nms_one_call_route_limits():
+    """ayolo_nms_class_fast's own limits, each against the oracle: an image above max_nms candidates (exact top-30 000 cut on
+    the device: radix select), a (image, class) segment above the LDS bit-matrix size (blockwise kernel) and above the segment
+    capacity (declined -> general path), and a candidate buffer that is too small on the first call (resized once)."""
+    from ayolov2_amd import metrics as M
+    # (1) > 30 000 candidates in one image
+    pred = synth_pred(1, 25200, 80, 640, -6.0, seed=21)
+    want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.65, multi_label=True)
+    _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.65, multi_label=True), want, True, "max_nms cut")
+    # (2) one class holds most candidates: ~1 500 in a segment (blockwise kernel), then ~6 000 (over SEG_CAP: declined)
+    for n_hot, what in ((1500, "large segment"), (6000, "segment over capacity")):
+        pred = synth_pred(2, 8000, 80, 640, -9.0, seed=22)
+        pred[0, :n_hot, 4] = torch.linspace(0.9, 0.2, n_hot)
+        pred[0, :n_hot, 5:] = 0.0
+        pred[0, :n_hot, 5 + 3] = 0.9
+        want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.5, multi_label=True)
+        _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.5, multi_label=True), want, True, what)
+    # (3) candidate buffer smaller than needed on the first call of a shape
+    M._FAST_STATE.clear()
+    pred = synth_pred(1, 4096, 80, 640, 2.0, seed=23)           # nearly every (row, class) pair passes the threshold
+    want = ops_ref.non_max_suppression(pred.numpy(), conf_thres=0.001, iou_thres=0.65, multi_label=True)
+    _cmp(M.non_max_suppression(pred.cuda(), 0.001, 0.65, multi_label=True), want, True, "buffer resized")
 
 
 @pytest.mark.parametrize("cpb", ["1", "5"])
