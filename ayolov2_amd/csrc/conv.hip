@@ -40,7 +40,7 @@ struct GConvP {
     int OH, OW, ish, isw;
     int YH, YW, ldy, osh, osw, oah, oaw;
     int C, ntaps, K, ldw, Nout;
-    int epi; const float* scale; const float* shift; float* stats;
+    int epi; const float* scale; const float* shift; double* stats;
     int head_no; int accumulate; int stat_reps;
     int x_linear, y_linear, ntn, nslots;
     long long Mtotal;
@@ -153,7 +153,7 @@ struct GT {
     static constexpr int WM = TM / (32 * MI), WP = 4 / WM, NI = TP / (32 * WP);
     static constexpr int NACC = MI * NI;            // accumulator blocks per wave
     static constexpr int NST = NACC * 4;            // store instructions per thread per epilogue
-    static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 6 * TM * sizeof(float);   // stats [2][TM] + BNR constants [4][TM]
+    static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 8 * TM * sizeof(float);   // statistics [2][TM] fp64 + BNR constants [4][TM]
 };
 
 // Explicit MFMA-result hazard pad (see the comment in k_gconv's step loop).  The pad only works if the MFMAs stay in front of
@@ -615,24 +615,30 @@ __device__ __forceinline__ int g_stat_chan(int r, int hsel) {
     else return (r >> 4) * 32 + 4 * hsel + 8 * ((r & 15) >> 2) + (r & 3);
 }
 
+// Statistics accumulate in DOUBLE from the workgroup level on (LDS and global atomics).  Per-lane partial sums and the wave
+// reductions are fp32 in a fixed order; what is order-dependent -- which wavefront / workgroup adds first -- then rounds at
+// 1e-16, far below one fp32 ulp of the mean / variance derived from the totals, so a step's BatchNorm statistics (and with
+// them the fp16 rounding of every activation) repeat from run to run.  With fp32 atomics two identical fp16 train steps
+// differed by cosine 0.993-0.998 in their gradients (tools/cond_explore.py), which is the noise floor every fp16 parity
+// threshold had to sit under.
 // workgroup totals in sStat [2][TM] -> global accumulators: forward statistics [reps][2][Nout], or (BNR) the
 // [reps][2][C] accumulators of the segment each channel belongs to
 template <int TM, bool BNR>
-__device__ __forceinline__ void g_stats_to_global(const GConvP& p, const float* sStat, int tid, int n0, unsigned slot) {
+__device__ __forceinline__ void g_stats_to_global(const GConvP& p, const double* sStat, int tid, int n0, unsigned slot) {
     if constexpr (BNR) {
         for (int i = tid; i < TM; i += 256) {
             const int c = n0 + i;
             const int sg = (p.bnr > 1 && c >= p.bseg[1].c0) ? 1 : 0;
             const int cl = c - p.bseg[sg].c0, C = p.bseg[sg].C;
             if (c < p.Nout && cl >= 0 && cl < C) {
-                float* st = p.bseg[sg].sums + (size_t)(slot % (unsigned)p.bnr_reps) * 2 * C;
+                double* st = p.bseg[sg].sums + (size_t)(slot % (unsigned)p.bnr_reps) * 2 * C;
                 atomicAdd(&st[cl], sStat[i]);
                 atomicAdd(&st[C + cl], sStat[TM + i]);
             }
         }
     } else {
         // replicated accumulators: workgroups spread over stat_reps copies so L2 atomics do not serialise
-        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
+        double* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
         for (int i = tid; i < TM; i += 256) {
             if (n0 + i < p.Nout) {
                 atomicAdd(&st[n0 + i], sStat[i]);
@@ -643,9 +649,9 @@ __device__ __forceinline__ void g_stats_to_global(const GConvP& p, const float* 
 }
 
 template <typename T, int TM, int MI, bool BNR = false>
-__device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int tid, int lane, int wm, int n0, unsigned slot,
+__device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, int tid, int lane, int wm, int n0, unsigned slot,
                                               const float (&ssum)[16 * MI], const float (&ssq)[16 * MI]) {
-    for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+    for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16 * MI; ++r) {
@@ -657,12 +663,12 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, float* sStat, int
         }
         if ((lane & 31) == 0) {
             const int cl = wm * 32 * MI + g_stat_chan<BNR>(r, lane >> 5);
-            atomicAdd(&sStat[cl], a);
-            atomicAdd(&sStat[TM + cl], b);
+            atomicAdd(&sStat[cl], (double)a);
+            atomicAdd(&sStat[TM + cl], (double)b);
         }
     }
     __syncthreads();
-    g_stats_to_global<TM, BNR>(p, sStat, tid, n0, slot);
+    g_stats_to_global<TM, BNR>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
 }
 
 template <typename T, int TM, int EM, int TPX, bool BNR = false>
@@ -717,11 +723,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
         }
     }
     constexpr bool TILE_RED = BNR && TM == 128;
-    if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 2 * TM, n0, tid);
+    if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 4 * TM, n0, tid);
     if constexpr (TILE_RED) {
-        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+        for (int i = tid; i < 2 * TM; i += 256) reinterpret_cast<double*>(sStat)[i] = 0.0;
     }
-    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 2 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
+    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 4 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
     const unsigned lds_tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sTiles);
@@ -839,15 +845,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
                 // living in 32-64 registers across the step loop next to the accumulators and the fragments
                 int lq = lane;
                 asm volatile("" : "+v"(lq));
-                float* sl = sStat + wm * 32 * G::MI;
+                double* sl = reinterpret_cast<double*>(sStat) + wm * 32 * G::MI;
 #pragma unroll
                 for (int r = 0; r < 16 * G::MI; ++r) {
                     const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
                     ssum[r] = 0.0f; ssq[r] = 0.0f;
                     if ((lq & 15) == 0) {
                         const int cl = g_stat_chan<true>(r, lq >> 5);
-                        atomicAdd(&sl[cl], a);
-                        atomicAdd(&sl[TM + cl], b);
+                        atomicAdd(&sl[cl], (double)a);
+                        atomicAdd(&sl[TM + cl], (double)b);
                     }
                 }
             }
@@ -870,9 +876,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     wait_vm<0>();                             // the trailing zero-fill DMAs must land before this LDS is released
     if constexpr (TILE_RED) {
         __syncthreads();
-        g_stats_to_global<TM, true>(p, sStat, tid, n0, slot);
-    } else if constexpr (BNR) g_stats_flush<T, TM, G::MI, true>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
-    else if (want_stats) g_stats_flush<T, TM, G::MI>(p, sStat, tid, lane, wm, n0, slot, ssum, ssq);
+        g_stats_to_global<TM, true>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
+    } else if constexpr (BNR) g_stats_flush<T, TM, G::MI, true>(p, reinterpret_cast<double*>(sStat), tid, lane, wm, n0, slot, ssum, ssq);
+    else if (want_stats) g_stats_flush<T, TM, G::MI>(p, reinterpret_cast<double*>(sStat), tid, lane, wm, n0, slot, ssum, ssq);
 }
 
 
@@ -898,7 +904,7 @@ struct GT3 {
     static constexpr int XS = XROWS * G::ROWB;               // bytes per x stage
     static constexpr int WS = G::WSTAGE;
     static constexpr int XP = G::XR / 2;                     // DMA instructions per thread in x parts 0 and 1
-    static constexpr size_t LDS = 3 * (size_t)XS + 3 * (size_t)WS + 6 * TM * sizeof(float);
+    static constexpr size_t LDS = 3 * (size_t)XS + 3 * (size_t)WS + 8 * TM * sizeof(float);
     static_assert(G::XR % 2 == 0 && G::ES == 2, "fp16, 128- or 256-pixel tiles");
 };
 
@@ -940,8 +946,8 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
             sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
         }
     }
-    if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 2 * TM, n0, tid);
-    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 2 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
+    if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 4 * TM, n0, tid);
+    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 4 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
     const unsigned lds_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sX);
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
     const bool want_stats = !BNR && (EM == 0) && (p.stats != nullptr);
     const bool any_stats = BNR || want_stats;
     if constexpr (EM == 0 || BNR) {
-        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+        for (int i = tid; i < 2 * TM; i += 256) reinterpret_cast<double*>(sStat)[i] = 0.0;
     }
     // ... except for the narrow channel tiles (32 registers, plenty of room, and only 9-18 sub-steps per tile to amortise a
     // per-tile reduction over): those keep them in registers across tiles like k_gconv
@@ -1137,14 +1143,14 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
             if (any_stats && !SREG) {
                 int lq = lane;                              // opaque: keeps the LDS addresses below from being hoisted out of the
                 asm volatile("" : "+v"(lq));                // tile loop (and spilled: every reload would drain the DMA queue)
-                float* sl = sStat + wm * 32 * G::MI;
+                double* sl = reinterpret_cast<double*>(sStat) + wm * 32 * G::MI;
 #pragma unroll
                 for (int r = 0; r < 16 * G::MI; ++r) {
                     const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
                     if ((lq & 15) == 0) {
                         const int cl = g_stat_chan<BNR>(r, lq >> 5);
-                        atomicAdd(&sl[cl], a);
-                        atomicAdd(&sl[TM + cl], b);
+                        atomicAdd(&sl[cl], (double)a);
+                        atomicAdd(&sl[TM + cl], (double)b);
                     }
                 }
             }
@@ -1160,12 +1166,12 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
 #undef G3_SETUP
     wait_vm<0>();                             // trailing DMAs must land before this LDS is released
     if constexpr (SREG) {
-        if (any_stats) g_stats_flush<T, TM, G::MI, BNR>(p, sStat, tid, lane, wm, n0, slot, rsum, rsq);
+        if (any_stats) g_stats_flush<T, TM, G::MI, BNR>(p, reinterpret_cast<double*>(sStat), tid, lane, wm, n0, slot, rsum, rsq);
         return;
     }
     if (any_stats) {
         __syncthreads();
-        g_stats_to_global<TM, BNR>(p, sStat, tid, n0, slot);
+        g_stats_to_global<TM, BNR>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
     }
 }
 
@@ -1229,11 +1235,11 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
     const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sW);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     if constexpr (BNR) {
-        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
-        g_bnr_setup<TM>(p, sStat + 2 * TM, n0, tid);
+        for (int i = tid; i < 2 * TM; i += 256) reinterpret_cast<double*>(sStat)[i] = 0.0;
+        g_bnr_setup<TM>(p, sStat + 4 * TM, n0, tid);
         __syncthreads();
     }
-    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 2 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
+    const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 4 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
 
     const int slotc = lane & (G::CPR - 1);
     const int rowin = lane / G::CPR;
@@ -1400,14 +1406,14 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
                 // 32 more registers living across the step loop do not fit next to the 128 accumulators
                 int lq = lane;
                 asm volatile("" : "+v"(lq));
-                float* sl = sStat + wm * 32;
+                double* sl = reinterpret_cast<double*>(sStat) + wm * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
                     if ((lq & 15) == 0) {
                         const int cl = g_stat_chan<true>(r, lq >> 5);
-                        atomicAdd(&sl[cl], a);
-                        atomicAdd(&sl[TM + cl], b);
+                        atomicAdd(&sl[cl], (double)a);
+                        atomicAdd(&sl[TM + cl], (double)b);
                     }
                 }
             }
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
     wait_vm<0>();
     if constexpr (BNR) {
         __syncthreads();
-        g_stats_to_global<TM, true>(p, sStat, tid, n0, slot);
+        g_stats_to_global<TM, true>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
     }
 }
 
@@ -1484,7 +1490,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
     }
     const bool want_stats = (EM == 0) && (p.stats != nullptr);
     if constexpr (EM == 0) {
-        for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0f;
+        for (int i = tid; i < 2 * TM; i += 256) reinterpret_cast<double*>(sStat)[i] = 0.0;
     }
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
@@ -1652,14 +1658,14 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
             if (want_stats) {
                 int lq = lane;
                 asm volatile("" : "+v"(lq));
-                float* sl = sStat + wm * 32 * G::MI + 4 * (lq >> 5);
+                double* sl = reinterpret_cast<double*>(sStat) + wm * 32 * G::MI + 4 * (lq >> 5);
 #pragma unroll
                 for (int r = 0; r < 16 * G::MI; ++r) {
                     const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
                     if ((lq & 15) == 0) {
                         const int cl = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + (r & 3);
-                        atomicAdd(&sl[cl], a);
-                        atomicAdd(&sl[TM + cl], b);
+                        atomicAdd(&sl[cl], (double)a);
+                        atomicAdd(&sl[TM + cl], (double)b);
                     }
                 }
             }
@@ -1676,13 +1682,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
     wait_vm<0>();
     if (want_stats) {
         __syncthreads();
-        float* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
-        for (int i = tid; i < TM; i += 256) {
-            if (n0 + i < p.Nout) {
-                atomicAdd(&st[n0 + i], sStat[i]);
-                atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
-            }
-        }
+        g_stats_to_global<TM, false>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
     }
 }
 
@@ -1733,7 +1733,7 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     if constexpr (sizeof(T) == 2 && EM != 3 && EM != 1) {
         if (p.s2f) {                         // forward 3x3 / stride 2 with the odd-column taps sharing one row run
             constexpr size_t lds2 = 3 * (size_t)(G::TP + 16) * G::ROWB + 3 * (size_t)(2 * TM * G::ROWB < 4096 ? 4096 : 2 * TM * G::ROWB) +
-                                    2 * TM * sizeof(float);
+                                    4 * TM * sizeof(float);
             const long long slots2 = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc_env > 0 ? bpc_env : 2).slots;
             p.nslots = (int)slots2;
             static bool attr2_set[16] = {false};
@@ -1821,7 +1821,7 @@ template <int TM, int EM, int TPX, bool BNR = false>
 static int launch_dgrad_s2(GConvP p, hipStream_t s) {
     using G = GT<half_t, TM, TPX>;
     // nine tap tiles; the one-tap step D still issues one piece per wave (4 KiB): one tile of slack behind it for TM = 32
-    const size_t lds = 3 * (size_t)(G::TP + 16) * G::ROWB + (9 + (TM == 32 ? 1 : 0)) * (size_t)TM * G::ROWB + 6 * TM * sizeof(float);
+    const size_t lds = 3 * (size_t)(G::TP + 16) * G::ROWB + (9 + (TM == 32 ? 1 : 0)) * (size_t)TM * G::ROWB + 8 * TM * sizeof(float);
     p.ntn = (p.Nout + TM - 1) / TM;
     const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, 2).slots;
     p.nslots = (int)slots;
@@ -1958,7 +1958,7 @@ static int check_desc(const ayolo_conv_desc* d, const char* who) {
 }
 
 extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void* y, int epilogue,
-                              const float* scale, const float* shift, float* stats, int stat_reps, int head_no,
+                              const float* scale, const float* shift, double* stats, int stat_reps, int head_no,
                               ayolo_stream s) {
     int rc = check_desc(d, "conv_fwd");
     if (rc) return rc;

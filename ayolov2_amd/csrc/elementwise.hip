@@ -59,15 +59,15 @@ static unsigned grid_for(long long work_items, int per_block) {
 // ---------------------------------------------------------------------------------------------------
 // BN finalize
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_bn_finalize(const float* stats, int reps, int C, double count, const float* gamma, const float* beta,
+__global__ void k_bn_finalize(const double* stats, int reps, int C, double count, const float* gamma, const float* beta,
                               float eps, float momentum, float* rmean, float* rvar, float* smean, float* sinv,
                               float* scale, float* shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
     for (int r = 0; r < reps; ++r) {
-        s1 += (double)stats[(size_t)r * 2 * C + c];
-        s2 += (double)stats[(size_t)r * 2 * C + C + c];
+        s1 += stats[(size_t)r * 2 * C + c];
+        s2 += stats[(size_t)r * 2 * C + C + c];
     }
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
@@ -86,7 +86,7 @@ __global__ void k_bn_finalize(const float* stats, int reps, int C, double count,
     }
 }
 
-extern "C" int ayolo_bn_finalize(const float* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
+extern "C" int ayolo_bn_finalize(const double* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
                                  float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                                  float* save_invstd, float* scale, float* shift, ayolo_stream s) {
     AY_CHECK_ARG(stats && scale && shift && C > 0 && count > 0, "bn_finalize: bad args");
@@ -211,7 +211,7 @@ static unsigned grid_pixels(long long npix, int C, int ve, int min_iters) {
 // k_bn_finalize), workgroup 0 also writes save_mean / save_invstd and updates the running statistics.
 template <typename T, int ACT, int RES>
 __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a, int lda, long long npix, int C,
-                                                      const float* stats, int reps, int sld, double count, const float* gamma,
+                                                      const double* stats, int reps, int sld, double count, const float* gamma,
                                                       const float* beta, float eps, float momentum, float* rmean, float* rvar,
                                                       float* smean, float* sinv, const T* res, int ldr) {
     constexpr int VE = VecT<T>::VE;
@@ -221,14 +221,15 @@ __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a,
     for (int c = threadIdx.x; c < C; c += 256) {
         double s1 = 0.0, s2 = 0.0;
         for (int r = 0; r < reps; ++r) {
-            s1 += (double)stats[(size_t)r * 2 * sld + c];
-            s2 += (double)stats[(size_t)r * 2 * sld + sld + c];
+            s1 += stats[(size_t)r * 2 * sld + c];
+            s2 += stats[(size_t)r * 2 * sld + sld + c];
         }
-        const double icount = 1.0 / count;            // uniform: one fp64 reciprocal, then multiplies only
-        const double mean = s1 * icount;
-        double var = s2 * icount - mean * mean;       // the cancellation-prone step stays in fp64
+        // the SAME expression sequence as k_bn_finalize (the per-module path): with reproducible statistics the two routes
+        // then derive bit-identical scale / shift vectors, and a route comparison in fp16 is about the kernels only
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;        // the cancellation-prone step stays in fp64
         if (var < 0) var = 0;
-        const float invstd = 1.0f / sqrtf((float)var + eps);
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
         const float sc = g * invstd;
         sc_sh[c] = sc;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a,
     }
 }
 
-extern "C" int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* stats,
+extern "C" int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const double* stats,
                                   int stat_reps, int stat_ld, double count, const float* gamma, const float* beta, float eps, float momentum,
                                   float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
                                   const void* residual, int ldr, ayolo_stream s) {
@@ -333,7 +334,7 @@ __device__ __forceinline__ void bn_bwd_elem(float z, float da, float mu, float i
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, const T* da, int ldda, long long npix, int C,
                                                        const float* mean, const float* invstd, const float* gamma,
-                                                       const float* beta, float* sums, int reps) {
+                                                       const float* beta, double* sums, int reps) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float bs[];   // [RPB][2*C] per-pixel-row partial sums (<= 16 KiB)
     const int CG = C / VE;
@@ -392,17 +393,18 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* z, int ldz, cons
     }
     __syncthreads();
     // column sums over the RPB pixel rows (plain LDS reads, no LDS atomics), one global atomic per channel sum
-    float* dst = sums + (size_t)(blockIdx.x % (unsigned)reps) * 2 * C;
+    // (fp64 from here on: see the note on BatchNorm accumulators in ayolo.h)
+    double* dst = sums + (size_t)(blockIdx.x % (unsigned)reps) * 2 * C;
     for (int i = threadIdx.x; i < 2 * C; i += 256) {
         float t = 0.0f;
         for (int r = 0; r < RPB; ++r) t += bs[(size_t)r * 2 * C + i];
-        atomicAdd(&dst[i], t);
+        atomicAdd(&dst[i], (double)t);
     }
 }
 
 extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const void* da, int ldda, int64_t npix, int C,
                                        const float* save_mean, const float* save_invstd, const float* gamma,
-                                       const float* beta, int act, float* sums, int sum_reps, ayolo_stream s) {
+                                       const float* beta, int act, double* sums, int sum_reps, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
     if (sum_reps < 1) sum_reps = 1;
     AY_CHECK_ARG(z && da && sums && save_mean && save_invstd, "bn_bwd_reduce: null pointer");
@@ -423,7 +425,7 @@ extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const 
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const T* da, int ldda, T* dz, int lddz,
                                                       long long npix, int C, const float* mean, const float* invstd,
-                                                      const float* gamma, const float* beta, const float* sums,
+                                                      const float* gamma, const float* beta, const double* sums,
                                                       int reps, float* dgamma, float* dbeta, float grad_scale) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sh[];   // [6][C]: mean, invstd, gamma, beta, sum_du/n, sum_dux/n
@@ -432,8 +434,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     for (int i = threadIdx.x; i < C; i += 256) {
         sh[i] = mean[i]; sh[C + i] = invstd[i];
         sh[2 * C + i] = gamma ? gamma[i] : 1.0f; sh[3 * C + i] = beta ? beta[i] : 0.0f;
-        float s1 = 0.0f, s2 = 0.0f;
-        for (int r = 0; r < reps; ++r) { s1 += sums[(size_t)r * 2 * C + i]; s2 += sums[(size_t)r * 2 * C + C + i]; }
+        double d1 = 0.0, d2 = 0.0;
+        for (int r = 0; r < reps; ++r) { d1 += sums[(size_t)r * 2 * C + i]; d2 += sums[(size_t)r * 2 * C + C + i]; }
+        const float s1 = (float)d1, s2 = (float)d2;
         sh[4 * C + i] = s1 * invn; sh[5 * C + i] = s2 * invn;
         if (blockIdx.x == 0) {
             if (dbeta) dbeta[i] = s1 * grad_scale;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
 
 extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
                                       int64_t npix, int C, const float* save_mean, const float* save_invstd,
-                                      const float* gamma, const float* beta, int act, const float* sums, int sum_reps,
+                                      const float* gamma, const float* beta, int act, const double* sums, int sum_reps,
                                       float* dgamma, float* dbeta, float grad_scale, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
     if (sum_reps < 1) sum_reps = 1;

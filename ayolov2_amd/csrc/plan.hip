@@ -167,7 +167,7 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
             break;
         case AYOLO_OP_CONV_FWD:
             rc = ayolo_conv_fwd(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const float*)o.p[3], (const float*)o.p[4],
-                                (float*)o.p[5], o.i[1], o.i[2], cs);
+                                (double*)o.p[5], o.i[1], o.i[2], cs);
             break;
         case AYOLO_OP_CONV_DGRAD:
             // i[1] > 0: the BatchNorm-backward sums of the i[1] block(s) that produced dx ride in the epilogue
@@ -185,7 +185,7 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
             rc = ayolo_cast_weights((const ayolo_cast_job*)o.p[0], o.i[0], o.i[1], cs);
             break;
         case AYOLO_OP_BN_FINALIZE:
-            rc = ayolo_bn_finalize((const float*)o.p[0], o.i[0], o.i[1], o.d[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
+            rc = ayolo_bn_finalize((const double*)o.p[0], o.i[0], o.i[1], o.d[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
                                    o.f[1], (float*)o.p[3], (float*)o.p[4], (float*)o.p[5], (float*)o.p[6], (float*)o.p[7],
                                    (float*)o.p[8], cs);
             break;
@@ -194,19 +194,19 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
                                       (const float*)o.p[3], o.i[4], o.p[4], o.i[5], cs);
             break;
         case AYOLO_OP_BN_TRAIN_ACT:
-            rc = ayolo_bn_train_act(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], (const float*)o.p[2], o.i[4], o.i[7], o.d[0],
+            rc = ayolo_bn_train_act(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], (const double*)o.p[2], o.i[4], o.i[7], o.d[0],
                                     (const float*)o.p[3], (const float*)o.p[4], o.f[0], o.f[1], (float*)o.p[5], (float*)o.p[6],
                                     (float*)o.p[7], (float*)o.p[8], o.i[5], o.p[9], o.i[6], cs);
             break;
         case AYOLO_OP_BN_BWD_REDUCE:
             rc = ayolo_bn_act_bwd_reduce(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], (const float*)o.p[2],
-                                         (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5], o.i[4], (float*)o.p[6],
+                                         (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5], o.i[4], (double*)o.p[6],
                                          o.i[5], cs);
             break;
         case AYOLO_OP_BN_BWD_APPLY:
             rc = ayolo_bn_act_bwd_apply(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.p[2], o.i[3], o.l[0], o.i[4],
                                         (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5], (const float*)o.p[6],
-                                        o.i[5], (const float*)o.p[7], o.i[6], (float*)o.p[8], (float*)o.p[9], o.f[0], cs);
+                                        o.i[5], (const double*)o.p[7], o.i[6], (float*)o.p[8], (float*)o.p[9], o.f[0], cs);
             break;
         case AYOLO_OP_MAXPOOL_FWD:
             rc = ayolo_maxpool_fwd(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], (unsigned char*)o.p[2], o.i[3], o.i[4], o.i[5], o.i[6],

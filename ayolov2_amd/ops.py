@@ -113,7 +113,9 @@ ARENA = _ZeroArena()
 
 
 def zero_stats(C: int, device) -> torch.Tensor:
-    return ARENA.take(STAT_REPS * 2 * C, device)[:STAT_REPS * 2 * C].view(STAT_REPS, 2 * C)
+    """Zeroed BatchNorm accumulators [STAT_REPS][2 * C], fp64 (ayolo.h: every statistics accumulator is double)."""
+    n = STAT_REPS * 2 * C
+    return ARENA.take(2 * n, device)[:2 * n].view(torch.float64).view(STAT_REPS, 2 * C)
 
 
 def conv_fwd(desc: ConvDesc, x, w, y, epilogue=_lib.EPI_NONE, scale=None, shift=None, stats=None, head_no=0):

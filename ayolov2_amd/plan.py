@@ -105,9 +105,12 @@ class Act:
 
 
 class _FloatArena:
-    def __init__(self):
+    """Bump allocator over ONE flat tensor (fp32 by default; the BatchNorm accumulators are fp64, see ayolo.h)."""
+
+    def __init__(self, dtype: torch.dtype = torch.float32):
         self.reqs: List[Tuple[int, list]] = []
         self.total = 0
+        self.dtype = dtype
         self.buf: Optional[torch.Tensor] = None
 
     def request(self, n: int) -> int:
@@ -116,7 +119,7 @@ class _FloatArena:
         return off
 
     def allocate(self, device):
-        self.buf = torch.zeros(max(self.total, 64), dtype=torch.float32, device=device)
+        self.buf = torch.zeros(max(self.total, 64), dtype=self.dtype, device=device)
 
     def view(self, off: int, n: int) -> torch.Tensor:
         return self.buf[off:off + n]
@@ -133,8 +136,8 @@ class TrainPlan:
         self.casts: List[Op] = []
         self.bwd_emitters: List[Callable[[], None]] = []
         self.bwd: List[Op] = []
-        self.stats = _FloatArena()                  # BN forward accumulators (zeroed at the start of forward)
-        self.sums = _FloatArena()                   # BN backward accumulators (zeroed at the start of backward)
+        self.stats = _FloatArena(torch.float64)     # BN forward accumulators (zeroed at the start of forward)
+        self.sums = _FloatArena(torch.float64)      # BN backward accumulators (zeroed at the start of forward)
         self.small = _FloatArena()                  # mean / invstd / scale / shift
         self.gradarena = _FloatArena()              # every parameter gradient (zeroed at the start of backward)
         self.param_grad_view: Dict[int, Callable[[], torch.Tensor]] = {}
@@ -282,7 +285,7 @@ class TrainPlan:
             def bind_fwd(op_act=op_act, c0=c0, co=co, sm_off=sm_off):
                 st = self.stats.view(st_off, R * 2 * Ct)
                 sm = self.small.view(sm_off, 4 * co)
-                op_act.p[2] = st.data_ptr() + 4 * c0
+                op_act.p[2] = st.data_ptr() + 8 * c0
                 op_act.p[7] = sm[0:co].data_ptr()              # save_mean
                 op_act.p[8] = sm[co:2 * co].data_ptr()         # save_invstd
 
@@ -563,8 +566,8 @@ class TrainPlan:
             fn()
         # all accumulators are zeroed at the START OF THE FORWARD (one fill each): the gradient arena too, because the
         # fused loss adds the head bias gradients into it before the backward list runs
-        head_ops = [_op(OP_MEMSET, l=(self.stats.buf.numel() * 4,), p=(self.stats.buf,)),
-                    _op(OP_MEMSET, l=(self.sums.buf.numel() * 4,), p=(self.sums.buf,)),
+        head_ops = [_op(OP_MEMSET, l=(self.stats.buf.numel() * 8,), p=(self.stats.buf,)),
+                    _op(OP_MEMSET, l=(self.sums.buf.numel() * 8,), p=(self.sums.buf,)),
                     _op(OP_MEMSET, l=(self.gradarena.buf.numel() * 4,), p=(self.gradarena.buf,))]
         nhead = len(head_ops) + (1 if self.casts else 0)
         self.fwd = head_ops + self._batched_casts() + self.fwd

@@ -63,13 +63,16 @@ typedef struct ayolo_conv_desc {
 #define AYOLO_EPI_AFFINE_RES 4      /* y += conv*scale[c] + shift[c]        (in-place residual: Bottleneck shortcut)  */
 #define AYOLO_EPI_AFFINE_SILU_RES 5 /* y += silu(conv*scale[c] + shift[c])  (inference: `x + cv2(cv1(x))` over x)     */
 
-/* y = conv(x, w).  `stats` (nullable, EPI_NONE only): float[stat_reps][2*Cout] zero-initialised by the caller;
+/* y = conv(x, w).  `stats` (nullable, EPI_NONE only): double[stat_reps][2*Cout] zero-initialised by the caller;
  * receives per-channel sum and sum of squares of the fp32 accumulators rounded to the output dtype (training-mode
  * BN), spread over stat_reps replicas (workgroup b adds into replica b % stat_reps) to avoid serialising L2
- * atomics; ayolo_bn_finalize sums the replicas.
+ * atomics; ayolo_bn_finalize sums the replicas.  Every BatchNorm accumulator of this library (`stats` here, `sums` of
+ * the backward passes) is DOUBLE from the workgroup level on: the order in which workgroups add is not defined, and only
+ * at 1e-16 does that order stay below one fp32 ulp of the statistics derived from the totals -- a train step's
+ * statistics, and with them the fp16 rounding of every activation, then repeat from run to run.
  * scale/shift: float[Cout] (nullable where unused).  head_no: `no` for AYOLO_EPI_HEAD (y is fp32). */
 int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void* y, int epilogue,
-                   const float* scale, const float* shift, float* stats, int stat_reps, int head_no, ayolo_stream s);
+                   const float* scale, const float* shift, double* stats, int stat_reps, int head_no, ayolo_stream s);
 
 /* dx (+)= conv_transpose(dy, w).  wt is the transposed weight [Cin][kh][kw][Cout] (see ayolo_cast_weight).
  * accumulate != 0 adds into the existing dx. d describes the FORWARD conv (x:B,H,W,Cin  y:B,Ho,Wo,Cout);
@@ -92,7 +95,7 @@ typedef struct ayolo_bn_seg {
     const float* mean_invstd; /* float[2*C]: save_mean | save_invstd of the forward pass               */
     const float* gamma;       /* float[C] or NULL (= 1)                                                */
     const float* beta;        /* float[C] or NULL (= 0)                                                */
-    float* sums;              /* float[reps][2*C] accumulators                                         */
+    double* sums;             /* double[reps][2*C] accumulators                                        */
     int ldz, c0, C, reserved;
 } ayolo_bn_seg;
 int ayolo_conv_dgrad_bn(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
@@ -142,14 +145,14 @@ int ayolo_cast_weights(const ayolo_cast_job* jobs_dev, int njobs, int dtype, ayo
 /* From stats (sum,sumsq over `count` elements per channel): mean/invstd, running-stat update
  * (momentum, unbiased var), scale = gamma*invstd, shift = beta - mean*scale.  save_mean/save_invstd/scale/
  * shift: float[C].  running_* nullable. */
-int ayolo_bn_finalize(const float* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
+int ayolo_bn_finalize(const double* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                       float* save_invstd, float* scale, float* shift, ayolo_stream s);
 /* ayolo_bn_finalize + ayolo_affine_act(_res) in one pass over z: a = act(batchnorm_train(z)) (+ residual), running
  * statistics updated and save_mean / save_invstd written (all four nullable) by the kernel itself.
- * stats: float[stat_reps][2][stat_ld] as accumulated by ayolo_conv_fwd, pointing at this layer's first channel;
+ * stats: double[stat_reps][2][stat_ld] as accumulated by ayolo_conv_fwd, pointing at this layer's first channel;
  * stat_ld (0 = C) is the channel count of the conv that produced z when this layer is a channel slice of it. */
-int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* stats,
+int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const double* stats,
                        int stat_reps, int stat_ld, double count, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, int act,
                        const void* residual, int ldr, ayolo_stream s);
@@ -157,13 +160,13 @@ int ayolo_bn_train_act(int dtype, const void* z, int ldz, void* a, int lda, int6
 int ayolo_affine_act(int dtype, const void* z, int ldz, void* a, int lda, int64_t npix, int C, const float* scale,
                      const float* shift, int act, ayolo_stream s);
 /* Backward of a = silu(bn(z)): pass 1 accumulates sums[r][0:C] = sum(du), sums[r][C:2C] = sum(du * xhat) over
- * sum_reps replicas (float[sum_reps][2*C], zeroed by caller); pass 2 sums the replicas, writes dz and dgamma/dbeta. */
+ * sum_reps replicas (double[sum_reps][2*C], zeroed by caller); pass 2 sums the replicas, writes dz and dgamma/dbeta. */
 int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const void* da, int ldda, int64_t npix, int C,
                             const float* save_mean, const float* save_invstd, const float* gamma,
-                            const float* beta, int act, float* sums, int sum_reps, ayolo_stream s);
+                            const float* beta, int act, double* sums, int sum_reps, ayolo_stream s);
 int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
                            int64_t npix, int C, const float* save_mean, const float* save_invstd,
-                           const float* gamma, const float* beta, int act, const float* sums, int sum_reps,
+                           const float* gamma, const float* beta, int act, const double* sums, int sum_reps,
                            float* dgamma, float* dbeta, float grad_scale, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------

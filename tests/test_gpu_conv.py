@@ -236,7 +236,7 @@ def test_conv_epilogue_statistics_fp16(shape):
     geo = F_._Geometry((B, Cin, H, W), wt.shape, (s_, s_), (p_, p_), dt)
     w, _ = F_._WeightCache().get(wt.contiguous(memory_format=torch.channels_last), dt, Cout, geo.cin_pad)
     y = ops.new_act(B, Cout, geo.Ho, geo.Wo, dt, x.device)
-    stats = torch.zeros((ops.STAT_REPS, 2 * Cout), dtype=torch.float32, device="cuda")
+    stats = torch.zeros((ops.STAT_REPS, 2 * Cout), dtype=torch.float64, device="cuda")
     ops.conv_fwd(geo.desc(dt, geo.Cin_k, Cout), x, w, y, 0, stats=stats)
     torch.cuda.synchronize()
     tot = stats.double().sum(0).cpu()
@@ -420,9 +420,9 @@ def test_dgrad_with_bn_backward_sums(case, accumulate):
         gamma = torch.randn(C, device="cuda", generator=g)
         beta = torch.randn(C, device="cuda", generator=g) * 0.5
         mi = torch.cat((mean, invstd)).contiguous()
-        sums = torch.zeros((ops.STAT_REPS, 2 * C), device="cuda")
+        sums = torch.zeros((ops.STAT_REPS, 2 * C), dtype=torch.float64, device="cuda")
         seg_args.append((z, mi, gamma, beta, sums, c0))
-        ref = torch.zeros((ops.STAT_REPS, 2 * C), device="cuda")
+        ref = torch.zeros((ops.STAT_REPS, 2 * C), dtype=torch.float64, device="cuda")
         da = dx_ref[:, c0:c0 + C]
         call("ayolo_bn_act_bwd_reduce", ops.dtype_code(dt), z.data_ptr(), C, da.data_ptr(), Cin, B * H * W, C, mean.data_ptr(),
              invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, ref.data_ptr(), ops.STAT_REPS, torch.cuda.current_stream().cuda_stream)

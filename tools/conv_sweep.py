@@ -55,7 +55,7 @@ def main():
         w, wt = F_._WeightCache().get(conv.weight, dt, cout, geo.cin_pad)
         y = ops.new_act(batch, cout, geo.Ho, geo.Wo, dt, dev)
         y.normal_()
-        stats = torch.zeros((ops.STAT_REPS, 2 * cout), dtype=torch.float32, device=dev)
+        stats = torch.zeros((ops.STAT_REPS, 2 * cout), dtype=torch.float64, device=dev)
         d = geo.desc(dt, geo.Cin_k, cout)
         flop = 2.0 * batch * geo.Ho * geo.Wo * cout * cin * k * k
         byts = 2.0 * (xk.numel() + y.numel())

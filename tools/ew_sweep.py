@@ -15,7 +15,7 @@ for C, H in shapes:
     n = z.numel() * 2
     t1 = timeit(lambda: ops.affine_act(z, a, sc, sh, 1))
     from ayolov2_amd._lib import call
-    sums = torch.zeros(ops.STAT_REPS, 2 * C, device=dev)
+    sums = torch.zeros(ops.STAT_REPS, 2 * C, dtype=torch.float64, device=dev)
     code = ops.dtype_code(dt); npix = B * H * H
     t2 = timeit(lambda: call("ayolo_bn_act_bwd_reduce", code, z.data_ptr(), C, da.data_ptr(), C, npix, C, mean.data_ptr(), inv.data_ptr(), sc.data_ptr(), sh.data_ptr(), 1, sums.data_ptr(), ops.STAT_REPS, torch.cuda.current_stream().cuda_stream))
     dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)

@@ -50,7 +50,7 @@ def main():
             with torch.cuda.stream(side):
                 junk[:128 << 20].copy_(junk[128 << 20:])
             y = ops.new_act(batch, cout, geo.Ho, geo.Wo, dt, dev)
-            stats = torch.zeros((ops.STAT_REPS, 2 * cout), dtype=torch.float32, device=dev)
+            stats = torch.zeros((ops.STAT_REPS, 2 * cout), dtype=torch.float64, device=dev)
             ops.conv_fwd(d, xk, w, y, 0, stats=stats)
             ys.append(y)
             if not geo.needs_pack:
