@@ -32,10 +32,8 @@ extern "C" int ayolo_fill_zero(void* ptr, size_t bytes, ayolo_stream s) {
 // scripts/train/train_model_builder.py:132-133 runs one thread per device) and two threads may run op lists on the
 // same device without sharing events.  ayolo_release_thread_state() frees the calling thread's objects.
 #define AY_MAX_DEVICES 16
-#define AY_MAX_SIDE 4
-// `nside` side streams used round-robin (AYOLO_SIDE_STREAMS, default 1): more than one lets consecutive weight gradients --
-// latency-bound on the small maps -- overlap each other as well as the caller's chain
-struct SideCtx { hipStream_t side = nullptr; hipStream_t more[AY_MAX_SIDE - 1] = {nullptr, nullptr, nullptr}; hipEvent_t fork = nullptr, join = nullptr; int nside = 1; int next = 0; };
+// ONE side stream (several round-robin streams measured no better, profiles/r03_scheduling_ab.txt)
+struct SideCtx { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 static thread_local SideCtx t_side[AY_MAX_DEVICES];
 
 static int side_ctx(SideCtx** out) {
@@ -52,7 +50,6 @@ static int side_ctx(SideCtx** out) {
         // quarter of the chip stretches them far beyond the backward window)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        c.nside = 1;
         AY_CHECK_HIP(hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, least));
         AY_CHECK_HIP(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
         AY_CHECK_HIP(hipEventCreateWithFlags(&c.join, hipEventDisableTiming));
@@ -67,8 +64,6 @@ extern "C" int ayolo_release_thread_state(void) {
         if (!c.side) continue;
         (void)hipStreamSynchronize(c.side);
         (void)hipStreamDestroy(c.side);
-        for (int k = 0; k < AY_MAX_SIDE - 1; ++k)
-            if (c.more[k]) { (void)hipStreamSynchronize(c.more[k]); (void)hipStreamDestroy(c.more[k]); }
         (void)hipEventDestroy(c.fork);
         (void)hipEventDestroy(c.join);
         c = SideCtx();
@@ -76,24 +71,19 @@ extern "C" int ayolo_release_thread_state(void) {
     return AYOLO_OK;
 }
 
-// fork: the next side stream (round-robin) waits for everything enqueued so far on the caller's stream; returns it
+// fork: the side stream waits for everything enqueued so far on the caller's stream; returns it
 static int side_fork(SideCtx* c, hipStream_t main, hipStream_t* out) {
-    hipStream_t st = c->next == 0 ? c->side : c->more[c->next - 1];
-    c->next = (c->next + 1) % c->nside;
     AY_CHECK_HIP(hipEventRecord(c->fork, main));
-    AY_CHECK_HIP(hipStreamWaitEvent(st, c->fork, 0));
-    *out = st;
+    AY_CHECK_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+    *out = c->side;
     return AYOLO_OK;
 }
 
-// the caller's stream continues only after the side streams have drained (also on the error path: work already forked
+// the caller's stream continues only after the side stream has drained (also on the error path: work already forked
 // must not outlive the call unordered)
 static int side_join(SideCtx* c, hipStream_t main) {
-    for (int k = 0; k < c->nside; ++k) {
-        hipStream_t st = k == 0 ? c->side : c->more[k - 1];
-        AY_CHECK_HIP(hipEventRecord(c->join, st));
-        AY_CHECK_HIP(hipStreamWaitEvent(main, c->join, 0));
-    }
+    AY_CHECK_HIP(hipEventRecord(c->join, c->side));
+    AY_CHECK_HIP(hipStreamWaitEvent(main, c->join, 0));
     return AYOLO_OK;
 }
 
