@@ -47,6 +47,14 @@ def test_fused_loss_vs_reference_golden(golden_dir):
         gr = preds[i].grad.cpu()
         np.testing.assert_allclose(gr.sum((2, 3)).numpy(), g[f"grad{i}_sum"], rtol=2e-4, atol=1e-6)
         np.testing.assert_allclose(gr.abs().sum().numpy(), g[f"grad{i}_abs_total"], rtol=1e-4)
+    # G6b: elementwise -- all 85 logits of every matched cell, objectness logit on a 3 x 3 sub-lattice (the reference's run)
+    gb = np.load(os.path.join(golden_dir, "g6b_loss_grads.npz"))
+    for i in range(3):
+        b, a, gj, gi = (torch.from_numpy(v) for v in g[f"idx{i}"])
+        gr = preds[i].grad.cpu()
+        scale = float(np.abs(gb[f"rows{i}"]).max())
+        np.testing.assert_allclose(gr[b, a, gj, gi].numpy(), gb[f"rows{i}"], rtol=2e-4, atol=2e-6 * scale)
+        np.testing.assert_allclose(gr[:, :, ::3, ::3, 4].numpy(), gb[f"obj{i}"], rtol=2e-4, atol=2e-6 * scale)
 
 
 @pytest.mark.parametrize("variant", ["plain", "smooth_pw_gr", "strided_scaled"])

@@ -98,6 +98,14 @@ def test_loss_vs_golden(golden_dir):
         np.testing.assert_allclose(anch[i].numpy(), g[f"anch{i}"])
         np.testing.assert_allclose(preds[i].grad.sum((2, 3)).numpy(), g[f"grad{i}_sum"], rtol=2e-4, atol=1e-6)
         np.testing.assert_allclose(preds[i].grad.abs().sum().numpy(), g[f"grad{i}_abs_total"], rtol=1e-4)
+    # G6b: the same run's gradient ELEMENTWISE -- all 85 logits of every matched cell and the objectness logit on a 3 x 3
+    # sub-lattice of every level (tools/make_golden.py g6b)
+    gb = np.load(os.path.join(golden_dir, "g6b_loss_grads.npz"))
+    for i in range(3):
+        b, a, gj, gi = (torch.from_numpy(v) for v in g[f"idx{i}"])
+        scale = float(np.abs(gb[f"rows{i}"]).max())
+        np.testing.assert_allclose(preds[i].grad[b, a, gj, gi].numpy(), gb[f"rows{i}"], rtol=1e-4, atol=1e-6 * scale)
+        np.testing.assert_allclose(preds[i].grad[:, :, ::3, ::3, 4].numpy(), gb[f"obj{i}"], rtol=1e-4, atol=1e-6 * scale)
 
 
 def test_c_abi_exports_every_declared_symbol():

@@ -210,6 +210,87 @@ def g9_tta():
     np.savez_compressed(os.path.join(OUT, "g9_tta.npz"), **g9)
 
 
+def g6_loss(only_b=False):
+    """G6: ComputeLoss value / items / build_targets / gradient sums; G6b: ELEMENTWISE gradients of the same run -- every logit of
+    every matched cell, and the objectness logit on a 3 x 3 sub-lattice of every level (the dense part of the gradient)."""
+    # ---- G6 ComputeLoss on a fake model (hyp after set_model_params scaling, model_manager.py:252-258)
+    from scripts.loss import losses as rl
+    import yaml
+    hyp = yaml.safe_load(open(os.path.join(REF, "res/configs/cfg/train_config.yaml")))["hyper_params"]
+    nl, nc, imgsz = 3, 80, 640
+    hyp["box"] *= 3.0 / nl
+    hyp["cls"] *= nc / 80.0 * 3.0 / nl
+    hyp["obj"] *= (imgsz / 640) ** 2 * 3.0 / nl
+    mcfg = yaml.safe_load(open(os.path.join(REF, "res/configs/model/yolov5s.yaml")))
+    strides = torch.tensor([8., 16., 32.])
+    anchors = torch.tensor(mcfg["anchors"]).float().view(3, 3, 2) / strides.view(-1, 1, 1)
+
+    class Head(torch.nn.Module):
+        pass
+
+    head = Head()
+    head.nl, head.na, head.nc, head.anchors, head.stride = 3, 3, 80, anchors, strides
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.model = torch.nn.ModuleList([torch.nn.Identity(), head])
+            self.hyp = hyp
+
+    rl.is_parallel = lambda m: False
+    fake = Fake()
+    g = torch.Generator().manual_seed(3)
+    preds = [torch.randn(2, 3, s, s, 85, generator=g).requires_grad_(True) for s in (80, 40, 20)]
+    # targets from the reference's own test labels (class x y w h normalised)
+    lab_dir = os.path.join(REF, "tests/res/datasets/coco/labels/train2017")
+    files = sorted(os.listdir(lab_dir))[:2]
+    tg = []
+    for bi, f in enumerate(files):
+        arr = np.loadtxt(os.path.join(lab_dir, f), ndmin=2).astype(np.float32)[:, :5]
+        tg.append(np.concatenate([np.full((arr.shape[0], 1), bi, np.float32), arr], 1))
+    targets = torch.from_numpy(np.concatenate(tg, 0))
+    # torch-1.9 -> 2.x compat shim (the reference pins torch 1.9.1, environment.yml:27): losses.py:385 clamps a
+    # LongTensor in place with 0-dim FLOAT tensor bounds, which torch 1.9 accepted (bound cast to the self
+    # dtype) and torch 2.x rejects.  Reproduce the 1.9 behaviour without touching the reference.
+    _orig_clamp_ = torch.Tensor.clamp_
+
+    def _clamp_compat(self, min=None, max=None):
+        if not self.is_floating_point():
+            min = int(min) if torch.is_tensor(min) else min
+            max = int(max) if torch.is_tensor(max) else max
+        return _orig_clamp_(self, min, max)
+
+    torch.Tensor.clamp_ = _clamp_compat
+    cl = rl.ComputeLoss(fake)
+    loss, items = cl(preds, targets)
+    loss.backward()
+    tcls, tbox, indices, anch = cl.build_targets(preds, targets)
+    g6 = dict(targets=targets.numpy(), loss=loss.detach().numpy(), items=items.numpy(),
+              hyp_box=hyp["box"], hyp_cls=hyp["cls"], hyp_obj=hyp["obj"], anchors=anchors.numpy())
+    for i in range(3):
+        g6[f"pred{i}"] = preds[i].detach().numpy().astype(np.float32)
+        g6[f"grad{i}_sum"] = preds[i].grad.sum((2, 3)).numpy()
+        nz = preds[i].grad.abs().sum(-1) > 1e-3 * preds[i].grad.abs().max()
+        g6[f"grad{i}_abs_total"] = preds[i].grad.abs().sum().numpy()
+        g6[f"tcls{i}"] = tcls[i].numpy()
+        g6[f"tbox{i}"] = tbox[i].numpy()
+        g6[f"idx{i}"] = torch.stack(indices[i]).numpy()
+        g6[f"anch{i}"] = anch[i].numpy()
+    # predictions are regenerated from the seed in the test (too large to store): keep only a checksum
+    for i in range(3):
+        del g6[f"pred{i}"]
+    g6["pred_seed"] = 3
+    g6b = {}
+    for i in range(3):
+        b, a, gj, gi = indices[i]
+        g6b[f"rows{i}"] = preds[i].grad[b, a, gj, gi].numpy()
+        g6b[f"obj{i}"] = preds[i].grad[:, :, ::3, ::3, 4].numpy()
+    np.savez_compressed(os.path.join(OUT, "g6b_loss_grads.npz"), **g6b)
+    if not only_b:
+        np.savez_compressed(os.path.join(OUT, "g6_loss.npz"), **g6)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
@@ -221,6 +302,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         g9_tta()
         print("g9 written")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g6b":
+        g6_loss(only_b=True)
+        print("g6b written")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g7b":
         from scripts.tensor_decomposition import decomposition as rd
@@ -309,75 +394,7 @@ def main():
                     g5[f"{nms_type}_a{int(agn)}_n{nb}_{bi}"] = r.numpy()
     np.savez_compressed(os.path.join(OUT, "g5_batched_nms.npz"), **g5)
 
-    # ---- G6 ComputeLoss on a fake model (hyp after set_model_params scaling, model_manager.py:252-258)
-    from scripts.loss import losses as rl
-    import yaml
-    hyp = yaml.safe_load(open(os.path.join(REF, "res/configs/cfg/train_config.yaml")))["hyper_params"]
-    nl, nc, imgsz = 3, 80, 640
-    hyp["box"] *= 3.0 / nl
-    hyp["cls"] *= nc / 80.0 * 3.0 / nl
-    hyp["obj"] *= (imgsz / 640) ** 2 * 3.0 / nl
-    mcfg = yaml.safe_load(open(os.path.join(REF, "res/configs/model/yolov5s.yaml")))
-    strides = torch.tensor([8., 16., 32.])
-    anchors = torch.tensor(mcfg["anchors"]).float().view(3, 3, 2) / strides.view(-1, 1, 1)
-
-    class Head(torch.nn.Module):
-        pass
-
-    head = Head()
-    head.nl, head.na, head.nc, head.anchors, head.stride = 3, 3, 80, anchors, strides
-
-    class Fake(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.p = torch.nn.Parameter(torch.zeros(1))
-            self.model = torch.nn.ModuleList([torch.nn.Identity(), head])
-            self.hyp = hyp
-
-    rl.is_parallel = lambda m: False
-    fake = Fake()
-    g = torch.Generator().manual_seed(3)
-    preds = [torch.randn(2, 3, s, s, 85, generator=g).requires_grad_(True) for s in (80, 40, 20)]
-    # targets from the reference's own test labels (class x y w h normalised)
-    lab_dir = os.path.join(REF, "tests/res/datasets/coco/labels/train2017")
-    files = sorted(os.listdir(lab_dir))[:2]
-    tg = []
-    for bi, f in enumerate(files):
-        arr = np.loadtxt(os.path.join(lab_dir, f), ndmin=2).astype(np.float32)[:, :5]
-        tg.append(np.concatenate([np.full((arr.shape[0], 1), bi, np.float32), arr], 1))
-    targets = torch.from_numpy(np.concatenate(tg, 0))
-    # torch-1.9 -> 2.x compat shim (the reference pins torch 1.9.1, environment.yml:27): losses.py:385 clamps a
-    # LongTensor in place with 0-dim FLOAT tensor bounds, which torch 1.9 accepted (bound cast to the self
-    # dtype) and torch 2.x rejects.  Reproduce the 1.9 behaviour without touching the reference.
-    _orig_clamp_ = torch.Tensor.clamp_
-
-    def _clamp_compat(self, min=None, max=None):
-        if not self.is_floating_point():
-            min = int(min) if torch.is_tensor(min) else min
-            max = int(max) if torch.is_tensor(max) else max
-        return _orig_clamp_(self, min, max)
-
-    torch.Tensor.clamp_ = _clamp_compat
-    cl = rl.ComputeLoss(fake)
-    loss, items = cl(preds, targets)
-    loss.backward()
-    tcls, tbox, indices, anch = cl.build_targets(preds, targets)
-    g6 = dict(targets=targets.numpy(), loss=loss.detach().numpy(), items=items.numpy(),
-              hyp_box=hyp["box"], hyp_cls=hyp["cls"], hyp_obj=hyp["obj"], anchors=anchors.numpy())
-    for i in range(3):
-        g6[f"pred{i}"] = preds[i].detach().numpy().astype(np.float32)
-        g6[f"grad{i}_sum"] = preds[i].grad.sum((2, 3)).numpy()
-        nz = preds[i].grad.abs().sum(-1) > 1e-3 * preds[i].grad.abs().max()
-        g6[f"grad{i}_abs_total"] = preds[i].grad.abs().sum().numpy()
-        g6[f"tcls{i}"] = tcls[i].numpy()
-        g6[f"tbox{i}"] = tbox[i].numpy()
-        g6[f"idx{i}"] = torch.stack(indices[i]).numpy()
-        g6[f"anch{i}"] = anch[i].numpy()
-    # predictions are regenerated from the seed in the test (too large to store): keep only a checksum
-    for i in range(3):
-        del g6[f"pred{i}"]
-    g6["pred_seed"] = 3
-    np.savez_compressed(os.path.join(OUT, "g6_loss.npz"), **g6)
+    g6_loss()
 
     # ---- G7 EVBMF ranks + Tucker layer loss through the reference driver
     from scripts.tensor_decomposition import decomposition as rd
