@@ -118,6 +118,25 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 #define GNS 3                      // LDS stages
+
+// Timeline probe (tools/gconv_probe.py; built only with -DAYOLO_PROBE into ab/libayolo_probe.so, never into the product
+// library): wave 0 of the first 512 workgroups records s_memtime at the marks of its first tile's step loop.
+#ifdef AYOLO_PROBE
+#define AY_PROBE_N 96
+__device__ unsigned long long g_probe[512 * AY_PROBE_N];
+extern "C" int ayolo_probe_read(void* dst, unsigned long long bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#define AY_PROBE(k_)                                                                                   \
+    do {                                                                                               \
+        if (probe_on && (k_) < AY_PROBE_N) {                                                           \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+            if (threadIdx.x == 0) s_probe[(k_)] = t_;   /* LDS: a global store would sit in the vmcnt queue */ \
+        }                                                                                              \
+    } while (0)
+#else
+#define AY_PROBE(k_) do { } while (0)
+#endif
 #define G_OOB 0x80000000u          // buffer offset beyond any descriptor (tensors are < 2 GiB, checked on the host)
 
 typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
@@ -141,16 +160,22 @@ struct GT {
     // pixels per block tile: 128, or 256 for the narrow channel tiles on multi-step reductions (K >= 128) so that a
     // wave still has 4-8 MFMAs per barrier
     static constexpr int TP = TPX;
+    // wavefronts per workgroup: 4; the 256-channel x 256-pixel fp16 tile (k_gconv only) runs 8 -- 4 (channels) x 2 (pixels) of
+    // the same 64 x 128 wave tile as the 128 x 256 workgroup tile, so that a 32-deep step moves 4 DMA pieces per wave next to
+    // its 16 MFMAs instead of 6 (the L2 -> LDS DMA rate is what bounds the deep-reduction layers)
+    static constexpr int NW = TM == 256 ? 8 : 4;
+    static constexpr int NT = NW * 64;
+    static constexpr int PIECE = NW * 1024;         // bytes one DMA instruction of every wave covers
     static constexpr int XSTAGE = TP * ROWB;        // 8-16 KiB / 16-32 KiB
-    static constexpr int XR = XSTAGE / 4096;        // x DMA instructions per thread per step
-    static constexpr int WSTAGE = TM * ROWB < 4096 ? 4096 : TM * ROWB;
-    static constexpr int WR = WSTAGE / 4096;
+    static constexpr int XR = XSTAGE / PIECE;       // x DMA instructions per thread per step
+    static constexpr int WSTAGE = TM * ROWB < PIECE ? PIECE : TM * ROWB;
+    static constexpr int WR = WSTAGE / PIECE;
     static constexpr int STAGE = XSTAGE + WSTAGE;
     static constexpr int LPS = XR + WR;             // DMA instructions per thread per step
     // wave tile: MI x NI MFMA blocks of 32 channels x 32 pixels.  The 128-channel x 256-pixel fp16 tile gives each wave
     // 64 channels x 128 pixels (2 x 4 blocks: 6 LDS fragments per 8 MFMAs) instead of 32 x 256 (1 x 8: 9 per 8).
-    static constexpr int MI = (ES == 2 && TPX == 256 && ((TM == 128 && AYOLO_GCONV_MI2) || (TM == 64 && AYOLO_GCONV_MI2_64))) ? 2 : 1;
-    static constexpr int WM = TM / (32 * MI), WP = 4 / WM, NI = TP / (32 * WP);
+    static constexpr int MI = (ES == 2 && TPX == 256 && ((TM >= 128 && AYOLO_GCONV_MI2) || (TM == 64 && AYOLO_GCONV_MI2_64))) ? 2 : 1;
+    static constexpr int WM = TM / (32 * MI), WP = NW / WM, NI = TP / (32 * WP);
     static constexpr int NACC = MI * NI;            // accumulator blocks per wave
     static constexpr int NST = NACC * 4;            // store instructions per thread per epilogue
     static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 8 * TM * sizeof(float);   // statistics [2][TM] fp64 + BNR constants [4][TM]
@@ -209,7 +234,7 @@ __device__ __forceinline__ void g_setup_rows(const GConvP& p, unsigned tile, boo
     using G = GT<T, TM, TPX>;
 #pragma unroll
     for (int r = 0; r < G::XR; ++r) {
-        const int row = (r * 4 + wave) * G::RW + rowin;
+        const int row = (r * G::NW + wave) * G::RW + rowin;
         const unsigned mu = tile * G::TP + row;            // < 2^31 + TP: pixel counts are < 2^31 (host check)
         const bool ok = valid & (mu < (unsigned)p.Mtotal);
         const unsigned t = fdiv(mu, p.dOW);
@@ -241,12 +266,12 @@ __device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T,
         const unsigned ih = (unsigned)(xh0[r] + te.y), iw = (unsigned)(xw0[r] + te.z);
         const bool ok = (ih < (unsigned)p.XH) & (iw < (unsigned)p.XW);
         const unsigned off = ok ? (unsigned)(xoff[r] + te.x + cb) : G_OOB;
-        glds16(rsX, lds_tiles + so + (r * 4 + wave) * 1024, off);
+        glds16(rsX, lds_tiles + so + (r * G::NW + wave) * 1024, off);
     }
 #pragma unroll
     for (int r = 0; r < G::WR; ++r) {
         const unsigned off = woff[r] + (unsigned)te.w + (unsigned)cb;
-        glds16(rsW, lds_tiles + so + G::XSTAGE + (r * 4 + wave) * 1024, off);
+        glds16(rsW, lds_tiles + so + G::XSTAGE + (r * G::NW + wave) * 1024, off);
     }
 }
 
@@ -302,6 +327,52 @@ __device__ __forceinline__ void g_mma_k(const GFragK<T, TM, TPX>& f, float16v (&
         for (int ni = 0; ni < G::NI; ++ni) mma_step(f.a[mi], f.b[ni], acc[mi * G::NI + ni]);
 }
 
+// The same step in two parts, for the interleaved schedule of the 8-block wave tiles: g_issue_prep does the address work
+// (tap decode, halo test) into per-piece offsets, g_issue_piece<I> issues piece I.  A DMA instruction costs ~60 issue cycles
+// among bare MFMAs but 100-185 in a block of its own next to fragment reads (MI355X_MICROARCH.md), and a wave has ~5 free
+// issue slots behind every 32 x 32 x 16 MFMA: issued one per MFMA, the six pieces of a step ride in the matrix pipe's shadow
+// instead of standing in front of it (probe, 512 -> 512 1x1 on 20 x 20 x 64: step body 1 300 cycles for 512 of MFMA).
+template <typename T, int TM, int TPX>
+__device__ __forceinline__ void g_issue_prep(const GConvP& p, const int (&xoff)[GT<T, TM, TPX>::XR], const int (&xh0)[GT<T, TM, TPX>::XR],
+                                             const int (&xw0)[GT<T, TM, TPX>::XR], const unsigned (&woff)[GT<T, TM, TPX>::WR], int kt,
+                                             int tap0, int ntap, const int4* sTap, int kc, unsigned (&offs)[GT<T, TM, TPX>::LPS]) {
+    using G = GT<T, TM, TPX>;
+    const unsigned k0 = (unsigned)(kt * BK + kc * G::CE);
+    unsigned tap = fdiv(k0, p.dC);
+    const int cb = (int)(k0 - tap * (unsigned)p.C) * G::ES;
+    tap = tap < (unsigned)ntap ? (unsigned)tap0 + tap : MAX_TAPS;
+    const int4 te = sTap[tap];
+#pragma unroll
+    for (int r = 0; r < G::XR; ++r) {
+        const unsigned ih = (unsigned)(xh0[r] + te.y), iw = (unsigned)(xw0[r] + te.z);
+        const bool ok = (ih < (unsigned)p.XH) & (iw < (unsigned)p.XW);
+        offs[r] = ok ? (unsigned)(xoff[r] + te.x + cb) : G_OOB;
+    }
+#pragma unroll
+    for (int r = 0; r < G::WR; ++r) offs[G::XR + r] = woff[r] + (unsigned)te.w + (unsigned)cb;
+}
+template <typename T, int TM, int TPX, int I>
+__device__ __forceinline__ void g_issue_piece(const unsigned (&offs)[GT<T, TM, TPX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
+                                              v4i32 rsW, int wave) {
+    using G = GT<T, TM, TPX>;
+    if constexpr (I < G::XR) glds16(rsX, lds_tiles + so + (I * G::NW + wave) * 1024, offs[I]);
+    else if constexpr (I < G::LPS) glds16(rsW, lds_tiles + so + G::XSTAGE + ((I - G::XR) * G::NW + wave) * 1024, offs[I]);
+}
+// first 16-deep half of a step with the step's DMA pieces interleaved: MFMA q, then piece q (q < LPS <= 8)
+template <typename T, int TM, int TPX, int Q = 0>
+__device__ __forceinline__ void g_mma_k_issue(const GFragK<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC],
+                                              const unsigned (&offs)[GT<T, TM, TPX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
+                                              v4i32 rsW, int wave) {
+    using G = GT<T, TM, TPX>;
+    static_assert(G::LPS <= G::NACC, "one DMA piece per MFMA of the first half");
+    if constexpr (Q < G::NACC) {
+        mma_step(f.a[Q / G::NI], f.b[Q % G::NI], acc[Q]);
+        g_issue_piece<T, TM, TPX, Q>(offs, lds_tiles, so, rsX, rsW, wave);
+        __builtin_amdgcn_sched_barrier(0);
+        g_mma_k_issue<T, TM, TPX, Q + 1>(f, acc, offs, lds_tiles, so, rsX, rsW, wave);
+    }
+}
+
 template <typename T, int TM, int TPX>
 __device__ __forceinline__ void g_mma_frags(const GFrags<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC]) {
     using G = GT<T, TM, TPX>;
@@ -311,6 +382,25 @@ __device__ __forceinline__ void g_mma_frags(const GFrags<T, TM, TPX>& f, float16
         for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < G::NI; ++ni) mma_step(f.a[kk][mi], f.b[kk][ni], acc[mi * G::NI + ni]);
+}
+
+// whole-step variant of g_mma_k_issue (tiles with fewer than 8 accumulator blocks per wave): MFMA q of the step, then DMA
+// piece q; pieces beyond the step's MFMA count (32-channel tiles) follow the last MFMA
+template <typename T, int TM, int TPX, int Q = 0>
+__device__ __forceinline__ void g_mma_frags_issue(const GFrags<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC],
+                                                  const unsigned (&offs)[GT<T, TM, TPX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
+                                                  v4i32 rsW, int wave) {
+    using G = GT<T, TM, TPX>;
+    constexpr int NMMA = (BK / 16) * G::NACC;
+    if constexpr (Q < (NMMA > G::LPS ? NMMA : G::LPS)) {
+        if constexpr (Q < NMMA) {
+            constexpr int kk = Q / G::NACC, blk = Q % G::NACC;
+            mma_step(f.a[kk][blk / G::NI], f.b[kk][blk % G::NI], acc[blk]);
+        }
+        g_issue_piece<T, TM, TPX, Q>(offs, lds_tiles, so, rsX, rsW, wave);
+        __builtin_amdgcn_sched_barrier(0);
+        g_mma_frags_issue<T, TM, TPX, Q + 1>(f, acc, offs, lds_tiles, so, rsX, rsW, wave);
+    }
 }
 
 // fp32 (exact-parity mode): fragments are fetched and consumed pair by pair
@@ -361,7 +451,7 @@ struct BnrCtx {
 // du = 0 there: the accumulators of padding channels are exact zeros)
 template <int TM>
 __device__ __forceinline__ void g_bnr_setup(const GConvP& p, float* sBn, int n0, int tid) {
-    for (int i = tid; i < TM; i += 256) {
+    for (int i = tid; i < TM; i += (int)blockDim.x) {
         const int c = n0 + i;
         const int sg = (p.bnr > 1 && c >= p.bseg[1].c0) ? 1 : 0;
         const int cl = c - p.bseg[sg].c0;
@@ -433,7 +523,28 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
                 }
         }
     };
+    // accumulate epilogues (fp16): the old values of a pixel block are requested one block ahead as well.  Fetched where they
+    // are added, every 16-byte group is load -> wait -> add -> store with the next load stuck behind the store (same buffer: the
+    // compiler must keep the order), i.e. 2 * MI * NI serial memory round trips per tile
+    constexpr bool YPRE = sizeof(T) == 2 && (EM == 1 || EM == 4);
+    half8 ynext[YPRE ? G::MI : 1][2];
+    auto y_request = [&](bool pv_, unsigned ypix_) {
+        if constexpr (YPRE) {
+#pragma unroll
+            for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = cbase + mi * 32 - 4 * (lane >> 5) + 8 * (2 * j + (lane >> 5));
+                    const unsigned off = (pv_ && c < p.Nout) ? ypix_ * (unsigned)p.ldy * 2u + (unsigned)c * 2u : G_OOB;
+                    ynext[mi][j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+                }
+        }
+    };
+    // next to the z prefetch of a BNR kernel the old values are fetched per block (all 2 * MI groups at once, at the top of the
+    // block) instead of a block ahead: both look-aheads together do not fit the register budget of the 128 x 256 tile
+    constexpr bool YAHEAD = YPRE && !BNR;
     pixel_of(0, pv_n, ypix_n);
+    if constexpr (YAHEAD) y_request(pv_n, ypix_n);
     z_request(pv_n, ypix_n);
 #pragma unroll
     for (int ni = 0; ni < G::NI; ++ni) {
@@ -441,12 +552,19 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
         const unsigned ypix = ypix_n;
         const unsigned yo = ypix * (unsigned)p.ldy * YES;
         half8 zcur[BNR ? G::MI : 1][2];
+        half8 ycur[YPRE ? G::MI : 1][2];
         if constexpr (BNR) {
 #pragma unroll
             for (int mi = 0; mi < G::MI; ++mi) { zcur[mi][0] = znext[mi][0]; zcur[mi][1] = znext[mi][1]; }
         }
+        if constexpr (YPRE && !YAHEAD) y_request(pv, ypix);
+        if constexpr (YPRE) {
+#pragma unroll
+            for (int mi = 0; mi < G::MI; ++mi) { ycur[mi][0] = ynext[mi][0]; ycur[mi][1] = ynext[mi][1]; }
+        }
         if (ni + 1 < G::NI) {
             pixel_of(ni + 1, pv_n, ypix_n);
+            if constexpr (YAHEAD) y_request(pv_n, ypix_n);
             z_request(pv_n, ypix_n);
         }
 #pragma unroll
@@ -502,7 +620,7 @@ __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int o
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { w8[e] = v[2 * j][e]; w8[4 + e] = v[2 * j + 1][e]; }
                     if constexpr (EM == 1 || EM == 4) {
-                        const half8 o = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsY, off, 0, 0));
+                        const half8 o = ycur[mi][j];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) w8[e] += (float)o[e];
                     }
@@ -626,7 +744,7 @@ __device__ __forceinline__ int g_stat_chan(int r, int hsel) {
 template <int TM, bool BNR>
 __device__ __forceinline__ void g_stats_to_global(const GConvP& p, const double* sStat, int tid, int n0, unsigned slot) {
     if constexpr (BNR) {
-        for (int i = tid; i < TM; i += 256) {
+        for (int i = tid; i < TM; i += (int)blockDim.x) {
             const int c = n0 + i;
             const int sg = (p.bnr > 1 && c >= p.bseg[1].c0) ? 1 : 0;
             const int cl = c - p.bseg[sg].c0, C = p.bseg[sg].C;
@@ -639,7 +757,7 @@ __device__ __forceinline__ void g_stats_to_global(const GConvP& p, const double*
     } else {
         // replicated accumulators: workgroups spread over stat_reps copies so L2 atomics do not serialise
         double* st = p.stats + (size_t)(slot % (unsigned)p.stat_reps) * 2 * p.Nout;
-        for (int i = tid; i < TM; i += 256) {
+        for (int i = tid; i < TM; i += (int)blockDim.x) {
             if (n0 + i < p.Nout) {
                 atomicAdd(&st[n0 + i], sStat[i]);
                 atomicAdd(&st[p.Nout + n0 + i], sStat[TM + i]);
@@ -651,16 +769,14 @@ __device__ __forceinline__ void g_stats_to_global(const GConvP& p, const double*
 template <typename T, int TM, int MI, bool BNR = false>
 __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, int tid, int lane, int wm, int n0, unsigned slot,
                                               const float (&ssum)[16 * MI], const float (&ssq)[16 * MI]) {
-    for (int i = tid; i < 2 * TM; i += 256) sStat[i] = 0.0;
+    for (int i = tid; i < 2 * TM; i += (int)blockDim.x) sStat[i] = 0.0;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16 * MI; ++r) {
-        float a = ssum[r], b = ssq[r];
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            a += __shfl_xor(a, off);
-            b += __shfl_xor(b, off);
-        }
+        // 32 pixel lanes per half-wave: DPP sums over each 16-lane row (no LDS traffic), then ONE exchange between the rows
+        float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
+        a += __shfl_xor(a, 16);
+        b += __shfl_xor(b, 16);
         if ((lane & 31) == 0) {
             const int cl = wm * 32 * MI + g_stat_chan<BNR>(r, lane >> 5);
             atomicAdd(&sStat[cl], (double)a);
@@ -672,7 +788,8 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, in
 }
 
 template <typename T, int TM, int EM, int TPX, bool BNR = false>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
+__global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 ? 1 : (GT<T, TM, TPX>::LDS > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4))) : 1)) void k_gconv(GConvP p) {
+    static_assert(TM != 256 || (sizeof(T) == 2 && TPX == 256), "the 8-wave tile is fp16 256 x 256 only");
     using G = GT<T, TM, TPX>;
     // stores per thread and epilogue (the step loop's vmcnt arithmetic): fp16 tiles leave in 16-byte stores
     constexpr int NSTK = (sizeof(T) == 2 && EM != 3) ? G::NACC * 2 : G::NST;
@@ -689,6 +806,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     // ---- block -> (channel tile, XCD band, slot).  Workgroups are dealt round-robin to the 8 XCDs; all channel
     // tiles of one pixel tile go to the SAME XCD back to back, and each XCD walks a contiguous band of pixel tiles.
     const unsigned Lb = blockIdx.x;
+#ifdef AYOLO_PROBE
+    __shared__ unsigned long long s_probe[AY_PROBE_N];
+    const bool probe_on = blockIdx.x < 512;
+    int probe_k = 2;
+    if (threadIdx.x < AY_PROBE_N) s_probe[threadIdx.x] = 0;
+    __syncthreads();
+    AY_PROBE(0);
+    if (threadIdx.x == 0) s_probe[AY_PROBE_N - 3] = __builtin_amdgcn_s_memrealtime();   // 100 MHz, chip-wide
+#endif
     const unsigned xcd = Lb & 7u, idx = Lb >> 3;
     const unsigned nt = idx % (unsigned)p.ntn;
     const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
@@ -703,29 +829,54 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     if (cur_tile >= ntiles) return;
 
     // ---- tap table -> LDS: {x byte delta, dh, dw, w column byte offset}; entries >= ntaps never hit (K padding)
-    typedef __attribute__((address_space(4))) const signed char* kptr_t;
-    const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh);
+    // The three byte arrays come through SCALAR loads of their 27 dwords (uniform, compile-time offsets) and a per-lane select:
+    // indexed per lane they are vector loads from the kernarg segment, and every workgroup then waits ~2 000 cycles for a
+    // memory round trip before its first DMA can be issued (probe, tools/gconv_probe.py)
+    static_assert(MAX_TAPS % 4 == 0 && offsetof(GConvP, dh) % 4 == 0 && offsetof(GConvP, dw) == offsetof(GConvP, dh) + MAX_TAPS &&
+                  offsetof(GConvP, wt) == offsetof(GConvP, dh) + 2 * MAX_TAPS, "tap arrays: three packed dword-aligned byte arrays");
+    typedef __attribute__((address_space(4))) const int* kiptr_t;
+    typedef __attribute__((address_space(4))) const char* kcptr_t;
+    const kiptr_t kwords = (kiptr_t)((kcptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(GConvP, dh));
+    static_assert(MAX_TAPS / 4 == 9, "three groups of nine dwords below");
+    int kw_[3 * (MAX_TAPS / 4)];
+#pragma unroll
+    for (int i = 0; i < 3 * (MAX_TAPS / 4); ++i) kw_[i] = kwords[i];
+    // loaded HERE, all at once (wide s_loads, one wait): left alone the loads sink into 27 conditional blocks of the selects
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+        asm volatile("" : "+s"(kw_[9 * g]), "+s"(kw_[9 * g + 1]), "+s"(kw_[9 * g + 2]), "+s"(kw_[9 * g + 3]), "+s"(kw_[9 * g + 4]),
+                          "+s"(kw_[9 * g + 5]), "+s"(kw_[9 * g + 6]), "+s"(kw_[9 * g + 7]), "+s"(kw_[9 * g + 8]));
     if (tid <= MAX_TAPS) {
         int4 e;
         const int tq = tid < MAX_TAPS ? tid : 0;
-        const int dh = ktab[tq], dw = ktab[MAX_TAPS + tq], wt = ktab[2 * MAX_TAPS + tq];
+        int s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_TAPS / 4; ++i) {
+            const bool me = (tq >> 2) == i;
+            s0 = me ? kw_[i] : s0;
+            s1 = me ? kw_[MAX_TAPS / 4 + i] : s1;
+            s2 = me ? kw_[2 * (MAX_TAPS / 4) + i] : s2;
+        }
+        const int sh8 = 8 * (tq & 3);
+        const int dh = (int)(signed char)(s0 >> sh8), dw = (int)(signed char)(s1 >> sh8), wt = (int)(signed char)(s2 >> sh8);
         if (tid < p.ntaps) { e.x = (dh * p.XW + dw) * p.ldx * G::ES; e.y = dh; e.z = dw; e.w = wt * p.C * G::ES; }
         else { e.x = 0; e.y = -100000; e.z = 0; e.w = 0x40000000; }
         sTap[tid] = e;
     }
+    AY_PROBE(AY_PROBE_N - 4);
 
     if constexpr (EM == 2 || EM == 4) {
         // affine epilogue constants of this channel tile -> LDS [scale | shift] (identity beyond Nout / for null pointers)
-        for (int i = tid; i < TM; i += 256) {
+        for (int i = tid; i < TM; i += (int)blockDim.x) {
             const bool in = n0 + i < p.Nout;
             sStat[i] = (in && p.scale) ? p.scale[n0 + i] : 1.0f;
             sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
         }
     }
-    constexpr bool TILE_RED = BNR && TM == 128;
+    constexpr bool TILE_RED = BNR && TM >= 128;
     if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 4 * TM, n0, tid);
     if constexpr (TILE_RED) {
-        for (int i = tid; i < 2 * TM; i += 256) reinterpret_cast<double*>(sStat)[i] = 0.0;
+        for (int i = tid; i < 2 * TM; i += (int)blockDim.x) reinterpret_cast<double*>(sStat)[i] = 0.0;
     }
     const BnrCtx<G::MI> bctx = BNR ? g_bnr_ctx<G::MI>(p, sStat + 4 * TM, n0 + wm * 32 * G::MI) : BnrCtx<G::MI>{};
 
@@ -744,7 +895,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     unsigned woff[G::WR];
 #pragma unroll
     for (int r = 0; r < G::WR; ++r) {
-        const int row = (r * 4 + wave) * G::RW + rowin;
+        const int row = (r * G::NW + wave) * G::RW + rowin;
         const bool ok = (row < TM) & (n0 + row < p.Nout);
         woff[r] = ok ? (unsigned)(n0 + row) * (unsigned)p.ldw * G::ES : G_OOB;   // the k-chunk offset comes from g_issue
     }
@@ -778,7 +929,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     int ld_tap0 = p.ctap0[0], ld_ntap = p.cnt[0];
     bool ld_valid = true;
     g_setup_rows<T, TM, TPX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
+    AY_PROBE(AY_PROBE_N - 5);
     __syncthreads();                          // tap table visible
+    AY_PROBE(AY_PROBE_N - 6);
 #define G_ISSUE(so) g_issue<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, lds_tiles, so, rsX, rsW, wave, kc);
 #define G_ADVANCE()                                                                           \
     {                                                                                         \
@@ -801,31 +954,44 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
     G_ADVANCE()
 
     bool after_epi = false;
+    AY_PROBE(1);
     while (true) {
         // step s landed (this wave's part), then: everyone's part landed AND everyone finished reading step s-1
+#ifdef AYOLO_PROBE
+        AY_PROBE(probe_k); ++probe_k;
+#endif
         if (after_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
+#ifdef AYOLO_PROBE
+        AY_PROBE(probe_k); ++probe_k;
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef AYOLO_PROBE
+        AY_PROBE(probe_k); ++probe_k;
+#endif
         if constexpr (sizeof(T) == 2 && G::NACC >= 8) {
             static_assert(BK == 32, "two 16-deep halves per step");
             GFragK<T, TM, TPX> f0, f1;
             g_fetch_k<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, 0, f0);
             __builtin_amdgcn_sched_barrier(0);
-            G_ISSUE(so2)                                 // step s+2 -> the stage step s-1 used
-            G_ADVANCE()
+            // address work of step s+2 (covers the LDS latency of the fetch), its DMA pieces one per MFMA of the first half
+            unsigned offs[G::LPS];
+            g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
             __builtin_amdgcn_sched_barrier(0);
-            g_mma_k<T, TM, TPX>(f0, acc);
-            __builtin_amdgcn_sched_barrier(0);
+            g_mma_k_issue<T, TM, TPX>(f0, acc, offs, lds_tiles, so2, rsX, rsW, wave);   // -> the stage step s-1 used
             g_fetch_k<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            G_ADVANCE()
             __builtin_amdgcn_sched_barrier(0);
             g_mma_k<T, TM, TPX>(f1, acc);
         } else if constexpr (sizeof(T) == 2) {
             GFrags<T, TM, TPX> fr;
             g_fetch_frags<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, fr);
             __builtin_amdgcn_sched_barrier(0);
-            G_ISSUE(so2)                                 // step s+2 -> the stage step s-1 used
-            G_ADVANCE()
+            unsigned offs[G::LPS];
+            g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
             __builtin_amdgcn_sched_barrier(0);
-            g_mma_frags<T, TM, TPX>(fr, acc);
+            g_mma_frags_issue<T, TM, TPX>(fr, acc, offs, lds_tiles, so2, rsX, rsW, wave);   // step s+2 -> the stage step s-1 used
+            G_ADVANCE()
         } else {
             G_ISSUE(so2)
             G_ADVANCE()
@@ -836,6 +1002,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
         // with v_accvgpr_read of the accumulator's last register, which came back stale) -- pad it here, explicitly.
         if constexpr (sizeof(T) == 4) AY_MFMA_PAD("s_nop 15\n\ts_nop 3");
         after_epi = false;
+#ifdef AYOLO_PROBE
+        AY_PROBE(probe_k); ++probe_k;
+#endif
         if (cur_kt == cur_nk - 1) {
             if constexpr (sizeof(T) == 2) AY_MFMA_PAD("s_nop 11");   // fp16: accumulators are only read here
             g_epilogue<T, TM, EM, TPX, BNR>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq,
@@ -874,6 +1043,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (GT<T, TM, TPX>::LDS > 56 * 
 #undef G_NK
 #undef G_ADVANCE
     wait_vm<0>();                             // the trailing zero-fill DMAs must land before this LDS is released
+#ifdef AYOLO_PROBE
+    AY_PROBE(AY_PROBE_N - 1);
+    if (threadIdx.x == 0) s_probe[AY_PROBE_N - 2] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (probe_on && threadIdx.x < AY_PROBE_N) g_probe[blockIdx.x * AY_PROBE_N + threadIdx.x] = s_probe[threadIdx.x];
+#endif
     if constexpr (TILE_RED) {
         __syncthreads();
         g_stats_to_global<TM, true>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
@@ -1730,7 +1905,7 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     constexpr int bpc_env = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if constexpr (sizeof(T) == 2 && EM != 3 && EM != 1) {
+    if constexpr (sizeof(T) == 2 && EM != 3 && EM != 1 && TM != 256) {
         if (p.s2f) {                         // forward 3x3 / stride 2 with the odd-column taps sharing one row run
             constexpr size_t lds2 = 3 * (size_t)(G::TP + 16) * G::ROWB + 3 * (size_t)(2 * TM * G::ROWB < 4096 ? 4096 : 2 * TM * G::ROWB) +
                                     4 * TM * sizeof(float);
@@ -1747,7 +1922,7 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
             return AYOLO_OK;
         }
     }
-    if constexpr (sizeof(T) == 2 && EM != 3) {
+    if constexpr (sizeof(T) == 2 && EM != 3 && TM != 256) {
         if (p.row3) {                        // 3x3 / stride 1: x rows shared by the three taps of a kernel row (k_gconv3)
             using G3 = GT3<T, TM, TPX>;
             const long long slots3 = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc_env > 0 ? bpc_env : 2).slots;
@@ -1773,7 +1948,7 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
                             (int)lds);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR>), grid, dim3(G::NT), lds, s, p);
     AY_CHECK_LAUNCH("k_gconv");
     return AYOLO_OK;
 }
@@ -1788,6 +1963,7 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     //  * many waves: the wider tile wins through fewer barriers and LDS fragment reads per MFMA when the reduction is
     //    deep enough -- TM 64: always; TM 128: K >= 256 (3x3); TM 32: K >= 128 (stem) -- and loses a few % on one- and
     //    two-step 1x1 layers (lower occupancy).
+    if constexpr (TM == 256) return launch_gconv_tp<T, TM, EM, 256, BNR>(p, s);
     static const int force = getenv("AYOLO_GCONV_TP") ? atoi(getenv("AYOLO_GCONV_TP")) : 0;
     bool wide;
     if (force) wide = force == 256;
@@ -1802,12 +1978,15 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     }
     if (p.s2f && TM == 128) wide = false;          // k_gconv_s2f: the 128 x 256 tile would spill (all four fragment sets live)
     if (wide) return launch_gconv_tp<T, TM, EM, 256, BNR>(p, s);
-    return launch_gconv_tp<T, TM, EM, 128, BNR>(p, s);
+    if constexpr (TM != 256) return launch_gconv_tp<T, TM, EM, 128, BNR>(p, s);
+    return AYOLO_EINVAL;
 }
 
 template <typename T, int TM>
 static int launch_gconv(const GConvP& p, hipStream_t s) {
-    if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
+    if constexpr (TM != 256) {
+        if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
+    }
     if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_gconv_em<T, TM, 2>(p, s);
     if (p.epi == AYOLO_EPI_AFFINE_RES || p.epi == AYOLO_EPI_AFFINE_SILU_RES) return launch_gconv_em<T, TM, 4>(p, s);
     if constexpr (sizeof(T) == 2) {
@@ -1858,7 +2037,11 @@ static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
     // 154 vs 169 us; on the 160x160 maps the 128-wide tiles still win)
     if (p.Nout > 128 && p.Nout % 128 == 64 && p.Mtotal <= 65536) tm = 64;
     if (force_tm == 32 || force_tm == 64 || force_tm == 128) tm = force_tm;
+    // 256-channel tiles (8 wavefronts, 256 x 256): fp16, per-tap path only (not the row-sharing kernels, not the head)
+    const bool can256 = dtype == AYOLO_F16 && p.Nout >= 256 && !p.row3 && !p.s2f && p.epi != AYOLO_EPI_HEAD;
+    if (can256 && force_tm == 256) tm = 256;
     if (dtype == AYOLO_F16) {
+        if (tm == 256) return launch_gconv<half_t, 256>(p, s);
         if (tm == 32) return launch_gconv<half_t, 32>(p, s);
         if (tm == 64) return launch_gconv<half_t, 64>(p, s);
         return launch_gconv<half_t, 128>(p, s);
@@ -2105,6 +2288,7 @@ struct WGradP {
     unsigned x_bytes, y_bytes;     // buffer descriptor extents (k_wgrad)
     unsigned gx, gy, splits;       // column tiles, channel tiles, pixel splits
     FastDiv dOW, dOH, dC;
+    int linear;                    // 1x1 / stride 1 / no padding: the x row of pixel pp is row pp (no decode, no halo test)
 };
 
 #define TNW 128     // dw columns per block tile
@@ -2187,9 +2371,28 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     const bool xcol_ok = xcol < p.K;
     const unsigned xtap = fdiv(xcol_ok ? (unsigned)xcol : 0u, p.dC);
     const int xcb = (int)((xcol_ok ? (unsigned)xcol : 0u) - xtap * (unsigned)p.C) * W::ES;
-    typedef __attribute__((address_space(4))) const signed char* kptr_t;
-    const kptr_t ktab = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WGradP, dh);
-    const int xdh = ktab[xtap < MAX_TAPS ? xtap : 0], xdw = ktab[MAX_TAPS + (xtap < MAX_TAPS ? xtap : 0)];
+    // tap offsets of this lane's column: scalar loads of the two byte arrays + per-lane select (see k_gconv: indexed per lane
+    // they would be vector loads from the kernarg segment, ~2 000 cycles before the first DMA)
+    static_assert(offsetof(WGradP, dh) % 4 == 0 && offsetof(WGradP, dw_) == offsetof(WGradP, dh) + MAX_TAPS, "tap arrays");
+    typedef __attribute__((address_space(4))) const int* kiptr_t;
+    typedef __attribute__((address_space(4))) const char* kcptr_t;
+    const kiptr_t kwords = (kiptr_t)((kcptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WGradP, dh));
+    int kw_[2 * (MAX_TAPS / 4)];
+#pragma unroll
+    for (int i = 0; i < 2 * (MAX_TAPS / 4); ++i) kw_[i] = kwords[i];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        asm volatile("" : "+s"(kw_[9 * g]), "+s"(kw_[9 * g + 1]), "+s"(kw_[9 * g + 2]), "+s"(kw_[9 * g + 3]), "+s"(kw_[9 * g + 4]),
+                          "+s"(kw_[9 * g + 5]), "+s"(kw_[9 * g + 6]), "+s"(kw_[9 * g + 7]), "+s"(kw_[9 * g + 8]));
+    const unsigned xtq = xtap < MAX_TAPS ? xtap : 0u;
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for (int i = 0; i < MAX_TAPS / 4; ++i) {
+        const bool me = (xtq >> 2) == (unsigned)i;
+        s0 = me ? kw_[i] : s0;
+        s1 = me ? kw_[MAX_TAPS / 4 + i] : s1;
+    }
+    const int xdh = (int)(signed char)(s0 >> (8 * (xtq & 3))), xdw = (int)(signed char)(s1 >> (8 * (xtq & 3)));
     // ---- dy loader lanes
     const int yslot = lane % W::YCPR, yrowin = lane / W::YCPR;
     int ysrc = yslot;
@@ -2239,8 +2442,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
         if constexpr (sizeof(T) == 4) W_ISSUE(kt + 2, so2)
         if constexpr (sizeof(T) == 2) {
             // every fragment of the step first (see g_fetch_frags: hipcc otherwise serialises ds_read -> lgkmcnt(0) ->
-            // v_mfma through one register quad), then the pixel decode + DMA issue of step kt+2 while the transposing
-            // reads are in flight, then the MFMAs back to back
+            // v_mfma through one register quad), then the address work of step kt+2 while the transposing reads are in
+            // flight, then the MFMAs with that step's DMA pieces issued one per MFMA (see g_mma_k_issue)
             half8 fa[W::BP / 16], fb[W::BP / 16][W::NI];
             const int csub = ((lane >> 4) & 1) * 16;
 #pragma unroll
@@ -2252,12 +2455,41 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
                     fb[kk][ni] = tr_frag_sw<W::XROWB, W::XG, W::XRPB>(cX, k0, wn * W::NI * 32 + ni * 32 + csub, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
-            W_ISSUE(kt + 2, so2)
+            unsigned offs[W::LPS];
+            {
+                const unsigned pt = pbeg + (unsigned)(kt + 2) * W::BP;
+#pragma unroll
+                for (int r = 0; r < W::XR; ++r) {
+                    const unsigned pp = pt + (r * 4 + wave) * W::XRW + xrowin;
+                    if (p.linear) {
+                        offs[r] = ((pp < pend) & xcol_ok) ? pp * (unsigned)p.ldx * W::ES + (unsigned)xcb : G_OOB;
+                    } else {
+                        const unsigned t = fdiv(pp, p.dOW);
+                        const int ow = (int)(pp - t * (unsigned)p.OW);
+                        const unsigned n = fdiv(t, p.dOH);
+                        const int oh = (int)(t - n * (unsigned)p.OH);
+                        const unsigned ih = (unsigned)(oh * p.sh + xdh), iw = (unsigned)(ow * p.sw + xdw);
+                        const bool ok = (pp < pend) & xcol_ok & (ih < (unsigned)p.XH) & (iw < (unsigned)p.XW);
+                        offs[r] = ok ? ((n * (unsigned)p.XH + ih) * (unsigned)p.XW + iw) * (unsigned)p.ldx * W::ES + (unsigned)xcb : G_OOB;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < W::YR; ++r) {
+                    const unsigned row = (r * 4 + wave) * W::YRW + yrowin;
+                    const unsigned pp = pt + row;
+                    const bool ok = (row < (unsigned)W::BP) & (pp < pend) & ycol_ok;
+                    offs[W::XR + r] = ok ? pp * (unsigned)p.ldy * W::ES + ycb : G_OOB;
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
+            constexpr int NMMA = (W::BP / 16) * W::NI;
 #pragma unroll
-            for (int kk = 0; kk < W::BP / 16; ++kk)
-#pragma unroll
-                for (int ni = 0; ni < W::NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk], fb[kk][ni], acc[ni], 0, 0, 0);
+            for (int q = 0; q < (NMMA > W::LPS ? NMMA : W::LPS); ++q) {
+                if (q < NMMA) acc[q % W::NI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[q / W::NI], fb[q / W::NI][q % W::NI], acc[q % W::NI], 0, 0, 0);
+                if (q < W::XR) glds16(rsX, lds_tiles + so2 + (q * 4 + wave) * 1024, offs[q]);
+                else if (q < W::LPS) glds16(rsY, lds_tiles + so2 + W::XSTAGE + ((q - W::XR) * 4 + wave) * 1024, offs[q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < W::BP / 16; ++kk) {
@@ -2350,6 +2582,7 @@ static int wgrad_dispatch(const ayolo_conv_desc* d, WGradP p, hipStream_t st) {
     }
     p.x_bytes = (unsigned)(x_img * p.B); p.y_bytes = (unsigned)(y_img * p.B);
     p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)p.C);
+    p.linear = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0) ? 1 : 0;
     const int tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
     if (d->dtype == AYOLO_F16) {
         if (tm == 32) return launch_wgrad<half_t, 32>(p, st);
