@@ -19,6 +19,7 @@ channels, per-call scale/shift arithmetic, weight casts) and ~300 Python-level l
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -36,6 +37,48 @@ OP_HEAD_DECODE = 20
 MAX_INFER_PLANS = 4
 
 
+TUCKER_FORMS = os.environ.get("AYOLO_TUCKER_FORM", "auto")      # auto | factors | first | last | dense (A/B switch of _tucker_form)
+
+
+class _MergedConv:
+    """Consecutive LINEAR convs of a Tucker block (1x1 factor, k x k core, 1x1 factor: decomposition.py:363-424 puts no
+    activation between them) presented as ONE conv: the composed weight is computed in fp32 when a source changes.  Only the
+    last part may carry a bias (a bias in front of a zero-padded k x k conv does not commute with the padding)."""
+
+    def __init__(self, parts: Sequence[nn.Conv2d]):
+        self.parts = list(parts)
+        core = max(self.parts, key=lambda c: c.kernel_size[0] * c.kernel_size[1])
+        if sum(1 for c in self.parts if c.kernel_size != (1, 1)) > 1 or any(c.bias is not None for c in self.parts[:-1]):
+            raise PlanUnsupported("Tucker merge: more than one k x k part or an inner bias")
+        for c in self.parts:
+            if c is not core and (_pair(c.stride) != (1, 1) or _pair(c.padding) != (0, 0)):
+                raise PlanUnsupported("Tucker merge: strided / padded factor conv")
+        self.kernel_size, self.stride, self.padding = core.kernel_size, core.stride, core.padding
+        self.dilation, self.groups = (1, 1), 1
+        self.in_channels, self.out_channels = self.parts[0].in_channels, self.parts[-1].out_channels
+        self.bias = self.parts[-1].bias
+        self.weight = None
+        self.recompute()
+
+    def sources(self) -> List[torch.Tensor]:
+        return [t for c in self.parts for t in (c.weight, c.bias) if t is not None]
+
+    @torch.no_grad()
+    def recompute(self) -> None:
+        w = None
+        for c in self.parts:
+            cw = c.weight.detach().float()
+            if w is None:
+                w = cw
+            elif cw.shape[2:] == (1, 1):                      # 1x1 after what has been composed so far
+                w = torch.einsum("oa,aihw->oihw", cw[:, :, 0, 0], w)
+            elif w.shape[2:] == (1, 1):                       # k x k after a 1x1
+                w = torch.einsum("oahw,ai->oihw", cw, w[:, :, 0, 0])
+            else:
+                raise PlanUnsupported("Tucker merge: two spatial kernels")
+        self.weight = w.contiguous()
+
+
 class _Fold:
     """One conv launch's host-side state: the fp32 KRSC weight source, the folded scale / shift vectors."""
 
@@ -46,9 +89,12 @@ class _Fold:
         self.w32: Optional[torch.Tensor] = None
 
     def tensors(self) -> List[torch.Tensor]:
-        ts = [self.conv.weight]
-        if self.conv.bias is not None:
-            ts.append(self.conv.bias)
+        if isinstance(self.conv, _MergedConv):
+            ts = self.conv.sources()
+        else:
+            ts = [self.conv.weight]
+            if self.conv.bias is not None:
+                ts.append(self.conv.bias)
         if self.bn is not None:
             ts += [t for t in (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var) if t is not None]
         return ts
@@ -56,6 +102,8 @@ class _Fold:
     @torch.no_grad()
     def refresh(self, w32_buf: torch.Tensor) -> None:
         """fp32 KRSC copy of the weight for the cast kernel + BatchNorm / bias folded into scale / shift."""
+        if isinstance(self.conv, _MergedConv):
+            self.conv.recompute()
         w = self.conv.weight.detach()
         w32_buf.copy_(w.permute(0, 2, 3, 1))                       # (Cout, kh, kw, Cin) fp32, from any dtype / layout
         co = w.shape[0]
@@ -84,6 +132,7 @@ class InferPlan:
         self.folds: List[Tuple[_Fold, torch.Tensor]] = []
         self.pack_op: Optional[Op] = None
         self.raw_specs: list = []
+        self.tucker_forms: List[str] = []                      # launch form chosen for every Tucker block (_tucker_form)
         self.out: Optional[torch.Tensor] = None
         self._versions = None
         self._compile()
@@ -101,7 +150,7 @@ class InferPlan:
               image: bool = False) -> Act:
         """One conv launch: y = act(bn(conv(x))) [+ bias], written into `dst` (a channel slice of a wider buffer is fine) or
         a new buffer whose channel count is rounded up to the vector width (extra channels are exact zeros)."""
-        if not isinstance(conv, nn.Conv2d) or conv.groups != 1 or _pair(conv.dilation) != (1, 1):
+        if not isinstance(conv, (nn.Conv2d, _MergedConv)) or conv.groups != 1 or _pair(conv.dilation) != (1, 1):
             raise PlanUnsupported("non-standard conv")
         dt, dev, ce = self.dt, self.device, self._ce()
         Cout, Cin, kh, kw = conv.weight.shape
@@ -144,6 +193,46 @@ class InferPlan:
                             conv=geo.desc(dt, ldx, ldy, cout=cout_pad if dst is None else Cout)))
         return y
 
+    def _tucker_form(self, convs: List[nn.Conv2d], xt: Optional[torch.Tensor], image: bool) -> str:
+        """How a Tucker block 1x1 (Cin -> r1) -> k x k (r1 -> r2) -> 1x1 (r2 -> Cout) is launched.  The three convs are linear
+        with nothing in between, so any adjacent pair -- or all three -- may be multiplied out when the plan is compiled:
+          factors: three launches (fewest FLOP, two rank-wide intermediates through HBM, the first at INPUT resolution);
+          first  : k x k (Cin -> r2) then 1x1: no r1 intermediate (at stride 2 it alone is as large as the block's output);
+          last   : 1x1 then k x k (r1 -> Cout);
+          dense  : the block's own k x k conv again (what an HBM-bound layer with ranks near C/2 is cheapest as).
+        Chosen per block by a two-term roofline per launch, max(bytes / 3 TB/s, FLOP / 500 TF/s) + 6 us, with the rates this
+        executor's conv kernels sustain on such layers (profiles/r03_conv_layer_sweep.txt).  AYOLO_TUCKER_FORM forces one
+        form for A/B runs.  Reference: decomposition.py:363-424 (the Sequential), decompose_model.py:63-74."""
+        if len(convs) != 3 or convs[0].kernel_size != (1, 1) or convs[2].kernel_size != (1, 1) or convs[0].bias is not None \
+                or convs[1].bias is not None or _pair(convs[1].dilation) != (1, 1):
+            return "factors"
+        if TUCKER_FORMS in ("factors", "first", "last", "dense"):
+            return TUCKER_FORMS
+        ce = self._ce()
+        es = 2 if self.dt == torch.float16 else 4
+        core = convs[1]
+        cin, r1, r2, cout = convs[0].in_channels, convs[0].out_channels, core.out_channels, convs[2].out_channels
+        kh, kw = core.kernel_size
+        H, W = (self.H, self.W) if image else (xt.shape[2], xt.shape[3])
+        sh, sw = _pair(core.stride)
+        ph, pw = _pair(core.padding)
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        pin, pout = self.B * H * W, self.B * Ho * Wo
+        up = lambda c: F_._round_up(c, ce)
+        cin_e, r1p, r2p = (4 if image else up(cin)), up(r1), up(r2)
+
+        def launch(ci, co, taps, p_in, p_out):
+            byts = es * (p_in * ci + p_out * co)
+            flop = 2.0 * p_out * taps * ci * co
+            return max(byts / 3.0e12, flop / 5.0e14) + 6e-6
+
+        k2 = kh * kw
+        cost = {"factors": launch(cin_e, r1p, 1, pin, pin) + launch(r1p, r2p, k2, pin, pout) + launch(r2p, cout, 1, pout, pout),
+                "first": launch(cin_e, r2p, k2, pin, pout) + launch(r2p, cout, 1, pout, pout),
+                "last": launch(cin_e, r1p, 1, pin, pin) + launch(r1p, cout, k2, pin, pout),
+                "dense": launch(cin_e, cout, k2, pin, pout)}
+        return min(cost, key=cost.get)
+
     def _block(self, mod: Conv, x: Optional[Act], dst: Optional[Act], residual_in_place: bool = False, image: bool = False) -> Act:
         """A kindle Conv block in eval mode: conv (plain, fused-with-bias, or the 3-conv Tucker Sequential) -> BN -> act."""
         act = _act_code(mod.activation)
@@ -154,10 +243,23 @@ class InferPlan:
             convs = list(conv)
             if len(convs) < 2 or not all(isinstance(c, nn.Conv2d) for c in convs):
                 raise PlanUnsupported("unexpected members in a decomposed block")
+            form = self._tucker_form(convs, xt, image)
+            self.tucker_forms.append(form)
+            if form == "dense":
+                groups = [convs]
+            elif form == "first":
+                groups = [convs[:2], convs[2:]]
+            elif form == "last":
+                groups = [convs[:1], convs[1:]]
+            else:
+                groups = [[c] for c in convs]
             t = xt
-            for j, c in enumerate(convs[:-1]):                 # factor / core convs: plain (+ their own bias if any)
-                t = self._conv(c, None, 0, t, None, image=(image and j == 0)).t
-            return self._conv(convs[-1], bn, act, t, dst, residual_in_place)
+            for j, g in enumerate(groups):
+                c = g[0] if len(g) == 1 else _MergedConv(g)
+                if j + 1 < len(groups):                        # factor / core launches: plain, no bias
+                    t = self._conv(c, None, 0, t, None, image=(image and j == 0)).t
+                else:
+                    return self._conv(c, bn, act, t, dst, residual_in_place, image=(image and j == 0))
         return self._conv(conv, bn, act, xt, dst, residual_in_place, image)
 
     # ------------------------------------------------------------------ composite blocks

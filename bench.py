@@ -368,7 +368,7 @@ def _timed(fn, reps, warm=2):
     return (time.perf_counter() - t0) / reps
 
 
-def config_extras(device):
+def config_extras(device, only=None):
     """BASELINE.json configurations 4 and 5 (secondary lines; the headline is configuration 2), on the inference executor:
       cfg 4: Tucker-decomposed YOLOv5s (decompose_model defaults loss_thr 0.1 / prune_step 0.01 are kept except prune_step = 0
              to bound the SVD count; weights carry a planted rank-1/4 structure because random-init weights have none),
@@ -403,15 +403,22 @@ def config_extras(device):
             return model(x4)[0]
 
     t4 = _timed(lambda: fwd4(dec), 5)
+    forms = {}
+    for pl in getattr(dec, "_plans", {}).values():
+        for f in getattr(pl, "tucker_forms", []) if pl else []:
+            forms[f] = forms.get(f, 0) + 1
     m = m.to(device).eval()
     t4o = _timed(lambda: fwd4(m), 5)
     out["cfg4"] = {"workload": "Tucker-decomposed yolov5s, batch 128, 640x640, fp16 eval forward + decode",
                    "params": info["params_after"], "params_original": info["params_before"],
                    "decomposed_convs": len(info["ranks"]), "ranks_in_out": sorted(set(info["ranks"].values())),
+                   "launch_forms": forms,
                    "decompose_s_cpu": round(t_dec, 1), "ms_per_batch": round(t4 * 1e3, 2), "img_per_s": round(128 / t4, 1),
                    "undecomposed_ms_per_batch": round(t4o * 1e3, 2), "undecomposed_img_per_s": round(128 / t4o, 1)}
     del dec, m, x4
     torch.cuda.empty_cache()
+    if only == "cfg4":
+        return out
     # ---- cfg 5
     torch.manual_seed(0)
     mx = YOLOModel(os.path.join(cfgdir, "yolov5x.yaml")).to(device).fuse().eval()
