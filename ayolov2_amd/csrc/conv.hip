@@ -2289,6 +2289,7 @@ struct WGradP {
     unsigned gx, gy, splits;       // column tiles, channel tiles, pixel splits
     FastDiv dOW, dOH, dC;
     int linear;                    // 1x1 / stride 1 / no padding: the x row of pixel pp is row pp (no decode, no halo test)
+    int tmap, tgrp;                // tmap: all pixel splits of a dw tile on a group of `tgrp` XCDs (see k_wgrad's block map)
 };
 
 #define TNW 128     // dw columns per block tile
@@ -2349,9 +2350,35 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     const int wm = wave % W::WM, wn = wave / W::WM;
 
     // block -> (tile, pixel split): split zz lives on XCD zz % 8 and its gx*gy tiles are consecutive there
+#ifdef AYOLO_PROBE
+    __shared__ unsigned long long s_probe[AY_PROBE_N];
+    const bool probe_on = blockIdx.x < 512;
+    int probe_k = 2;
+    if (threadIdx.x < AY_PROBE_N) s_probe[threadIdx.x] = 0;
+    __syncthreads();
+    AY_PROBE(0);
+    if (threadIdx.x == 0) s_probe[AY_PROBE_N - 3] = __builtin_amdgcn_s_memrealtime();
+#endif
     const unsigned Lb = blockIdx.x, xcd = Lb & 7u, local = Lb >> 3;
     const unsigned ntile = p.gx * p.gy;
-    const unsigned tile = local % ntile, zz = (local / ntile) * 8u + xcd;
+    unsigned tile, zz;
+    if (p.tmap) {
+        // tile-major: every pixel split of a dw tile runs on the same group of tgrp XCDs, so the fp32 atomics on its lines stay
+        // in (tgrp) L2s instead of migrating between all eight
+        if (ntile >= 8u) {
+            const unsigned tpx = (ntile + 7u) / 8u;
+            tile = xcd + 8u * (local % tpx);
+            zz = local / tpx;
+        } else {
+            const unsigned G = (unsigned)p.tgrp;
+            tile = xcd / G;
+            zz = local * G + xcd % G;
+        }
+        if (tile >= ntile) return;
+    } else {
+        tile = local % ntile;
+        zz = (local / ntile) * 8u + xcd;
+    }
     if (zz >= p.splits) return;
     const int j0 = (int)(tile % p.gx) * TNW;          // dw column tile (tap*C + c)
     const int n0 = (int)(tile / p.gx) * TM;           // output-channel tile
@@ -2434,9 +2461,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     unsigned so0 = 0, so1 = W::STAGE, so2 = 2 * W::STAGE;
     W_ISSUE(0, so0)
     W_ISSUE(1, so1)
+    AY_PROBE(1);
     for (int kt = 0; kt < nk; ++kt) {
+#ifdef AYOLO_PROBE
+        AY_PROBE(probe_k); ++probe_k;
+#endif
         wait_vm<W::LPS>();                       // step kt landed (this wave's part) ...
+#ifdef AYOLO_PROBE
+        AY_PROBE(probe_k); ++probe_k;
+#endif
         __builtin_amdgcn_s_barrier();            // ... everyone's part landed, everyone finished reading step kt-1
+#ifdef AYOLO_PROBE
+        AY_PROBE(probe_k); ++probe_k;
+#endif
         const unsigned char* cX = smem_raw + so0;
         const unsigned char* cY = smem_raw + so0 + W::XSTAGE;
         if constexpr (sizeof(T) == 4) W_ISSUE(kt + 2, so2)
@@ -2510,10 +2547,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
             }
         }
         if constexpr (sizeof(T) == 4) AY_MFMA_PAD("s_nop 15\n\ts_nop 3");   // see k_gconv: MFMA result hazard across the back edge
+#ifdef AYOLO_PROBE
+        AY_PROBE(probe_k); ++probe_k;
+#endif
         const unsigned t = so0; so0 = so1; so1 = so2; so2 = t;
     }
 #undef W_ISSUE
     wait_vm<0>();                                // trailing zero-fill DMAs must land before this LDS is released
+    AY_PROBE(AY_PROBE_N - 4);
     // acc[ni][r]: row (out channel) = n0 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); col = j0 + wn*NI*32 + ni*32 + (lane&31)
 #pragma unroll
     for (int ni = 0; ni < W::NI; ++ni) {
@@ -2525,6 +2566,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
             if (row < p.N) unsafeAtomicAdd(&p.dw[(long long)row * p.K + col], acc[ni][r] * p.alpha);
         }
     }
+#ifdef AYOLO_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AY_PROBE(AY_PROBE_N - 1);
+    if (threadIdx.x == 0) s_probe[AY_PROBE_N - 2] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (probe_on && threadIdx.x < AY_PROBE_N) g_probe[blockIdx.x * AY_PROBE_N + threadIdx.x] = s_probe[threadIdx.x];
+#endif
 }
 
 template <typename T, int TM>
@@ -2550,7 +2598,15 @@ static int launch_wgrad(WGradP p, hipStream_t s) {
     splits = (p.P + chunk - 1) / chunk;
     p.chunk = chunk;
     p.splits = (unsigned)splits;
-    const long long blocks = tiles * ((splits + 7) / 8 * 8);
+    // Block map.  Default: pixel split zz on XCD zz % 8 with all its tiles back to back there (operand re-reads -- dy once per
+    // column tile, x once per tap -- hit that XCD's L2).  With very many tiles (>= 64: dw of 1 M+ elements over few pixels, e.g.
+    // 256 -> 512 3x3 on 20 x 20) the fp32 atomics dominate and their lines migrate between the eight L2s: there every split
+    // of a tile runs on ONE XCD instead (measured, profiles/r03_wgrad_tile_major_map.txt: 131 -> 92 us on that layer, 1.1-2.1x
+    // SLOWER on every layer with fewer tiles)
+    p.tmap = tiles >= 64 ? 1 : 0;
+    p.tgrp = tiles >= 8 ? 1 : (int)(8 / tiles);
+    long long blocks = tiles * ((splits + 7) / 8 * 8);
+    if (p.tmap) blocks = tiles >= 8 ? 8 * ((tiles + 7) / 8) * splits : 8 * ((splits + p.tgrp - 1) / p.tgrp);
     AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
     static bool attr_set[16] = {false};
     int dev = 0;

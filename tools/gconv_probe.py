@@ -31,6 +31,19 @@ def main():
         y = F_.ConvFn.apply(x, w, (s, s), (p, p), cache)
         ev1.record()
     torch.cuda.synchronize()
+    if len(sys.argv) > 9 and sys.argv[9] == "wgrad":         # the weight-gradient kernel of the same layer (probe marks of k_wgrad)
+        from ayolov2_amd import ops
+        geo = F_._Geometry((B, Cin, H, W), w.shape, (s, s), (p, p), torch.float16)
+        d = geo.desc(torch.float16, geo.Cin_k, Cout)
+        dw = torch.zeros((Cout, geo.kdims[0] * geo.kdims[1] * geo.Cin_k), dtype=torch.float32, device="cuda")
+        dy = torch.randn_like(y)
+        for _ in range(3):
+            ops.conv_wgrad(d, x, dy, dw)
+        torch.cuda.synchronize()
+        ev0.record()
+        ops.conv_wgrad(d, x, dy, dw)
+        ev1.record()
+        torch.cuda.synchronize()
     print(f"launch {ev0.elapsed_time(ev1) * 1e3:.1f} us (with probe overhead)")
     lib = _lib.lib()
     buf = np.zeros(512 * N, dtype=np.uint64)
@@ -46,7 +59,7 @@ def main():
             continue
         marks = r[2:N - 6]
         nstep = int((marks > 0).sum()) // 4
-        print(f"--- workgroup {b}: prologue: tap table written +{r[N - 4] - r[0]}, rows set up +{r[N - 5] - r[0]}, barrier passed +{r[N - 6] - r[0]}, "
+        print(f"--- workgroup {b}: prologue marks (k_gconv: tap table / rows / barrier; k_wgrad: N-4 = loop drained): +{r[N - 4] - r[0]}, +{r[N - 5] - r[0]}, +{r[N - 6] - r[0]}, "
               f"loop entered +{r[1] - r[0]}; end +{r[N - 1] - r[0]} cycles, {nstep} steps recorded; after last step -> end {r[N - 1] - marks[4 * nstep - 1]}")
         prev = r[1]
         for i in range(nstep):
