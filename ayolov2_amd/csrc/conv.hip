@@ -2604,6 +2604,11 @@ static int launch_wgrad(WGradP p, hipStream_t s) {
     // of a tile runs on ONE XCD instead (measured, profiles/r03_wgrad_tile_major_map.txt: 131 -> 92 us on that layer, 1.1-2.1x
     // SLOWER on every layer with fewer tiles)
     p.tmap = tiles >= 64 ? 1 : 0;
+    // Two more experiments on the atomics, both measured and removed (profiles/r03_wgrad_atomics_experiments.txt): per-XCD
+    // copies of dw summed afterwards (-2.6 % on the sweep before the cost of zeroing and summing the copies: the L2's atomic
+    // rate, not line migration, is what the epilogue waits for on layers with few tiles); workgroups of 2-3 four-wavefront
+    // groups that add their tiles in LDS before one set of atomics (1.5-2.3x SLOWER: the shared step barrier couples 12
+    // wavefronts and one 144 KB workgroup per CU schedules worse than three independent ones).
     p.tgrp = tiles >= 8 ? 1 : (int)(8 / tiles);
     long long blocks = tiles * ((splits + 7) / 8 * 8);
     if (p.tmap) blocks = tiles >= 8 ? 8 * ((tiles + 7) / 8) * splits : 8 * ((splits + p.tgrp - 1) / p.tgrp);
