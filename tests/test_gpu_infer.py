@@ -112,6 +112,71 @@ def test_infer_plan_fp16_yolov5s():
         assert err <= 0.02 * float(b.max() - b.min()), err
 
 
+_TUCKER_CACHE = {}
+
+
+@pytest.mark.parametrize("form", ["factors", "first", "last", "dense", "auto"])
+def test_tucker_launch_forms_fp32(form, monkeypatch):
+    """The inference executor may multiply a Tucker block's linear convs out (infer_plan._tucker_form): every launch form --
+    three factor launches, first factor merged into the core, core merged into the last factor, the dense conv again, and the
+    cost model's own pick -- must give the decomposed module's result (per-module path, exact-fp32 mode) to 1e-4 of the logit
+    range, and a weight update must reach the merged weights.  YOLOv5n, decomposed incl. the 6x6 stem."""
+    from ayolov2_amd import decomposition as D, infer_plan as IP
+    from ayolov2_amd.modules import Conv
+    if "m" not in _TUCKER_CACHE:                             # decompose once (host-side SVDs), copy per launch form
+        m0, _ = _pair("n", seed=31)
+        with torch.no_grad():
+            for mod in m0.modules():
+                if isinstance(mod, Conv) and mod.conv.kernel_size != (1, 1):
+                    w = mod.conv.weight.data
+                    co, ci, kh, kw = w.shape
+                    ro, ri = max(co // 4, 2), max(ci // 4, 2)
+                    std = 1.0 / (ci * kh * kw) ** 0.5
+                    w.copy_(torch.einsum("abhw,oa,ib->oihw", torch.randn(ro, ri, kh, kw), torch.randn(co, ro), torch.randn(ci, ri))
+                            * (std / (ro * ri) ** 0.5) + 0.05 * std * torch.randn_like(w))
+        D.decompose_model(m0, loss_thr=0.1, prune_step=0.0)
+        assert len(D.decomposed_ranks(m0)) >= 10
+        _TUCKER_CACHE["m"] = m0
+    m = copy.deepcopy(_TUCKER_CACHE["m"])
+    m = m.cuda().eval()
+    x = torch.rand(2, 3, 128, 160).cuda()
+    monkeypatch.setattr(IP, "TUCKER_FORMS", form)
+    with torch.no_grad():
+        m.use_plan = False
+        _, raws_ref = m(x)
+        raws_ref = [t.clone() for t in raws_ref]
+        m.use_plan = True
+        m.__dict__.pop("_plans", None)
+        _, raws = m(x)
+        assert _has_plan(m, "eval")
+        plan = [p for p in m._plans.values() if p][0]
+        assert len(plan.tucker_forms) >= 10 and (form == "auto" or set(plan.tucker_forms) == {form}), plan.tucker_forms
+        for a, b in zip(raws, raws_ref):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.max() - b.min()) + 1e-5
+        # a weight update of a factor reaches the multiplied-out weights (version-tracked sources)
+        seq = next(mod.conv for mod in m.modules() if isinstance(mod, Conv) and isinstance(mod.conv, torch.nn.Sequential))
+        seq[0].weight.mul_(-2.0)
+        m.use_plan = False
+        _, raws_ref2 = m(x)
+        raws_ref2 = [t.clone() for t in raws_ref2]
+        m.use_plan = True
+        _, raws2 = m(x)
+        for a, b in zip(raws2, raws_ref2):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.max() - b.min()) + 1e-5
+        assert any(float((a - b).abs().max()) > 1e-6 * float(b.max() - b.min()) for a, b in zip(raws_ref2, raws_ref))   # the update is visible at all
+
+
+def test_wide_channel_tile_opt_in():
+    """The 256-channel x 256-pixel / 8-wavefront k_gconv tile is opt-in (AYOLO_GCONV_TM=256, read once per process: measured
+    neutral-to-slower, profiles/r03_tm256_tile_sweep.txt) -- keep it correct: tools/tm256_check.py in a process of its own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AYOLO_GCONV_TM="256")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "tm256_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("all ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_cfg4_tucker_decomposed_yolov5s_fp16_eval():
     """BASELINE cfg 4: decompose_model() (scripts/tensor_decomposition/decomposition.py:237-339, defaults of
     decompose_model.py:63-74 except prune_step 0 to bound the SVD count) on YOLOv5s -- every k > 1 conv incl. the 6x6
