@@ -1506,7 +1506,11 @@ __device__ __forceinline__ bool iou_above(float inter, float u, double thr_mid, 
 }
 
 #define MAT_CAP 512
-__global__ __launch_bounds__(256) void k_seg_nms_small(SegNmsP p) {
+// SMALL_NT threads: the three parallel phases (rank sort, overlap bits, exact-IoU pass) are the segment's critical path -- one
+// workgroup per segment, the largest segment bounds the launch -- so eight wavefronts instead of four halve them; three
+// workgroups of ~50 KB LDS still fit a CU, i.e. the 640 segments of an 8 x 80-class batch stay one round
+#define SMALL_NT 512
+__global__ __launch_bounds__(SMALL_NT) void k_seg_nms_small(SegNmsP p) {
     __shared__ uint64_t skin[MAT_CAP], skey[MAT_CAP];          // keys as loaded / sorted
     __shared__ float4 sbox[MAT_CAP];                           // sorted boxes + class offset
     __shared__ uint16_t sidx[MAT_CAP], skl[MAT_CAP];           // sorted position -> position in the segment; kept list
@@ -1519,30 +1523,27 @@ __global__ __launch_bounds__(256) void k_seg_nms_small(SegNmsP p) {
     if (n == 0 || n > MAT_CAP) return;
     const uint32_t off = p.seg_off[sg];
     const int img = sg / p.nc, cls = sg - img * p.nc;
-    for (int i = tid; i < n; i += 256) skin[i] = p.gkey[off + i];
+    for (int i = tid; i < n; i += SMALL_NT) skin[i] = p.gkey[off + i];
     __syncthreads();
     // rank sort: keys are unique, so the ranks are a permutation
     {
-        const uint64_t k0 = tid < n ? skin[tid] : 0ull, k1 = tid + 256 < n ? skin[tid + 256] : 0ull;
-        int r0 = 0, r1 = 0;
+        static_assert(SMALL_NT >= MAT_CAP, "one key per thread");
+        const uint64_t k0 = tid < n ? skin[tid] : 0ull;
+        int r0 = 0;
         const int n8 = n & ~7;
         for (int j = 0; j < n8; j += 8) {                      // eight independent broadcast reads in flight per step
             uint64_t kj[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) kj[u] = skin[j + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { r0 += kj[u] < k0; r1 += kj[u] < k1; }
+            for (int u = 0; u < 8; ++u) r0 += kj[u] < k0;
         }
-        for (int j = n8; j < n; ++j) {
-            const uint64_t kj = skin[j];
-            r0 += kj < k0; r1 += kj < k1;
-        }
+        for (int j = n8; j < n; ++j) r0 += skin[j] < k0;
         if (tid < n) { skey[r0] = k0; sidx[r0] = (uint16_t)tid; }
-        if (tid + 256 < n) { skey[r1] = k1; sidx[r1] = (uint16_t)(tid + 256); }
     }
     __syncthreads();
     const float o = (float)cls * 4096.0f;                      // metrics.py:383: boxes + cls * max_wh, in float32
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += SMALL_NT) {
         const float4 b = reinterpret_cast<const float4*>(p.gbox)[off + sidx[i]];
         sbox[i] = make_float4(b.x + o, b.y + o, b.z + o, b.w + o);
     }
@@ -1553,7 +1554,7 @@ __global__ __launch_bounds__(256) void k_seg_nms_small(SegNmsP p) {
     //   pass 1: OVERLAP bits of every pair of the upper triangle -- 64 x 64 tiles, lane = column box, row boxes broadcast
     //           from LDS, the row word straight from a ballot (4 compares per pair; a superset of `inter > 0`);
     //   pass 2: every thread walks the set bits of its share of the words and keeps those whose IoU is above the threshold.
-    for (int t = wave; t < nb * nb; t += 4) {
+    for (int t = wave; t < nb * nb; t += SMALL_NT / 64) {
         const int rb = t / nb, cb = t - rb * nb;
         if (cb < rb) continue;
         const int j = cb * 64 + lane;
@@ -1577,7 +1578,7 @@ __global__ __launch_bounds__(256) void k_seg_nms_small(SegNmsP p) {
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < n * nb; idx += 256) {
+    for (int idx = tid; idx < n * nb; idx += SMALL_NT) {
         const int ri = idx / nb, cb = idx - ri * nb;
         if (cb < (ri >> 6)) continue;
         uint64_t word = smat[ri * (MAT_CAP / 64) + cb], out = 0;
@@ -1638,7 +1639,7 @@ __global__ __launch_bounds__(256) void k_seg_nms_small(SegNmsP p) {
     if (tid == 0) s_base = atomicAdd(&p.kcnt[img], kept);
     __syncthreads();
     const uint32_t base = s_base;
-    for (uint32_t r = tid; r < kept; r += 256) {
+    for (uint32_t r = tid; r < kept; r += SMALL_NT) {
         const uint32_t j = skl[r];
         const size_t dst = (size_t)img * ((size_t)p.nc * p.max_det) + base + r;
         p.kkey[dst] = skey[j];
@@ -2007,7 +2008,7 @@ extern "C" int ayolo_nms_class_fast(const float* pred, int B, int N, int no, flo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_img_topk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)topk_lds);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_seg_nms_small, dim3((unsigned)nseg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_seg_nms_small, dim3((unsigned)nseg), dim3(SMALL_NT), 0, st, p);
     AY_CHECK_LAUNCH("k_seg_nms_small");
     hipLaunchKernelGGL(k_seg_nms, dim3((unsigned)nseg), dim3(256), seg_lds, st, p);
     AY_CHECK_LAUNCH("k_seg_nms");
