@@ -27,6 +27,24 @@ __device__ __forceinline__ void store_vec(T* p, const float (&v)[VecT<T>::VE]) {
     *reinterpret_cast<uint4*>(p) = raw;
 }
 
+// Per-channel constants staged in LDS by a prologue and read back as ONE 8- (4-) channel group per thread: the fp16 kernels'
+// threads would read 32-byte runs at a 32-byte lane stride (2- to 8-way bank conflicts: 0.68-0.73 of the LDS-active cycles of
+// the BatchNorm kernels in the round-2 / round-3 SQ counters).  The two 16-byte halves of a group therefore live in two planes,
+// so that consecutive lanes read consecutive 16-byte words: channel c of a C-channel array sits at pl_idx<VE>(c, C).
+template <int VE> __device__ __forceinline__ int pl_idx(int c, int C) {
+    if constexpr (VE == 8) return ((c >> 2) & 1) * (C >> 1) + (c >> 3) * 4 + (c & 3);
+    else return c;
+}
+// the VE constants of channel group cg from such an array (16-byte LDS reads)
+template <int VE> __device__ __forceinline__ void pl_load(const float* arr, int cg, int C, float (&out)[VE]) {
+    const float4 lo = *reinterpret_cast<const float4*>(arr + cg * 4);
+    out[0] = lo.x; out[1] = lo.y; out[2] = lo.z; out[3] = lo.w;
+    if constexpr (VE == 8) {
+        const float4 hi = *reinterpret_cast<const float4*>(arr + (C >> 1) + cg * 4);
+        out[4] = hi.x; out[5] = hi.y; out[6] = hi.z; out[7] = hi.w;
+    }
+}
+
 // SiLU and its derivative.  The fp32 (exact-parity) instantiation uses expf + IEEE division; the fp16-storage
 // instantiation uses v_exp_f32 / v_rcp_f32 (error ~1e-6 relative, far below the fp16 output rounding) so these
 // HBM-bound passes are not VALU-limited.
@@ -232,8 +250,8 @@ __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a,
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
         const float sc = g * invstd;
-        sc_sh[c] = sc;
-        sc_sh[C + c] = b - (float)mean * sc;
+        sc_sh[pl_idx<VE>(c, C)] = sc;
+        sc_sh[C + pl_idx<VE>(c, C)] = b - (float)mean * sc;
         if (blockIdx.x == 0) {
             if (smean) smean[c] = (float)mean;
             if (sinv) sinv[c] = invstd;
@@ -252,8 +270,8 @@ __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a,
     if (prow >= RPB) return;
     for (int cg = cgl; cg < CG; cg += CGT) {
         float sc[VE], sh[VE];
-#pragma unroll
-        for (int i = 0; i < VE; ++i) { sc[i] = sc_sh[cg * VE + i]; sh[i] = sc_sh[C + cg * VE + i]; }
+        pl_load<VE>(sc_sh, cg, C, sc);
+        pl_load<VE>(sc_sh + C, cg, C, sh);
         affine_act_rows<T, ACT, RES>(z, ldz, a, lda, npix, cg, sc, sh, res, ldr, (long long)blockIdx.x * RPB + prow,
                                      (long long)gridDim.x * RPB);
     }
@@ -432,12 +450,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     const float invn = 1.0f / (float)npix;
     // cooperative prologue: replica sums once per workgroup, then every thread keeps ITS channel group in registers
     for (int i = threadIdx.x; i < C; i += 256) {
-        sh[i] = mean[i]; sh[C + i] = invstd[i];
-        sh[2 * C + i] = gamma ? gamma[i] : 1.0f; sh[3 * C + i] = beta ? beta[i] : 0.0f;
+        const int q = pl_idx<VE>(i, C);
+        sh[q] = mean[i]; sh[C + q] = invstd[i];
+        sh[2 * C + q] = gamma ? gamma[i] : 1.0f; sh[3 * C + q] = beta ? beta[i] : 0.0f;
         double d1 = 0.0, d2 = 0.0;
         for (int r = 0; r < reps; ++r) { d1 += sums[(size_t)r * 2 * C + i]; d2 += sums[(size_t)r * 2 * C + C + i]; }
         const float s1 = (float)d1, s2 = (float)d2;
-        sh[4 * C + i] = s1 * invn; sh[5 * C + i] = s2 * invn;
+        sh[4 * C + q] = s1 * invn; sh[5 * C + q] = s2 * invn;
         if (blockIdx.x == 0) {
             if (dbeta) dbeta[i] = s1 * grad_scale;
             if (dgamma) dgamma[i] = s2 * grad_scale;
@@ -452,11 +471,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     for (int cg = cgl; cg < CG; cg += CGT) {
         // fp16 storage: dz = du*P + (xhat*Rr + Q) with P = gamma*invstd, Q = -P*m1, Rr = -P*m2 (two fmas)
         float mu[VE], is[VE], ga[VE], be[VE], m1[VE], m2[VE], A[VE], Bc[VE], nmi[VE], P[VE], Q[VE], Rr[VE];
+        pl_load<VE>(sh, cg, C, mu); pl_load<VE>(sh + C, cg, C, is); pl_load<VE>(sh + 2 * C, cg, C, ga);
+        pl_load<VE>(sh + 3 * C, cg, C, be); pl_load<VE>(sh + 4 * C, cg, C, m1); pl_load<VE>(sh + 5 * C, cg, C, m2);
 #pragma unroll
         for (int i = 0; i < VE; ++i) {
-            const int c = cg * VE + i;
-            mu[i] = sh[c]; is[i] = sh[C + c]; ga[i] = sh[2 * C + c]; be[i] = sh[3 * C + c];
-            m1[i] = sh[4 * C + c]; m2[i] = sh[5 * C + c];
             A[i] = is[i] * ga[i]; Bc[i] = be[i] - mu[i] * A[i]; nmi[i] = -mu[i] * is[i];
             P[i] = ga[i] * is[i]; Q[i] = -P[i] * m1[i]; Rr[i] = -P[i] * m2[i];
         }

@@ -5,7 +5,10 @@ SQ_VALU_MFMA_BUSY_CYCLES is cycles summed over SIMDs, GRBM_GUI_ACTIVE is the ker
 (checked against launch durations: 71 launches x 45 us = 7.7 M cycles vs 66.9 M counted).
   mfma_busy      = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024 SIMDs)    share of all SIMD-cycles with the matrix pipe busy
   parked/stalled/issuing = WAIT_ANY / WAIT_INST_ANY / ACTIVE_INST_ANY over WAVE_CYCLES  (disjoint, ~1 in sum)
-  lds_conflict   = LDS_BANK_CONFLICT / LDS_IDX_ACTIVE           share of LDS-array cycles lost to bank conflicts"""
+  lds_conflict   = LDS_BANK_CONFLICT / LDS_IDX_ACTIVE           share of LDS-array cycles lost to bank conflicts
+  lds_busy       = LDS_IDX_ACTIVE / (GUI_ACTIVE / 8 * 256 CUs)  how much of the kernel the LDS array is active AT ALL: a high
+                   conflict share over a tiny lds_busy (the BatchNorm kernels read six per-channel constants per thread once, in
+                   the prologue) costs nothing"""
 import collections
 import csv
 import json
@@ -30,7 +33,8 @@ for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0
               "parked": round(c.get("SQ_WAIT_ANY", 0.0) / wave, 3),
               "issue_stalled": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wave, 3),
               "issuing": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / wave, 3),
-              "lds_conflict": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / lds, 4) if lds > 0 else None}
+              "lds_conflict": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / lds, 4) if lds > 0 else None,
+              "lds_busy": round(lds / (gui * 256), 4)}
 json.dump(res, open(out, "w"), indent=1)
 for k, v in list(res.items())[:14]:
     print(f"{k[:58]:58s} {v}")
