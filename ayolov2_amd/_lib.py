@@ -60,6 +60,8 @@ _SIGNATURES = {
     "ayolo_bn_act_bwd_reduce": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P],
     "ayolo_bn_act_bwd_apply": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, c_int,
                                _P, _P, c_float, _P],
+    "ayolo_bn_act_bwd_apply_res": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, c_int,
+                                   _P, _P, c_float, _P, c_int, c_int, _P],
     "ayolo_maxpool_fwd": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "ayolo_maxpool_bwd": [c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ayolo_upsample2x_fwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],

@@ -440,11 +440,14 @@ extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const 
     return AYOLO_OK;
 }
 
-template <typename T, int ACT>
+// RESOUT: the block's output also fed a shortcut add (Bottleneck: out = x + act(bn(z))), so d(x) (+)= da.  The pass reads da
+// anyway: it forwards it to the shortcut's gradient buffer `dres` instead of a separate strided copy re-reading it.
+template <typename T, int ACT, bool RESOUT = false>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const T* da, int ldda, T* dz, int lddz,
                                                       long long npix, int C, const float* mean, const float* invstd,
                                                       const float* gamma, const float* beta, const double* sums,
-                                                      int reps, float* dgamma, float* dbeta, float grad_scale) {
+                                                      int reps, float* dgamma, float* dbeta, float grad_scale,
+                                                      T* dres = nullptr, int lddres = 0, int res_acc = 0) {
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sh[];   // [6][C]: mean, invstd, gamma, beta, sum_du/n, sum_dux/n
     const float invn = 1.0f / (float)npix;
@@ -487,6 +490,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
                 load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, zz[j]);
                 load_vec<T>(da + (pix + j * stride) * ldda + cg * VE, dd[j]);
             }
+            if constexpr (RESOUT) {
+                float rr[4][VE];
+                if (res_acc) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) load_vec<T>(dres + (pix + j * stride) * lddres + cg * VE, rr[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) rr[j][i] = res_acc ? rr[j][i] + dd[j][i] : dd[j][i];
+                    store_vec<T>(dres + (pix + j * stride) * lddres + cg * VE, rr[j]);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -503,6 +519,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
             float zv[VE], dv[VE];
             load_vec<T>(z + pix * ldz + cg * VE, zv);
             load_vec<T>(da + pix * ldda + cg * VE, dv);
+            if constexpr (RESOUT) {
+                float rv[VE];
+                if (res_acc) load_vec<T>(dres + pix * lddres + cg * VE, rv);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) rv[i] = res_acc ? rv[i] + dv[i] : dv[i];
+                store_vec<T>(dres + pix * lddres + cg * VE, rv);
+            }
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
                 float xh, du;
@@ -515,24 +538,42 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     }
 }
 
-extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
-                                      int64_t npix, int C, const float* save_mean, const float* save_invstd,
-                                      const float* gamma, const float* beta, int act, const double* sums, int sum_reps,
-                                      float* dgamma, float* dbeta, float grad_scale, ayolo_stream s) {
+extern "C" int ayolo_bn_act_bwd_apply_res(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
+                                          int64_t npix, int C, const float* save_mean, const float* save_invstd,
+                                          const float* gamma, const float* beta, int act, const double* sums, int sum_reps,
+                                          float* dgamma, float* dbeta, float grad_scale, void* dres, int lddres,
+                                          int res_accumulate, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
     if (sum_reps < 1) sum_reps = 1;
     AY_CHECK_ARG(z && da && dz && sums, "bn_bwd_apply: null pointer");
     AY_CHECK_ARG(C > 0 && C % ve == 0 && ldz % ve == 0 && ldda % ve == 0 && lddz % ve == 0 && C <= 2048, "bn_bwd_apply: C=%d", C);
+    AY_CHECK_ARG(!dres || (lddres >= C && lddres % ve == 0 && dres != da && dres != dz), "bn_bwd_apply: shortcut gradient lddres=%d", lddres);
     if (npix == 0) return AYOLO_OK;
     // the per-workgroup prologue stages (6 + 2*reps)*C floats in LDS: scale the elements per workgroup with C
     unsigned grid = grid_pixels(npix, C, ve, C >= 256 ? 16 : 8);
     if (grid > 2048u) grid = 2048u;
-    DISPATCH_T(dtype, DISPATCH_AR(act, false,
-               (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s,
-                                  (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,
-                                  save_invstd, gamma, beta, sums, sum_reps, dgamma, dbeta, grad_scale);))
+    if (dres) {
+        DISPATCH_T(dtype, DISPATCH_AR(act, false,
+                   (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT, true>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s,
+                                      (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,
+                                      save_invstd, gamma, beta, sums, sum_reps, dgamma, dbeta, grad_scale, (T*)dres, lddres,
+                                      res_accumulate);))
+    } else {
+        DISPATCH_T(dtype, DISPATCH_AR(act, false,
+                   (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT, false>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s,
+                                      (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,
+                                      save_invstd, gamma, beta, sums, sum_reps, dgamma, dbeta, grad_scale, (T*)nullptr, 0, 0);))
+    }
     AY_CHECK_LAUNCH("k_bn_bwd_apply");
     return AYOLO_OK;
+}
+
+extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
+                                      int64_t npix, int C, const float* save_mean, const float* save_invstd,
+                                      const float* gamma, const float* beta, int act, const double* sums, int sum_reps,
+                                      float* dgamma, float* dbeta, float grad_scale, ayolo_stream s) {
+    return ayolo_bn_act_bwd_apply_res(dtype, z, ldz, da, ldda, dz, lddz, npix, C, save_mean, save_invstd, gamma, beta, act, sums,
+                                      sum_reps, dgamma, dbeta, grad_scale, nullptr, 0, 0, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -194,9 +194,11 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
                                          o.i[5], cs);
             break;
         case AYOLO_OP_BN_BWD_APPLY:
-            rc = ayolo_bn_act_bwd_apply(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.p[2], o.i[3], o.l[0], o.i[4],
-                                        (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5], (const float*)o.p[6],
-                                        o.i[5], (const double*)o.p[7], o.i[6], (float*)o.p[8], (float*)o.p[9], o.f[0], cs);
+            // p[10] / i[7] / i[8]: gradient buffer of a shortcut fed by the same output (NULL: none), its row stride, accumulate
+            rc = ayolo_bn_act_bwd_apply_res(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.p[2], o.i[3], o.l[0], o.i[4],
+                                            (const float*)o.p[3], (const float*)o.p[4], (const float*)o.p[5], (const float*)o.p[6],
+                                            o.i[5], (const double*)o.p[7], o.i[6], (float*)o.p[8], (float*)o.p[9], o.f[0],
+                                            o.p[10], o.i[7], o.i[8], cs);
             break;
         case AYOLO_OP_MAXPOOL_FWD:
             rc = ayolo_maxpool_fwd(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], (unsigned char*)o.p[2], o.i[3], o.i[4], o.i[5], o.i[6],

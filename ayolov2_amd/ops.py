@@ -180,8 +180,9 @@ def affine_act(z, a, scale, shift, act: int):
          _stream())
 
 
-def bn_act_bwd(z, da, save_mean, save_invstd, gamma, beta, act: int, want_param_grads=True):
-    """Returns (dz, dgamma, dbeta) for a = act(bn(z)) with batch statistics."""
+def bn_act_bwd(z, da, save_mean, save_invstd, gamma, beta, act: int, want_param_grads=True, dres=None, res_accumulate=False):
+    """Returns (dz, dgamma, dbeta) for a = act(bn(z)) with batch statistics.  `dres` (NHWC tensor of da's shape, any channel
+    stride): the gradient buffer of a shortcut fed by the same output, dres (+)= da written by the apply pass."""
     B, C, H, W, ldz = nhwc_info(z)
     _, _, _, _, ldda = nhwc_info(da)
     npix = B * H * W
@@ -193,8 +194,13 @@ def bn_act_bwd(z, da, save_mean, save_invstd, gamma, beta, act: int, want_param_
          _ptr(gamma), _ptr(beta), act, _ptr(sums), STAT_REPS, _stream())
     dgamma = torch.empty(C, dtype=torch.float32, device=dev) if want_param_grads else None
     dbeta = torch.empty(C, dtype=torch.float32, device=dev) if want_param_grads else None
-    call("ayolo_bn_act_bwd_apply", dt, _ptr(z), ldz, _ptr(da), ldda, _ptr(dz), C, npix, C, _ptr(save_mean),
-         _ptr(save_invstd), _ptr(gamma), _ptr(beta), act, _ptr(sums), STAT_REPS, _ptr(dgamma), _ptr(dbeta), 1.0, _stream())
+    if dres is None:
+        call("ayolo_bn_act_bwd_apply", dt, _ptr(z), ldz, _ptr(da), ldda, _ptr(dz), C, npix, C, _ptr(save_mean),
+             _ptr(save_invstd), _ptr(gamma), _ptr(beta), act, _ptr(sums), STAT_REPS, _ptr(dgamma), _ptr(dbeta), 1.0, _stream())
+    else:
+        call("ayolo_bn_act_bwd_apply_res", dt, _ptr(z), ldz, _ptr(da), ldda, _ptr(dz), C, npix, C, _ptr(save_mean),
+             _ptr(save_invstd), _ptr(gamma), _ptr(beta), act, _ptr(sums), STAT_REPS, _ptr(dgamma), _ptr(dbeta), 1.0,
+             _ptr(dres), nhwc_info(dres)[4], int(bool(res_accumulate)), _stream())
     return dz, dgamma, dbeta
 
 

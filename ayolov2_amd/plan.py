@@ -37,7 +37,7 @@ OP_JOIN_SIDE = 21
 
 class Op(ctypes.Structure):
     _fields_ = [("kind", c_int), ("i", c_int * 12), ("f", c_float * 2), ("d", c_double * 1), ("l", c_int64 * 1),
-                ("p", c_void_p * 10), ("conv", ConvDesc)]
+                ("p", c_void_p * 12), ("conv", ConvDesc)]
 
 
 def _op(kind, i=(), f=(), d=(), l=(), p=(), conv: Optional[ConvDesc] = None) -> Op:
@@ -62,6 +62,7 @@ import os as _os
 
 OP_SIDE = 0x100
 WGRAD_SIDE_STREAM = _os.environ.get("AYOLO_WGRAD_STREAM", "1") == "1"
+FOLD_SHORTCUT_GRAD = True     # Bottleneck shortcut gradients written by the BatchNorm-backward apply pass (ayolo_bn_act_bwd_apply_res)
 MAX_PLANS = int(_os.environ.get("AYOLO_MAX_PLANS", "4"))                 # cached plans per model (multi-scale training)
 MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: cv1 | cv2 as one conv
 # BatchNorm-backward sums (the first of the two backward passes of a Conv-BN-act block) computed in the epilogue of the
@@ -329,17 +330,23 @@ class TrainPlan:
                 dbet = ga.view(gb_off, co) if gb_off is not None else None
                 self.bwd.append(_op(OP_BN_BWD_REDUCE, i=(code, Ct, ldda, co, act, R), l=(npix,),
                                     p=(zj, da, sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su)))
-                self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R), l=(npix,), f=(1.0,),
-                                    p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet)))
+                # shortcut (Bottleneck: out = x + a): d(x) (+)= d(a) leaves with the same pass (it reads da anyway) instead of a
+                # strided copy of its own
+                dr = residual.grad() if residual is not None else None
+                fold_res = dr is not None and FOLD_SHORTCUT_GRAD
+                self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R) + ((ops.nhwc_info(dr)[4], int(residual.is_init())) if fold_res else (0, 0)),
+                                    l=(npix,), f=(1.0,),
+                                    p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet,
+                                       dr if fold_res else None)))
                 self._wrote(gg_off, co)
                 self._wrote(gb_off, co)
                 self.bwd_sync.append((len(self.bwd) - 2, su))  # sync_bn: all-reduce of the sums between reduce and apply
                 self._bn_layers.append(dict(reduce=len(self.bwd) - 2, a=a, z=zj, ldz=Ct, sm=sm[0:2 * co], gamma=bn.weight,
                                             beta=bn.bias, sums=su, C=co, act=act, R=R))
                 if residual is not None:      # shortcut: d(residual) += d(a)
-                    dr = residual.grad()
-                    self.bwd.append(_op(OP_COPY2D, i=(code, ldda, ops.nhwc_info(dr)[4], co, int(residual.is_init())), l=(npix,),
-                                        p=(da, dr)))
+                    if not fold_res:
+                        self.bwd.append(_op(OP_COPY2D, i=(code, ldda, ops.nhwc_info(dr)[4], co, int(residual.is_init())), l=(npix,),
+                                            p=(da, dr)))
                     self._gw(residual, False)
                     residual.mark_init()
             def wgrad():
@@ -767,7 +774,8 @@ class TrainPlan:
             elif kind == OP_BN_BWD_REDUCE:
                 out.append(("bn_bwd_reduce", es * o.l[0] * o.i[3] * 2, 0.0))
             elif kind == OP_BN_BWD_APPLY:
-                out.append(("bn_bwd_apply", es * o.l[0] * o.i[4] * 3, 0.0))
+                # + the shortcut gradient written (and, accumulating, read) by the same pass
+                out.append(("bn_bwd_apply", es * o.l[0] * o.i[4] * (3 + ((2 if o.i[8] else 1) if o.p[10] else 0)), 0.0))
             elif kind in (OP_MAXPOOL_FWD, OP_UPSAMPLE_FWD):
                 n = o.i[3] * o.i[4] * o.i[5] * o.i[6] * (4 if kind == OP_UPSAMPLE_FWD else 1)
                 out.append(("pool_upsample", es * n * (1.25 if kind == OP_UPSAMPLE_FWD else 2) + (n if kind == OP_MAXPOOL_FWD else 0), 0.0))

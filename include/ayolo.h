@@ -168,6 +168,13 @@ int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const void* da, in
                            int64_t npix, int C, const float* save_mean, const float* save_invstd,
                            const float* gamma, const float* beta, int act, const double* sums, int sum_reps,
                            float* dgamma, float* dbeta, float grad_scale, ayolo_stream s);
+/* the same pass for a block whose output also fed a shortcut add (Bottleneck, kindle `Bottleneck.forward`: x + cv2(cv1(x));
+ * autograd's AddBackward): dres[p][0:C] (+)= da[p][0:C] is written from the da values the pass reads anyway, instead of a
+ * separate ayolo_copy2d over da.  dres == NULL: identical to ayolo_bn_act_bwd_apply. */
+int ayolo_bn_act_bwd_apply_res(int dtype, const void* z, int ldz, const void* da, int ldda, void* dz, int lddz,
+                               int64_t npix, int C, const float* save_mean, const float* save_invstd, const float* gamma,
+                               const float* beta, int act, const double* sums, int sum_reps, float* dgamma, float* dbeta,
+                               float grad_scale, void* dres, int lddres, int res_accumulate, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Small NHWC ops: kindle SPPF's MaxPool2d(5,1,2), UpSample(None,2) nearest, input packing, bias grad.
@@ -403,7 +410,7 @@ typedef struct ayolo_op {
     float f[2];
     double d[1];
     int64_t l[1];
-    void* p[10];
+    void* p[12];
     ayolo_conv_desc conv;
 } ayolo_op;
 int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s);

@@ -437,3 +437,30 @@ def test_dgrad_with_bn_backward_sums(case, accumulate):
         mass = float(dx_ref[:, c0:c0 + C].float().abs().sum() / C)
         err = float((got - want).abs().max())
         assert err <= 2e-5 * mass + 1e-6, (err, mass, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_bn_backward_apply_forwards_the_shortcut_gradient(dt, accumulate):
+    """ayolo_bn_act_bwd_apply_res: the BatchNorm + SiLU backward pass of a block whose output also fed a shortcut add writes
+    d(shortcut) (+)= da from the da values it reads anyway (kindle Bottleneck: x + cv2(cv1(x))); dz / dgamma / dbeta must be
+    those of the plain pass bit for bit, the shortcut gradient exact (a copy, or one fp addition in the storage dtype),
+    also into a channel slice of a wider buffer."""
+    from ayolov2_amd import ops
+    torch.manual_seed(7)
+    B, C, H, W = 3, 64, 9, 11                         # 297 pixels: the four-pixel main loop and the tail
+    z = torch.randn(B, C, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    da = torch.randn(B, C, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    mean = z.float().mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(z.float().var((0, 2, 3), unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    ref = ops.bn_act_bwd(z, da, mean, invstd, gamma, beta, 1)
+    wide = torch.randn(B, 2 * C, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    old = wide.clone()
+    dres = wide[:, C:]                                 # channel slice: row stride 2C
+    out = ops.bn_act_bwd(z, da, mean, invstd, gamma, beta, 1, dres=dres, res_accumulate=accumulate)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    want = (old[:, C:].float() + da.float()).to(dt) if accumulate else da
+    assert torch.equal(wide[:, C:], want)
+    assert torch.equal(wide[:, :C], old[:, :C])        # the other half of the wide buffer is untouched
