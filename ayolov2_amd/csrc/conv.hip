@@ -2626,7 +2626,223 @@ static int launch_wgrad(WGradP p, hipStream_t s) {
     return AYOLO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_stem_wgrad: weight gradient of the packed stem conv (image as pixel pairs [B][H][W/2][8 halves]; the 6x6 / stride 2 / pad 2
+// conv of kindle's first Conv row -- res/configs/model/yolov5s.yaml:21 -- is a 6 x 3 / stride (2, 1) / pad (2, 1) conv over
+// pairs, see functional._Geometry), fp16, Cout <= 64.
+// It is the LAST kernel of backward -- nothing is left to overlap it with -- and the generic k_wgrad gathers its x tile in
+// 16-byte taps (one DMA lane per (pixel, tap)), spends half of its second 128-column tile on padding (K = 144) and pays the
+// atomics of ~600 pixel splits: 320-390 us at 1.9 TB/s with the chip to itself.  Here the input patch of a 4 x 64 output tile
+// is staged ONCE, as it lies (12 rows x 68 pairs, 13 KB): for output pixel (r, c) and kernel row dh the three pair taps are
+// the 48 contiguous bytes at patch[2r + dh][c .. c + 2], consecutive pixels 16 bytes apart -- exactly a pixel-major operand
+// with a 16-byte row stride, which the transposing LDS read turns into MFMA fragments (columns = 3 pairs x 8 halves + one
+// junk pair = 32).  Per 16 pixels: one dy fragment per 32 output channels and six x fragments (one per dh), six MFMAs; every
+// wavefront keeps the whole 32 x (6 x 32) gradient for its row of the tile in registers across ALL tiles of the workgroup
+// and the workgroup sends ONE set of atomics at the very end.  398 -> 141 us at batch 64, 640 x 640 (tools/stem_probe.py: tile
+// loop 92-126 us = the 524 MB at 4.5-5 TB/s, reduction + atomics 5 us), train step -0.2 ms (profiles/r03_stem_wgrad.txt).
+// ---------------------------------------------------------------------------------------------------
+struct StemWP {
+    const half_t* x; const half_t* dy; float* dw;
+    int B, H, WP, Ho, Wo, ldy, N, K;       // WP = pairs per image row; K = 6 * 24 (row length of dw)
+    float alpha;
+    int tw, th;                            // tiles per row / per column of one image
+    long long ntiles;
+    unsigned x_bytes, y_bytes;             // buffer descriptor extents (< 2 GiB, host check)
+};
+#define STEM_TR 4                          // output rows per tile = wavefronts
+#define STEM_TC 64                         // output columns per tile
+#define STEM_PR (2 * STEM_TR + 4)          // patch rows: 2 * TR + (6 - 2)
+#define STEM_PC (STEM_TC + 4)              // patch pair columns: TC + 2 (taps) + 1 (junk pair) rounded to 68
+
+template <int MB>
+__global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p) {
+    constexpr int DYROW = 64 * MB;                                   // bytes per pixel row of the dy tile
+    constexpr int PATCH_B = STEM_PR * STEM_PC * 16, DY_B = STEM_TR * STEM_TC * DYROW;
+    constexpr int NPCH = STEM_PR * STEM_PC, NDCH = STEM_TR * STEM_TC * 4 * MB;     // 16-byte chunks per tile
+    constexpr int PPT = (NPCH + 255) / 256, DPT = NDCH / 256;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm[];           // [2][patch | dy tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    float16v acc[MB][6];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int g = 0; g < 6; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.0f;
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.dy), 0, p.y_bytes, 0x00020000);
+    // two register sets: the loads of tile i+2 are issued while tile i is computed and are written to LDS one iteration later,
+    // so a tile's global-load latency has a whole iteration (and the other workgroup of the CU) to hide behind
+    uint4 rp[2][PPT], rd[2][DPT];
+    auto fetch = [&](long long t, uint4 (&fp)[PPT], uint4 (&fd)[DPT]) {
+        const bool live = t < p.ntiles;
+        const long long tt = live ? t : 0;
+        const int tx = (int)(tt % p.tw);
+        const long long u = tt / p.tw;
+        const int ty = (int)(u % p.th), n = (int)(u / p.th);
+        const int oh0 = ty * STEM_TR, ow0 = tx * STEM_TC;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int i = tid + 256 * j;
+            const int row = i / STEM_PC, col = i - row * STEM_PC;
+            const int ih = 2 * oh0 - 2 + row, ip = ow0 - 1 + col;
+            const bool ok = live && i < NPCH && (unsigned)ih < (unsigned)p.H && (unsigned)ip < (unsigned)p.WP;
+            // branch-free: out-of-image chunks take the descriptor's out-of-range offset (hardware returns 0).  Written as
+            // `ok ? *ptr : 0` every load becomes a branch + s_waitcnt vmcnt(0) and the eight loads of a tile run one after
+            // the other (see "Why LDS-DMA + counted waits" in DESIGN.md)
+            const unsigned off = ok ? (unsigned)((((unsigned)n * (unsigned)p.H + (unsigned)ih) * (unsigned)p.WP + (unsigned)ip) * 16u) : G_OOB;
+            fp[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            const int i = tid + 256 * j;
+            const int px = i / (4 * MB), part = i - px * (4 * MB);
+            const int oh = oh0 + px / STEM_TC, ow = ow0 + px % STEM_TC;
+            const bool ok = live && oh < p.Ho && ow < p.Wo && part * 8 < p.N;     // N % 8 == 0 (host check)
+            const unsigned off = ok ? ((((unsigned)n * (unsigned)p.Ho + (unsigned)oh) * (unsigned)p.Wo + (unsigned)ow) * (unsigned)p.ldy + (unsigned)part * 8u) * 2u : G_OOB;
+            fd[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0));
+        }
+    };
+    auto stash = [&](int buf, const uint4 (&fp)[PPT], const uint4 (&fd)[DPT]) {
+        unsigned char* b = sm + buf * (PATCH_B + DY_B);
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int i = tid + 256 * j;
+            if (i < NPCH) *reinterpret_cast<uint4*>(b + i * 16) = fp[j];
+        }
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) *reinterpret_cast<uint4*>(b + PATCH_B + (tid + 256 * j) * 16) = fd[j];
+    };
+    const int csub = ((lane >> 4) & 1) * 16;
+    auto compute = [&](int buf) {
+        const unsigned char* pb = sm + buf * (PATCH_B + DY_B);
+        const unsigned char* db = pb + PATCH_B;
+        // this wavefront: output row `wave` of the tile, 64 pixels = four 16-deep slices
+#pragma unroll
+        for (int kq = 0; kq < STEM_TC / 16; ++kq) {
+            const int c0 = kq * 16 + (lane >> 5) * 8;          // first of this lane's 8 pixels (k values)
+            half8 fa[MB], fb[6];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) fa[m] = tr_frag_sw<DYROW, 1, 1>(db, wave * STEM_TC + c0, m * 32 + csub, lane);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) fb[g] = tr_frag_sw<16, 1, 1>(pb + (2 * wave + g) * (STEM_PC * 16), c0, csub, lane);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int g = 0; g < 6; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb[g], acc[m][g], 0, 0, 0);
+        }
+    };
+
+    const long long step = gridDim.x;
+    long long t = blockIdx.x;
+    if (t >= p.ntiles) return;
+#ifdef AYOLO_PROBE
+#define STEM_MARK(k_) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_probe[blockIdx.x * AY_PROBE_N + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STEM_MARK(k_) do { } while (0)
+#endif
+    STEM_MARK(0);
+    fetch(t, rp[0], rd[0]);
+    stash(0, rp[0], rd[0]);
+    fetch(t + step, rp[1], rd[1]);                             // tile 1 in flight
+    __syncthreads();
+    STEM_MARK(1);
+    // two tiles per trip so that the register sets are named at compile time: buffer 0 holds tile t, set 1 tile t + step
+    for (; t < p.ntiles; t += 2 * step) {
+        fetch(t + 2 * step, rp[0], rd[0]);
+        compute(0);
+        stash(1, rp[1], rd[1]);                                // tile t + step (zeros beyond the last tile)
+        __syncthreads();
+        if (t + step >= p.ntiles) break;
+        fetch(t + 3 * step, rp[1], rd[1]);
+        compute(1);
+        stash(0, rp[0], rd[0]);                                // tile t + 2 * step
+        __syncthreads();
+    }
+    STEM_MARK(2);
+    // ---- the four wavefronts' tiles summed through LDS with plain stores / loads in two rounds (waves 2, 3 -> waves 0, 1; wave 1
+    // -> wave 0; ds_add_f32 for the same job took 24 us: ~190 cycles per 64-lane LDS atomic), the total back to LDS, then 1/4
+    // of the global atomics from each wavefront
+    float* red = reinterpret_cast<float*>(sm);                 // [2][MB * 6 * 16][64]
+    constexpr int NE = MB * 6 * 16;
+    // (the launch allocates max(tile buffers, reduction buffers): launch_stem_wgrad)
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int g = 0; g < 6; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((m * 6 + g) * 16 + r) * 64 + lane] = acc[m][g][r];
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int g = 0; g < 6; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][g][r] += src[((m * 6 + g) * 16 + r) * 64 + lane];
+    };
+    if (wave >= 2) put(red + (wave - 2) * NE * 64);
+    __syncthreads();
+    if (wave < 2) add(red + wave * NE * 64);
+    __syncthreads();
+    if (wave == 1) put(red);
+    __syncthreads();
+    if (wave == 0) { add(red); }
+    __syncthreads();
+    if (wave == 0) put(red);
+    __syncthreads();
+    STEM_MARK(3);
+    // acc row (output channel) = m * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); column = lane & 31 = pair tap * 8 + half
+    const int col = lane & 31;
+    if (col < 24) {
+        for (int e = wave; e < MB * 6 * 16; e += 4) {
+            const int r = e & 15, g = (e >> 4) % 6, m = e / 96;
+            const int co = m * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (co < p.N) unsafeAtomicAdd(&p.dw[(long long)co * p.K + g * 24 + col], red[e * 64 + lane] * p.alpha);
+        }
+    }
+#ifdef AYOLO_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STEM_MARK(4);
+}
+
+template <int MB>
+static int launch_stem_wgrad(StemWP p, hipStream_t s) {
+    constexpr size_t lds_tiles = 2 * (size_t)(STEM_PR * STEM_PC * 16 + STEM_TR * STEM_TC * 64 * MB);
+    constexpr size_t lds_red = 2 * (size_t)(MB * 6 * 16) * 64 * sizeof(float);
+    constexpr size_t lds = lds_tiles > lds_red ? lds_tiles : lds_red;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    long long grid = (long long)num_cus() * (MB == 1 ? 2 : 1);
+    if (grid > p.ntiles) grid = p.ntiles;
+    hipLaunchKernelGGL((k_stem_wgrad<MB>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    AY_CHECK_LAUNCH("k_stem_wgrad");
+    return AYOLO_OK;
+}
+
 static int wgrad_dispatch(const ayolo_conv_desc* d, WGradP p, hipStream_t st) {
+    // the packed stem (see k_stem_wgrad)
+    if (d->dtype == AYOLO_F16 && d->kh == 6 && d->kw == 3 && d->sh == 2 && d->sw == 1 && d->ph == 2 && d->pw == 1 && d->Cin == 8 &&
+        d->ldx == 8 && d->Cout <= 64 && d->Cout % 8 == 0 && d->Ho == (d->H + 4 - 6) / 2 + 1 && d->Wo == d->W &&
+        (long long)d->B * d->H * d->W * 16 < (1ll << 31) - 4096 && (long long)d->B * d->Ho * d->Wo * d->ldy * 2 < (1ll << 31) - 4096) {
+        StemWP q{};
+        q.x = (const half_t*)p.x; q.dy = (const half_t*)p.dy; q.dw = p.dw;
+        q.B = d->B; q.H = d->H; q.WP = d->W; q.Ho = d->Ho; q.Wo = d->Wo; q.ldy = d->ldy; q.N = d->Cout; q.K = p.K; q.alpha = p.alpha;
+        q.tw = (d->Wo + STEM_TC - 1) / STEM_TC; q.th = (d->Ho + STEM_TR - 1) / STEM_TR;
+        q.ntiles = (long long)d->B * q.tw * q.th;
+        q.x_bytes = (unsigned)((long long)d->B * d->H * d->W * 16); q.y_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * d->ldy * 2);
+        return d->Cout <= 32 ? launch_stem_wgrad<1>(q, st) : launch_stem_wgrad<2>(q, st);
+    }
     // buffer descriptors address < 2 GiB: larger activations are reduced as independent batch halves (dw accumulates)
     const long long es = d->dtype == AYOLO_F16 ? 2 : 4;
     const long long LIM = (1ll << 31) - 4096;

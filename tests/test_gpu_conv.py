@@ -464,3 +464,26 @@ def test_bn_backward_apply_forwards_the_shortcut_gradient(dt, accumulate):
     want = (old[:, C:].float() + da.float()).to(dt) if accumulate else da
     assert torch.equal(wide[:, C:], want)
     assert torch.equal(wide[:, :C], old[:, :C])        # the other half of the wide buffer is untouched
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 96), (3, 16, 70, 100), (1, 48, 38, 132), (2, 64, 24, 40), (2, 80, 64, 96)])
+def test_stem_weight_gradient_kernel(shape):
+    """k_stem_wgrad (the packed 6x6 / stride 2 / pad 2 stem, fp16, Cout <= 64: input patch staged once per 4 x 64 output tile,
+    fragments by transposing LDS reads at a 16-byte pixel stride) against torch's fp32 weight gradient on fp16-rounded
+    operands: 1e-4 of the largest element, for every YOLOv5 stem width up to l (16 / 32 / 48 / 64 output channels) and maps
+    that end inside a tile in both directions; 80 channels (YOLOv5x) stay on the generic k_wgrad path, same bar."""
+    from ayolov2_amd import functional as F_
+    B, Cout, H, W = shape
+    g = torch.Generator().manual_seed(B + Cout + H)
+    x = torch.rand(B, 3, H, W, generator=g).half().float()
+    w = (torch.randn(Cout, 3, 6, 6, generator=g) / 108 ** 0.5).half().float()
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, 2, 2)
+    gy = torch.randn(yr.shape, generator=g).half().float()
+    yr.backward(gy)
+    wg = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        yg = F_.ConvFn.apply(x.cuda(), wg, (2, 2), (2, 2), F_._WeightCache())
+    yg.backward(gy.cuda().half())
+    assert _rel_err(yg.float().cpu(), yr.detach()) < 2e-3
+    assert _rel_err(wg.grad.float().cpu(), wr.grad) < 1e-4
