@@ -2140,6 +2140,9 @@ static int check_desc(const ayolo_conv_desc* d, const char* who) {
     return AYOLO_OK;
 }
 
+static bool is_packed_stem(const ayolo_conv_desc* d);
+static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void* w, void* y, double* stats, int stat_reps, hipStream_t s);
+
 extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void* y, int epilogue,
                               const float* scale, const float* shift, double* stats, int stat_reps, int head_no,
                               ayolo_stream s) {
@@ -2149,6 +2152,7 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
     AY_CHECK_ARG(epilogue >= 0 && epilogue <= 5, "conv_fwd: epilogue %d", epilogue);
     AY_CHECK_ARG(epilogue != AYOLO_EPI_HEAD || (head_no > 0 && d->Cout % head_no == 0), "conv_fwd: head_no=%d", head_no);
     AY_CHECK_ARG(stats == nullptr || epilogue == AYOLO_EPI_NONE, "conv_fwd: stats need EPI_NONE");
+    if (epilogue == AYOLO_EPI_NONE && is_packed_stem(d)) return stem_fwd_dispatch(d, x, w, y, stats, stat_reps, (hipStream_t)s);
     GConvP p{};
     p.x = x; p.w = w; p.y = y;
     p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = d->ldx;
@@ -2639,7 +2643,7 @@ static int launch_wgrad(WGradP p, hipStream_t s) {
 // junk pair = 32).  Per 16 pixels: one dy fragment per 32 output channels and six x fragments (one per dh), six MFMAs; every
 // wavefront keeps the whole 32 x (6 x 32) gradient for its row of the tile in registers across ALL tiles of the workgroup
 // and the workgroup sends ONE set of atomics at the very end.  398 -> 141 us at batch 64, 640 x 640 (tools/stem_probe.py: tile
-// loop 92-126 us = the 524 MB at 4.5-5 TB/s, reduction + atomics 5 us), train step -0.2 ms (profiles/r03_stem_wgrad.txt).
+// loop 92-126 us = the 524 MB at 4.5-5 TB/s, reduction + atomics 5 us), train step -0.2 ms (profiles/r03_stem_kernels.txt).
 // ---------------------------------------------------------------------------------------------------
 struct StemWP {
     const half_t* x; const half_t* dy; float* dw;
@@ -2830,11 +2834,228 @@ static int launch_stem_wgrad(StemWP p, hipStream_t s) {
     return AYOLO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_stem_fwd: training forward of the packed stem conv (see k_stem_wgrad for the layout), fp16, Cout <= 64, plain store +
+// BatchNorm statistics.  The generic k_gconv reaches this layer's 8-channel taps as 16-byte DMA gathers -- 4.5 32-deep steps
+// of 5 pieces per wave for 18 MFMAs -- and ran it at 2.4 TB/s.  Here the same input patch as in k_stem_wgrad is staged
+// once per 4 x 64 output tile; the 144 reduction values of an output pixel are 18 runs of 8 halves -- run (dh, tap) is the 16
+// bytes at patch[2r + dh][c + tap] -- i.e. every B fragment of the 32 x 32 x 16 MFMA is ONE ds_read_b128 (nine 16-deep slices,
+// no junk columns), and the weight fragments (9 x 16 bytes per lane and 32 output channels) are loaded once per kernel and stay
+// in registers.  Statistics are taken from the rounded values in registers across all tiles of the workgroup.
+// ---------------------------------------------------------------------------------------------------
+struct StemFP {
+    const half_t* x; const half_t* w; half_t* y; double* stats;
+    int B, H, WP, Ho, Wo, ldy, N, ldw, stat_reps;
+    int tw, th;
+    long long ntiles;
+    unsigned x_bytes, y_bytes;
+};
+
+template <int MB>
+__global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_fwd(StemFP p) {
+    constexpr int PATCH_B = STEM_PR * STEM_PC * 16;
+    constexpr int NPCH = STEM_PR * STEM_PC, PPT = (NPCH + 255) / 256;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm[];           // [2][patch], then [2][32 * MB] doubles
+    const int tid = threadIdx.x, lane = tid & 63, hsel = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    // weight fragments: lane (co = lane & 31, k group = lane >> 5) of slice kk holds w[co][(2 * kk + group) * 8 .. + 8]
+    half8 fw[MB][9];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int co = m * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) {
+            half8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.0f;
+            if (co < p.N) v = *reinterpret_cast<const half8*>(p.w + (long long)co * p.ldw + (2 * kk + hsel) * 8);
+            fw[m][kk] = v;
+        }
+    }
+    // patch offset of this lane's run in slice kk: run = 2 * kk + group = dh * 3 + tap
+    int roff[9];
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+        const int run = 2 * kk + hsel;
+        roff[kk] = ((run / 3) * STEM_PC + (run % 3)) * 16;
+    }
+    float ssum[MB][16], ssq[MB][16];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ssum[m][r] = 0.0f; ssq[m][r] = 0.0f; }
+
+    uint4 rp[2][PPT];
+    auto fetch = [&](long long t, uint4 (&fp)[PPT]) {
+        const bool live = t < p.ntiles;
+        const long long tt = live ? t : 0;
+        const int tx = (int)(tt % p.tw);
+        const long long u = tt / p.tw;
+        const int ty = (int)(u % p.th), n = (int)(u / p.th);
+        const int oh0 = ty * STEM_TR, ow0 = tx * STEM_TC;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int i = tid + 256 * j;
+            const int row = i / STEM_PC, col = i - row * STEM_PC;
+            const int ih = 2 * oh0 - 2 + row, ip = ow0 - 1 + col;
+            const bool ok = live && i < NPCH && (unsigned)ih < (unsigned)p.H && (unsigned)ip < (unsigned)p.WP;
+            const unsigned off = ok ? (unsigned)((((unsigned)n * (unsigned)p.H + (unsigned)ih) * (unsigned)p.WP + (unsigned)ip) * 16u) : G_OOB;
+            fp[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
+        }
+    };
+    auto stash = [&](int buf, const uint4 (&fp)[PPT]) {
+        unsigned char* b = sm + buf * PATCH_B;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int i = tid + 256 * j;
+            if (i < NPCH) *reinterpret_cast<uint4*>(b + i * 16) = fp[j];
+        }
+    };
+    auto compute = [&](int buf, long long t) {
+        const unsigned char* pb = sm + buf * PATCH_B + (2 * wave) * (STEM_PC * 16);
+        const int tx = (int)(t % p.tw);
+        const long long u = t / p.tw;
+        const int ty = (int)(u % p.th), n = (int)(u / p.th);
+        const int oh = ty * STEM_TR + wave;
+#pragma unroll
+        for (int blk = 0; blk < STEM_TC / 32; ++blk) {
+            const int c = blk * 32 + (lane & 31);                  // this lane's output column inside the tile
+            float16v acc[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+            half8 fb[9];
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) fb[kk] = *reinterpret_cast<const half8*>(pb + c * 16 + roff[kk]);
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[m][kk], fb[kk], acc[m], 0, 0, 0);
+            // acc[m][r]: channel m * 32 + 8 * (r >> 2) + 4 * hsel + (r & 3) of pixel (oh, ow)
+            const int ow = tx * STEM_TC + c;
+            const bool pv = oh < p.Ho && ow < p.Wo;
+            const unsigned yo = (((unsigned)n * (unsigned)p.Ho + (unsigned)oh) * (unsigned)p.Wo + (unsigned)ow) * (unsigned)p.ldy * 2u;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                float v[4][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[g][e] = acc[m][g * 4 + e];
+                        const float q = pv ? (float)(half_t)v[g][e] : 0.0f;
+                        ssum[m][g * 4 + e] += q;
+                        ssq[m][g * 4 + e] += q * q;
+                    }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const v2u32 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * j][e]), __float_as_uint(v[2 * j + 1][e]), false, false);
+                        v[2 * j][e] = __uint_as_float(sw[0]);
+                        v[2 * j + 1][e] = __uint_as_float(sw[1]);
+                    }
+                    const int ch = m * 32 + 8 * (2 * j + hsel);     // 8 channels: v[2j][0..3], v[2j+1][0..3]
+                    half8 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = (half_t)v[2 * j][e]; h[4 + e] = (half_t)v[2 * j + 1][e]; }
+                    const unsigned off = (pv && ch < p.N) ? yo + (unsigned)ch * 2u : G_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, h), rsY, off, 0, 0);
+                }
+            }
+        }
+    };
+
+    const long long step = gridDim.x;
+    long long t = blockIdx.x;
+    if (t >= p.ntiles) return;
+    fetch(t, rp[0]);
+    stash(0, rp[0]);
+    fetch(t + step, rp[1]);
+    __syncthreads();
+    for (; t < p.ntiles; t += 2 * step) {
+        fetch(t + 2 * step, rp[0]);
+        compute(0, t);
+        stash(1, rp[1]);
+        __syncthreads();
+        if (t + step >= p.ntiles) break;
+        fetch(t + 3 * step, rp[1]);
+        compute(1, t + step);
+        stash(0, rp[0]);
+        __syncthreads();
+    }
+    // ---- statistics: lane sums -> channel sums (DPP rows + one exchange), workgroup total in LDS (fp64), one replica slot
+    if (p.stats) {
+        double* sst = reinterpret_cast<double*>(sm);              // [2][32 * MB]
+        for (int i = tid; i < 2 * 32 * MB; i += 256) sst[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = row16_sum(ssum[m][r]), b = row16_sum(ssq[m][r]);
+                a += __shfl_xor(a, 16);
+                b += __shfl_xor(b, 16);
+                if ((lane & 31) == 0) {
+                    const int ch = m * 32 + 8 * (r >> 2) + 4 * hsel + (r & 3);
+                    atomicAdd(&sst[ch], (double)a);
+                    atomicAdd(&sst[32 * MB + ch], (double)b);
+                }
+            }
+        __syncthreads();
+        double* st = p.stats + (size_t)(blockIdx.x % (unsigned)p.stat_reps) * 2 * p.N;
+        for (int i = tid; i < 32 * MB; i += 256) {
+            if (i < p.N) {
+                atomicAdd(&st[i], sst[i]);
+                atomicAdd(&st[p.N + i], sst[32 * MB + i]);
+            }
+        }
+    }
+}
+
+template <int MB>
+static int launch_stem_fwd(StemFP p, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)(STEM_PR * STEM_PC * 16);
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    long long grid = (long long)num_cus() * 2;
+    if (grid > p.ntiles) grid = p.ntiles;
+    hipLaunchKernelGGL((k_stem_fwd<MB>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    AY_CHECK_LAUNCH("k_stem_fwd");
+    return AYOLO_OK;
+}
+
+// the packed stem geometry of functional._Geometry (6 x 3 taps of 8 halves over pixel pairs, stride (2, 1), pad (2, 1)), fp16,
+// at most 64 output channels, everything inside the 2 GiB buffer descriptors
+static bool is_packed_stem(const ayolo_conv_desc* d) {
+    return d->dtype == AYOLO_F16 && d->kh == 6 && d->kw == 3 && d->sh == 2 && d->sw == 1 && d->ph == 2 && d->pw == 1 && d->Cin == 8 &&
+           d->ldx == 8 && d->Cout <= 64 && d->Cout % 8 == 0 && d->Ho == (d->H + 4 - 6) / 2 + 1 && d->Wo == d->W &&
+           (long long)d->B * d->H * d->W * 16 < (1ll << 31) - 4096 && (long long)d->B * d->Ho * d->Wo * d->ldy * 2 < (1ll << 31) - 4096;
+}
+
+static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void* w, void* y, double* stats, int stat_reps, hipStream_t s) {
+    StemFP q{};
+    q.x = (const half_t*)x; q.w = (const half_t*)w; q.y = (half_t*)y; q.stats = stats;
+    q.B = d->B; q.H = d->H; q.WP = d->W; q.Ho = d->Ho; q.Wo = d->Wo; q.ldy = d->ldy; q.N = d->Cout; q.ldw = 6 * 3 * 8;
+    q.stat_reps = stat_reps > 0 ? stat_reps : 1;
+    q.tw = (d->Wo + STEM_TC - 1) / STEM_TC; q.th = (d->Ho + STEM_TR - 1) / STEM_TR;
+    q.ntiles = (long long)d->B * q.tw * q.th;
+    q.x_bytes = (unsigned)((long long)d->B * d->H * d->W * 16); q.y_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * d->ldy * 2);
+    return d->Cout <= 32 ? launch_stem_fwd<1>(q, s) : launch_stem_fwd<2>(q, s);
+}
+
 static int wgrad_dispatch(const ayolo_conv_desc* d, WGradP p, hipStream_t st) {
     // the packed stem (see k_stem_wgrad)
-    if (d->dtype == AYOLO_F16 && d->kh == 6 && d->kw == 3 && d->sh == 2 && d->sw == 1 && d->ph == 2 && d->pw == 1 && d->Cin == 8 &&
-        d->ldx == 8 && d->Cout <= 64 && d->Cout % 8 == 0 && d->Ho == (d->H + 4 - 6) / 2 + 1 && d->Wo == d->W &&
-        (long long)d->B * d->H * d->W * 16 < (1ll << 31) - 4096 && (long long)d->B * d->Ho * d->Wo * d->ldy * 2 < (1ll << 31) - 4096) {
+    if (is_packed_stem(d)) {
         StemWP q{};
         q.x = (const half_t*)p.x; q.dy = (const half_t*)p.dy; q.dw = p.dw;
         q.B = d->B; q.H = d->H; q.WP = d->W; q.Ho = d->Ho; q.Wo = d->Wo; q.ldy = d->ldy; q.N = d->Cout; q.K = p.K; q.alpha = p.alpha;

@@ -487,3 +487,32 @@ def test_stem_weight_gradient_kernel(shape):
     yg.backward(gy.cuda().half())
     assert _rel_err(yg.float().cpu(), yr.detach()) < 2e-3
     assert _rel_err(wg.grad.float().cpu(), wr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 96), (3, 16, 70, 100), (1, 48, 38, 132), (2, 64, 24, 40), (64, 32, 128, 128)])
+def test_stem_forward_kernel_and_statistics(shape):
+    """k_stem_fwd (training forward of the packed stem: patch staged once per 4 x 64 tile, every B fragment one 16-byte LDS
+    read, weight fragments register-resident): the stored fp16 output against torch's fp32 conv on fp16-rounded operands
+    (3e-3 of the largest element = the output rounding) and the BatchNorm sums against the sums of the stored output."""
+    from ayolov2_amd import functional as F_, ops
+    B, Cout, H, W = shape
+    dt = torch.float16
+    g = torch.Generator().manual_seed(B + Cout + H)
+    x = torch.rand(B, 3, H, W, generator=g).half().float()
+    wt = (torch.randn(Cout, 3, 6, 6, generator=g) / 108 ** 0.5).half().float()
+    geo = F_._Geometry((B, 3, H, W), wt.shape, (2, 2), (2, 2), dt)
+    assert geo.packed_stem
+    xk = F_._prepare_input(x.cuda(), geo, dt)
+    w, _ = F_._WeightCache().get(wt.cuda().contiguous(memory_format=torch.channels_last), dt, Cout, geo.cin_pad)
+    y = ops.new_act(B, Cout, geo.Ho, geo.Wo, dt, xk.device)
+    y.fill_(float("nan"))                                       # every valid element must be written
+    stats = torch.zeros((ops.STAT_REPS, 2 * Cout), dtype=torch.float64, device="cuda")
+    ops.conv_fwd(geo.desc(dt, geo.Cin_k, Cout), xk, w, y, 0, stats=stats)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, wt, None, 2, 2)
+    assert float((y.float().cpu() - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+    tot = stats.sum(0).cpu()
+    yf = y.double()
+    P = B * geo.Ho * geo.Wo
+    np.testing.assert_allclose(tot[:Cout].numpy(), yf.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-6 * P)
+    np.testing.assert_allclose(tot[Cout:].numpy(), (yf * yf).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-6 * P)
