@@ -48,6 +48,7 @@ _SIGNATURES = {
     "ayolo_conv_dgrad": [POINTER(ConvDesc), _P, _P, _P, c_int, _P],
     "ayolo_conv_dgrad_bn": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P],
     "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P],
+    "ayolo_stem_bn_wgrad": [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_float, c_float, _P],
     "ayolo_cast_weight": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "ayolo_ema_update": [_P, c_int, c_float, _P],
     "ayolo_cast_weights": [_P, c_int, c_int, _P],

@@ -2652,19 +2652,29 @@ struct StemWP {
     int tw, th;                            // tiles per row / per column of one image
     long long ntiles;
     unsigned x_bytes, y_bytes;             // buffer descriptor extents (< 2 GiB, host check)
+    // BN mode (k_stem_wgrad<MB, true>): `dy` is da, the gradient of the block's OUTPUT a = act(bn(z)); the kernel forms
+    // dz = bn_act_backward(da, z) on the way to LDS -- the stem has no dgrad, so nobody else reads its dz and the separate
+    // BatchNorm-backward apply pass (read da, read z, write dz: 1.26 GB at batch 64) disappears
+    const half_t* z; int ldz; unsigned z_bytes;
+    const float* mean; const float* invstd; const float* gamma; const float* beta;
+    const double* sums; int reps, act;
+    float* dgamma; float* dbeta; float grad_scale;
 };
 #define STEM_TR 4                          // output rows per tile = wavefronts
 #define STEM_TC 64                         // output columns per tile
 #define STEM_PR (2 * STEM_TR + 4)          // patch rows: 2 * TR + (6 - 2)
 #define STEM_PC (STEM_TC + 4)              // patch pair columns: TC + 2 (taps) + 1 (junk pair) rounded to 68
 
-template <int MB>
+template <int MB, bool BN = false>
 __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p) {
     constexpr int DYROW = 64 * MB;                                   // bytes per pixel row of the dy tile
     constexpr int PATCH_B = STEM_PR * STEM_PC * 16, DY_B = STEM_TR * STEM_TC * DYROW;
     constexpr int NPCH = STEM_PR * STEM_PC, NDCH = STEM_TR * STEM_TC * 4 * MB;     // 16-byte chunks per tile
     constexpr int PPT = (NPCH + 255) / 256, DPT = NDCH / 256;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char sm[];           // [2][patch | dy tile]
+    constexpr int NE = MB * 6 * 16;
+    constexpr size_t TILES_B = 2 * (size_t)(PATCH_B + DY_B), RED_B = 2 * (size_t)NE * 64 * 4;
+    constexpr size_t CST_OFF = TILES_B > RED_B ? TILES_B : RED_B;                 // BN constants [5][32 * MB] floats behind both
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm[];           // [2][patch | dy tile] (| constants)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -2678,16 +2688,47 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p)
 
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.dy), 0, p.y_bytes, 0x00020000);
-    // two register sets: the loads of tile i+2 are issued while tile i is computed and are written to LDS one iteration later,
-    // so a tile's global-load latency has a whole iteration (and the other workgroup of the CU) to hide behind
-    uint4 rp[2][PPT], rd[2][DPT];
-    auto fetch = [&](long long t, uint4 (&fp)[PPT], uint4 (&fd)[DPT]) {
-        const bool live = t < p.ntiles;
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(BN ? p.z : p.dy), 0, BN ? p.z_bytes : p.y_bytes, 0x00020000);
+    float* cst = reinterpret_cast<float*>(sm + CST_OFF);
+    if constexpr (BN) {
+        // per-channel constants (fp16 form of k_bn_bwd_apply): u = z*A + Bc, du = da * act'(u), dz = du*P + z*R2 + Q2 with
+        // P = gamma*invstd, R2 = -P*m2*invstd, Q2 = P*(m2*mean*invstd - m1), m1 = sum(du)/n, m2 = sum(du*xhat)/n
+        const float invn = 1.0f / ((float)p.B * (float)p.Ho * (float)p.Wo);
+        for (int c = tid; c < 32 * MB; c += 256) {
+            float A = 0.0f, Bc = 0.0f, P = 0.0f, R2 = 0.0f, Q2 = 0.0f;
+            if (c < p.N) {
+                double d1 = 0.0, d2 = 0.0;
+                for (int r = 0; r < p.reps; ++r) { d1 += p.sums[(size_t)r * 2 * p.N + c]; d2 += p.sums[(size_t)r * 2 * p.N + p.N + c]; }
+                const float s1 = (float)d1, s2 = (float)d2;
+                const float mu = p.mean[c], is = p.invstd[c], ga = p.gamma ? p.gamma[c] : 1.0f, be = p.beta ? p.beta[c] : 0.0f;
+                const float m1 = s1 * invn, m2 = s2 * invn;
+                A = is * ga; Bc = be - mu * A; P = ga * is;
+                const float Rr = -P * m2, Q = -P * m1, nmi = -mu * is;
+                R2 = is * Rr; Q2 = __builtin_fmaf(nmi, Rr, Q);
+                if (blockIdx.x == 0) {
+                    if (p.dbeta) p.dbeta[c] = s1 * p.grad_scale;
+                    if (p.dgamma) p.dgamma[c] = s2 * p.grad_scale;
+                }
+            }
+            cst[c] = A; cst[32 * MB + c] = Bc; cst[2 * 32 * MB + c] = P; cst[3 * 32 * MB + c] = R2; cst[4 * 32 * MB + c] = Q2;
+        }
+        __syncthreads();
+    }
+    // patch: two register sets, the loads of tile i+2 are issued while tile i is computed and written to LDS an iteration later;
+    // dy (BN: da and z): one set, loaded at the top of an iteration and written (BN: transformed) at its end
+    uint4 rp[2][PPT], rd[DPT], rz[BN ? DPT : 1];
+    unsigned dok = 0;                                          // BN: bit j = chunk j of the fetched dy set lies inside the map / channels
+    auto tile_of = [&](long long t, bool& live, int& n, int& oh0, int& ow0) {
+        live = t < p.ntiles;
         const long long tt = live ? t : 0;
         const int tx = (int)(tt % p.tw);
         const long long u = tt / p.tw;
-        const int ty = (int)(u % p.th), n = (int)(u / p.th);
-        const int oh0 = ty * STEM_TR, ow0 = tx * STEM_TC;
+        const int ty = (int)(u % p.th);
+        n = (int)(u / p.th); oh0 = ty * STEM_TR; ow0 = tx * STEM_TC;
+    };
+    auto fetch_patch = [&](long long t, uint4 (&fp)[PPT]) {
+        bool live; int n, oh0, ow0;
+        tile_of(t, live, n, oh0, ow0);
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const int i = tid + 256 * j;
@@ -2695,30 +2736,70 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p)
             const int ih = 2 * oh0 - 2 + row, ip = ow0 - 1 + col;
             const bool ok = live && i < NPCH && (unsigned)ih < (unsigned)p.H && (unsigned)ip < (unsigned)p.WP;
             // branch-free: out-of-image chunks take the descriptor's out-of-range offset (hardware returns 0).  Written as
-            // `ok ? *ptr : 0` every load becomes a branch + s_waitcnt vmcnt(0) and the eight loads of a tile run one after
-            // the other (see "Why LDS-DMA + counted waits" in DESIGN.md)
+            // `ok ? *ptr : 0` every load becomes a branch + s_waitcnt vmcnt(0) and the loads of a tile run one after the other
+            // (see "Why LDS-DMA + counted waits" in DESIGN.md)
             const unsigned off = ok ? (unsigned)((((unsigned)n * (unsigned)p.H + (unsigned)ih) * (unsigned)p.WP + (unsigned)ip) * 16u) : G_OOB;
             fp[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
         }
+    };
+    auto fetch_dy = [&](long long t) {
+        bool live; int n, oh0, ow0;
+        tile_of(t, live, n, oh0, ow0);
 #pragma unroll
         for (int j = 0; j < DPT; ++j) {
             const int i = tid + 256 * j;
             const int px = i / (4 * MB), part = i - px * (4 * MB);
             const int oh = oh0 + px / STEM_TC, ow = ow0 + px % STEM_TC;
             const bool ok = live && oh < p.Ho && ow < p.Wo && part * 8 < p.N;     // N % 8 == 0 (host check)
-            const unsigned off = ok ? ((((unsigned)n * (unsigned)p.Ho + (unsigned)oh) * (unsigned)p.Wo + (unsigned)ow) * (unsigned)p.ldy + (unsigned)part * 8u) * 2u : G_OOB;
-            fd[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0));
+            const unsigned pix = ((unsigned)n * (unsigned)p.Ho + (unsigned)oh) * (unsigned)p.Wo + (unsigned)ow;
+            if constexpr (BN) dok = ok ? (dok | (1u << j)) : (dok & ~(1u << j));
+            rd[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsD, ok ? (pix * (unsigned)p.ldy + (unsigned)part * 8u) * 2u : G_OOB, 0, 0));
+            if constexpr (BN)
+                rz[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, ok ? (pix * (unsigned)p.ldz + (unsigned)part * 8u) * 2u : G_OOB, 0, 0));
         }
     };
-    auto stash = [&](int buf, const uint4 (&fp)[PPT], const uint4 (&fd)[DPT]) {
+    auto stash_patch = [&](int buf, const uint4 (&fp)[PPT]) {
         unsigned char* b = sm + buf * (PATCH_B + DY_B);
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const int i = tid + 256 * j;
             if (i < NPCH) *reinterpret_cast<uint4*>(b + i * 16) = fp[j];
         }
+    };
+    auto stash_dy = [&](int buf) {
+        unsigned char* b = sm + buf * (PATCH_B + DY_B) + PATCH_B;
 #pragma unroll
-        for (int j = 0; j < DPT; ++j) *reinterpret_cast<uint4*>(b + PATCH_B + (tid + 256 * j) * 16) = fd[j];
+        for (int j = 0; j < DPT; ++j) {
+            uint4 v = rd[j];
+            if constexpr (BN) {
+                // this thread's 8 channels are the same for every chunk it owns (256 is a multiple of 4 * MB)
+                const int c8 = ((tid + 256 * j) % (4 * MB)) * 8;
+                const half8 da = __builtin_bit_cast(half8, rd[j]), zz = __builtin_bit_cast(half8, rz[j]);
+                half8 o;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4v kA = *reinterpret_cast<const float4v*>(cst + c8 + 4 * q);
+                    const float4v kB = *reinterpret_cast<const float4v*>(cst + 32 * MB + c8 + 4 * q);
+                    const float4v kP = *reinterpret_cast<const float4v*>(cst + 2 * 32 * MB + c8 + 4 * q);
+                    const float4v kR = *reinterpret_cast<const float4v*>(cst + 3 * 32 * MB + c8 + 4 * q);
+                    const float4v kQ = *reinterpret_cast<const float4v*>(cst + 4 * 32 * MB + c8 + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float zf = (float)zz[4 * q + e], df = (float)da[4 * q + e];
+                        float du = df;
+                        if (p.act) {
+                            const float u = __builtin_fmaf(zf, kA[e], kB[e]);
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+                            du = df * (sg * __builtin_fmaf(u, 1.0f - sg, 1.0f));
+                        }
+                        o[4 * q + e] = (half_t)__builtin_fmaf(du, kP[e], __builtin_fmaf(zf, kR[e], kQ[e]));
+                    }
+                }
+                // a chunk outside the map has da = z = 0 but dz = Q2 != 0 by the formula: it must contribute nothing
+                v = ((dok >> j) & 1u) ? __builtin_bit_cast(uint4, o) : make_uint4(0, 0, 0, 0);
+            }
+            *reinterpret_cast<uint4*>(b + (tid + 256 * j) * 16) = v;
+        }
     };
     const int csub = ((lane >> 4) & 1) * 16;
     auto compute = [&](int buf) {
@@ -2749,21 +2830,27 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p)
 #define STEM_MARK(k_) do { } while (0)
 #endif
     STEM_MARK(0);
-    fetch(t, rp[0], rd[0]);
-    stash(0, rp[0], rd[0]);
-    fetch(t + step, rp[1], rd[1]);                             // tile 1 in flight
+    fetch_patch(t, rp[0]);
+    fetch_dy(t);
+    stash_patch(0, rp[0]);
+    stash_dy(0);
+    fetch_patch(t + step, rp[1]);                              // tile 1's patch in flight
     __syncthreads();
     STEM_MARK(1);
-    // two tiles per trip so that the register sets are named at compile time: buffer 0 holds tile t, set 1 tile t + step
+    // two tiles per trip so that the register sets are named at compile time: buffer 0 holds tile t, set 1 the patch of t + step
     for (; t < p.ntiles; t += 2 * step) {
-        fetch(t + 2 * step, rp[0], rd[0]);
+        fetch_patch(t + 2 * step, rp[0]);
+        fetch_dy(t + step);
         compute(0);
-        stash(1, rp[1], rd[1]);                                // tile t + step (zeros beyond the last tile)
+        stash_patch(1, rp[1]);                                 // tile t + step (zeros beyond the last tile)
+        stash_dy(1);
         __syncthreads();
         if (t + step >= p.ntiles) break;
-        fetch(t + 3 * step, rp[1], rd[1]);
+        fetch_patch(t + 3 * step, rp[1]);
+        fetch_dy(t + 2 * step);
         compute(1);
-        stash(0, rp[0], rd[0]);                                // tile t + 2 * step
+        stash_patch(0, rp[0]);                                 // tile t + 2 * step
+        stash_dy(0);
         __syncthreads();
     }
     STEM_MARK(2);
@@ -2771,8 +2858,6 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p)
     // -> wave 0; ds_add_f32 for the same job took 24 us: ~190 cycles per 64-lane LDS atomic), the total back to LDS, then 1/4
     // of the global atomics from each wavefront
     float* red = reinterpret_cast<float*>(sm);                 // [2][MB * 6 * 16][64]
-    constexpr int NE = MB * 6 * 16;
-    // (the launch allocates max(tile buffers, reduction buffers): launch_stem_wgrad)
     auto put = [&](float* dst) {
 #pragma unroll
         for (int m = 0; m < MB; ++m)
@@ -2815,21 +2900,21 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p)
     STEM_MARK(4);
 }
 
-template <int MB>
+template <int MB, bool BN>
 static int launch_stem_wgrad(StemWP p, hipStream_t s) {
     constexpr size_t lds_tiles = 2 * (size_t)(STEM_PR * STEM_PC * 16 + STEM_TR * STEM_TC * 64 * MB);
     constexpr size_t lds_red = 2 * (size_t)(MB * 6 * 16) * 64 * sizeof(float);
-    constexpr size_t lds = lds_tiles > lds_red ? lds_tiles : lds_red;
+    constexpr size_t lds = (lds_tiles > lds_red ? lds_tiles : lds_red) + (BN ? 5 * 32 * MB * sizeof(float) : 0);
     static bool attr_set[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_wgrad<MB, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     long long grid = (long long)num_cus() * (MB == 1 ? 2 : 1);
     if (grid > p.ntiles) grid = p.ntiles;
-    hipLaunchKernelGGL((k_stem_wgrad<MB>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_stem_wgrad<MB, BN>), dim3((unsigned)grid), dim3(256), lds, s, p);
     AY_CHECK_LAUNCH("k_stem_wgrad");
     return AYOLO_OK;
 }
@@ -3062,7 +3147,7 @@ static int wgrad_dispatch(const ayolo_conv_desc* d, WGradP p, hipStream_t st) {
         q.tw = (d->Wo + STEM_TC - 1) / STEM_TC; q.th = (d->Ho + STEM_TR - 1) / STEM_TR;
         q.ntiles = (long long)d->B * q.tw * q.th;
         q.x_bytes = (unsigned)((long long)d->B * d->H * d->W * 16); q.y_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * d->ldy * 2);
-        return d->Cout <= 32 ? launch_stem_wgrad<1>(q, st) : launch_stem_wgrad<2>(q, st);
+        return d->Cout <= 32 ? launch_stem_wgrad<1, false>(q, st) : launch_stem_wgrad<2, false>(q, st);
     }
     // buffer descriptors address < 2 GiB: larger activations are reduced as independent batch halves (dw accumulates)
     const long long es = d->dtype == AYOLO_F16 ? 2 : 4;
@@ -3112,6 +3197,30 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
             p.dw_[i * d->kw + j] = (signed char)(j - d->pw);
         }
     return wgrad_dispatch(d, p, (hipStream_t)s);
+}
+
+// Stem block backward in ONE launch (see k_stem_wgrad<MB, true>): BatchNorm + activation backward of the stem's output
+// gradient and the weight gradient of its conv.  `d` is the packed-stem descriptor with ldy = row stride of da.
+extern "C" int ayolo_stem_bn_wgrad(const ayolo_conv_desc* d, const void* x, const void* z, int ldz, const void* da,
+                                   const float* save_mean, const float* save_invstd, const float* gamma, const float* beta,
+                                   int act, const double* sums, int sum_reps, float* dw, float* dgamma, float* dbeta,
+                                   float alpha, float grad_scale, ayolo_stream s) {
+    int rc = check_desc(d, "stem_bn_wgrad");
+    if (rc) return rc;
+    AY_CHECK_ARG(x && z && da && dw && save_mean && save_invstd && sums && sum_reps >= 1, "stem_bn_wgrad: null pointer");
+    AY_CHECK_ARG(is_packed_stem(d) && ldz % 8 == 0 && ldz >= d->Cout && d->ldy % 8 == 0 &&
+                 (long long)d->B * d->Ho * d->Wo * ldz * 2 < (1ll << 31) - 4096,
+                 "stem_bn_wgrad: needs the packed stem geometry (fp16, 6x3 pair taps, <= 64 output channels, < 2 GiB tensors)");
+    StemWP q{};
+    q.x = (const half_t*)x; q.dy = (const half_t*)da; q.dw = dw;
+    q.B = d->B; q.H = d->H; q.WP = d->W; q.Ho = d->Ho; q.Wo = d->Wo; q.ldy = d->ldy; q.N = d->Cout; q.K = 6 * 3 * 8; q.alpha = alpha;
+    q.tw = (d->Wo + STEM_TC - 1) / STEM_TC; q.th = (d->Ho + STEM_TR - 1) / STEM_TR;
+    q.ntiles = (long long)d->B * q.tw * q.th;
+    q.x_bytes = (unsigned)((long long)d->B * d->H * d->W * 16); q.y_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * d->ldy * 2);
+    q.z = (const half_t*)z; q.ldz = ldz; q.z_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * ldz * 2);
+    q.mean = save_mean; q.invstd = save_invstd; q.gamma = gamma; q.beta = beta; q.sums = sums; q.reps = sum_reps; q.act = act ? 1 : 0;
+    q.dgamma = dgamma; q.dbeta = dbeta; q.grad_scale = grad_scale;
+    return d->Cout <= 32 ? launch_stem_wgrad<1, true>(q, (hipStream_t)s) : launch_stem_wgrad<2, true>(q, (hipStream_t)s);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -230,6 +230,12 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
         case AYOLO_OP_JOIN_SIDE:
             if (used_side) rc = side_join(sc, (hipStream_t)s);
             break;
+        case AYOLO_OP_STEM_BN_WGRAD:
+            // p: x, z, da, mean, invstd, gamma, beta, sums, dw, dgamma, dbeta; i: ldz, act, sum_reps; f: alpha, grad_scale
+            rc = ayolo_stem_bn_wgrad(&o.conv, o.p[0], o.p[1], o.i[0], o.p[2], (const float*)o.p[3], (const float*)o.p[4],
+                                     (const float*)o.p[5], (const float*)o.p[6], o.i[1], (const double*)o.p[7], o.i[2],
+                                     (float*)o.p[8], (float*)o.p[9], (float*)o.p[10], o.f[0], o.f[1], cs);
+            break;
         case AYOLO_OP_HEAD_DECODE: {
             const int64_t st[4] = {o.i[5], o.i[6], o.i[7], o.i[8]};            // element strides of (b, a, y, x)
             rc = ayolo_head_decode((const float*)o.p[0], st, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], (const float*)o.p[1], o.f[0],

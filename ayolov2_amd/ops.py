@@ -204,6 +204,15 @@ def bn_act_bwd(z, da, save_mean, save_invstd, gamma, beta, act: int, want_param_
     return dz, dgamma, dbeta
 
 
+def stem_bn_wgrad(desc, x, z, da, save_mean, save_invstd, gamma, beta, act: int, sums, dw, dgamma=None, dbeta=None,
+                  alpha: float = 1.0):
+    """Backward of the stem block in one launch (ayolo_stem_bn_wgrad): dw += alpha * weight gradient with
+    dz = bn_act_backward(da, z; sums) formed on the fly; dgamma / dbeta from the sums.  `desc`: packed-stem descriptor whose
+    ldy is the row stride of da."""
+    call("ayolo_stem_bn_wgrad", desc, _ptr(x), _ptr(z), nhwc_info(z)[4], _ptr(da), _ptr(save_mean), _ptr(save_invstd),
+         _ptr(gamma), _ptr(beta), act, _ptr(sums), sums.shape[0], _ptr(dw), _ptr(dgamma), _ptr(dbeta), alpha, 1.0, _stream())
+
+
 def maxpool_fwd(x, k: int, y=None, want_argmax=True):
     B, C, H, W, ldx = nhwc_info(x)
     if y is None:

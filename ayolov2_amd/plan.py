@@ -33,6 +33,7 @@ from .modules import C3, SPPF, Bottleneck, Concat, Conv, UpSample, YOLOHead, _ac
  OP_BN_BWD_APPLY, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_UPSAMPLE_FWD, OP_UPSAMPLE_BWD, OP_PACK_INPUT, OP_HEAD_GRAD_PACK,
  OP_COPY2D, OP_MEMSET, OP_BN_EVAL_AFFINE, OP_BN_TRAIN_ACT, OP_CAST_WEIGHTS) = range(1, 20)
 OP_JOIN_SIDE = 21
+OP_STEM_BN_WGRAD = 22
 
 
 class Op(ctypes.Structure):
@@ -62,6 +63,7 @@ import os as _os
 
 OP_SIDE = 0x100
 WGRAD_SIDE_STREAM = _os.environ.get("AYOLO_WGRAD_STREAM", "1") == "1"
+FUSE_STEM_BACKWARD = True     # stem block: BatchNorm-backward apply inside its weight-gradient kernel (ayolo_stem_bn_wgrad)
 FOLD_SHORTCUT_GRAD = True     # Bottleneck shortcut gradients written by the BatchNorm-backward apply pass (ayolo_bn_act_bwd_apply_res)
 MAX_PLANS = int(_os.environ.get("AYOLO_MAX_PLANS", "4"))                 # cached plans per model (multi-scale training)
 MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: cv1 | cv2 as one conv
@@ -315,10 +317,13 @@ class TrainPlan:
             e.append(self._register_param(bn.bias, co, lambda b: b) if bn.bias is not None else None)
         x_act = x
 
+        stem_fused = (FUSE_STEM_BACKWARD and image and geo.packed_stem and dt == torch.float16 and len(mods) == 1 and residual is None
+                      and Ct <= 64 and Ct % 8 == 0)
+
         def emit_bwd():
             ga = self.gradarena
-            dz = self._dz(npix * Ct)
-            dzv = dz.view(self.B, geo.Ho, geo.Wo, Ct).permute(0, 3, 1, 2)
+            dz = self._dz(npix * Ct) if not stem_fused else None
+            dzv = dz.view(self.B, geo.Ho, geo.Wo, Ct).permute(0, 3, 1, 2) if dz is not None else None
             for bn, act, a, zj, c0, co, sm_off, su_off, gg_off, gb_off in per:
                 da = a.grad()
                 if not a.is_init():
@@ -334,10 +339,18 @@ class TrainPlan:
                 # strided copy of its own
                 dr = residual.grad() if residual is not None else None
                 fold_res = dr is not None and FOLD_SHORTCUT_GRAD
-                self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R) + ((ops.nhwc_info(dr)[4], int(residual.is_init())) if fold_res else (0, 0)),
-                                    l=(npix,), f=(1.0,),
-                                    p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet,
-                                       dr if fold_res else None)))
+                if stem_fused:
+                    # the stem has no input gradient: its dz has one reader, the weight-gradient kernel, which forms it from
+                    # (da, z) on the way to LDS -- no apply pass, no dz buffer traffic (ayolo_stem_bn_wgrad)
+                    self.bwd.append(_op(OP_STEM_BN_WGRAD, i=(Ct, act, R), f=(1.0, 1.0),
+                                        p=(xk, zj, da, sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, ga.view(gw_off0, Ct * K), dgam, dbet),
+                                        conv=geo.desc(dt, ldx, ldda)))
+                    self._wrote(gw_off0, Ct * K)
+                else:
+                    self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R) + ((ops.nhwc_info(dr)[4], int(residual.is_init())) if fold_res else (0, 0)),
+                                        l=(npix,), f=(1.0,),
+                                        p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet,
+                                           dr if fold_res else None)))
                 self._wrote(gg_off, co)
                 self._wrote(gb_off, co)
                 self.bwd_sync.append((len(self.bwd) - 2, su))  # sync_bn: all-reduce of the sums between reduce and apply
@@ -354,6 +367,8 @@ class TrainPlan:
                                     conv=geo.desc(dt, ldx, Ct)))
                 self._wrote(gw_off0, Ct * K)
 
+            if stem_fused:
+                return
             if not image:
                 dx = x_act.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
@@ -769,6 +784,8 @@ class TrainPlan:
                 out.append(("conv_dgrad", es * (yout + wts + xin * (2 if o.i[0] else 1)) + zb, 2.0 * macs))
             elif kind == OP_CONV_WGRAD:
                 out.append(("conv_wgrad", es * (xin + yout) + 4 * wts, 2.0 * macs))
+            elif kind == OP_STEM_BN_WGRAD:          # x, da and z read once, dw written
+                out.append(("conv_wgrad", es * (xin + 2 * yout) + 4 * wts, 2.0 * macs))
             elif kind == OP_BN_TRAIN_ACT:
                 out.append(("bn_act_fwd", es * o.l[0] * o.i[3] * (3 if o.p[9] else 2), 0.0))
             elif kind == OP_BN_BWD_REDUCE:

@@ -104,6 +104,18 @@ int ayolo_conv_dgrad_bn(const ayolo_conv_desc* d, const void* dy, const void* wt
 /* dw[Cout][kh][kw][Cin] (fp32, must be zeroed by the caller) += sum_pixels dy (x) x ; alpha scales the result. */
 int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha,
                      ayolo_stream s);
+/* Backward of the STEM block (kindle Conv row 0, res/configs/model/yolov5s.yaml:21: Conv-BN-SiLU on the image) in one launch:
+ * the BatchNorm + activation backward of its output gradient da and the weight gradient of its conv.  The stem has no input
+ * gradient, so its dz has no other reader: the kernel forms dz = bn_act_backward(da, z; sums) on the way from HBM to LDS
+ * instead of a separate ayolo_bn_act_bwd_apply pass writing it (autograd: NativeBatchNormBackward + SiluBackward +
+ * ConvolutionBackward's weight leg, yolo_trainer.py:327-329).  `d`: the packed-stem descriptor (fp16, image as pixel pairs,
+ * 6 x 3 taps of 8 halves, stride (2, 1), pad (2, 1), Cout <= 64) with ldy = row stride of da; z: the conv output (row stride
+ * ldz); sums: [sum_reps][2][Cout] doubles as left by ayolo_bn_act_bwd_reduce / ayolo_conv_dgrad_bn; dw += alpha * gradient
+ * ([Cout][6][3][8] fp32); dgamma / dbeta (may be NULL) = grad_scale * the two sums. */
+int ayolo_stem_bn_wgrad(const ayolo_conv_desc* d, const void* x, const void* z, int ldz, const void* da,
+                        const float* save_mean, const float* save_invstd, const float* gamma, const float* beta, int act,
+                        const double* sums, int sum_reps, float* dw, float* dgamma, float* dbeta, float alpha,
+                        float grad_scale, ayolo_stream s);
 
 /* fp32 KRSC master weight [Cout][kh][kw][Cin] -> compute-dtype copy `w` [Cout_pad][kh][kw][Cin_pad] and
  * transposed copy `wt` [Cin_pad][kh][kw][Cout_pad] (either nullable); padding rows/channels are zero
@@ -402,7 +414,8 @@ enum {
     AYOLO_OP_AFFINE_ACT, AYOLO_OP_BN_BWD_REDUCE, AYOLO_OP_BN_BWD_APPLY, AYOLO_OP_MAXPOOL_FWD, AYOLO_OP_MAXPOOL_BWD,
     AYOLO_OP_UPSAMPLE_FWD, AYOLO_OP_UPSAMPLE_BWD, AYOLO_OP_PACK_INPUT, AYOLO_OP_HEAD_GRAD_PACK, AYOLO_OP_COPY2D,
     AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT, AYOLO_OP_CAST_WEIGHTS, AYOLO_OP_HEAD_DECODE,
-    AYOLO_OP_JOIN_SIDE          /* the caller's stream waits for everything enqueued so far on the side stream */
+    AYOLO_OP_JOIN_SIDE,         /* the caller's stream waits for everything enqueued so far on the side stream */
+    AYOLO_OP_STEM_BN_WGRAD      /* ayolo_stem_bn_wgrad */
 };
 typedef struct ayolo_op {
     int kind;

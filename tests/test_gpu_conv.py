@@ -516,3 +516,44 @@ def test_stem_forward_kernel_and_statistics(shape):
     P = B * geo.Ho * geo.Wo
     np.testing.assert_allclose(tot[:Cout].numpy(), yf.sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-6 * P)
     np.testing.assert_allclose(tot[Cout:].numpy(), (yf * yf).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-6 * P)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 96), (3, 16, 70, 100), (2, 64, 24, 40)])
+@pytest.mark.parametrize("act", [1, 0])
+def test_stem_backward_in_one_launch(shape, act):
+    """ayolo_stem_bn_wgrad: BatchNorm + SiLU backward of the stem's output gradient and the weight gradient of its conv in one
+    kernel (dz formed from (da, z) on the way to LDS) against the two-kernel sequence ayolo_bn_act_bwd_apply -> ayolo_conv_wgrad
+    with the same sums: dgamma / dbeta identical, dw within 2e-3 of its largest element (the fused kernel folds two of the
+    per-channel constants, so a dz element may round to the neighbouring fp16 value)."""
+    from ayolov2_amd import functional as F_, ops
+    B, Cout, H, W = shape
+    dt = torch.float16
+    torch.manual_seed(B + Cout + H + act)
+    x = torch.rand(B, 3, H, W)
+    geo = F_._Geometry((B, 3, H, W), (Cout, 3, 6, 6), (2, 2), (2, 2), dt)
+    xk = F_._prepare_input(x.cuda(), geo, dt)
+    z = torch.randn(B, Cout, geo.Ho, geo.Wo, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    da = torch.randn(B, Cout, geo.Ho, geo.Wo, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    mean = z.float().mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(z.float().var((0, 2, 3), unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
+    npix = B * geo.Ho * geo.Wo
+    code = ops.dtype_code(dt)
+    sums = ops.zero_stats(Cout, z.device)
+    from ayolov2_amd._lib import call
+    call("ayolo_bn_act_bwd_reduce", code, z.data_ptr(), Cout, da.data_ptr(), Cout, npix, Cout, mean.data_ptr(), invstd.data_ptr(),
+         gamma.data_ptr(), beta.data_ptr(), act, sums.data_ptr(), ops.STAT_REPS, torch.cuda.current_stream().cuda_stream)
+    dz = torch.empty_like(z)
+    dg_ref, db_ref = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    call("ayolo_bn_act_bwd_apply", code, z.data_ptr(), Cout, da.data_ptr(), Cout, dz.data_ptr(), Cout, npix, Cout, mean.data_ptr(),
+         invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, sums.data_ptr(), ops.STAT_REPS, dg_ref.data_ptr(), db_ref.data_ptr(),
+         1.0, torch.cuda.current_stream().cuda_stream)
+    d = geo.desc(dt, geo.Cin_k, Cout)
+    dw_ref = torch.zeros((Cout, 144), dtype=torch.float32, device="cuda")
+    ops.conv_wgrad(d, xk, dz, dw_ref)
+    dw = torch.zeros_like(dw_ref)
+    dg, db = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    ops.stem_bn_wgrad(d, xk, z, da, mean, invstd, gamma, beta, act, sums, dw, dg, db)
+    torch.cuda.synchronize()
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    assert float((dw - dw_ref).abs().max()) <= 2e-3 * float(dw_ref.abs().max())

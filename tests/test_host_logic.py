@@ -291,7 +291,7 @@ def test_plan_gradient_buckets_cover_the_arena():
     # C3's cv1 | cv2 run as one conv: 8 fewer forward / dgrad / wgrad launches than the 60 convolutions of the model
     from collections import Counter
     kinds = Counter(o.kind & 0xff for o in pl.bwd)
-    assert kinds[3] == 52 and kinds[2] == 51
+    assert kinds[3] + kinds[22] == 52 and kinds[2] == 51 and kinds[22] == 1      # 22: the stem's fused BN-backward + weight gradient
     # sync_bn cut points: one per conv launch (forward), one per BatchNorm layer (backward)
     assert len(pl.fwd_sync_idx) == 49 and len(pl.bwd_sync) == 57
     # fp16 plans fold the BatchNorm-backward sums of every layer whose output gradient is last written by a conv dgrad into
