@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does a k_gconv step go?  Runs one conv forward through the probe build (ab/libayolo_probe.so: conv.hip compiled with
--DAYOLO_PROBE, see the Makefile-free recipe in DESIGN.md section 7) and prints, per workgroup class, the s_memtime marks of the
+-DAYOLO_PROBE: `make -C ayolov2_amd/csrc probe`) and prints, per workgroup class, the s_memtime marks of the
 first tile's step loop: [top | DMA wait done | barrier passed | MFMAs issued] per step, in shader cycles.
 usage (GPU box): AYOLO_LIB=$PWD/ab/libayolo_probe.so python tools/gconv_probe.py B Cin Cout k s p H W [dgrad]"""
 import ctypes
