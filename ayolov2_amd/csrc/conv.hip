@@ -2141,7 +2141,8 @@ static int check_desc(const ayolo_conv_desc* d, const char* who) {
 }
 
 static bool is_packed_stem(const ayolo_conv_desc* d);
-static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void* w, void* y, double* stats, int stat_reps, hipStream_t s);
+static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void* w, void* y, double* stats, int stat_reps, int epilogue,
+                             const float* scale, const float* shift, hipStream_t s);
 
 extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const void* w, void* y, int epilogue,
                               const float* scale, const float* shift, double* stats, int stat_reps, int head_no,
@@ -2152,7 +2153,8 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
     AY_CHECK_ARG(epilogue >= 0 && epilogue <= 5, "conv_fwd: epilogue %d", epilogue);
     AY_CHECK_ARG(epilogue != AYOLO_EPI_HEAD || (head_no > 0 && d->Cout % head_no == 0), "conv_fwd: head_no=%d", head_no);
     AY_CHECK_ARG(stats == nullptr || epilogue == AYOLO_EPI_NONE, "conv_fwd: stats need EPI_NONE");
-    if (epilogue == AYOLO_EPI_NONE && is_packed_stem(d)) return stem_fwd_dispatch(d, x, w, y, stats, stat_reps, (hipStream_t)s);
+    if ((epilogue == AYOLO_EPI_NONE || epilogue == AYOLO_EPI_AFFINE || epilogue == AYOLO_EPI_AFFINE_SILU) && is_packed_stem(d))
+        return stem_fwd_dispatch(d, x, w, y, stats, stat_reps, epilogue, scale, shift, (hipStream_t)s);
     GConvP p{};
     p.x = x; p.w = w; p.y = y;
     p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = d->ldx;
@@ -2934,9 +2936,13 @@ struct StemFP {
     int tw, th;
     long long ntiles;
     unsigned x_bytes, y_bytes;
+    const float* scale; const float* shift; int act;      // AFF: y = act(conv * scale + shift) (the inference executor's fused stem)
 };
 
-template <int MB>
+// AFF: the inference epilogue of k_gconv's EM = 2 (per-channel scale / shift = folded BatchNorm + bias, optional SiLU) instead of
+// the plain store + statistics of the training forward -- the same arithmetic on the fp32 accumulator, so results match the
+// generic kernel bit for bit
+template <int MB, bool AFF = false>
 __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_fwd(StemFP p) {
     constexpr int PATCH_B = STEM_PR * STEM_PC * 16;
     constexpr int NPCH = STEM_PR * STEM_PC, PPT = (NPCH + 255) / 256;
@@ -2972,6 +2978,15 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_fwd(StemFP p) {
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ssum[m][r] = 0.0f; ssq[m][r] = 0.0f; }
+    float* aff = reinterpret_cast<float*>(sm + 2 * PATCH_B);               // AFF: [scale | shift] of the 32 * MB channels
+    if constexpr (AFF) {
+        for (int c = tid; c < 32 * MB; c += 256) {
+            const bool in = c < p.N;
+            aff[c] = (in && p.scale) ? p.scale[c] : 1.0f;
+            aff[32 * MB + c] = (in && p.shift) ? p.shift[c] : 0.0f;
+        }
+        __syncthreads();
+    }
 
     uint4 rp[2][PPT];
     auto fetch = [&](long long t, uint4 (&fp)[PPT]) {
@@ -3032,9 +3047,16 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_fwd(StemFP p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[g][e] = acc[m][g * 4 + e];
-                        const float q = pv ? (float)(half_t)v[g][e] : 0.0f;
-                        ssum[m][g * 4 + e] += q;
-                        ssq[m][g * 4 + e] += q * q;
+                        if constexpr (AFF) {
+                            // channel of this register before the lane swap: m * 32 + 8 * g + 4 * hsel + e
+                            const int ch0 = m * 32 + 8 * g + 4 * hsel + e;
+                            const float u = v[g][e] * aff[ch0] + aff[32 * MB + ch0];
+                            v[g][e] = p.act ? silu_e<half_t>(u) : u;
+                        } else {
+                            const float q = pv ? (float)(half_t)v[g][e] : 0.0f;
+                            ssum[m][g * 4 + e] += q;
+                            ssq[m][g * 4 + e] += q * q;
+                        }
                     }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -3074,7 +3096,7 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_fwd(StemFP p) {
         __syncthreads();
     }
     // ---- statistics: lane sums -> channel sums (DPP rows + one exchange), workgroup total in LDS (fp64), one replica slot
-    if (p.stats) {
+    if (!AFF && p.stats) {
         double* sst = reinterpret_cast<double*>(sm);              // [2][32 * MB]
         for (int i = tid; i < 2 * 32 * MB; i += 256) sst[i] = 0.0;
         __syncthreads();
@@ -3102,19 +3124,19 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_fwd(StemFP p) {
     }
 }
 
-template <int MB>
+template <int MB, bool AFF>
 static int launch_stem_fwd(StemFP p, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)(STEM_PR * STEM_PC * 16);
+    constexpr size_t lds = 2 * (size_t)(STEM_PR * STEM_PC * 16) + (AFF ? 2 * 32 * MB * sizeof(float) : 0);
     static bool attr_set[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<MB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stem_fwd<MB, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     long long grid = (long long)num_cus() * 2;
     if (grid > p.ntiles) grid = p.ntiles;
-    hipLaunchKernelGGL((k_stem_fwd<MB>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((k_stem_fwd<MB, AFF>), dim3((unsigned)grid), dim3(256), lds, s, p);
     AY_CHECK_LAUNCH("k_stem_fwd");
     return AYOLO_OK;
 }
@@ -3127,7 +3149,8 @@ static bool is_packed_stem(const ayolo_conv_desc* d) {
            (long long)d->B * d->H * d->W * 16 < (1ll << 31) - 4096 && (long long)d->B * d->Ho * d->Wo * d->ldy * 2 < (1ll << 31) - 4096;
 }
 
-static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void* w, void* y, double* stats, int stat_reps, hipStream_t s) {
+static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void* w, void* y, double* stats, int stat_reps, int epilogue,
+                             const float* scale, const float* shift, hipStream_t s) {
     StemFP q{};
     q.x = (const half_t*)x; q.w = (const half_t*)w; q.y = (half_t*)y; q.stats = stats;
     q.B = d->B; q.H = d->H; q.WP = d->W; q.Ho = d->Ho; q.Wo = d->Wo; q.ldy = d->ldy; q.N = d->Cout; q.ldw = 6 * 3 * 8;
@@ -3135,7 +3158,9 @@ static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void
     q.tw = (d->Wo + STEM_TC - 1) / STEM_TC; q.th = (d->Ho + STEM_TR - 1) / STEM_TR;
     q.ntiles = (long long)d->B * q.tw * q.th;
     q.x_bytes = (unsigned)((long long)d->B * d->H * d->W * 16); q.y_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * d->ldy * 2);
-    return d->Cout <= 32 ? launch_stem_fwd<1>(q, s) : launch_stem_fwd<2>(q, s);
+    q.scale = scale; q.shift = shift; q.act = epilogue == AYOLO_EPI_AFFINE_SILU ? 1 : 0;
+    if (epilogue != AYOLO_EPI_NONE) return d->Cout <= 32 ? launch_stem_fwd<1, true>(q, s) : launch_stem_fwd<2, true>(q, s);
+    return d->Cout <= 32 ? launch_stem_fwd<1, false>(q, s) : launch_stem_fwd<2, false>(q, s);
 }
 
 static int wgrad_dispatch(const ayolo_conv_desc* d, WGradP p, hipStream_t st) {

@@ -557,3 +557,28 @@ def test_stem_backward_in_one_launch(shape, act):
     torch.cuda.synchronize()
     assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
     assert float((dw - dw_ref).abs().max()) <= 2e-3 * float(dw_ref.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 96), (3, 16, 70, 100), (2, 64, 24, 40)])
+@pytest.mark.parametrize("act", [True, False])
+def test_stem_forward_kernel_inference_epilogue(shape, act):
+    """k_stem_fwd with the inference executor's epilogue (per-channel scale / shift = folded BatchNorm, optional SiLU) against
+    torch on fp16-rounded operands: 3e-3 of the largest element (the fp16 output rounding)."""
+    from ayolov2_amd import functional as F_, ops, _lib
+    B, Cout, H, W = shape
+    dt = torch.float16
+    g = torch.Generator().manual_seed(B + Cout + H + int(act))
+    x = torch.rand(B, 3, H, W, generator=g).half().float()
+    wt = (torch.randn(Cout, 3, 6, 6, generator=g) / 108 ** 0.5).half().float()
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    geo = F_._Geometry((B, 3, H, W), wt.shape, (2, 2), (2, 2), dt)
+    xk = F_._prepare_input(x.cuda(), geo, dt)
+    w, _ = F_._WeightCache().get(wt.cuda().contiguous(memory_format=torch.channels_last), dt, Cout, geo.cin_pad)
+    y = ops.new_act(B, Cout, geo.Ho, geo.Wo, dt, xk.device)
+    y.fill_(float("nan"))
+    ops.conv_fwd(geo.desc(dt, geo.Cin_k, Cout), xk, w, y, _lib.EPI_AFFINE_SILU if act else _lib.EPI_AFFINE, scale.cuda(), shift.cuda())
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, wt, None, 2, 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if act:
+        ref = F.silu(ref)
+    assert float((y.float().cpu() - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
