@@ -331,3 +331,43 @@ def test_model_ema_follows_reassigned_tensors_cpu():
                     v += (1 - d) * msd[k].detach()
     for (k, a), b in zip(ema.ema.state_dict().items(), ref.state_dict().values()):
         assert torch.equal(a, b), k
+
+
+def test_tucker_block_merge_algebra_and_launch_form_cpu():
+    """infer_plan._MergedConv multiplies the linear convs of a Tucker block out (decomposition.py:363-424 puts nothing between them):
+    first factor into the core, core into the last factor, all three -- each must reproduce the Sequential on the CPU; and
+    the per-block cost model (_tucker_form) must keep the factors apart only where that is cheaper: a stride-2 block never keeps
+    the rank-r1 intermediate at input resolution, an HBM-bound large-map block with ranks C/2 goes back to the dense conv, a
+    small-map block with ranks C/4 keeps a factorised form."""
+    import types
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ayolov2_amd import infer_plan as IP
+    torch.manual_seed(0)
+    a, b, c = nn.Conv2d(16, 4, 1, bias=False), nn.Conv2d(4, 6, 3, 2, 1, bias=False), nn.Conv2d(6, 20, 1, bias=True)
+    x = torch.randn(2, 16, 9, 11)
+    with torch.no_grad():
+        ref = c(b(a(x)))
+        m3 = IP._MergedConv([a, b, c])
+        assert float((F.conv2d(x, m3.weight, m3.bias, m3.stride, m3.padding) - ref).abs().max()) < 1e-5
+        m_first = IP._MergedConv([a, b])
+        assert float((c(F.conv2d(x, m_first.weight, None, m_first.stride, m_first.padding)) - ref).abs().max()) < 1e-5
+        m_last = IP._MergedConv([b, c])
+        assert float((F.conv2d(a(x), m_last.weight, m_last.bias, m_last.stride, m_last.padding) - ref).abs().max()) < 1e-5
+        # a factor update reaches the merged weight on recompute (the plan calls it when a source's version changes)
+        a.weight.mul_(-2.0)
+        m3.recompute()
+        assert float((F.conv2d(x, m3.weight, m3.bias, m3.stride, m3.padding) - c(b(a(x)))).abs().max()) < 1e-5
+    with pytest.raises(IP.PlanUnsupported):
+        IP._MergedConv([nn.Conv2d(4, 4, 1, bias=True), nn.Conv2d(4, 4, 3, 1, 1, bias=False)])     # inner bias does not commute with padding
+
+    def form(cin, r1, r2, cout, k, s, H, W, B=128, image=False):
+        plan = types.SimpleNamespace(B=B, dt=torch.float16, H=H, W=W, _ce=lambda: 8)
+        convs = [nn.Conv2d(cin, r1, 1, bias=False), nn.Conv2d(r1, r2, k, s, k // 2, bias=False), nn.Conv2d(r2, cout, 1, bias=True)]
+        xt = None if image else torch.empty(B, cin, H, W, device="meta")
+        return IP.InferPlan._tucker_form(plan, convs, xt, image)
+
+    assert form(64, 16, 32, 128, 3, 2, 160, 160) in ("first", "dense")            # stride 2: no r1 intermediate at input resolution
+    assert form(32, 16, 16, 32, 3, 1, 160, 160) == "dense"                         # large map, ranks C/2: HBM-bound either way
+    assert form(256, 64, 64, 256, 3, 1, 20, 20) in ("first", "last", "factors")     # small map, ranks C/4: the factors pay
+    assert form(3, 2, 8, 32, 6, 2, 640, 640, image=True) in ("first", "dense")      # the stem
