@@ -75,6 +75,8 @@ _SIGNATURES = {
     "ayolo_yolo_loss_bwd_packed": [POINTER(LossLevel), c_int] + [c_float] * 8 + [_P, _P],
     "ayolo_match_detections": [_P, _P, c_int64, _P, _P, c_int64, _P, c_int, _P, _P, _P, _P, _P],
     "ayolo_head_decode": [_P, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int64, c_int64, _P],
+    "ayolo_head_decode_aug": [_P, POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, c_int64, c_int64, c_float, c_int,
+                              c_float, c_int64, c_int64, _P],
     "ayolo_nms_candidates": [_P, c_int, c_int, c_int, c_float, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_uint32, c_int,
                              _P],
     "ayolo_nms_key_bits": [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)],

@@ -2064,20 +2064,26 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     const long long w_bytes = (long long)p.Nout * p.ldw * es;
     AY_CHECK_ARG(w_bytes < (1ll << 30), "conv: weight matrix of %lld bytes unsupported", w_bytes);
     AY_CHECK_ARG(x_img < LIM && y_img < LIM, "conv: a single image of %lld / %lld bytes unsupported", x_img, y_img);
-    if (x_img * p.B >= LIM || y_img * p.B >= LIM) {
+    // BNR: the z buffers of the BatchNorm segments have y's pixels (possibly a wider channel stride) and split with it
+    long long z_img_max = 0;
+    for (int k = 0; k < p.bnr; ++k) {
+        const long long z_img = (long long)p.YH * p.YW * p.bseg[k].ldz * 2;
+        z_img_max = z_img > z_img_max ? z_img : z_img_max;
+    }
+    AY_CHECK_ARG(z_img_max < LIM, "conv: a single image of z (%lld bytes) unsupported", z_img_max);
+    if (x_img * p.B >= LIM || y_img * p.B >= LIM || z_img_max * p.B >= LIM) {
+        AY_CHECK_ARG(p.B > 1, "conv: one image exceeds the 2 GiB descriptor range");
         GConvP a = p, b = p;
         a.B = p.B / 2; b.B = p.B - a.B;
         a.Mtotal = (long long)a.B * p.OH * p.OW; b.Mtotal = (long long)b.B * p.OH * p.OW;
         b.x = (const char*)p.x + x_img * a.B;
         b.y = (char*)p.y + y_img * a.B;
-        for (int k = 0; k < p.bnr; ++k) {        // BNR: z has y's pixels
-            const long long z_img = (long long)p.YH * p.YW * p.bseg[k].ldz * 2;
-            b.bseg[k].z = (const char*)p.bseg[k].z + z_img * a.B;
-            a.z_bytes[k] = (unsigned)(z_img * a.B); b.z_bytes[k] = (unsigned)(z_img * b.B);
-        }
+        for (int k = 0; k < p.bnr; ++k)
+            b.bseg[k].z = (const char*)p.bseg[k].z + (long long)p.YH * p.YW * p.bseg[k].ldz * 2 * a.B;
         int rc = dispatch_gconv(dtype, a, s);
         return rc ? rc : dispatch_gconv(dtype, b, s);
     }
+    for (int k = 0; k < p.bnr; ++k) p.z_bytes[k] = (unsigned)((long long)p.YH * p.YW * p.bseg[k].ldz * 2 * p.B);
     if (p.epi != AYOLO_EPI_HEAD) {
         AY_CHECK_ARG(p.Nout % 4 == 0 && p.ldy % 4 == 0, "conv: Cout=%d / channel stride %d must be multiples of 4", p.Nout, p.ldy);
         AY_CHECK_ARG(dtype != AYOLO_F16 || (p.Nout % 8 == 0 && p.ldy % 8 == 0),
@@ -2194,7 +2200,6 @@ extern "C" int ayolo_conv_dgrad_bn(const ayolo_conv_desc* d, const void* dy, con
         AY_CHECK_ARG(g.z && g.mean_invstd && g.sums, "conv_dgrad_bn: null pointer in segment %d", k);
         AY_CHECK_ARG(g.C > 0 && g.C % 8 == 0 && g.c0 >= 0 && g.c0 % 8 == 0 && g.ldz % 8 == 0 && g.ldz >= g.C && g.c0 + g.C <= d->Cin,
                      "conv_dgrad_bn: segment %d: c0=%d C=%d ldz=%d", k, g.c0, g.C, g.ldz);
-        AY_CHECK_ARG((long long)d->B * d->H * d->W * g.ldz * 2 < (1ll << 31) - 4096, "conv_dgrad_bn: z of segment %d exceeds 2 GiB", k);
     }
     // a 32-channel block of dx belongs to ONE segment (wave-uniform descriptor choice in the epilogue)
     AY_CHECK_ARG(nseg == 1 || (segs[1].c0 % 32 == 0 && segs[0].c0 + segs[0].C <= segs[1].c0),
@@ -2230,10 +2235,7 @@ static int conv_dgrad_impl(const ayolo_conv_desc* d, const void* dy, const void*
             p.C = d->Cout; p.ldw = d->kh * d->kw * d->Cout; p.Nout = d->Cin;
             p.epi = AYOLO_EPI_NONE; p.accumulate = accumulate; p.stat_reps = 1;
             p.bnr = nseg; p.bnr_act = act; p.bnr_reps = sum_reps;
-            for (int k = 0; k < nseg; ++k) {
-                p.bseg[k] = segs[k];
-                p.z_bytes[k] = (unsigned)((long long)d->B * d->H * d->W * segs[k].ldz * 2);
-            }
+            for (int k = 0; k < nseg; ++k) p.bseg[k] = segs[k];        // z_bytes: dispatch_gconv, after its batch split
             p.y_linear = (d->sh == 1 && d->sw == 1) ? 1 : 0;
             p.x_linear = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0) ? 1 : 0;
             p.Mtotal = (long long)d->B * p.OH * p.OW;

@@ -815,10 +815,15 @@ extern "C" int ayolo_copy2d(int dtype, const void* x, int ldx, void* y, int ldy,
 // ---------------------------------------------------------------------------------------------------
 // YOLOHead: eval decode and gradient repack
 // ---------------------------------------------------------------------------------------------------
+// AUG: the decode of one augmented forward of test-time augmentation (ayolo_head_decode_aug) -- the augmentation's inverse is
+// applied to the value on its way out (xywh / scale as a true division, then the flip about the ORIGINAL image extent) and a
+// row is stored only if its destination index lies inside [win_lo, win_hi): the tail clip is a window, not a copy
+template <bool AUG>
 __global__ __launch_bounds__(256) void k_head_decode(const float* raw, long long sb, long long sa, long long sy, long long sx,
                                                      int B, int na, int ny, int nx, int no,
                                                      const float* anchors_px, float stride, float* out,
-                                                     long long rows_total, long long row_off) {
+                                                     long long rows_total, long long row_off,
+                                                     float aug_scale, int aug_flip, float aug_extent, long long win_lo, long long win_hi) {
     const long long per_img = (long long)na * ny * nx;
     const long long total = (long long)B * per_img * no;
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
@@ -830,27 +835,56 @@ __global__ __launch_bounds__(256) void k_head_decode(const float* raw, long long
         r /= ny;
         int a = (int)(r % na);
         long long b = r / na;
+        long long row = row_off + ((long long)a * ny + y) * nx + x;
+        if constexpr (AUG) {
+            if (row < win_lo || row >= win_hi) continue;
+        }
         float sg = 1.0f / (1.0f + expf(-raw[b * sb + a * sa + y * sy + x * sx + o]));
         float v = sg;
         if (o == 0) v = (sg * 2.0f - 0.5f + (float)x) * stride;
         else if (o == 1) v = (sg * 2.0f - 0.5f + (float)y) * stride;
         else if (o == 2 || o == 3) { float q = sg * 2.0f; v = q * q * anchors_px[a * 2 + (o - 2)]; }
-        long long row = row_off + ((long long)a * ny + y) * nx + x;
+        if constexpr (AUG) {
+            if (o < 4) v = v / aug_scale;
+            if (o == 0 && aug_flip == 3) v = aug_extent - v;
+            if (o == 1 && aug_flip == 2) v = aug_extent - v;
+        }
         out[(b * rows_total + row) * no + o] = v;
     }
+}
+
+static int head_decode_launch(bool aug, const float* raw, const int64_t* raw_strides, int B, int na, int ny, int nx, int no,
+                              const float* anchors_px, float stride, float* out, int64_t rows_total, int64_t row_off,
+                              float aug_scale, int aug_flip, float aug_extent, int64_t win_lo, int64_t win_hi, ayolo_stream s) {
+    AY_CHECK_ARG(raw && out && anchors_px && no > 4, "head_decode: bad args");
+    long long total = (long long)B * na * ny * nx * no;
+    long long sb = (long long)na * ny * nx * no, sa = (long long)ny * nx * no, sy = (long long)nx * no, sx = no;
+    if (raw_strides) { sb = raw_strides[0]; sa = raw_strides[1]; sy = raw_strides[2]; sx = raw_strides[3]; }
+    if (total == 0) return AYOLO_OK;
+    if (aug)
+        hipLaunchKernelGGL(k_head_decode<true>, dim3(grid_for(total, 256 * 4)), dim3(256), 0, (hipStream_t)s, raw, sb, sa, sy, sx, B, na,
+                           ny, nx, no, anchors_px, stride, out, (long long)rows_total, (long long)row_off, aug_scale, aug_flip,
+                           aug_extent, (long long)win_lo, (long long)win_hi);
+    else
+        hipLaunchKernelGGL(k_head_decode<false>, dim3(grid_for(total, 256 * 4)), dim3(256), 0, (hipStream_t)s, raw, sb, sa, sy, sx, B, na,
+                           ny, nx, no, anchors_px, stride, out, (long long)rows_total, (long long)row_off, 1.0f, 0, 0.0f, 0LL, 0LL);
+    AY_CHECK_LAUNCH("k_head_decode");
+    return AYOLO_OK;
 }
 
 extern "C" int ayolo_head_decode(const float* raw, const int64_t* raw_strides, int B, int na, int ny, int nx, int no,
                                  const float* anchors_px, float stride, float* out, int64_t rows_total, int64_t row_off,
                                  ayolo_stream s) {
-    AY_CHECK_ARG(raw && out && anchors_px && no > 4, "head_decode: bad args");
-    long long total = (long long)B * na * ny * nx * no;
-    long long sb = (long long)na * ny * nx * no, sa = (long long)ny * nx * no, sy = (long long)nx * no, sx = no;
-    if (raw_strides) { sb = raw_strides[0]; sa = raw_strides[1]; sy = raw_strides[2]; sx = raw_strides[3]; }
-    hipLaunchKernelGGL(k_head_decode, dim3(grid_for(total, 256 * 4)), dim3(256), 0, (hipStream_t)s, raw, sb, sa, sy, sx, B, na, ny, nx, no,
-                       anchors_px, stride, out, (long long)rows_total, (long long)row_off);
-    AY_CHECK_LAUNCH("k_head_decode");
-    return AYOLO_OK;
+    return head_decode_launch(false, raw, raw_strides, B, na, ny, nx, no, anchors_px, stride, out, rows_total, row_off, 1.0f, 0, 0.0f, 0, 0, s);
+}
+
+extern "C" int ayolo_head_decode_aug(const float* raw, const int64_t* raw_strides, int B, int na, int ny, int nx, int no,
+                                     const float* anchors_px, float stride, float* out, int64_t rows_total, int64_t row_off,
+                                     float scale, int flip, float flip_extent, int64_t win_lo, int64_t win_hi, ayolo_stream s) {
+    AY_CHECK_ARG(scale > 0.0f && (flip == 0 || flip == 2 || flip == 3) && win_lo >= 0 && win_hi <= rows_total,
+                 "head_decode_aug: scale > 0, flip in {0, 2, 3}, window inside the output");
+    return head_decode_launch(true, raw, raw_strides, B, na, ny, nx, no, anchors_px, stride, out, rows_total, row_off, scale, flip,
+                              flip_extent, win_lo, win_hi, s);
 }
 
 // d(raw) (B,na,ny,nx,no) fp32 -> NHWC gradient dz[pix][ldz] (channel c = a*no + o; channels >= na*no zero) and

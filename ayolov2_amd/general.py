@@ -2,7 +2,7 @@
 glue -- plain torch/numpy ops on whatever device the boxes live on."""
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -34,6 +34,27 @@ def xywh2xyxy(x, ratio=(1.0, 1.0), wh=(1.0, 1.0), pad=(0.0, 0.0)):
     y[:, 2] = ratio[0] * wh[0] * (x[:, 0] + hw) + pad[0]
     y[:, 3] = ratio[1] * wh[1] * (x[:, 1] + hh) + pad[1]
     return y
+
+
+def xyxy2xywh(x, wh: Tuple[float, float] = (1.0, 1.0), clip_eps: Optional[float] = None, check_validity: bool = True):
+    """(n, 4) corner boxes -> centre / size boxes divided by the image size `wh` (interface of general.py:252-294, pinned by
+    golden G3b).  Both axes are handled at once: centre = ((lo + hi) / 2) / wh, size = (hi - lo) / wh; with
+    `check_validity` a box that overhangs [0, 1] is shrunk on that axis by twice the overhang (low side first, then the
+    high side from the already shrunk size) and everything is clipped to [1e-12, 1].  `clip_eps` is accepted for interface
+    parity: the reference clips a COPY and then derives every output column from the unclipped input, so it changes nothing
+    (G3b `sized_clip` == `sized`)."""
+    tensor = isinstance(x, torch.Tensor)
+    size = x.new_tensor(wh[:2]) if tensor else np.asarray(wh[:2], dtype=x.dtype)
+    lo, hi = x[:, 0:2], x[:, 2:4]
+    centre = ((lo + hi) / 2) / size
+    extent = (hi - lo) / size
+    if check_validity:
+        below = centre - extent / 2                       # < 0: the box starts before the image
+        extent = extent + (below.clamp(max=0) if tensor else np.minimum(below, 0)) * 2
+        above = centre + extent / 2                       # > 1: it ends beyond it
+        extent = extent - ((above.clamp(min=1) if tensor else np.maximum(above, 1)) - 1) * 2
+    out = torch.cat((centre, extent), 1) if tensor else np.concatenate((centre, extent), 1)
+    return out.clip(1e-12, 1) if check_validity else out
 
 
 def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):

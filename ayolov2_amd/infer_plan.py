@@ -460,11 +460,8 @@ class InferPlan:
     def valid(self) -> bool:
         return tuple(t.data_ptr() for t in self._tracked) == self._ptrs
 
-    def run(self, x: torch.Tensor):
-        x = x.detach()
-        if x.dtype != torch.float32 or not x.is_contiguous():
-            x = x.float().contiguous()
-        st = torch.cuda.current_stream().cuda_stream
+    def _trunk(self, x: torch.Tensor, st, n_ops: int) -> None:
+        """refresh derived weights if a parameter changed, point the pack op at `x`, run the first `n_ops` ops"""
         vers = tuple(t._version for t in self._tracked)
         if vers != self._versions:                            # a parameter / buffer changed: refold + recast everything
             for fold, w32 in self.folds:
@@ -473,6 +470,18 @@ class InferPlan:
             self._versions = vers
         self._x_keep = x
         self.fwd_arr[self.pack_idx].p[0] = x.data_ptr()
+        _lib.check(_lib.lib().ayolo_run_ops(self.fwd_arr, n_ops, st), "ayolo_run_ops(inference)")
+
+    @staticmethod
+    def _as_input(x: torch.Tensor) -> torch.Tensor:
+        x = x.detach()
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        return x
+
+    def run(self, x: torch.Tensor):
+        x = self._as_input(x)
+        st = torch.cuda.current_stream().cuda_stream
         # The decoded prediction -- what val.py keeps, post-processes and may hold across batches (`out, train_out =
         # model(img)`, train_utils.py:441-444) -- is written into a tensor that belongs to THIS call: the decode ops are
         # pointed at a fresh allocation (caching allocator: no device malloc, no extra copy).  model.static_outputs = True
@@ -480,16 +489,35 @@ class InferPlan:
         out = self.out if getattr(self.model, "static_outputs", False) else torch.empty_like(self.out)
         for k in self.decode_idx:
             self.fwd_arr[k].p[2] = out.data_ptr()
-        _lib.check(_lib.lib().ayolo_run_ops(self.fwd_arr, len(self.fwd), st), "ayolo_run_ops(inference)")
+        self._trunk(x, st, len(self.fwd))
         # the raw per-level logits stay views of the executor's static buffers (valid until the next forward of this shape)
         raws = [buf.as_strided(shape, strides) for buf, shape, strides in self.raw_specs]
         return out, raws
 
+    @property
+    def rows(self) -> int:
+        return int(self.out.shape[1])
 
-def plan_forward_eval(model, x: torch.Tensor):
-    """Eval forward through the cached inference plan; returns (decoded, raws) or None if the structure is unsupported.
-    `decoded` is a tensor of its own (the decode kernels write into a fresh allocation per call); the raw per-level logits
-    are views of plan-owned static buffers that the next forward of the same shape overwrites."""
+    def run_augmented(self, x: torch.Tensor, merged: torch.Tensor, row_off: int, win: Tuple[int, int], scale: float, flip: int,
+                      extent: float) -> None:
+        """One forward of test-time augmentation (tta.inference_with_tta): everything up to the head convs as `run`, then the
+        decode of every level writes its rows -- already de-scaled and de-flipped -- at `row_off` of the merged prediction
+        `merged` (B, rows of all augmentations, no); rows outside the window `win` (the clipped tails) are not stored."""
+        assert self.decode_idx == list(range(len(self.fwd) - len(self.decode_idx), len(self.fwd))), "decode ops close the list"
+        assert merged.is_contiguous() and merged.dtype == torch.float32 and merged.shape[0] == self.B and merged.shape[2] == self.out.shape[2]
+        x = self._as_input(x)
+        st = torch.cuda.current_stream().cuda_stream
+        self._trunk(x, st, len(self.fwd) - len(self.decode_idx))
+        for k in self.decode_idx:
+            o = self.fwd_arr[k]
+            strides = (_lib.c_int64 * 4)(o.i[5], o.i[6], o.i[7], o.i[8])
+            _lib.call("ayolo_head_decode_aug", o.p[0], strides, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.p[1], o.f[0],
+                      merged.data_ptr(), merged.shape[1], row_off + o.i[9], float(scale), int(flip), float(extent),
+                      int(win[0]), int(win[1]), st)
+
+
+def eval_plan_for(model, x: torch.Tensor) -> Optional["InferPlan"]:
+    """The cached inference plan of (input shape, dtype, device), compiled on first use; None if the structure is unsupported."""
     w = next((p for p in model.parameters()), None)
     dt = torch.float16 if (torch.is_autocast_enabled() or (w is not None and w.dtype == torch.float16)) else torch.float32
     key = ("eval", tuple(x.shape), dt, x.device)
@@ -509,6 +537,16 @@ def plan_forward_eval(model, x: torch.Tensor):
         while len(live) >= MAX_INFER_PLANS:
             cache.pop(live.pop(0))
         cache[key] = plan
+    return plan
+
+
+def plan_forward_eval(model, x: torch.Tensor):
+    """Eval forward through the cached inference plan; returns (decoded, raws) or None if the structure is unsupported.
+    `decoded` is a tensor of its own (the decode kernels write into a fresh allocation per call); the raw per-level logits
+    are views of plan-owned static buffers that the next forward of the same shape overwrites."""
+    plan = eval_plan_for(model, x)
+    if plan is None:
+        return None
     out, raws = plan.run(x)
     head = model.model[-1]
     if getattr(head, "out_xyxy", False):

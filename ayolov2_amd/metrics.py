@@ -274,12 +274,21 @@ def _greedy_nms_by_class(cand: _Candidates, seg_n: np.ndarray, iou_thres: float,
     return True
 
 
-_FAST_STATE: dict = {}       # (device, B, N, no, multi_label) -> [capacity, workspace, pinned status copy]
+import threading
+
+_FAST_TLS = threading.local()   # per host thread: {(device, B, N, no, multi_label) -> [capacity, workspace, pinned status copy]}
+                                # (the reference's builder validates with one thread per device: the pinned status buffer of a
+                                # key must not be shared between two threads' copy -> synchronize -> read sequences)
 NMS_FAST = os.environ.get("AYOLO_NMS_FAST", "1") != "0"           # the one-call LDS-resident route of the `nms` branch
 
 
-def _nms_class_fast(pred: torch.Tensor, conf_thres: float, iou_thres: float, multi_label: bool,
-                    classes: Optional[Sequence[int]], max_det: int, output: List[torch.Tensor]) -> bool:
+def _nms_class_fast(pred: torch.Tensor, *args) -> bool:
+    with torch.cuda.device(pred.device):                   # kernels, stream and allocations on the device the prediction lives on
+        return _nms_class_fast_on_device(pred, *args)
+
+
+def _nms_class_fast_on_device(pred: torch.Tensor, conf_thres: float, iou_thres: float, multi_label: bool,
+                              classes: Optional[Sequence[int]], max_det: int, output: List[torch.Tensor]) -> bool:
     """The class-aware `nms` branch in ONE library call (ayolo_nms_class_fast: no library sorts, no intermediate host
     read).  The work buffers are sized from the previous call of the same shape; the single host read at the end returns
     the per-image counts together with the status flags.  Returns False when a limit of that path did not hold (the
@@ -296,14 +305,15 @@ def _nms_class_fast(pred: torch.Tensor, conf_thres: float, iou_thres: float, mul
                 words[c >> 6] |= np.uint64(1) << np.uint64(c & 63)
         class_mask = torch.from_numpy(words.view(np.int64)).to(dev)
     key = (dev, B, N, no, multi_label)
-    st = _FAST_STATE.get(key)
+    states = _FAST_TLS.__dict__.setdefault("states", {})
+    st = states.get(key)
     worst = B * N * (nc if multi_label else 1)
     if st is None:
-        st = _FAST_STATE[key] = [min(worst, max(1 << 16, B * N * 2)), None, torch.empty(2 + 2 * B, dtype=torch.int32).pin_memory()]
-        while len(_FAST_STATE) > 8:
-            _FAST_STATE.pop(next(iter(_FAST_STATE)))
+        st = states[key] = [min(worst, max(1 << 16, B * N * 2)), None, torch.empty(2 + 2 * B, dtype=torch.int32).pin_memory()]
+        while len(states) > 8:
+            states.pop(next(iter(states)))
     thr_f = thr_as_float_for_double_compare(iou_thres)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.current_stream(dev)                                    # the stream of pred's device, not the current device's
     for _ in range(2):
         capacity = int(st[0])
         need = _lib.c_size_t(0)

@@ -317,8 +317,15 @@ class TrainPlan:
             e.append(self._register_param(bn.bias, co, lambda b: b) if bn.bias is not None else None)
         x_act = x
 
+        # the fused stem backward (ayolo_stem_bn_wgrad) exists for exactly the kernel's geometry -- pixel-pair taps 6 x 3, stride
+        # (2, 1), padding (2, 1), <= 64 output channels -- with x, z and da each inside one 2 GiB buffer descriptor; anything
+        # else (other packed stems, a batch / resolution whose stem tensors reach 2 GiB) keeps the separate apply + weight
+        # gradient ops, which split large batches on the C side
+        lim = (1 << 31) - 4096
         stem_fused = (FUSE_STEM_BACKWARD and image and geo.packed_stem and dt == torch.float16 and len(mods) == 1 and residual is None
-                      and Ct <= 64 and Ct % 8 == 0)
+                      and Ct <= 64 and Ct % 8 == 0 and tuple(geo.kdims) == (6, 3) and tuple(geo.sdims) == (2, 1)
+                      and tuple(geo.pdims) == (2, 1) and self.B * self.H * self.W * 8 < lim and 2 * npix * Ct < lim
+                      and (dsts[0] is None or 2 * npix * dsts[0].root.C < lim))
 
         def emit_bwd():
             ga = self.gradarena
@@ -730,11 +737,12 @@ class TrainPlan:
             if world > 1:
                 with torch.no_grad():
                     for bn, sm_off, co, n in self.bn_sync_fix:
-                        if bn.running_var is None or n < 2:
+                        if bn.running_var is None or n < 2 or bn.momentum is None:     # (cumulative-average BN never plans)
                             continue
                         inv = self.small.view(sm_off, 4 * co)[co:2 * co]
                         N = world * n
-                        bn.running_var.add_((inv.pow(-2) - bn.eps) * (bn.momentum * (N / (N - 1) - n / (n - 1))))
+                        var = (inv.pow(-2) - bn.eps).clamp_min_(0.0)                   # rounding must not make it negative
+                        bn.running_var.add_(var * (bn.momentum * (N / (N - 1) - n / (n - 1))))
         else:
             self._run(self.fwd_arr, 0, len(self.fwd), st, "forward")
         if self.bn_counters:
@@ -813,21 +821,33 @@ class TrainPlan:
                 out.append(("other", 0.0, 0.0))
         return out
 
-    def _grad_out_buffer(self) -> torch.Tensor:
-        """The flat buffer this step's gradients are handed out in.  A pool of two persistent buffers, reused whenever no
-        parameter's .grad still lives in them (zero_grad(set_to_none=True) after every step, yolo_trainer.py:336): the
-        gradient addresses then repeat from step to step, which is what lets optim.SGD keep its job table instead of
-        rebuilding and re-uploading it every step.  A buffer still referenced by a .grad (gradient accumulation over
-        several backward passes) is never overwritten -- a fresh one is allocated instead."""
+    @staticmethod
+    def _storage_refs(t: torch.Tensor) -> int:
+        """Tensors (and Python storage wrappers) that share `t`'s storage right now, `t` included; -1 if this torch cannot
+        tell (then pooled buffers are never reused)."""
+        fn = getattr(torch._C, "_storage_Use_Count", None)
+        return int(fn(t.untyped_storage()._cdata)) if fn is not None else -1
+
+    def _grad_out_buffer(self):
+        """The flat buffer this step's gradients are handed out in.  A pool of two persistent buffers: the gradient addresses
+        then repeat from step to step, which is what lets optim.SGD keep its job table instead of rebuilding and re-uploading
+        it every step.  A pooled buffer is reused only when it is PROVABLY unreferenced -- its storage (and the storage of
+        every side buffer handed out with it) is back at the reference count it had when only the pool held it.  That is the
+        case after `zero_grad(set_to_none=True)` (yolo_trainer.py:336) once nobody else holds a gradient of that backward: a
+        `.grad` that is still set (gradient accumulation), a `torch.autograd.grad` result, a list of gradients kept across
+        steps or a hook that stashed one all keep the count up, and a fresh buffer is allocated instead -- gradients returned
+        by one backward are never overwritten by a later one (autograd semantics)."""
         pool = self.__dict__.setdefault("_flat_pool", [])
-        live = {p.grad.untyped_storage().data_ptr() for p in self.params if p.grad is not None}
-        for b, extra in pool:
-            if b.untyped_storage().data_ptr() not in live and not any(e.untyped_storage().data_ptr() in live for e in extra.values()):
-                return b, extra
-        b, extra = torch.empty_like(self.gradarena.buf), {}
+        for entry in pool:
+            flat, extra, base = entry
+            if base[0] > 0 and self._storage_refs(flat) == base[0] and all(self._storage_refs(e) == base[1] for e in extra.values()):
+                return entry
+        flat = torch.empty_like(self.gradarena.buf)
+        probe = torch.empty(1, device=flat.device)
+        entry = (flat, {}, [self._storage_refs(flat), self._storage_refs(probe)])     # idle counts: the flat buffer / a side buffer
         if len(pool) < 2:
-            pool.append((b, extra))
-        return b, extra
+            pool.append(entry)
+        return entry
 
     def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
         from .losses import take_packed_head_grad
@@ -891,7 +911,7 @@ class TrainPlan:
                 sync.reduce_flat(self.gradarena.buf)              # one blocking all-reduce of the whole arena
         # The arena is scratch that the next forward zeroes: hand out gradients that OWN their memory (autograd steals
         # them as p.grad and may keep them across steps for gradient accumulation) -- one flat copy, views into it.
-        flat, extra = self._grad_out_buffer()
+        flat, extra, _ = self._grad_out_buffer()
         flat.copy_(self.gradarena.buf)
         lo_, hi_ = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
         grads = []

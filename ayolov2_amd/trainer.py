@@ -135,6 +135,10 @@ class _FlatSync:
         assert self.compress in (None, "fp16", "bf16"), self.compress
         self._works = []
         self._comm = None
+        # measurement mode (bench.py): timing events at every bucket's end on the communication stream and at the compute
+        # stream's arrival at wait_all -> exposed_ms()
+        self.measure = False
+        self._marks = []
 
     def active(self) -> bool:
         return self.world > 1 or os.getenv("AYOLO_FORCE_DDP") == "1"      # the env switch exercises the RCCL calls on one GPU
@@ -189,18 +193,55 @@ class _FlatSync:
             # whatever the backend did (NCCL: the collective runs on its own stream behind `w`; gloo / compression: the work
             # was waited for and the scaling / write-back was enqueued on the communication stream), an event on the
             # communication stream marks the point the compute stream must wait for
-            ev = torch.cuda.Event()
+            if self.measure and w is not None:
+                w.wait()                                                     # communication stream behind the collective
+            ev = torch.cuda.Event(enable_timing=self.measure)
             ev.record(comm)
         self._works.append((w, ev))
+        if self.measure:
+            self._marks.append(("bucket", ev, view.numel() * view.element_size()))
 
     def wait_all(self) -> None:
         cur = torch.cuda.current_stream() if self._works and torch.cuda.is_available() else None
+        if self.measure and cur is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(cur)
+            self._marks.append(("join", ev0, 0))
         for w, ev in self._works:
             if w is not None:
                 w.wait()                                                     # current stream waits for the collective
             if cur is not None:
                 cur.wait_event(ev)                                           # ... and for what the communication stream did after it
         self._works = []
+
+    def exposed_ms(self) -> dict:
+        """Measurement mode: per step, how long each bucket's exchange ran PAST the moment the compute stream reached
+        wait_all (0 = fully hidden behind backward), from the timing events of the measured steps (call after a device
+        synchronize)."""
+        steps, cur = [], []
+        for kind, ev, nbytes in self._marks:
+            cur.append((kind, ev, nbytes))
+            if kind == "join":
+                steps.append(cur)
+                cur = []
+        self._marks = []
+        per_bucket, sizes = None, None
+        for st in steps:
+            join = st[-1][1]
+            edge, row = 0.0, []
+            for kind, ev, nbytes in st[:-1]:
+                t = max(join.elapsed_time(ev), 0.0)          # ms the bucket finished after the join point (<= 0: hidden)
+                row.append(max(t - edge, 0.0))
+                edge = max(edge, t)
+            if per_bucket is None:
+                per_bucket, sizes = [0.0] * len(row), [b for _, _, b in st[:-1]]
+            if len(row) == len(per_bucket):
+                per_bucket = [a + b for a, b in zip(per_bucket, row)]
+        n = max(len(steps), 1)
+        per_bucket = [round(v / n, 4) for v in (per_bucket or [])]
+        return {"buckets": len(per_bucket), "bucket_mb": [round(b / 1e6, 2) for b in (sizes or [])],
+                "exposed_ms_per_bucket": per_bucket, "exposed_ms_per_step": round(sum(per_bucket), 4),
+                "overlap": self.overlap, "compress": self.compress, "measured_steps": len(steps)}
 
     def average_now(self, t: torch.Tensor) -> None:
         """sync_bn: in-stream average of one layer's BatchNorm accumulators (sum, sum of squares / backward sums) over
@@ -210,7 +251,8 @@ class _FlatSync:
             self._avg(t, False)
 
     def __getstate__(self):                       # checkpoints pickle the whole model: a process group cannot travel
-        return {"group": None, "world": 1, "sync_bn": False, "overlap": True, "compress": None, "_works": [], "_comm": None}
+        return {"group": None, "world": 1, "sync_bn": False, "overlap": True, "compress": None, "_works": [], "_comm": None,
+                "measure": False, "_marks": []}
 
 
 class FlatGradDDP(nn.Module):

@@ -3,6 +3,7 @@
 backward + SGD step, fp16 autocast with fp32 master weights) on N MI355X, one process per GPU.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...            # no rendezvous in the environment: re-executes itself under the launcher below
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -449,6 +450,64 @@ def config_extras(device, only=None):
     return out
 
 
+def self_launch(argv, gpus):
+    """`bench.py --gpus N` without a rendezvous in the environment: re-execute under the reference's launcher
+    (README.md:163 `python3 -m torch.distributed.run --nproc_per_node N`), one process per GPU, loopback rendezvous on a
+    free port.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def timed_region(step, steps, warmup, world, sync, barrier, all_max):
+    """The contract's timed region: W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both
+    sides; the MAX over ranks is what counts."""
+    last = None
+    for _ in range(warmup):
+        step()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    sync()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        el = all_max(el)
+    return el, last
+
+
+def stub_main(args, world, rank):
+    """Test hook (tests/test_bench_launch.py): the launcher / rendezvous / timed-region / one-JSON-line logic of this file
+    on CPU ranks over gloo with a step that only sleeps.  No kernel runs and the line says so ("stub": true)."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+
+    def all_max(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    el, _ = timed_region(lambda: time.sleep(0.002 * (rank + 1)), args.steps, args.warmup, world, lambda: None,
+                         (dist.barrier if world > 1 else (lambda: None)), all_max)
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "stub": True, "value": round(world * args.batch * args.steps / el, 2), "unit": "img/s",
+                          "n_gpus": world, "ranks": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(el / args.steps * 1e3, 3)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,15 +517,24 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / NMS legs")
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # a run labelled n_gpus N must BE N ranks: a launcher / flag mismatch is an error, never a silently smaller job
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}"
+    if args.stub_step:
+        return stub_main(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    assert torch.cuda.device_count() > local, f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} visible GPUs"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     force_ddp = os.environ.get("AYOLO_FORCE_DDP") == "1"       # exercise the DDP/RCCL path on a single GPU
+    rccl_ranks = None
     if world > 1 or force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -474,6 +542,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
+        rccl_ranks = dist.get_world_size()
+        assert rccl_ranks == world, (rccl_ranks, world)
 
     model, run_model, opt, loss_fn, scaler = build_train_objects(args.model, device, 2 if force_ddp and world == 1 else world)
     gen = torch.Generator().manual_seed(1234 + rank)
@@ -498,29 +568,32 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=device, dtype=torch.float64)
+    def all_max(v):
+        t = torch.tensor([v], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
+        return float(t.item())
+
+    el, loss = timed_region(step, args.steps, args.warmup, world, torch.cuda.synchronize, barrier, all_max)
     assert math.isfinite(float(loss)), "non-finite loss"
 
     peak_train_gb = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
+    comm = None
+    sync_obj = getattr(model, "_ayolo_grad_sync", None)
+    if sync_obj is not None and sync_obj.active():
+        # per-bucket EXPOSED communication: how long the compute stream stood at wait_all for each bucket's all-reduce
+        # (events on the communication stream vs. the compute stream's arrival at the join), 3 steps after the timed region
+        sync_obj.measure = True
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        comm = sync_obj.exposed_ms()
+        sync_obj.measure = False
     if rank == 0:
         ms = el / args.steps * 1e3
         value = world * args.batch * args.steps / el
         out = {
             "metric": "img/s fwd+bwd YOLOv5s 640x640 bs=64 train step", "value": round(value, 2), "unit": "img/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.size}x{args.size} per-GPU batch {args.batch}: forward + ComputeLoss "
                                    f"+ backward + SGD-nesterov step, fp16 autocast / fp32 master weights, random-init weights",
@@ -539,6 +612,8 @@ def main():
         # memory budget of the step (activations kept for backward, one private dz per layer for the side-stream weight
         # gradients, arenas, fp16 weight copies, optimiser + EMA state); measured before the secondary configurations ran
         out["peak_memory_gb_train_step"] = peak_train_gb
+        if comm is not None:
+            out["ddp"] = comm
     if world > 1 or force_ddp:
         torch.distributed.destroy_process_group()
     if rank == 0:

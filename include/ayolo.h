@@ -221,6 +221,14 @@ int ayolo_copy2d(int dtype, const void* x, int ldx, void* y, int ldy, int64_t np
 int ayolo_head_decode(const float* raw, const int64_t* raw_strides /* host int64[4] element strides of (b,a,y,x);
                       NULL = contiguous */, int B, int na, int ny, int nx, int no, const float* anchors_px,
                       float stride, float* out, int64_t rows_total, int64_t row_off, ayolo_stream s);
+/* The decode of ONE augmented forward of test-time augmentation, written where the merged prediction wants it
+ * (scripts/utils/tta_utils.py:15-37 `descale_pred`, :40-59 `clip_augmented`, :62-86 `inference_with_tta`): the values of
+ * ayolo_head_decode, then xywh / scale (true division), flip 2: y = flip_extent - y (flip_extent = image height),
+ * flip 3: x = flip_extent - x (image width), 0: none; a row is stored only if its destination index
+ * row_off + (a*ny+y)*nx+x lies in [win_lo, win_hi) -- the clipped tails are never written (row_off may be negative). */
+int ayolo_head_decode_aug(const float* raw, const int64_t* raw_strides, int B, int na, int ny, int nx, int no,
+                          const float* anchors_px, float stride, float* out, int64_t rows_total, int64_t row_off,
+                          float scale, int flip, float flip_extent, int64_t win_lo, int64_t win_hi, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * YOLO loss, value and analytic gradient (scripts/loss/losses.py:227-300 `ComputeLoss.__call__`; box term

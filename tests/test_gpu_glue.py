@@ -55,6 +55,24 @@ def test_tta_through_the_hip_forward():
     assert yg.shape == yr.shape
     np.testing.assert_allclose(yg.cpu().numpy(), yr.numpy(), rtol=1e-4, atol=2e-3)
     assert torch.equal(yg, yg2)
+    # the decode-store route (ayolo_head_decode_aug: de-scale / de-flip / tail window inside the decode kernels, one merged
+    # tensor) against the tensor-op route around the SAME HIP forwards, incl. the up-down flip; CPU arithmetic of the
+    # tensor-op route (true division) so that the comparison is exact
+    s2, f2 = [1, 0.83, 0.67, 0.83], [None, 3, 2, 2]
+    with torch.no_grad():
+        fused, _ = tta.inference_with_tta(m, x.cuda(), s2, f2)
+
+        class HostSide(torch.nn.Module):                  # same HIP forwards, predictions post-processed on the host
+            def __init__(self):
+                super().__init__()
+                self.model, self.stride = m.model, m.stride
+
+            def forward(self, xi):
+                return m(xi)[0].cpu(), None
+
+        plain, _ = tta.inference_with_tta(HostSide(), x.cuda(), s2, f2)      # same (GPU-resized) inputs as the fused route
+    assert fused.shape == plain.shape
+    np.testing.assert_array_equal(fused.cpu().numpy(), plain.numpy())
 
 
 def test_result_writer_rows(tmp_path):

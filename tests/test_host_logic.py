@@ -133,6 +133,57 @@ def test_general_helpers_vs_golden(golden_dir):
         g["scale_b"])
 
 
+def test_xyxy2xywh_vs_golden(golden_dir):
+    """G3b: the reference's own xyxy2xywh (general.py:252-294) on numpy boxes incl. boxes that overhang the unit square;
+    the torch-tensor form must agree with the numpy form."""
+    from ayolov2_amd import general
+    g = np.load(os.path.join(golden_dir, "g3b_xyxy2xywh.npz"))
+    np.testing.assert_array_equal(general.xyxy2xywh(g["box"].copy()), g["default"])
+    np.testing.assert_array_equal(general.xyxy2xywh(g["box"].copy(), check_validity=False), g["no_check"])
+    np.testing.assert_array_equal(general.xyxy2xywh(g["px"].copy(), wh=(640.0, 480.0)), g["sized"])
+    np.testing.assert_array_equal(general.xyxy2xywh(g["px"].copy(), wh=(640.0, 480.0), clip_eps=1e-3), g["sized_clip"])
+    f32 = general.xyxy2xywh(g["box"].astype(np.float32))
+    assert f32.dtype == np.float32
+    np.testing.assert_array_equal(f32, g["f32"])
+    t = general.xyxy2xywh(torch.from_numpy(g["px"].copy()), wh=(640.0, 480.0))
+    np.testing.assert_array_equal(t.numpy(), g["sized"])
+
+
+def test_grad_pool_never_reuses_a_referenced_buffer():
+    """the plan hands gradients out as views of a pooled flat buffer; a buffer is reused only when nothing --
+    a .grad, an autograd.grad result, a detached alias, a stashed list -- still shares its storage."""
+    from ayolov2_amd.plan import TrainPlan
+
+    class Arena:
+        buf = torch.zeros(1000)
+
+    class P:
+        gradarena = Arena()
+        _storage_refs = staticmethod(TrainPlan._storage_refs)
+
+    pl = P()
+    get = lambda: TrainPlan._grad_out_buffer(pl)          # noqa: E731
+    f1 = get()[0]
+    g = f1[10:20]                                         # a gradient view handed out of buffer 1
+    f2 = get()[0]
+    assert f2 is not f1
+    alias = g.detach()                                    # what AccumulateGrad keeps as p.grad
+    del g
+    assert get()[0] is f2                                 # buffer 1 still pinned by the alias, buffer 2 idle
+    held = f2[0:5]
+    f3 = get()[0]
+    assert f3 is not f1 and f3 is not f2                  # both pinned: a fresh buffer, not an overwrite
+    del alias, held, f3
+    assert get()[0] is f1
+    entry = get()
+    side = torch.empty(5)
+    entry[1][7] = side                                    # a side buffer (the stem's compacted gradient) handed out with it
+    h = side.as_strided(side.shape, side.stride())
+    assert get()[0] is not f1
+    del h
+    assert get()[0] is f1
+
+
 def test_bbox_iou_vs_golden(golden_dir):
     from ayolov2_amd.metrics import bbox_iou
     g = np.load(os.path.join(golden_dir, "g2_bbox_iou.npz"))

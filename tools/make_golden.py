@@ -76,6 +76,24 @@ def synth_pred(B, N, nc, img, mu_obj, seed):
     return torch.cat((xy, wh, obj, cls), 2).float()
 
 
+def g3b_xyxy2xywh():
+    """G3b: xyxy2xywh (general.py:252-294) -- numpy boxes the way the label export calls it: normalised coordinates that
+    overhang the unit square (the validity shrink), pixel coordinates with an image size, clip_eps, check_validity off."""
+    from scripts.utils import general as rg
+    rng = np.random.default_rng(33)
+    lo = rng.uniform(-0.15, 0.9, (64, 2))
+    box = np.concatenate([lo, lo + rng.uniform(0.0, 0.4, (64, 2))], 1)
+    box[:4] = [[0.0, 0.0, 1.0, 1.0], [0.2, 0.2, 0.2, 0.2], [-0.2, 0.5, 0.1, 1.3], [0.95, -0.1, 1.2, 0.05]]
+    px = box * np.array([640.0, 480.0, 640.0, 480.0])
+    out = dict(box=box, px=px,
+               default=rg.xyxy2xywh(box.copy()),
+               no_check=rg.xyxy2xywh(box.copy(), check_validity=False),
+               sized=rg.xyxy2xywh(px.copy(), wh=(640.0, 480.0)),
+               sized_clip=rg.xyxy2xywh(px.copy(), wh=(640.0, 480.0), clip_eps=1e-3),
+               f32=rg.xyxy2xywh(box.astype(np.float32)))
+    np.savez_compressed(os.path.join(OUT, "g3b_xyxy2xywh.npz"), **out)
+
+
 def g8_validator():
     """G8: YoloValidator.process_batch (train_utils.py:294-333) on seeded detections / labels of several images and
     ap_per_class (metrics.py:476-548) on the stacked statistics -- the reference's own functions, run here."""
@@ -295,6 +313,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
     sys.path.insert(0, REF)
+    if len(sys.argv) > 1 and sys.argv[1] == "g3b":
+        g3b_xyxy2xywh()
+        print("g3b written")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8_validator()
         print("g8 written")
@@ -430,6 +452,7 @@ def main():
 
     g8_validator()
     g9_tta()
+    g3b_xyxy2xywh()
 
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
