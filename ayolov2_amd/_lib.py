@@ -28,6 +28,12 @@ class BnSeg(ctypes.Structure):
                 ("ldz", c_int), ("c0", c_int), ("C", c_int), ("reserved", c_int)]
 
 
+class WgradJob(ctypes.Structure):
+    """ayolo_wgrad_job (include/ayolo.h): one layer's weight gradient inside a grouped launch."""
+    _fields_ = [("conv", ConvDesc), ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("alpha", c_float),
+                ("dy_slot", c_int), ("overwrite", c_int), ("reserved", c_int)]
+
+
 class LossLevel(ctypes.Structure):
     _fields_ = ([("pred", c_void_p)] + [(n, c_int64) for n in ("sb", "sa", "sy", "sx")]
                 + [(n, c_int) for n in ("B", "na", "ny", "nx", "no", "n")]
@@ -47,7 +53,12 @@ _SIGNATURES = {
     "ayolo_conv_fwd": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, _P],
     "ayolo_conv_dgrad": [POINTER(ConvDesc), _P, _P, _P, c_int, _P],
     "ayolo_conv_dgrad_bn": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P],
-    "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P],
+    "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P, c_size_t, _P],
+    "ayolo_wgrad_group_size": [POINTER(WgradJob), c_int, POINTER(c_size_t), POINTER(c_size_t)],
+    "ayolo_wgrad_group_build": [POINTER(WgradJob), c_int, _P, c_size_t],
+    "ayolo_wgrad_group_run": [_P, _P, _P, c_size_t, POINTER(c_void_p), c_int, _P],
+    "ayolo_wgrad_group_info": [_P, c_int, POINTER(c_int64), c_int],
+    "ayolo_wgrad_group_item": [_P, c_int, c_int64, POINTER(c_int64)],
     "ayolo_stem_bn_wgrad": [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_float, c_float, _P],
     "ayolo_cast_weight": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "ayolo_ema_update": [_P, c_int, c_float, _P],
@@ -112,7 +123,7 @@ _SIGNATURES = {
     "ayolo_release_thread_state": [],
 }
 
-EXPORTED = sorted(list(_SIGNATURES) + ["ayolo_version", "ayolo_last_error"])
+EXPORTED = sorted(list(_SIGNATURES) + ["ayolo_version", "ayolo_last_error", "ayolo_conv_wgrad_workspace"])
 
 _lib = None
 
@@ -130,6 +141,8 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
             fn.restype = c_int
         l.ayolo_version.restype = c_int
+        l.ayolo_conv_wgrad_workspace.argtypes = [POINTER(ConvDesc)]
+        l.ayolo_conv_wgrad_workspace.restype = c_size_t
         l.ayolo_last_error.restype = c_char_p
         _lib = l
     return _lib

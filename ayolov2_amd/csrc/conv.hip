@@ -16,7 +16,10 @@
 // (scripts/train/yolo_trainer.py:329).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <math.h>
+#include <algorithm>
+#include <vector>
 
 #define MAX_TAPS 36
 #define BK 32
@@ -178,7 +181,16 @@ struct GT {
     static constexpr int WM = TM / (32 * MI), WP = NW / WM, NI = TP / (32 * WP);
     static constexpr int NACC = MI * NI;            // accumulator blocks per wave
     static constexpr int NST = NACC * 4;            // store instructions per thread per epilogue
-    static constexpr size_t LDS = (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + 8 * TM * sizeof(float);   // statistics [2][TM] fp64 + BNR constants [4][TM]
+    // What follows the tiles in LDS, by epilogue: BatchNorm statistics [2][TM] fp64 (training forward, EM 0), the same + the
+    // BNR constants [4][TM] fp32 (dgrad with the BatchNorm-backward sums), else the affine constants [2][TM] fp32.  Sized per
+    // instantiation ON PURPOSE: LDS is allocated in 1 280-byte granules and three workgroups per CU need <= 53 760 bytes each --
+    // the 128 x 128 tiles sit right at that edge (49 744 bytes of stages + tap table).  Rounds 2 -> 3 grew this tail to 4 KB for
+    // every variant and the inference kernels of cfg 5 silently dropped to two workgroups per CU (k_gconv<128,2,128> 67 -> 88 us,
+    // k_gconv3<128,4,128> 119 -> 157 us; bisected in round 4, profiles/r04_cfg5_bisect.txt).
+    static constexpr size_t tail(int EM, bool BNR) {
+        return BNR ? 2 * TM * sizeof(double) + 4 * TM * sizeof(float) : (EM == 0 ? 2 * TM * sizeof(double) : 2 * TM * sizeof(float));
+    }
+    static constexpr size_t lds(int EM, bool BNR) { return (size_t)GNS * STAGE + (MAX_TAPS + 1) * 16 + tail(EM, BNR); }
 };
 
 // Explicit MFMA-result hazard pad (see the comment in k_gconv's step loop).  The pad only works if the MFMAs stay in front of
@@ -788,7 +800,7 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, in
 }
 
 template <typename T, int TM, int EM, int TPX, bool BNR = false>
-__global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 ? 1 : (GT<T, TM, TPX>::LDS > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4))) : 1)) void k_gconv(GConvP p) {
+__global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 ? 1 : (GT<T, TM, TPX>::lds(EM, BNR) > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4))) : 1)) void k_gconv(GConvP p) {
     static_assert(TM != 256 || (sizeof(T) == 2 && TPX == 256), "the 8-wave tile is fp16 256 x 256 only");
     using G = GT<T, TM, TPX>;
     // stores per thread and epilogue (the step loop's vmcnt arithmetic): fp16 tiles leave in 16-byte stores
@@ -1079,7 +1091,7 @@ struct GT3 {
     static constexpr int XS = XROWS * G::ROWB;               // bytes per x stage
     static constexpr int WS = G::WSTAGE;
     static constexpr int XP = G::XR / 2;                     // DMA instructions per thread in x parts 0 and 1
-    static constexpr size_t LDS = 3 * (size_t)XS + 3 * (size_t)WS + 8 * TM * sizeof(float);
+    static constexpr size_t lds(int EM, bool BNR) { return 3 * (size_t)XS + 3 * (size_t)WS + G::tail(EM, BNR); }   // see GT::tail
     static_assert(G::XR % 2 == 0 && G::ES == 2, "fp16, 128- or 256-pixel tiles");
 };
 
@@ -1876,11 +1888,12 @@ static int num_cus() {
 }
 
 // workgroups per CU of one k_gconv instantiation (LDS-bound; the launch bounds give the register budget to match)
-template <typename T, int TM, int TPX>
+template <typename T, int TM, int TPX, int EM, bool BNR>
 static constexpr int gconv_bpc() {
     using G = GT<T, TM, TPX>;
-    int bpc = (int)(160 * 1024 / G::LDS);
-    const int bpc_max = sizeof(T) == 2 ? (G::LDS > 56 * 1024 ? 2 : (TM == 128 ? 3 : 4)) : 1;
+    constexpr size_t lds_alloc = (G::lds(EM, BNR) + 1279) / 1280 * 1280;          // LDS allocation granule of gfx950
+    int bpc = (int)(160 * 1024 / lds_alloc);
+    const int bpc_max = sizeof(T) == 2 ? (G::lds(EM, BNR) > 56 * 1024 ? 2 : (TM == 128 ? 3 : 4)) : 1;
     return bpc > bpc_max ? bpc_max : bpc;
 }
 
@@ -1900,7 +1913,7 @@ static GGrid gconv_grid(long long Mtotal, int tp, int ntn, int bpc) {
 template <typename T, int TM, int EM, int TPX, bool BNR = false>
 static int launch_gconv_tp(GConvP p, hipStream_t s) {
     using G = GT<T, TM, TPX>;
-    const size_t lds = G::LDS;
+    const size_t lds = G::lds(EM, BNR);
     p.ntn = (p.Nout + TM - 1) / TM;
     constexpr int bpc_env = 0;
     int dev = 0;
@@ -1930,15 +1943,15 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
             static bool attr3_set[16] = {false};
             if (dev < 0 || dev >= 16 || !attr3_set[dev]) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv3<T, TM, EM, TPX, BNR>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3::LDS);
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3::lds(EM, BNR));
                 if (dev >= 0 && dev < 16) attr3_set[dev] = true;
             }
-            hipLaunchKernelGGL((k_gconv3<T, TM, EM, TPX, BNR>), dim3((unsigned)(slots3 * p.ntn)), dim3(256), G3::LDS, s, p);
+            hipLaunchKernelGGL((k_gconv3<T, TM, EM, TPX, BNR>), dim3((unsigned)(slots3 * p.ntn)), dim3(256), G3::lds(EM, BNR), s, p);
             AY_CHECK_LAUNCH("k_gconv3");
             return AYOLO_OK;
         }
     }
-    const int bpc = bpc_env > 0 ? bpc_env : gconv_bpc<T, TM, TPX>();
+    const int bpc = bpc_env > 0 ? bpc_env : gconv_bpc<T, TM, TPX, EM, BNR>();
     const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc).slots;
     p.nslots = (int)slots;
     dim3 grid((unsigned)(slots * p.ntn));
@@ -1970,8 +1983,8 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     else {
         const int ntn = (p.Nout + TM - 1) / TM;
         const int K = p.ntaps * p.C;
-        const long long w128 = gconv_grid(p.Mtotal, 128, ntn, p.row3 ? 2 : gconv_bpc<T, TM, 128>()).waves;
-        const long long w256 = gconv_grid(p.Mtotal, 256, ntn, p.row3 ? 2 : gconv_bpc<T, TM, 256>()).waves;
+        const long long w128 = gconv_grid(p.Mtotal, 128, ntn, p.row3 ? 2 : gconv_bpc<T, TM, 128, EM, BNR>()).waves;
+        const long long w256 = gconv_grid(p.Mtotal, 256, ntn, p.row3 ? 2 : gconv_bpc<T, TM, 256, EM, BNR>()).waves;
         if (w128 <= 1) wide = false;
         else if (w128 <= 3 && w256 < w128) wide = true;
         else wide = TM == 64 ? true : (TM == 128 ? K >= 256 : K >= 128);
@@ -2297,25 +2310,51 @@ struct WGradP {
     unsigned gx, gy, splits;       // column tiles, channel tiles, pixel splits
     FastDiv dOW, dOH, dC;
     int linear;                    // 1x1 / stride 1 / no padding: the x row of pixel pp is row pp (no decode, no halo test)
-    int tmap, tgrp;                // tmap: all pixel splits of a dw tile on a group of `tgrp` XCDs (see k_wgrad's block map)
+    // split-K partials: split zz of this job stores its N x K fp32 tile sums at ws[ws_off + (zz0 + zz) * N * K ...] with plain
+    // stores; k_wgrad_reduce adds the splits in a fixed order (see the header comment of k_wgrad)
+    unsigned long long ws_off;     // in floats
+    unsigned zz0;                  // first partial slot of this job (a logical layer cut into batch halves: the second half's
+                                   // slots follow the first's)
+    int dy_slot;                   // >= 0: dy is the launch's override pointer of that slot (YOLOHead levels: the loss hands a
+                                   // different buffer over each step), else `dy`
+    int tm;                        // output-channel tile of this job's launch class: 32 / 64 / 128
 };
 
 #define TNW 128     // dw columns per block tile
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+// one unit of work of a grouped weight-gradient launch: (job, dw tile, pixel split); job == ~0u: padding of an XCD queue
+struct WItem { unsigned job, tile, zz, pad; };
+// one block of the reduction: n <= WRED_N consecutive elements of one layer's dw, S partials `stride` floats apart
+#define WRED_N 2048
+struct WRed { unsigned long long ws_off, stride; float* dst; unsigned n, S; float alpha; int overwrite; };
+struct WOvr { const void* q[4]; };           // dy override pointers of a launch (WGradP::dy_slot)
+
 // A/B fragments for v_mfma_f32_32x32x16_f16 come out of the pixel-major LDS tiles t[pixel][channel] through the gfx950
 // transposing LDS read (tr_frag_sw below): each 16-lane group reads a 4(pixel) x 16(channel) block, lane q supplies the
 // address of row q/4, channels (q%4)*4.. and receives channel q of all 4 rows.
 // ---------------------------------------------------------------------------------------------------
-// k_wgrad: dw[n][tap*C + c] += sum_pixels dy[pixel][n] * x[pixel @ tap][c], split over pixel ranges.
+// k_wgrad: dw[n][tap*C + c] = sum_pixels dy[pixel][n] * x[pixel @ tap][c], split over pixel ranges.
 // Same machinery as k_gconv: both operand tiles ([32 pixels][TM channels] of dy, [32 pixels][128 dw columns] of x)
 // arrive by LDS-DMA two steps ahead (3 LDS stages, one raw barrier per step, counted vmcnt, branch-free loader with
 // out-of-range zero fill).  Both operands are pixel-major in HBM, i.e. k-major for this GEMM: they are staged as
 // they lie and transposed on the way to the MFMA by ds_read_b64_tr_b16.  The unpadded lane-linear image would put the
 // 4 pixel rows of one transposing read on the same banks; the 64-byte groups of a row are therefore XOR-swizzled by the
-// row (on the source address).  All column / channel tiles of one pixel split run on the SAME XCD back to back, so the
-// re-reads of dy (once per column tile) and x (once per tap) are L2 hits.
+// row (on the source address).
+//
+// Round 4: NO ATOMICS, FEW LAUNCHES.  Rounds 1-3 added every pixel split's tile into dw with fp32 atomics -- 30-40 % of a
+// workgroup's life on the small maps (profiles/r03_wgrad_probe_*) and a summation order that changed from run to run --
+// and launched one under-filled grid per layer.  Now
+//   * a workgroup STORES its tile (plain 128-byte row segments) into its own slot of a split-K workspace and
+//     k_wgrad_reduce adds the slots of an element in a fixed order: the weight gradient of a step is bit-reproducible;
+//   * the kernel takes its problem from a JOB TABLE in device memory and its (job, tile, split) from an ITEM LIST, so ONE
+//     launch covers the weight gradients of many layers (they have no mutual dependencies): the host (wgroup_plan) cuts
+//     every layer of a group into items of similar length and deals them to eight per-XCD queues -- all tiles of one pixel
+//     split back to back on one XCD, so the re-reads of dy (once per column tile) and x (once per tap) stay L2 hits --
+//     longest items first.  A single layer (ayolo_conv_wgrad) is the same kernel with the job passed by value.
+// The job struct is read through the constant address space (like the kernarg segment): uniform scalar loads the
+// compiler may repeat instead of holding ~50 SGPRs.
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int TM>
 struct WT {
@@ -2349,15 +2388,17 @@ __device__ __forceinline__ half8 tr_frag_sw(const unsigned char* tile, int k0, i
     return r;
 }
 
+typedef const __attribute__((address_space(4))) WGradP* wjob_cptr_t;
+
 template <typename T, int TM>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP pv, const WGradP* jobs, const WItem* items, float* ws,
+                                                                            WOvr ovr) {
     using W = WT<T, TM>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % W::WM, wn = wave / W::WM;
 
-    // block -> (tile, pixel split): split zz lives on XCD zz % 8 and its gx*gy tiles are consecutive there
 #ifdef AYOLO_PROBE
     __shared__ unsigned long long s_probe[AY_PROBE_N];
     const bool probe_on = blockIdx.x < 512;
@@ -2367,35 +2408,38 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     AY_PROBE(0);
     if (threadIdx.x == 0) s_probe[AY_PROBE_N - 3] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const unsigned Lb = blockIdx.x, xcd = Lb & 7u, local = Lb >> 3;
-    const unsigned ntile = p.gx * p.gy;
+    // ---- which (job, dw tile, pixel split): from the item list of a grouped launch, or -- single job, passed by value -- from
+    // the block index: split zz on XCD zz % 8 with its gx * gy tiles consecutive there
+    typedef __attribute__((address_space(4))) const char* kcptr_t;
+    wjob_cptr_t pj;
     unsigned tile, zz;
-    if (p.tmap) {
-        // tile-major: every pixel split of a dw tile runs on the same group of tgrp XCDs, so the fp32 atomics on its lines stay
-        // in (tgrp) L2s instead of migrating between all eight
-        if (ntile >= 8u) {
-            const unsigned tpx = (ntile + 7u) / 8u;
-            tile = xcd + 8u * (local % tpx);
-            zz = local / tpx;
-        } else {
-            const unsigned G = (unsigned)p.tgrp;
-            tile = xcd / G;
-            zz = local * G + xcd % G;
-        }
-        if (tile >= ntile) return;
+    if (items != nullptr) {
+        const WItem it = items[blockIdx.x];
+        const unsigned job = (unsigned)__builtin_amdgcn_readfirstlane((int)it.job);
+        if (job == 0xffffffffu) return;
+        pj = (wjob_cptr_t)(unsigned long long)(jobs + job);
+        tile = (unsigned)__builtin_amdgcn_readfirstlane((int)it.tile);
+        zz = (unsigned)__builtin_amdgcn_readfirstlane((int)it.zz);
     } else {
+        pj = (wjob_cptr_t)((kcptr_t)__builtin_amdgcn_kernarg_segment_ptr());     // pv is the first kernel argument
+        const unsigned Lb = blockIdx.x, xcd = Lb & 7u, local = Lb >> 3;
+        const unsigned ntile = pj->gx * pj->gy;
         tile = local % ntile;
         zz = (local / ntile) * 8u + xcd;
+        if (zz >= pj->splits) return;
     }
-    if (zz >= p.splits) return;
+#define p (*pj)
+#define WFD(f_) FastDiv{pj->f_.m, pj->f_.s1, pj->f_.s2}     /* member-wise: an address-space-4 struct has no copy constructor */
     const int j0 = (int)(tile % p.gx) * TNW;          // dw column tile (tap*C + c)
     const int n0 = (int)(tile / p.gx) * TM;           // output-channel tile
     const unsigned P = (unsigned)p.P;
     const unsigned pbeg = zz * (unsigned)p.chunk;
     const unsigned pend = pbeg + (unsigned)p.chunk < P ? pbeg + (unsigned)p.chunk : P;
-    if (pbeg >= pend) return;
+    // (the host never creates an empty split: every slot of the workspace is written)
 
-    const v4i32 rsX = make_srd(p.x, p.x_bytes), rsY = make_srd(p.dy, p.y_bytes);
+    const int slot = p.dy_slot;
+    const void* dyp = slot < 0 ? p.dy : (slot == 0 ? ovr.q[0] : (slot == 1 ? ovr.q[1] : (slot == 2 ? ovr.q[2] : ovr.q[3])));
+    const v4i32 rsX = make_srd(p.x, p.x_bytes), rsY = make_srd(dyp, p.y_bytes);
     const unsigned lds_tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)smem_raw);
 
     // ---- x loader lanes: LDS position (row piece*XRW + xrowin, chunk slot xslot) <- source chunk xsrc of that row
@@ -2404,14 +2448,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     if constexpr (sizeof(T) == 2) xsrc = ((((xslot >> 2) ^ ((xrowin / W::XRPB) & (W::XG - 1))) << 2) | (xslot & 3));
     const int xcol = j0 + xsrc * W::CE;
     const bool xcol_ok = xcol < p.K;
-    const unsigned xtap = fdiv(xcol_ok ? (unsigned)xcol : 0u, p.dC);
+    const unsigned xtap = fdiv(xcol_ok ? (unsigned)xcol : 0u, WFD(dC));
     const int xcb = (int)((xcol_ok ? (unsigned)xcol : 0u) - xtap * (unsigned)p.C) * W::ES;
     // tap offsets of this lane's column: scalar loads of the two byte arrays + per-lane select (see k_gconv: indexed per lane
-    // they would be vector loads from the kernarg segment, ~2 000 cycles before the first DMA)
+    // they would be vector loads, ~2 000 cycles before the first DMA)
     static_assert(offsetof(WGradP, dh) % 4 == 0 && offsetof(WGradP, dw_) == offsetof(WGradP, dh) + MAX_TAPS, "tap arrays");
     typedef __attribute__((address_space(4))) const int* kiptr_t;
-    typedef __attribute__((address_space(4))) const char* kcptr_t;
-    const kiptr_t kwords = (kiptr_t)((kcptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WGradP, dh));
+    const kiptr_t kwords = (kiptr_t)((kcptr_t)pj + offsetof(WGradP, dh));
     int kw_[2 * (MAX_TAPS / 4)];
 #pragma unroll
     for (int i = 0; i < 2 * (MAX_TAPS / 4); ++i) kw_[i] = kwords[i];
@@ -2448,9 +2491,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
         const unsigned pt = pbeg + (unsigned)(st) * W::BP;                                                          \
         _Pragma("unroll") for (int r = 0; r < W::XR; ++r) {                                                         \
             const unsigned pp = pt + (r * 4 + wave) * W::XRW + xrowin;                                              \
-            const unsigned t = fdiv(pp, p.dOW);                                                                     \
+            const unsigned t = fdiv(pp, WFD(dOW));                                                                     \
             const int ow = (int)(pp - t * (unsigned)p.OW);                                                          \
-            const unsigned n = fdiv(t, p.dOH);                                                                      \
+            const unsigned n = fdiv(t, WFD(dOH));                                                                      \
             const int oh = (int)(t - n * (unsigned)p.OH);                                                           \
             const unsigned ih = (unsigned)(oh * p.sh + xdh), iw = (unsigned)(ow * p.sw + xdw);                      \
             const bool ok = (pp < pend) & xcol_ok & (ih < (unsigned)p.XH) & (iw < (unsigned)p.XW);                  \
@@ -2509,9 +2552,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
                     if (p.linear) {
                         offs[r] = ((pp < pend) & xcol_ok) ? pp * (unsigned)p.ldx * W::ES + (unsigned)xcb : G_OOB;
                     } else {
-                        const unsigned t = fdiv(pp, p.dOW);
+                        const unsigned t = fdiv(pp, WFD(dOW));
                         const int ow = (int)(pp - t * (unsigned)p.OW);
-                        const unsigned n = fdiv(t, p.dOH);
+                        const unsigned n = fdiv(t, WFD(dOH));
                         const int oh = (int)(t - n * (unsigned)p.OH);
                         const unsigned ih = (unsigned)(oh * p.sh + xdh), iw = (unsigned)(ow * p.sw + xdw);
                         const bool ok = (pp < pend) & xcol_ok & (ih < (unsigned)p.XH) & (iw < (unsigned)p.XW);
@@ -2563,17 +2606,23 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
 #undef W_ISSUE
     wait_vm<0>();                                // trailing zero-fill DMAs must land before this LDS is released
     AY_PROBE(AY_PROBE_N - 4);
+    if constexpr (sizeof(T) == 2) AY_MFMA_PAD("s_nop 11");   // the accumulators are read right below
     // acc[ni][r]: row (out channel) = n0 + wm*32 + 8*(r>>2) + 4*(lane>>5) + (r&3); col = j0 + wn*NI*32 + ni*32 + (lane&31)
+    // -> this split's slot of the workspace, plain stores: lanes 0..31 of a store cover 128 contiguous bytes of one dw row
+    float* slotp = ws + p.ws_off + (unsigned long long)(p.zz0 + zz) * ((unsigned long long)p.N * (unsigned long long)p.K);
+    const int K = p.K, N = p.N;
 #pragma unroll
     for (int ni = 0; ni < W::NI; ++ni) {
-        int col = j0 + wn * W::NI * 32 + ni * 32 + (lane & 31);
-        if (col >= p.K) continue;
+        const int col = j0 + wn * W::NI * 32 + ni * 32 + (lane & 31);
+        if (col >= K) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int row = n0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            if (row < p.N) unsafeAtomicAdd(&p.dw[(long long)row * p.K + col], acc[ni][r] * p.alpha);
+            const int row = n0 + wm * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            if (row < N) slotp[(long long)row * K + col] = acc[ni][r];
         }
     }
+#undef p
+#undef WFD
 #ifdef AYOLO_PROBE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AY_PROBE(AY_PROBE_N - 1);
@@ -2583,55 +2632,36 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
 #endif
 }
 
-template <typename T, int TM>
-static int launch_wgrad(WGradP p, hipStream_t s) {
-    using W = WT<T, TM>;
-    p.gx = (unsigned)((p.K + TNW - 1) / TNW);
-    p.gy = (unsigned)((p.N + TM - 1) / TM);
-    const long long tiles = (long long)p.gx * p.gy;
-    // Split the pixel reduction.  More splits = more workgroups in flight but N*K fp32 atomics per split: with a step
-    // time t_step per workgroup and an L2 atomic rate R the cost A*s + B/(tiles*s) is minimal at
-    // s* = sqrt(steps_per_tile * t_step * R / (N*K))  (measured: t_step*R ~ 1.5e5), capped by ~3 workgroups per CU.
-    const double ka = 1.5e5;
-    const int bpc = sizeof(T) == 2 ? 3 : 1;
-    long long cap = ((long long)num_cus() * bpc + tiles - 1) / tiles;
-    const double steps_per_tile = (double)p.P / W::BP;
-    long long want = (long long)(sqrt(steps_per_tile * ka / ((double)p.N * (double)p.K)) + 0.5);
-    if (want > cap) want = cap;
-    long long max_splits = (p.P + 4 * W::BP - 1) / (4 * W::BP);
-    long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
-    if (splits < 1) splits = 1;
-    long long chunk = (p.P + splits - 1) / splits;
-    chunk = (chunk + W::BP - 1) / W::BP * W::BP;
-    splits = (p.P + chunk - 1) / chunk;
-    p.chunk = chunk;
-    p.splits = (unsigned)splits;
-    // Block map.  Default: pixel split zz on XCD zz % 8 with all its tiles back to back there (operand re-reads -- dy once per
-    // column tile, x once per tap -- hit that XCD's L2).  With very many tiles (>= 64: dw of 1 M+ elements over few pixels, e.g.
-    // 256 -> 512 3x3 on 20 x 20) the fp32 atomics dominate and their lines migrate between the eight L2s: there every split
-    // of a tile runs on ONE XCD instead (measured, profiles/r03_wgrad_tile_major_map.txt: 131 -> 92 us on that layer, 1.1-2.1x
-    // SLOWER on every layer with fewer tiles)
-    p.tmap = tiles >= 64 ? 1 : 0;
-    // Two more experiments on the atomics, both measured and removed (profiles/r03_wgrad_atomics_experiments.txt): per-XCD
-    // copies of dw summed afterwards (-2.6 % on the sweep before the cost of zeroing and summing the copies: the L2's atomic
-    // rate, not line migration, is what the epilogue waits for on layers with few tiles); workgroups of 2-3 four-wavefront
-    // groups that add their tiles in LDS before one set of atomics (1.5-2.3x SLOWER: the shared step barrier couples 12
-    // wavefronts and one 144 KB workgroup per CU schedules worse than three independent ones).
-    p.tgrp = tiles >= 8 ? 1 : (int)(8 / tiles);
-    long long blocks = tiles * ((splits + 7) / 8 * 8);
-    if (p.tmap) blocks = tiles >= 8 ? 8 * ((tiles + 7) / 8) * splits : 8 * ((splits + p.tgrp - 1) / p.tgrp);
-    AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
-    static bool attr_set[16] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)W::LDS);
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+// dst[i] (+)= alpha * sum_s ws[ws_off + s * stride + i]: four interleaved running sums over s (independent loads in flight),
+// combined in a fixed order -- the result does not depend on how the splits were scheduled.  One block per WRed entry of a
+// grouped launch (`red`), or -- single layer -- entry `rv` advanced by the block index.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WRed rv, const WRed* red, const float* ws) {
+    WRed r;
+    if (red != nullptr) r = red[blockIdx.x];
+    else {
+        r = rv;
+        const unsigned long long o = (unsigned long long)blockIdx.x * WRED_N;
+        const unsigned long long left = (unsigned long long)rv.n > o ? (unsigned long long)rv.n - o : 0ull;     // rv.n: all elements
+        r.n = (unsigned)(left < WRED_N ? left : WRED_N);
+        r.ws_off += o;
+        r.dst += o;
     }
-    hipLaunchKernelGGL((k_wgrad<T, TM>), dim3((unsigned)blocks), dim3(256), W::LDS, s, p);
-    AY_CHECK_LAUNCH("k_wgrad");
-    return AYOLO_OK;
+    for (unsigned i = threadIdx.x * 4; i < r.n; i += 1024) {
+        const float* src = ws + r.ws_off + i;
+        float4v a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+        unsigned s = 0;
+        for (; s + 4 <= r.S; s += 4) {
+            a0 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(s + 0) * r.stride);
+            a1 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(s + 1) * r.stride);
+            a2 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(s + 2) * r.stride);
+            a3 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(s + 3) * r.stride);
+        }
+        for (; s < r.S; ++s) a0 += *reinterpret_cast<const float4v*>(src + (unsigned long long)s * r.stride);
+        float4v v = ((a0 + a1) + (a2 + a3)) * r.alpha;
+        float4v* d = reinterpret_cast<float4v*>(r.dst + i);
+        if (!r.overwrite) v += *d;
+        *d = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3165,65 +3195,363 @@ static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void
     return d->Cout <= 32 ? launch_stem_fwd<1, false>(q, s) : launch_stem_fwd<2, false>(q, s);
 }
 
-static int wgrad_dispatch(const ayolo_conv_desc* d, WGradP p, hipStream_t st) {
-    // the packed stem (see k_stem_wgrad)
-    if (is_packed_stem(d)) {
-        StemWP q{};
-        q.x = (const half_t*)p.x; q.dy = (const half_t*)p.dy; q.dw = p.dw;
-        q.B = d->B; q.H = d->H; q.WP = d->W; q.Ho = d->Ho; q.Wo = d->Wo; q.ldy = d->ldy; q.N = d->Cout; q.K = p.K; q.alpha = p.alpha;
-        q.tw = (d->Wo + STEM_TC - 1) / STEM_TC; q.th = (d->Ho + STEM_TR - 1) / STEM_TR;
-        q.ntiles = (long long)d->B * q.tw * q.th;
-        q.x_bytes = (unsigned)((long long)d->B * d->H * d->W * 16); q.y_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * d->ldy * 2);
-        return d->Cout <= 32 ? launch_stem_wgrad<1, false>(q, st) : launch_stem_wgrad<2, false>(q, st);
-    }
-    // buffer descriptors address < 2 GiB: larger activations are reduced as independent batch halves (dw accumulates)
-    const long long es = d->dtype == AYOLO_F16 ? 2 : 4;
-    const long long LIM = (1ll << 31) - 4096;
-    const long long x_img = (long long)p.XH * p.XW * p.ldx * es, y_img = (long long)p.OH * p.OW * p.ldy * es;
-    AY_CHECK_ARG(x_img < LIM && y_img < LIM, "conv_wgrad: a single image of %lld / %lld bytes unsupported", x_img, y_img);
-    if (x_img * p.B >= LIM || y_img * p.B >= LIM) {
-        WGradP a = p, b = p;
-        a.B = p.B / 2; b.B = p.B - a.B;
-        a.P = (long long)a.B * p.OH * p.OW; b.P = (long long)b.B * p.OH * p.OW;
-        b.x = (const char*)p.x + x_img * a.B;
-        b.dy = (const char*)p.dy + y_img * a.B;
-        int rc = wgrad_dispatch(d, a, st);
-        return rc ? rc : wgrad_dispatch(d, b, st);
-    }
-    p.x_bytes = (unsigned)(x_img * p.B); p.y_bytes = (unsigned)(y_img * p.B);
-    p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)p.C);
-    p.linear = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0) ? 1 : 0;
-    const int tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
-    if (d->dtype == AYOLO_F16) {
-        if (tm == 32) return launch_wgrad<half_t, 32>(p, st);
-        if (tm == 64) return launch_wgrad<half_t, 64>(p, st);
-        return launch_wgrad<half_t, 128>(p, st);
-    } else {
-        if (tm == 32) return launch_wgrad<float, 32>(p, st);
-        if (tm == 64) return launch_wgrad<float, 64>(p, st);
-        return launch_wgrad<float, 128>(p, st);
-    }
+// ---------------------------------------------------------------------------------------------------
+// Weight gradients, host side: planning of a (grouped) launch, the C entries.
+// ---------------------------------------------------------------------------------------------------
+static int wgrad_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
-extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha,
-                                ayolo_stream s) {
-    int rc = check_desc(d, "conv_wgrad");
-    if (rc) return rc;
-    AY_CHECK_ARG(x && dy && dw, "conv_wgrad: null pointer");
-    const int ce = d->dtype == AYOLO_F16 ? 8 : 4;
-    AY_CHECK_ARG(d->ldy % ce == 0, "conv_wgrad: ldy=%d must be a multiple of %d", d->ldy, ce);
-    WGradP p{};
-    p.x = x; p.dy = dy; p.dw = dw;
+// geometry of one job (a layer, or one batch half of a layer whose tensors exceed the 2 GiB descriptor range)
+static int wgrad_fill(const ayolo_conv_desc* d, const void* x, const void* dy, WGradP& p) {
+    p = WGradP{};
+    p.x = x; p.dy = dy;
     p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = d->ldx; p.C = d->Cin;
     p.OH = d->Ho; p.OW = d->Wo; p.ldy = d->ldy; p.N = d->Cout;
-    p.sh = d->sh; p.sw = d->sw; p.ntaps = d->kh * d->kw; p.K = p.ntaps * p.C; p.alpha = alpha;
+    p.sh = d->sh; p.sw = d->sw; p.ntaps = d->kh * d->kw; p.K = p.ntaps * p.C; p.alpha = 1.0f;
     p.P = (long long)d->B * d->Ho * d->Wo;
     for (int i = 0; i < d->kh; ++i)
         for (int j = 0; j < d->kw; ++j) {
             p.dh[i * d->kw + j] = (signed char)(i - d->ph);
             p.dw_[i * d->kw + j] = (signed char)(j - d->pw);
         }
-    return wgrad_dispatch(d, p, (hipStream_t)s);
+    p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)p.C);
+    p.linear = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0) ? 1 : 0;
+    p.tm = p.N <= 32 ? 32 : (p.N <= 64 ? 64 : 128);
+    p.gx = (unsigned)((p.K + TNW - 1) / TNW);
+    p.gy = (unsigned)((p.N + p.tm - 1) / p.tm);
+    p.dy_slot = -1;
+    return AYOLO_OK;
+}
+
+// one logical layer -> 1 .. n jobs (batch halves until x and dy fit a buffer descriptor), appended to `out`
+static int wgrad_halves(const ayolo_conv_desc* d, WGradP p, std::vector<WGradP>& out) {
+    const long long es = d->dtype == AYOLO_F16 ? 2 : 4;
+    const long long LIM = (1ll << 31) - 4096;
+    const long long x_img = (long long)p.XH * p.XW * p.ldx * es, y_img = (long long)p.OH * p.OW * p.ldy * es;
+    AY_CHECK_ARG(x_img < LIM && y_img < LIM, "conv_wgrad: a single image of %lld / %lld bytes unsupported", x_img, y_img);
+    if (x_img * p.B >= LIM || y_img * p.B >= LIM) {
+        AY_CHECK_ARG(p.dy_slot < 0, "conv_wgrad: a dy override cannot be split into batch halves");
+        WGradP a = p, b = p;
+        a.B = p.B / 2; b.B = p.B - a.B;
+        a.P = (long long)a.B * p.OH * p.OW; b.P = (long long)b.B * p.OH * p.OW;
+        b.x = (const char*)p.x + x_img * a.B;
+        b.dy = (const char*)p.dy + y_img * a.B;
+        int rc = wgrad_halves(d, a, out);
+        return rc ? rc : wgrad_halves(d, b, out);
+    }
+    p.x_bytes = (unsigned)(x_img * p.B); p.y_bytes = (unsigned)(y_img * p.B);
+    out.push_back(p);
+    return AYOLO_OK;
+}
+
+// pixel splits of a job for a target item length of `q` 32-pixel steps (at least 4 steps per split, every split non-empty)
+static void wgrad_split(WGradP& p, double q) {
+    const long long steps = (p.P + 31) / 32;
+    long long S = (long long)((double)steps / (q > 1.0 ? q : 1.0) + 0.5);
+    const long long smax = (steps + 3) / 4;
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    long long chunk = (p.P + S - 1) / S;
+    chunk = (chunk + 31) / 32 * 32;
+    p.chunk = chunk;
+    p.splits = (unsigned)((p.P + chunk - 1) / chunk);
+}
+
+// A group table (one contiguous blob; the caller keeps a host copy and a device copy):
+//   WGroupHdr | WGradP jobs[njobs] | WItem items[class 0] | items[class 1] | items[class 2] | WRed red[n_red]
+struct WGroupHdr {
+    unsigned magic, dtype, njobs, n_red;
+    unsigned n_items[3];               // item count per tile class (TM 32 / 64 / 128), each a multiple of 8
+    unsigned off_jobs, off_items[3], off_red;
+    unsigned long long ws_floats, table_bytes;
+};
+#define WGROUP_MAGIC 0x57475234u
+
+struct WGroupPlan {
+    std::vector<WGradP> jobs;
+    std::vector<WItem> items[3];
+    std::vector<WRed> red;
+    unsigned long long ws_floats = 0;
+    int dtype = AYOLO_F16;
+};
+
+static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
+    AY_CHECK_ARG(jj && njobs > 0 && njobs < 4096, "wgrad_group: %d jobs", njobs);
+    g.dtype = jj[0].conv.dtype;
+    struct Layer { size_t j0, j1; float* dw; float alpha; int overwrite; };
+    std::vector<Layer> layers;
+    for (int k = 0; k < njobs; ++k) {
+        const ayolo_wgrad_job& a = jj[k];
+        int rc = check_desc(&a.conv, "wgrad_group");
+        if (rc) return rc;
+        AY_CHECK_ARG(a.conv.dtype == g.dtype, "wgrad_group: job %d: mixed dtypes", k);
+        AY_CHECK_ARG(a.x && (a.dy || a.dy_slot >= 0) && a.dw && a.dy_slot < 4, "wgrad_group: job %d: null pointer / dy_slot %d", k, a.dy_slot);
+        const int ce = a.conv.dtype == AYOLO_F16 ? 8 : 4;
+        AY_CHECK_ARG(a.conv.ldy % ce == 0, "wgrad_group: job %d: ldy=%d must be a multiple of %d", k, a.conv.ldy, ce);
+        AY_CHECK_ARG(!is_packed_stem(&a.conv), "wgrad_group: job %d is the packed stem (ayolo_conv_wgrad / ayolo_stem_bn_wgrad)", k);
+        AY_CHECK_ARG(((uintptr_t)a.dw % 16) == 0 && ((long long)a.conv.Cout * a.conv.kh * a.conv.kw * a.conv.Cin) % 4 == 0,
+                     "wgrad_group: job %d: dw must be 16-byte aligned with a multiple of 4 elements", k);
+        WGradP p;
+        wgrad_fill(&a.conv, a.x, a.dy, p);
+        p.dy_slot = a.dy_slot;
+        const size_t j0 = g.jobs.size();
+        rc = wgrad_halves(&a.conv, p, g.jobs);
+        if (rc) return rc;
+        layers.push_back({j0, g.jobs.size(), a.dw, a.alpha, a.overwrite});
+    }
+    // ---- item length.  All items of the group together should fill the chip's workgroup slots a few times over (so that the
+    // tail of the launch is short against its body) without cutting a layer finer than ~AYOLO_WGRAD_MINQ steps per item
+    // (prologue + epilogue of a workgroup cost ~10 steps' worth of time; every extra split is one more N x K slot to store and add)
+    const int bpc = g.dtype == AYOLO_F16 ? 3 : 1;
+    const double slots = (double)num_cus() * bpc;
+    const double waves = (double)wgrad_env("AYOLO_WGRAD_WAVES", 3);
+    const double minq = (double)wgrad_env("AYOLO_WGRAD_MINQ", 24);
+    double total = 0.0;
+    for (const WGradP& p : g.jobs) total += (double)p.gx * p.gy * (double)((p.P + 31) / 32);
+    double q = total / (slots * waves);
+    if (q < minq) q = minq;
+    for (WGradP& p : g.jobs) wgrad_split(p, q);
+    // ---- workspace slots + reduction blocks, layer by layer
+    unsigned long long off = 0;
+    for (const Layer& L : layers) {
+        unsigned S = 0;
+        const unsigned long long nk = (unsigned long long)g.jobs[L.j0].N * (unsigned long long)g.jobs[L.j0].K;
+        for (size_t j = L.j0; j < L.j1; ++j) { g.jobs[j].ws_off = off; g.jobs[j].zz0 = S; S += g.jobs[j].splits; }
+        for (unsigned long long e = 0; e < nk; e += WRED_N) {
+            WRed r{};
+            r.ws_off = off + e; r.stride = nk; r.dst = L.dw + e; r.n = (unsigned)(nk - e < WRED_N ? nk - e : WRED_N); r.S = S;
+            r.alpha = L.alpha; r.overwrite = L.overwrite;
+            g.red.push_back(r);
+        }
+        off += (unsigned long long)S * nk;
+        off = (off + 63) / 64 * 64;
+    }
+    g.ws_floats = off;
+    // ---- items: per tile class, (job, split) groups -- the gx * gy tiles of one pixel split, back to back on one XCD -- dealt
+    // longest first to the XCD queue with the least work so far; queues padded to equal length, interleaved block % 8 = XCD
+    for (int c = 0; c < 3; ++c) {
+        const int tm = 32 << c;
+        struct Grp { unsigned job, zz; double cost; };
+        std::vector<Grp> grps;
+        for (size_t j = 0; j < g.jobs.size(); ++j) {
+            const WGradP& p = g.jobs[j];
+            if (p.tm != tm) continue;
+            for (unsigned z = 0; z < p.splits; ++z) {
+                const long long pb = (long long)z * p.chunk, pe = pb + p.chunk < p.P ? pb + p.chunk : p.P;
+                grps.push_back({(unsigned)j, z, (double)((pe - pb + 31) / 32)});
+            }
+        }
+        if (grps.empty()) continue;
+        std::stable_sort(grps.begin(), grps.end(), [](const Grp& a, const Grp& b) { return a.cost > b.cost; });
+        std::vector<WItem> qs[8];
+        double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (const Grp& gr : grps) {
+            int best = 0;
+            for (int x = 1; x < 8; ++x)
+                if (load[x] < load[best]) best = x;
+            const WGradP& p = g.jobs[gr.job];
+            const unsigned nt = p.gx * p.gy;
+            for (unsigned t = 0; t < nt; ++t) qs[best].push_back({gr.job, t, gr.zz, 0u});
+            load[best] += gr.cost * nt;
+        }
+        size_t len = 0;
+        for (int x = 0; x < 8; ++x) len = qs[x].size() > len ? qs[x].size() : len;
+        g.items[c].resize(len * 8);
+        for (size_t i = 0; i < len; ++i)
+            for (int x = 0; x < 8; ++x) g.items[c][i * 8 + x] = i < qs[x].size() ? qs[x][i] : WItem{0xffffffffu, 0u, 0u, 0u};
+    }
+    return AYOLO_OK;
+}
+
+static size_t wgroup_bytes(const WGroupPlan& g, WGroupHdr* h) {
+    WGroupHdr t{};
+    size_t o = (sizeof(WGroupHdr) + 63) / 64 * 64;
+    t.off_jobs = (unsigned)o; o += (g.jobs.size() * sizeof(WGradP) + 63) / 64 * 64;
+    for (int c = 0; c < 3; ++c) { t.off_items[c] = (unsigned)o; t.n_items[c] = (unsigned)g.items[c].size(); o += (g.items[c].size() * sizeof(WItem) + 63) / 64 * 64; }
+    t.off_red = (unsigned)o; o += (g.red.size() * sizeof(WRed) + 63) / 64 * 64;
+    t.magic = WGROUP_MAGIC; t.dtype = (unsigned)g.dtype; t.njobs = (unsigned)g.jobs.size(); t.n_red = (unsigned)g.red.size();
+    t.ws_floats = g.ws_floats; t.table_bytes = o;
+    if (h) *h = t;
+    return o;
+}
+
+extern "C" int ayolo_wgrad_group_size(const ayolo_wgrad_job* jobs, int njobs, size_t* table_bytes, size_t* ws_bytes) {
+    AY_CHECK_ARG(table_bytes && ws_bytes, "wgrad_group_size: null pointer");
+    WGroupPlan g;
+    int rc = wgroup_plan(jobs, njobs, g);
+    if (rc) return rc;
+    *table_bytes = wgroup_bytes(g, nullptr);
+    *ws_bytes = (size_t)g.ws_floats * sizeof(float);
+    return AYOLO_OK;
+}
+
+extern "C" int ayolo_wgrad_group_build(const ayolo_wgrad_job* jobs, int njobs, void* table, size_t table_bytes) {
+    AY_CHECK_ARG(table, "wgrad_group_build: null table");
+    WGroupPlan g;
+    int rc = wgroup_plan(jobs, njobs, g);
+    if (rc) return rc;
+    WGroupHdr h;
+    AY_CHECK_ARG(wgroup_bytes(g, &h) <= table_bytes, "wgrad_group_build: table of %zu bytes, %zu needed", table_bytes, (size_t)h.table_bytes);
+    unsigned char* t = (unsigned char*)table;
+    memset(t, 0, (size_t)h.table_bytes);
+    memcpy(t, &h, sizeof(h));
+    memcpy(t + h.off_jobs, g.jobs.data(), g.jobs.size() * sizeof(WGradP));
+    for (int c = 0; c < 3; ++c)
+        if (!g.items[c].empty()) memcpy(t + h.off_items[c], g.items[c].data(), g.items[c].size() * sizeof(WItem));
+    memcpy(t + h.off_red, g.red.data(), g.red.size() * sizeof(WRed));
+    return AYOLO_OK;
+}
+
+// introspection of a group table (tests, tools): header counts and the split geometry of one job
+extern "C" int ayolo_wgrad_group_info(const void* table_host, int job, long long* out, int nout) {
+    AY_CHECK_ARG(table_host && out && nout >= 12, "wgrad_group_info: out[12]");
+    const WGroupHdr& h = *(const WGroupHdr*)table_host;
+    AY_CHECK_ARG(h.magic == WGROUP_MAGIC, "wgrad_group_info: not a group table");
+    out[0] = h.njobs; out[1] = h.n_items[0]; out[2] = h.n_items[1]; out[3] = h.n_items[2]; out[4] = h.n_red; out[5] = (long long)h.ws_floats;
+    for (int k = 6; k < 12; ++k) out[k] = 0;
+    if (job >= 0) {
+        AY_CHECK_ARG((unsigned)job < h.njobs, "wgrad_group_info: job %d of %u", job, h.njobs);
+        const WGradP& p = ((const WGradP*)((const unsigned char*)table_host + h.off_jobs))[job];
+        out[6] = p.tm; out[7] = p.gx; out[8] = p.gy; out[9] = p.splits; out[10] = p.chunk; out[11] = p.zz0;
+    }
+    return AYOLO_OK;
+}
+/* item `i` of tile class `cls` (0: 32, 1: 64, 2: 128 output channels per tile): out = {job or -1, tile, split} */
+extern "C" int ayolo_wgrad_group_item(const void* table_host, int cls, long long i, long long* out) {
+    AY_CHECK_ARG(table_host && out && cls >= 0 && cls < 3, "wgrad_group_item: bad args");
+    const WGroupHdr& h = *(const WGroupHdr*)table_host;
+    AY_CHECK_ARG(h.magic == WGROUP_MAGIC && i >= 0 && i < (long long)h.n_items[cls], "wgrad_group_item: index %lld", i);
+    const WItem& it = ((const WItem*)((const unsigned char*)table_host + h.off_items[cls]))[i];
+    out[0] = it.job == 0xffffffffu ? -1 : (long long)it.job; out[1] = it.tile; out[2] = it.zz;
+    return AYOLO_OK;
+}
+
+template <typename T, int TM>
+static int launch_wgrad_k(const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned blocks, float* ws, const WOvr& ovr, hipStream_t s) {
+    using W = WT<T, TM>;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((k_wgrad<T, TM>), dim3(blocks), dim3(256), W::LDS, s, pv, jobs, items, ws, ovr);
+    AY_CHECK_LAUNCH("k_wgrad");
+    return AYOLO_OK;
+}
+
+static int launch_wgrad_any(int dtype, int tm, const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned blocks, float* ws,
+                            const WOvr& ovr, hipStream_t s) {
+    if (dtype == AYOLO_F16) {
+        if (tm == 32) return launch_wgrad_k<half_t, 32>(pv, jobs, items, blocks, ws, ovr, s);
+        if (tm == 64) return launch_wgrad_k<half_t, 64>(pv, jobs, items, blocks, ws, ovr, s);
+        return launch_wgrad_k<half_t, 128>(pv, jobs, items, blocks, ws, ovr, s);
+    }
+    if (tm == 32) return launch_wgrad_k<float, 32>(pv, jobs, items, blocks, ws, ovr, s);
+    if (tm == 64) return launch_wgrad_k<float, 64>(pv, jobs, items, blocks, ws, ovr, s);
+    return launch_wgrad_k<float, 128>(pv, jobs, items, blocks, ws, ovr, s);
+}
+
+extern "C" int ayolo_wgrad_group_run(const void* table_host, const void* table_dev, void* ws, size_t ws_bytes,
+                                     const void* const* dy_override, int n_override, ayolo_stream s) {
+    AY_CHECK_ARG(table_host && table_dev && ws, "wgrad_group_run: null pointer");
+    const WGroupHdr& h = *(const WGroupHdr*)table_host;
+    AY_CHECK_ARG(h.magic == WGROUP_MAGIC, "wgrad_group_run: not a group table");
+    AY_CHECK_ARG((size_t)h.ws_floats * 4 <= ws_bytes && ((uintptr_t)ws % 16) == 0, "wgrad_group_run: workspace of %zu bytes, %llu needed (16-byte aligned)",
+                 ws_bytes, (unsigned long long)h.ws_floats * 4);
+    AY_CHECK_ARG(n_override >= 0 && n_override <= 4 && (n_override == 0 || dy_override), "wgrad_group_run: %d overrides", n_override);
+    WOvr ovr{};
+    for (int k = 0; k < n_override; ++k) ovr.q[k] = dy_override[k];
+    const WGradP* hjobs = (const WGradP*)((const unsigned char*)table_host + h.off_jobs);
+    for (unsigned j = 0; j < h.njobs; ++j)
+        AY_CHECK_ARG(hjobs[j].dy_slot < n_override && (hjobs[j].dy_slot < 0 || ovr.q[hjobs[j].dy_slot]), "wgrad_group_run: job %u needs dy override %d", j,
+                     hjobs[j].dy_slot);
+    const unsigned char* td = (const unsigned char*)table_dev;
+    const WGradP* djobs = (const WGradP*)(td + h.off_jobs);
+    const WGradP none{};
+    for (int c = 0; c < 3; ++c) {
+        if (!h.n_items[c]) continue;
+        int rc = launch_wgrad_any((int)h.dtype, 32 << c, none, djobs, (const WItem*)(td + h.off_items[c]), h.n_items[c], (float*)ws, ovr, (hipStream_t)s);
+        if (rc) return rc;
+    }
+    if (h.n_red) {
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(h.n_red), dim3(256), 0, (hipStream_t)s, WRed{}, (const WRed*)(td + h.off_red), (const float*)ws);
+        AY_CHECK_LAUNCH("k_wgrad_reduce");
+    }
+    return AYOLO_OK;
+}
+
+static bool is_packed_stem(const ayolo_conv_desc* d);
+
+// single layer: the job travels by value (no table, no copy); split for the chip to itself
+static int wgrad_single_plan(const ayolo_conv_desc* d, const void* x, const void* dy, std::vector<WGradP>& jobs, unsigned long long* ws_floats) {
+    WGradP p;
+    wgrad_fill(d, x, dy, p);
+    int rc = wgrad_halves(d, p, jobs);
+    if (rc) return rc;
+    const int bpc = d->dtype == AYOLO_F16 ? 3 : 1;
+    double total = 0.0;
+    for (const WGradP& q : jobs) total += (double)q.gx * q.gy * (double)((q.P + 31) / 32);
+    double q = total / ((double)num_cus() * bpc * 2.0);
+    const double minq = (double)wgrad_env("AYOLO_WGRAD_MINQ", 24);
+    if (q < minq) q = minq;
+    unsigned S = 0;
+    for (WGradP& j : jobs) { wgrad_split(j, q); j.ws_off = 0; j.zz0 = S; S += j.splits; }
+    *ws_floats = (unsigned long long)S * (unsigned long long)p.N * (unsigned long long)p.K;
+    return AYOLO_OK;
+}
+
+extern "C" size_t ayolo_conv_wgrad_workspace(const ayolo_conv_desc* d) {
+    if (!d || check_desc(d, "conv_wgrad_workspace") != AYOLO_OK || is_packed_stem(d)) return 0;
+    std::vector<WGradP> jobs;
+    unsigned long long wf = 0;
+    if (wgrad_single_plan(d, d, d, jobs, &wf) != AYOLO_OK) return 0;      // pointers are not looked at by the sizing
+    return (size_t)wf * sizeof(float);
+}
+
+extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha, void* ws, size_t ws_bytes,
+                                ayolo_stream s) {
+    int rc = check_desc(d, "conv_wgrad");
+    if (rc) return rc;
+    AY_CHECK_ARG(x && dy && dw, "conv_wgrad: null pointer");
+    const int ce = d->dtype == AYOLO_F16 ? 8 : 4;
+    AY_CHECK_ARG(d->ldy % ce == 0, "conv_wgrad: ldy=%d must be a multiple of %d", d->ldy, ce);
+    if (is_packed_stem(d)) {         // the packed stem (see k_stem_wgrad): one set of atomics per workgroup, no workspace
+        StemWP q{};
+        q.x = (const half_t*)x; q.dy = (const half_t*)dy; q.dw = dw;
+        q.B = d->B; q.H = d->H; q.WP = d->W; q.Ho = d->Ho; q.Wo = d->Wo; q.ldy = d->ldy; q.N = d->Cout; q.K = d->kh * d->kw * d->Cin; q.alpha = alpha;
+        q.tw = (d->Wo + STEM_TC - 1) / STEM_TC; q.th = (d->Ho + STEM_TR - 1) / STEM_TR;
+        q.ntiles = (long long)d->B * q.tw * q.th;
+        q.x_bytes = (unsigned)((long long)d->B * d->H * d->W * 16); q.y_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * d->ldy * 2);
+        return d->Cout <= 32 ? launch_stem_wgrad<1, false>(q, (hipStream_t)s) : launch_stem_wgrad<2, false>(q, (hipStream_t)s);
+    }
+    std::vector<WGradP> jobs;
+    unsigned long long wf = 0;
+    rc = wgrad_single_plan(d, x, dy, jobs, &wf);
+    if (rc) return rc;
+    AY_CHECK_ARG(ws && ((uintptr_t)ws % 16) == 0 && (size_t)wf * 4 <= ws_bytes,
+                 "conv_wgrad: split-K workspace of %zu bytes, %llu needed (ayolo_conv_wgrad_workspace; 16-byte aligned)", ws_bytes, wf * 4);
+    const unsigned long long nk = (unsigned long long)jobs[0].N * (unsigned long long)jobs[0].K;
+    AY_CHECK_ARG(((uintptr_t)dw % 16) == 0 && nk % 4 == 0, "conv_wgrad: dw must be 16-byte aligned with a multiple of 4 elements");
+    unsigned S = 0;
+    const WOvr ovr{};
+    for (const WGradP& j : jobs) {
+        const long long blocks = (long long)j.gx * j.gy * ((j.splits + 7) / 8 * 8);
+        AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
+        rc = launch_wgrad_any(d->dtype, j.tm, j, nullptr, nullptr, (unsigned)blocks, (float*)ws, ovr, (hipStream_t)s);
+        if (rc) return rc;
+        S += j.splits;
+    }
+    WRed r{};
+    r.ws_off = 0; r.stride = nk; r.dst = dw; r.S = S; r.alpha = alpha; r.overwrite = 0;
+    AY_CHECK_ARG(nk < (1ull << 32), "conv_wgrad: dw of %llu elements", nk);
+    r.n = (unsigned)nk;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nk + WRED_N - 1) / WRED_N)), dim3(256), 0, (hipStream_t)s, r, (const WRed*)nullptr, (const float*)ws);
+    AY_CHECK_LAUNCH("k_wgrad_reduce");
+    return AYOLO_OK;
 }
 
 // Stem block backward in ONE launch (see k_stem_wgrad<MB, true>): BatchNorm + activation backward of the stem's output

@@ -144,8 +144,26 @@ def conv_dgrad_bn(desc: ConvDesc, dy, wt, dx, segs, act: int, accumulate=False):
     call("ayolo_conv_dgrad_bn", desc, _ptr(dy), _ptr(wt), _ptr(dx), int(accumulate), arr, len(segs), int(act), reps, _stream())
 
 
+_WGRAD_WS: dict = {}         # (device, stream) -> split-K workspace of the single-layer weight gradient (grown on demand)
+
+
+def wgrad_workspace(nbytes: int, device) -> "torch.Tensor":
+    """Workspace for ayolo_conv_wgrad's split-K partial sums: one buffer per (device, stream) -- launches on a stream are
+    ordered, so consecutive layers can share it -- grown to the largest request seen."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WGRAD_WS[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        while len(_WGRAD_WS) > 16:
+            _WGRAD_WS.pop(next(iter(_WGRAD_WS)))
+    return ws
+
+
 def conv_wgrad(desc: ConvDesc, x, dy, dw, alpha=1.0):
-    call("ayolo_conv_wgrad", desc, _ptr(x), _ptr(dy), _ptr(dw), float(alpha), _stream())
+    """dw += alpha * sum_pixels dy (x) x (ayolo_conv_wgrad: split-K partials in a workspace, fixed-order reduction)."""
+    need = int(_lib.lib().ayolo_conv_wgrad_workspace(desc))
+    ws = wgrad_workspace(need, dw.device) if need else None
+    call("ayolo_conv_wgrad", desc, _ptr(x), _ptr(dy), _ptr(dw), float(alpha), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
 
 
 def cast_weight(w32_krsc: torch.Tensor, Cout, kh, kw, Cin, Cout_pad, Cin_pad, dtype: torch.dtype, want_w=True,

@@ -34,6 +34,7 @@ from .modules import C3, SPPF, Bottleneck, Concat, Conv, UpSample, YOLOHead, _ac
  OP_COPY2D, OP_MEMSET, OP_BN_EVAL_AFFINE, OP_BN_TRAIN_ACT, OP_CAST_WEIGHTS) = range(1, 20)
 OP_JOIN_SIDE = 21
 OP_STEM_BN_WGRAD = 22
+OP_WGRAD_GROUP = 23
 
 
 class Op(ctypes.Structure):
@@ -70,6 +71,12 @@ MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: c
 # BatchNorm-backward sums (the first of the two backward passes of a Conv-BN-act block) computed in the epilogue of the
 # dgrad that produces the block's output gradient, instead of a pass of its own over da and z (ayolo_conv_dgrad_bn)
 BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
+# Weight gradients run as a few GROUPED launches (ayolo_wgrad_group_run: one launch per tile class over the item list of all
+# layers of a group + one fixed-order reduction of the split-K partials) instead of one launch per layer.  The backward list is
+# cut into this many groups of similar work (the last one is halved AYOLO_WGRAD_TAIL more times: what the final group still has
+# to do when the main stream's backward ends is exposed); 0 = one launch per layer (same kernels, for A/B).
+WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "8"))
+WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
 
 
 class PlanUnsupported(Exception):
@@ -161,6 +168,9 @@ class TrainPlan:
         self.bwd_sync: list = []                            # sync_bn: (index of the reduce op, sums view)
         self.draw_ops: List[Op] = []
         self._head_dz: Dict[int, Tuple[int, int]] = {}
+        self._wjobs: List[dict] = []                        # weight-gradient jobs in backward order (grouped after emission)
+        self.wgroup_costs: Dict[int, Tuple[float, float, int]] = {}   # backward op index -> (bytes, flop, layers) of a group launch
+        self.wgroup_slots: List[Tuple[int, int]] = []       # (backward op index, head level) pairs: dy override pointers to patch
         self.pack_op: Optional[Op] = None
         self._compile()
 
@@ -188,11 +198,105 @@ class TrainPlan:
     def _dz(self, n: int) -> torch.Tensor:
         """Backward operand dz of one layer: a slice of the shared scratch buffer, or -- when weight gradients run on the
         side stream and therefore outlive the layer's turn -- a buffer of its own."""
-        if WGRAD_SIDE_STREAM:
+        if WGRAD_SIDE_STREAM or WGRAD_GROUPS > 0:           # grouped launches also read dz long after the layer's turn
             t = torch.empty(n, dtype=self.dt, device=self.device)
             self.keep.append(t)
             return t
         return self.dz_buf[:n]
+
+    def _wgrad_job(self, desc: ConvDesc, x: torch.Tensor, dy: torch.Tensor, off: int, n: int, dy_slot: int = -1) -> None:
+        """One layer's weight gradient: a slot in the backward list now (dz is complete here), the launch later
+        (_group_wgrads: the slot of the LAST layer of a group becomes the group's launch, the others stay empty)."""
+        self.bwd.append(_op(0))
+        self._wjobs.append(dict(idx=len(self.bwd) - 1, desc=desc, x=x, dy=dy, off=off, n=n, slot=dy_slot))
+
+    def _group_wgrads(self) -> None:
+        from ._lib import WgradJob
+        jobs = self._wjobs
+        if not jobs:
+            return
+        ga = self.gradarena
+        side = OP_SIDE if WGRAD_SIDE_STREAM else 0
+        lib = _lib.lib()
+        es = 2 if self.dt == torch.float16 else 4
+
+        def cost(j):                                       # 32-pixel steps x dw tiles: what a launch's duration scales with
+            d = j["desc"]
+            tm = 32 if d.Cout <= 32 else (64 if d.Cout <= 64 else 128)
+            tiles = -(-(d.kh * d.kw * d.Cin) // 128) * -(-d.Cout // tm)
+            return tiles * -(-(d.B * d.Ho * d.Wo) // 32)
+
+        def account(js):
+            by = sum(es * (j["desc"].B * j["desc"].H * j["desc"].W * j["desc"].Cin + j["desc"].B * j["desc"].Ho * j["desc"].Wo * j["desc"].Cout)
+                     + 4 * j["n"] for j in js)
+            fl = sum(2.0 * j["desc"].B * j["desc"].Ho * j["desc"].Wo * j["desc"].Cout * j["desc"].kh * j["desc"].kw * j["desc"].Cin for j in js)
+            return float(by), fl, len(js)
+
+        if WGRAD_GROUPS <= 0:
+            # one launch per layer (A/B against the grouped launches): the same kernels, a shared split-K workspace
+            need = max(int(lib.ayolo_conv_wgrad_workspace(j["desc"])) for j in jobs)
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+            self.keep.append(ws)
+            for j in jobs:
+                o = _op(OP_CONV_WGRAD | side, f=(1.0,), l=(ws.numel(),), p=(j["x"], j["dy"], ga.view(j["off"], j["n"]), ws), conv=j["desc"])
+                self.bwd[j["idx"]] = o
+                self.grad_done.append((j["idx"], j["off"], j["n"]))
+                if j["slot"] >= 0:
+                    self.wgroup_slots.append((j["idx"], j["slot"]))
+            self.wgroup_single = True
+            return
+        self.wgroup_single = False
+        # ---- cut the jobs (backward order) into groups of similar work; the tail is cut finer
+        costs = [cost(j) for j in jobs]
+        total = float(sum(costs))
+        targets = [total / WGRAD_GROUPS] * max(WGRAD_GROUPS - 1, 0)
+        rest = total / WGRAD_GROUPS
+        for _ in range(max(WGRAD_TAIL, 0)):
+            rest /= 2
+            targets.append(rest)
+        targets.append(rest)
+        groups, cur, acc, t = [], [], 0.0, 0
+        for j, c in zip(jobs, costs):
+            cur.append(j)
+            acc += c
+            if acc >= targets[min(t, len(targets) - 1)] * 0.999 and j is not jobs[-1]:
+                groups.append(cur)
+                cur, acc, t = [], 0.0, t + 1
+        if cur:
+            groups.append(cur)
+        # ---- one table per group (host copy + device copy), one workspace for all (they run back to back on one stream)
+        built = []
+        ws_need = 16
+        for js in groups:
+            arr = (WgradJob * len(js))()
+            for k, j in enumerate(js):
+                arr[k].conv = j["desc"]
+                arr[k].x, arr[k].dy = j["x"].data_ptr(), j["dy"].data_ptr()
+                arr[k].dw = ga.view(j["off"], j["n"]).data_ptr()
+                arr[k].alpha, arr[k].dy_slot, arr[k].overwrite = 1.0, j["slot"], 1       # nothing else writes these arena ranges
+            tb, wb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            _lib.check(lib.ayolo_wgrad_group_size(arr, len(js), ctypes.byref(tb), ctypes.byref(wb)), "ayolo_wgrad_group_size")
+            host = ctypes.create_string_buffer(tb.value)
+            _lib.check(lib.ayolo_wgrad_group_build(arr, len(js), host, tb.value), "ayolo_wgrad_group_build")
+            dev = torch.frombuffer(host, dtype=torch.uint8).clone().to(self.device)
+            ws_need = max(ws_need, wb.value)
+            built.append((js, host, dev))
+            self.keep += [host, dev]
+        ws = torch.empty(ws_need, dtype=torch.uint8, device=self.device)
+        self.keep.append(ws)
+        self.wgroup_ws_bytes = ws_need
+        for js, host, dev in built:
+            idx = js[-1]["idx"]                           # the group launches where its LAST layer's dz is complete
+            slots = sorted({j["slot"] for j in js if j["slot"] >= 0})
+            nov = (max(slots) + 1) if slots else 0
+            o = _op(OP_WGRAD_GROUP | side, i=(nov,), l=(ws.numel(),), p=(ctypes.addressof(host), dev, ws))
+            for j in js:
+                if j["slot"] >= 0:
+                    o.p[3 + j["slot"]] = j["dy"].data_ptr()
+                    self.wgroup_slots.append((idx, j["slot"]))
+                self.grad_done.append((idx, j["off"], j["n"]))
+            self.bwd[idx] = o
+            self.wgroup_costs[idx] = account(js)
 
     # ------------------------------------------------------------------ conv + BN + act
     def _conv_block(self, mod: Conv, x: Optional[Act], dst: Optional[Act], residual: Optional[Act] = None,
@@ -369,20 +473,17 @@ class TrainPlan:
                                             p=(da, dr)))
                     self._gw(residual, False)
                     residual.mark_init()
-            def wgrad():
-                self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(xk, dz, ga.view(gw_off0, Ct * K)),
-                                    conv=geo.desc(dt, ldx, Ct)))
-                self._wrote(gw_off0, Ct * K)
-
             if stem_fused:
                 return
+            # the weight gradient only needs dz: its slot comes BEFORE the layer's dgrad, so that a (grouped) launch forked
+            # here does not wait for that dgrad
+            self._wgrad_job(geo.desc(dt, ldx, Ct), xk, dz, gw_off0, Ct * K)
             if not image:
                 dx = x_act.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
                                     conv=geo.desc(dt, ops.nhwc_info(dx)[4], Ct)))
                 self._gw(x_act, True)
                 x_act.mark_init()
-            wgrad()
 
         self.bwd_emitters.append(emit_bwd)
         return outs
@@ -468,6 +569,8 @@ class TrainPlan:
 
     def _head(self, head: YOLOHead, xs: List[Act]) -> None:
         dt, dev = self.dt, self.device
+        if len(xs) > 4:
+            raise PlanUnsupported("more than four detection levels")      # dy override slots of a grouped weight gradient
         for lvl, x in enumerate(xs):
             conv = head.conv[lvl]
             if not isinstance(conv, nn.Conv2d) or conv.weight.dtype != torch.float32:
@@ -491,7 +594,7 @@ class TrainPlan:
             self.dz_elems = max(self.dz_elems, npix * cp)
             code = ops.dtype_code(dt)
 
-            def emit(x=x, geo=geo, wt=wt, cp=cp, Cin=Cin, Cout=Cout, B=B, H=H, W=W, gw_off=gw_off, gb_off=gb_off, ldx=ldx, npix=npix):
+            def emit(x=x, geo=geo, wt=wt, cp=cp, Cin=Cin, Cout=Cout, B=B, H=H, W=W, gw_off=gw_off, gb_off=gb_off, ldx=ldx, npix=npix, lvl=lvl):
                 ga = self.gradarena
                 dz = self._dz(npix * cp)
                 op = _op(OP_HEAD_GRAD_PACK, i=(B, head.na, H, W, head.no, code, cp),
@@ -503,9 +606,8 @@ class TrainPlan:
                                     conv=geo.desc(dt, ops.nhwc_info(dx)[4], cp, cout=cp)))
                 self._gw(x, True)
                 x.mark_init()
-                self.bwd.append(_op(OP_CONV_WGRAD | (OP_SIDE if WGRAD_SIDE_STREAM else 0), f=(1.0,), p=(x.t, dz, ga.view(gw_off, cp * Cin)),
-                                    conv=geo.desc(dt, ldx, cp, cout=cp)))
-                self._wrote(gw_off, cp * Cin)
+                # dy of a head level changes from step to step (the fused loss hands its own buffer over): override slot = level
+                self._wgrad_job(geo.desc(dt, ldx, cp, cout=cp), x.t, dz, gw_off, cp * Cin, dy_slot=lvl)
                 self._wrote(gb_off, Cout, at=0)          # bias gradient: pack op, or the fused loss before the list runs
 
             self.bwd_emitters.append(emit)
@@ -603,6 +705,7 @@ class TrainPlan:
         self.bwd = []
         for emit in reversed(self.bwd_emitters):
             emit()
+        self._group_wgrads()
         self._fold_bn_reduce()
         self.fwd_arr = (Op * len(self.fwd))(*self.fwd)
         self.bwd_arr = (Op * len(self.bwd))(*self.bwd)
@@ -775,8 +878,12 @@ class TrainPlan:
         fp32 weight gradients), flop = 2 * MAC of the convolutions."""
         es = 2 if self.dt == torch.float16 else 4
         out = []
-        for o in (self.fwd if what == "forward" else self.bwd):
+        for k_op, o in enumerate(self.fwd if what == "forward" else self.bwd):
             kind = o.kind & 0xff
+            if kind == OP_WGRAD_GROUP and what != "forward":
+                by, fl, _ = self.wgroup_costs[k_op]
+                out.append(("conv_wgrad", by, fl))
+                continue
             d = o.conv
             macs = d.B * d.Ho * d.Wo * d.Cout * d.kh * d.kw * d.Cin
             xin, yout, wts = d.B * d.H * d.W * d.Cin, d.B * d.Ho * d.Wo * d.Cout, d.Cout * d.kh * d.kw * d.Cin
@@ -849,6 +956,15 @@ class TrainPlan:
             pool.append(entry)
         return entry
 
+    def _head_wgrad_dy(self, lvl: int, ptr: int) -> None:
+        """this step's dz of head level `lvl` -> the weight-gradient launch that carries that level"""
+        for k, slot in self.wgroup_slots:
+            if slot == lvl:
+                if self.wgroup_single:
+                    self.bwd_arr[k].p[1] = ptr
+                else:
+                    self.bwd_arr[k].p[3 + lvl] = ptr
+
     def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
         from .losses import take_packed_head_grad
         keep = []
@@ -856,7 +972,7 @@ class TrainPlan:
         for idx, lvl in zip(self.draw_idx, self.draw_levels):
             d = draws[lvl]
             buf, shape = self.raw_specs[lvl][:2]
-            op, dg, wg = self.bwd_arr[idx], self.bwd_arr[idx + 1], self.bwd_arr[idx + 2]   # pack, head dgrad, head wgrad
+            op, dg = self.bwd_arr[idx], self.bwd_arr[idx + 1]                              # pack, head dgrad
             if idx not in self._head_dz:
                 self._head_dz[idx] = (op.p[1], op.p[2])
             dz0, dbias0 = self._head_dz[idx]
@@ -865,14 +981,14 @@ class TrainPlan:
                 # gradient already in the head conv's operand layout: skip the pack op, point dgrad / wgrad at it
                 op.kind = 0
                 dg.p[0] = pk[0].data_ptr()
-                wg.p[1] = pk[0].data_ptr()
+                self._head_wgrad_dy(lvl, pk[0].data_ptr())
                 keep += [pk[0], pk[1]]
                 if dbias0 and pk[1].data_ptr() != dbias0:
                     late_bias.append((dbias0, pk[1]))
                 continue
             op.kind = OP_HEAD_GRAD_PACK
             dg.p[0] = dz0
-            wg.p[1] = dz0
+            self._head_wgrad_dy(lvl, dz0)
             if d is None:
                 d = torch.zeros(shape, dtype=torch.float32, device=self.device)
             if d.dtype != torch.float32 or not d.is_contiguous():

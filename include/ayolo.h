@@ -101,9 +101,38 @@ typedef struct ayolo_bn_seg {
 int ayolo_conv_dgrad_bn(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
                         const ayolo_bn_seg* segs, int nseg, int act, int sum_reps, ayolo_stream s);
 
-/* dw[Cout][kh][kw][Cin] (fp32, must be zeroed by the caller) += sum_pixels dy (x) x ; alpha scales the result. */
-int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha,
+/* Weight gradient (autograd's ConvolutionBackward weight leg behind scripts/train/yolo_trainer.py:329):
+ * dw[Cout][kh][kw][Cin] (fp32) += alpha * sum_pixels dy (x) x.  The pixel reduction is split over workgroups; every split
+ * STORES its tile sums into its own slot of the caller's workspace `ws` (ayolo_conv_wgrad_workspace(d) bytes, 16-byte
+ * aligned) and a second kernel adds the slots in a fixed order -- no atomics, bit-reproducible.  The packed stem needs no
+ * workspace (0 bytes). */
+size_t ayolo_conv_wgrad_workspace(const ayolo_conv_desc* d);
+int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, float* dw, float alpha, void* ws, size_t ws_bytes,
                      ayolo_stream s);
+/* The weight gradients of SEVERAL layers as one launch per tile class + one reduction (they have no mutual dependencies:
+ * in the reference they are ~60 independent cuDNN wgrad launches inside loss.backward(), yolo_trainer.py:329; here a group
+ * = the layers of one reverse-layer gradient bucket, scripts/train/train_model_builder.py:75-78).  Planning (pixel splits,
+ * the per-XCD item queues) happens ONCE: _size reports the bytes of the group table and of the split-K workspace, _build
+ * fills the table in HOST memory, the caller keeps that copy and uploads another to the device; _run launches from both.
+ * dy_slot >= 0: the job's dy is dy_override[dy_slot] of the run call (YOLOHead levels: the loss hands over a different buffer
+ * each step); overwrite: dw = alpha * sum instead of dw += alpha * sum.  Workspaces of groups that run on the same stream may
+ * be shared.  The packed stem is not a group job (ayolo_conv_wgrad / ayolo_stem_bn_wgrad). */
+typedef struct ayolo_wgrad_job {
+    ayolo_conv_desc conv;     /* the forward conv's descriptor with ldy = channel stride of dy */
+    const void* x; const void* dy; float* dw;
+    float alpha;
+    int dy_slot, overwrite, reserved;
+} ayolo_wgrad_job;
+int ayolo_wgrad_group_size(const ayolo_wgrad_job* jobs, int njobs, size_t* table_bytes, size_t* ws_bytes);
+int ayolo_wgrad_group_build(const ayolo_wgrad_job* jobs, int njobs, void* table_host, size_t table_bytes);
+int ayolo_wgrad_group_run(const void* table_host, const void* table_dev, void* ws, size_t ws_bytes,
+                          const void* const* dy_override, int n_override, ayolo_stream s);
+/* introspection of a host table (tests / tools): out[0..5] = jobs (batch halves count as jobs), items of tile class 32 / 64 /
+ * 128, reduction blocks, workspace floats; job >= 0: out[6..11] = its tile class, column tiles, channel tiles, pixel splits,
+ * pixels per split, first workspace slot.  _item: {job or -1 (queue padding), tile, split} of item i of a tile class;
+ * block i of a class's launch runs on XCD i % 8. */
+int ayolo_wgrad_group_info(const void* table_host, int job, long long* out, int nout);
+int ayolo_wgrad_group_item(const void* table_host, int cls, long long i, long long* out);
 /* Backward of the STEM block (kindle Conv row 0, res/configs/model/yolov5s.yaml:21: Conv-BN-SiLU on the image) in one launch:
  * the BatchNorm + activation backward of its output gradient da and the weight gradient of its conv.  The stem has no input
  * gradient, so its dz has no other reader: the kernel forms dz = bn_act_backward(da, z; sums) on the way from HBM to LDS
@@ -423,7 +452,9 @@ enum {
     AYOLO_OP_UPSAMPLE_FWD, AYOLO_OP_UPSAMPLE_BWD, AYOLO_OP_PACK_INPUT, AYOLO_OP_HEAD_GRAD_PACK, AYOLO_OP_COPY2D,
     AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT, AYOLO_OP_CAST_WEIGHTS, AYOLO_OP_HEAD_DECODE,
     AYOLO_OP_JOIN_SIDE,         /* the caller's stream waits for everything enqueued so far on the side stream */
-    AYOLO_OP_STEM_BN_WGRAD      /* ayolo_stem_bn_wgrad */
+    AYOLO_OP_STEM_BN_WGRAD,     /* ayolo_stem_bn_wgrad */
+    AYOLO_OP_WGRAD_GROUP        /* ayolo_wgrad_group_run: p[0] table (host), p[1] table (device), p[2] workspace, l[0] its bytes,
+                                 * p[3..6] dy overrides, i[0] their count */
 };
 typedef struct ayolo_op {
     int kind;

@@ -582,3 +582,69 @@ def test_stem_forward_kernel_inference_epilogue(shape, act):
     if act:
         ref = F.silu(ref)
     assert float((y.float().cpu() - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32])
+def test_wgrad_grouped_launch_vs_single_layer_and_bit_reproducible(dt):
+    """ayolo_wgrad_group_run (one launch per tile class over the item list of several layers, split-K
+    partials stored with plain stores, fixed-order reduction) against the single-layer entry on the same operands -- all three
+    tile classes, 3x3 / stride 2 / 1x1 layers, one layer whose dy arrives through an override slot, overwrite and accumulate
+    reductions -- and against torch; two runs of either route must agree BIT FOR BIT (no atomics anywhere)."""
+    import ctypes
+    from ayolov2_amd import _lib, ops
+    from ayolov2_amd._lib import WgradJob
+    g = torch.Generator(device="cuda").manual_seed(77)
+    # (B, Cin, Cout, k, s, p, H, W)
+    layers = [(4, 64, 32, 3, 1, 1, 24, 20), (4, 32, 64, 3, 2, 1, 40, 40), (3, 128, 160, 1, 1, 0, 20, 24), (2, 64, 256, 3, 1, 1, 10, 12),
+              (4, 96, 48, 1, 1, 0, 16, 16)]
+    ops_, wants = [], []
+    for (B, Ci, Co, k, s, p, H, W) in layers:
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        x = torch.randn(B, Ci, H, W, device="cuda", generator=g).to(dt).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(B, Co, Ho, Wo, device="cuda", generator=g).to(dt).contiguous(memory_format=torch.channels_last)
+        want = torch.nn.grad.conv2d_weight(x.float().cpu(), (Co, Ci, k, k), dy.float().cpu(), stride=s, padding=p)
+        d = ops.make_desc(dt, B, H, W, Ci, Ci, Co, Co, (k, k), (s, s), (p, p), Ho, Wo)
+        ops_.append((d, x, dy))
+        wants.append(want.permute(0, 2, 3, 1).contiguous())            # KRSC, the layout of dw
+    n = len(layers)
+
+    def single():
+        outs = []
+        for d, x, dy in ops_:
+            dw = torch.zeros((d.Cout, d.kh, d.kw, d.Cin), dtype=torch.float32, device="cuda")
+            ops.conv_wgrad(d, x, dy, dw, alpha=0.5)
+            outs.append(dw)
+        return outs
+
+    lib = _lib.lib()
+    base = [torch.full((d.Cout, d.kh, d.kw, d.Cin), 3.0, dtype=torch.float32, device="cuda") for d, _, _ in ops_]
+
+    def grouped():
+        dws = [b.clone() for b in base]
+        arr = (WgradJob * n)()
+        for k, ((d, x, dy), dw) in enumerate(zip(ops_, dws)):
+            arr[k].conv = d
+            arr[k].x, arr[k].dw = x.data_ptr(), dw.data_ptr()
+            arr[k].dy = 0 if k == 2 else dy.data_ptr()                 # layer 2: dy through override slot 1
+            arr[k].alpha, arr[k].dy_slot, arr[k].overwrite = 0.5, (1 if k == 2 else -1), (0 if k == 4 else 1)
+        tb, wb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _lib.check(lib.ayolo_wgrad_group_size(arr, n, ctypes.byref(tb), ctypes.byref(wb)), "size")
+        host = ctypes.create_string_buffer(tb.value)
+        _lib.check(lib.ayolo_wgrad_group_build(arr, n, host, tb.value), "build")
+        dev = torch.frombuffer(host, dtype=torch.uint8).clone().cuda()
+        ws = torch.empty(max(wb.value, 16), dtype=torch.uint8, device="cuda")
+        ovr = (ctypes.c_void_p * 2)(None, ops_[2][2].data_ptr())
+        _lib.check(lib.ayolo_wgrad_group_run(ctypes.addressof(host), dev.data_ptr(), ws.data_ptr(), ws.numel(), ovr, 2,
+                                            torch.cuda.current_stream().cuda_stream), "run")
+        torch.cuda.synchronize()
+        return dws
+
+    s1, s2, g1, g2 = single(), single(), grouped(), grouped()
+    tol = 1e-4 if dt == torch.float32 else 2e-3
+    for k in range(n):
+        assert torch.equal(s1[k], s2[k]) and torch.equal(g1[k], g2[k]), f"layer {k}: not bit-reproducible"
+        want = 0.5 * wants[k]
+        scale = float(want.abs().max())
+        assert float((s1[k].cpu() - want).abs().max()) <= tol * scale, k
+        got = g1[k].cpu() - (3.0 if k == 4 else 0.0)                     # layer 4 accumulates onto its old contents
+        assert float((got - want).abs().max()) <= tol * scale + (1e-5 if k == 4 else 0.0), k

@@ -342,12 +342,73 @@ def test_plan_gradient_buckets_cover_the_arena():
     # C3's cv1 | cv2 run as one conv: 8 fewer forward / dgrad / wgrad launches than the 60 convolutions of the model
     from collections import Counter
     kinds = Counter(o.kind & 0xff for o in pl.bwd)
-    assert kinds[3] + kinds[22] == 52 and kinds[2] == 51 and kinds[22] == 1      # 22: the stem's fused BN-backward + weight gradient
+    # weight gradients: 51 layers in <= 12 grouped launches (23) + the stem's fused BN-backward + weight gradient (22)
+    assert kinds[3] == 0 and kinds[2] == 51 and kinds[22] == 1 and 4 <= kinds[23] <= 12
+    assert sum(v[2] for v in pl.wgroup_costs.values()) == 51 and len(pl.wgroup_costs) == kinds[23]
+    gidx = sorted(pl.wgroup_costs)
+    assert all((pl.bwd[k].kind & 0xff) == 23 for k in gidx)
+    # the tail of backward is cut finer than its body (what the last group still has to do after the main stream is exposed)
+    assert pl.wgroup_costs[gidx[-1]][1] < 0.6 * max(v[1] for v in pl.wgroup_costs.values())
     # sync_bn cut points: one per conv launch (forward), one per BatchNorm layer (backward)
     assert len(pl.fwd_sync_idx) == 49 and len(pl.bwd_sync) == 57
     # fp16 plans fold the BatchNorm-backward sums of every layer whose output gradient is last written by a conv dgrad into
     # that dgrad's epilogue (all but the three fed by pool / upsample backward ops): the separate reduce op becomes a no-op
     assert pl.bn_in_dgrad == 54 and kinds[0] >= 54 and kinds[7] == 3
+
+
+def test_wgrad_group_tables_cover_every_tile_once():
+    """The planner of the grouped weight-gradient launch (ayolo_wgrad_group_size / _build; needs no GPU): every (layer,
+    dw tile, pixel split) is exactly one item of its tile class, the gx * gy tiles of one split sit on ONE XCD queue (block
+    index % 8) back to back, queues are padded to equal length, the splits of a layer own disjoint workspace slots and a
+    layer whose tensors exceed the 2 GiB descriptor range is cut into batch halves that share one reduction."""
+    import ctypes
+    from ayolov2_amd import _lib, ops
+    from ayolov2_amd._lib import WgradJob
+    lib = _lib.lib()
+    F16 = 0
+    shapes = [  # (B, H, W, Cin, Cout, k, s)
+        (8, 40, 40, 128, 128, 3, 1), (8, 40, 40, 256, 64, 1, 1), (8, 80, 80, 64, 32, 3, 2), (8, 20, 20, 512, 255 + 1, 1, 1),
+        (192, 320, 320, 64, 64, 1, 1)]           # the last: x = dy = 2.5 GB -> two batch halves of 1.26 GB
+    arr = (WgradJob * len(shapes))()
+    for k, (B, H, W, Ci, Co, kk, st) in enumerate(shapes):
+        pd = kk // 2
+        Ho, Wo = (H + 2 * pd - kk) // st + 1, (W + 2 * pd - kk) // st + 1
+        arr[k].conv = ops.make_desc(torch.float16, B, H, W, Ci, Ci, Co, Co, (kk, kk), (st, st), (pd, pd), Ho, Wo)
+        arr[k].x, arr[k].dy, arr[k].dw = 0x10000, (0 if k == 3 else 0x20000), 0x30000 + 0x1000000 * k
+        arr[k].alpha, arr[k].dy_slot, arr[k].overwrite = 1.0, (1 if k == 3 else -1), 1
+    tb, wb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _lib.check(lib.ayolo_wgrad_group_size(arr, len(shapes), ctypes.byref(tb), ctypes.byref(wb)), "size")
+    host = ctypes.create_string_buffer(tb.value)
+    _lib.check(lib.ayolo_wgrad_group_build(arr, len(shapes), host, tb.value), "build")
+    out = (ctypes.c_int64 * 12)()
+    _lib.check(lib.ayolo_wgrad_group_info(host, -1, out, 12), "info")
+    njobs, n_items, n_red, ws_floats = out[0], [out[1], out[2], out[3]], out[4], out[5]
+    assert njobs == len(shapes) + 1 and ws_floats * 4 == wb.value           # the 320 x 320 layer became two halves
+    jobs = []
+    for j in range(njobs):
+        _lib.check(lib.ayolo_wgrad_group_info(host, j, out, 12), "info")
+        jobs.append(dict(tm=out[6], gx=out[7], gy=out[8], splits=out[9], chunk=out[10], zz0=out[11]))
+        assert jobs[-1]["splits"] >= 1 and jobs[-1]["chunk"] % 32 == 0
+    assert jobs[-1]["zz0"] == jobs[-2]["splits"] and jobs[-2]["zz0"] == 0   # second half's slots follow the first's
+    it = (ctypes.c_int64 * 3)()
+    seen = set()
+    for cls, n in enumerate(n_items):
+        assert n % 8 == 0
+        where = {}
+        for i in range(n):
+            _lib.check(lib.ayolo_wgrad_group_item(host, cls, i, it), "item")
+            if it[0] < 0:
+                continue
+            job, tile, zz = int(it[0]), int(it[1]), int(it[2])
+            assert jobs[job]["tm"] == 32 << cls and tile < jobs[job]["gx"] * jobs[job]["gy"] and zz < jobs[job]["splits"]
+            assert (job, tile, zz) not in seen
+            seen.add((job, tile, zz))
+            where.setdefault((job, zz), []).append(i)
+        for (job, zz), idxs in where.items():
+            assert len({i % 8 for i in idxs}) == 1                          # one XCD
+            assert [i // 8 for i in idxs] == list(range(idxs[0] // 8, idxs[0] // 8 + len(idxs)))   # back to back in its queue
+    assert len(seen) == sum(j["gx"] * j["gy"] * j["splits"] for j in jobs)
+    assert n_red == sum(-(-(Co * kk * kk * Ci) // 2048) for (_, _, _, Ci, Co, kk, _) in shapes)
 
 
 def test_model_ema_follows_reassigned_tensors_cpu():
