@@ -347,8 +347,7 @@ def _cos(a, b):
 def test_fp16_train_step_is_reproducible_and_routes_agree():
     """BatchNorm statistics are accumulated in fp64 from the workgroup level on, so the only order-dependent roundings of a
     step sit at 1e-16 -- below one fp32 ulp of every mean / variance -- and the fp16 rounding of every activation repeats:
-    two identical fp16 steps give the same loss and the same gradients (weight gradients still add fp32 partials with
-    atomics: 1e-6).  That makes every ROUTE comparison discriminating in the bench's own dtype: the plan executor vs the
+    two identical fp16 steps give the same loss and the same gradients (conv weight gradients bit for bit since round 4).  That makes every ROUTE comparison discriminating in the bench's own dtype: the plan executor vs the
     per-module path, and the BatchNorm-backward sums in the dgrad epilogue vs the separate reduce pass (different fp32
     summation order of the same rounded values), all within cosine 1 - 1e-4 of each other -- three orders of magnitude below what fp16
     storage itself costs against fp32, and far below any wrong tile (cosine < 0.9)."""
@@ -374,12 +373,21 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
         finally:
             P.BN_REDUCE_IN_DGRAD = old
             m.use_plan = True
+        last.append(g)
         return loss, _flat(g)
 
+    last = []
     l0, g0 = run()
     l1, g1 = run()
     assert l0 == l1, (l0, l1)
     assert _cos(g0, g1) >= 1.0 - 1e-9 and float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max())
+    # round 4: weight gradients are split-K partials added in a fixed order (no atomics) -- every conv weight gradient of the
+    # step repeats BIT FOR BIT (the stem's dedicated kernel still sends one set of atomics per workgroup; BatchNorm / bias
+    # gradients are sums of atomically accumulated fp32 / fp64 partials)
+    conv_w = [k for k, v in last[0].items() if v.dim() == 4 and not k.startswith("model.0.")]
+    assert len(conv_w) >= 59
+    not_equal = [k for k in conv_w if not torch.equal(last[0][k], last[1][k])]
+    assert not not_equal, not_equal
     l2, g2 = run(bnr=False)
     l3, g3 = run(use_plan=False)
     print("fp16 step: same route twice cos %.9f; epilogue sums vs reduce pass cos %.9f; plan vs module path cos %.9f"

@@ -58,6 +58,8 @@ def main():
             shape = ""
             if kind in (P.OP_CONV_FWD, P.OP_CONV_DGRAD, P.OP_CONV_WGRAD):
                 shape = f"{d.Cin:4d}->{d.Cout:4d} k{d.kh} s{d.sh} {d.H:3d}->{d.Ho:3d}"
+            elif kind == P.OP_WGRAD_GROUP and what == "backward":
+                shape = f"{plan.wgroup_costs[k][2]} layers in one grouped launch"
             elif kind in (P.OP_BN_TRAIN_ACT, P.OP_BN_BWD_REDUCE):
                 shape = f"C={o.i[3]:4d} npix={o.l[0]}"
             elif kind == P.OP_BN_BWD_APPLY:
