@@ -70,6 +70,10 @@ struct GConvP {
     int bnr, bnr_act, bnr_reps;
     ayolo_bn_seg bseg[2];
     unsigned z_bytes[2];
+    // XF kernels (transform on load, ayolo_conv_fwd_xf): x is the producer's pre-activation z; the operand the MFMAs see is
+    // act(z * xf_scale[c] + xf_shift[c]) -- the BatchNorm + SiLU pass that would have materialised it does not exist
+    int xf, xf_act;
+    const float* xf_scale; const float* xf_shift;
 };
 
 template <typename T> struct Tr;
@@ -799,9 +803,10 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, in
     g_stats_to_global<TM, BNR>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
 }
 
-template <typename T, int TM, int EM, int TPX, bool BNR = false>
+template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false>
 __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 ? 1 : (GT<T, TM, TPX>::lds(EM, BNR) > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4))) : 1)) void k_gconv(GConvP p) {
     static_assert(TM != 256 || (sizeof(T) == 2 && TPX == 256), "the 8-wave tile is fp16 256 x 256 only");
+    static_assert(!XF || (sizeof(T) == 2 && !BNR && TM != 256 && (EM == 0 || EM == 3)), "transform on load: fp16 forward of a 1x1 conv");
     using G = GT<T, TM, TPX>;
     // stores per thread and epilogue (the step loop's vmcnt arithmetic): fp16 tiles leave in 16-byte stores
     constexpr int NSTK = (sizeof(T) == 2 && EM != 3) ? G::NACC * 2 : G::NST;
@@ -885,6 +890,16 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 
             sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
         }
     }
+    // XF: per-input-channel scale | shift behind the epilogue's tail, [2][C rounded up to 32] floats (zeros beyond C: the
+    // zero-filled K padding stays zero under silu)
+    float* sXf = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sStat) + G::tail(EM, BNR));
+    const int xf_cp = (p.C + BK - 1) / BK * BK;
+    if constexpr (XF) {
+        for (int i = tid; i < xf_cp; i += (int)blockDim.x) {
+            sXf[i] = i < p.C ? p.xf_scale[i] : 0.0f;
+            sXf[xf_cp + i] = i < p.C ? p.xf_shift[i] : 0.0f;
+        }
+    }
     constexpr bool TILE_RED = BNR && TM >= 128;
     if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 4 * TM, n0, tid);
     if constexpr (TILE_RED) {
@@ -965,6 +980,37 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 
     G_ISSUE(so1)
     G_ADVANCE()
 
+    // XF: the x tile of a step is transformed IN PLACE in its LDS stage, one step before it is consumed, by the lanes whose
+    // DMA wrote it: lane l owns bytes [piece * 1024 + l * 16, +16) of every x piece of its wave -- 8 channels of one pixel --
+    // so its own counted vmcnt is all the ordering the read needs (no barrier between landing and transform), and the step's
+    // barrier publishes the result.  Same arithmetic as k_bn_train_act (fma, v_exp / v_rcp sigmoid, one fp16 rounding): the
+    // operand bits equal the materialised activation's.
+    auto xf_transform = [&](unsigned so, int kt) {
+        if constexpr (XF) {
+            const int c0 = kt * BK + kc * G::CE;
+            const float4v a0 = *reinterpret_cast<const float4v*>(sXf + c0), a1 = *reinterpret_cast<const float4v*>(sXf + c0 + 4);
+            const float4v b0 = *reinterpret_cast<const float4v*>(sXf + xf_cp + c0), b1 = *reinterpret_cast<const float4v*>(sXf + xf_cp + c0 + 4);
+            const bool act = p.xf_act != 0;
+#pragma unroll
+            for (int r = 0; r < G::XR; ++r) {
+                half8* q = reinterpret_cast<half8*>(sTiles + so + (r * G::NW + wave) * 1024 + lane * 16);
+                half8 h = *q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float u = __builtin_fmaf((float)h[e], e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? b0[e & 3] : b1[e & 3]);
+                    if (act) u = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+                    h[e] = (half_t)u;
+                }
+                *q = h;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // written before this wave reaches the next barrier
+        }
+    };
+    if constexpr (XF) {
+        wait_vm<G::LPS>();                                          // step 0's pieces (the older half of the two issues)
+        xf_transform(so0, 0);
+    }
+
     bool after_epi = false;
     AY_PROBE(1);
     while (true) {
@@ -972,6 +1018,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 
 #ifdef AYOLO_PROBE
         AY_PROBE(probe_k); ++probe_k;
 #endif
+        const bool prev_epi = after_epi;
         if (after_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
 #ifdef AYOLO_PROBE
         AY_PROBE(probe_k); ++probe_k;
@@ -1014,6 +1061,12 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 
         // with v_accvgpr_read of the accumulator's last register, which came back stale) -- pad it here, explicitly.
         if constexpr (sizeof(T) == 4) AY_MFMA_PAD("s_nop 15\n\ts_nop 3");
         after_epi = false;
+        if constexpr (XF) {
+            // step s+1's x pieces (issued during step s-1; behind them only the stores of an epilogue of step s-1 and this
+            // step's issues): transform them now, in the shadow of the other waves' MFMAs
+            if (prev_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
+            xf_transform(so1, cur_kt + 1 == cur_nk ? 0 : cur_kt + 1);
+        }
 #ifdef AYOLO_PROBE
         AY_PROBE(probe_k); ++probe_k;
 #endif
@@ -1910,10 +1963,10 @@ static GGrid gconv_grid(long long Mtotal, int tp, int ntn, int bpc) {
     return {slots, (tpx + spx - 1) / spx};
 }
 
-template <typename T, int TM, int EM, int TPX, bool BNR = false>
+template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false>
 static int launch_gconv_tp(GConvP p, hipStream_t s) {
     using G = GT<T, TM, TPX>;
-    const size_t lds = G::lds(EM, BNR);
+    const size_t lds = G::lds(EM, BNR) + (XF ? 2 * (size_t)((p.C + BK - 1) / BK * BK) * sizeof(float) : 0);
     p.ntn = (p.Nout + TM - 1) / TM;
     constexpr int bpc_env = 0;
     int dev = 0;
@@ -1951,22 +2004,26 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
             return AYOLO_OK;
         }
     }
-    const int bpc = bpc_env > 0 ? bpc_env : gconv_bpc<T, TM, TPX, EM, BNR>();
+    int bpc = bpc_env > 0 ? bpc_env : gconv_bpc<T, TM, TPX, EM, BNR>();
+    if constexpr (XF) {                      // the constants table counts against the LDS budget
+        const int fit = (int)(160 * 1024 / ((lds + 1279) / 1280 * 1280));
+        bpc = fit < bpc ? (fit < 1 ? 1 : fit) : bpc;
+    }
     const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc).slots;
     p.nslots = (int)slots;
     dim3 grid((unsigned)(slots * p.ntn));
-    static bool attr_set[16] = {false};      // per device: function attributes belong to the device's context
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX, BNR>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    static size_t attr_set[16] = {0};        // per device (function attributes belong to the device's context): largest size set
+    if (dev < 0 || dev >= 16 || attr_set[dev] < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX, BNR, XF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(XF ? 160 * 1024 : lds));
+        if (dev >= 0 && dev < 16) attr_set[dev] = XF ? 160 * 1024 : lds;
     }
-    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR>), grid, dim3(G::NT), lds, s, p);
+    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR, XF>), grid, dim3(G::NT), lds, s, p);
     AY_CHECK_LAUNCH("k_gconv");
     return AYOLO_OK;
 }
 
-template <typename T, int TM, int EM, bool BNR = false>
+template <typename T, int TM, int EM, bool BNR = false, bool XF = false>
 static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     // Pixel-tile size, 128 or 256 (measured per layer on the YOLOv5s shapes at batch 64, profiles/r02_conv_tile_sweep.txt):
     //  * one wave of 128-pixel tiles fits the chip: keep 128 (most workgroups in flight; the 20^2 maps);
@@ -1976,7 +2033,7 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     //  * many waves: the wider tile wins through fewer barriers and LDS fragment reads per MFMA when the reduction is
     //    deep enough -- TM 64: always; TM 128: K >= 256 (3x3); TM 32: K >= 128 (stem) -- and loses a few % on one- and
     //    two-step 1x1 layers (lower occupancy).
-    if constexpr (TM == 256) return launch_gconv_tp<T, TM, EM, 256, BNR>(p, s);
+    if constexpr (TM == 256) return launch_gconv_tp<T, TM, EM, 256, BNR, XF>(p, s);
     static const int force = getenv("AYOLO_GCONV_TP") ? atoi(getenv("AYOLO_GCONV_TP")) : 0;
     bool wide;
     if (force) wide = force == 256;
@@ -1990,13 +2047,16 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
         else wide = TM == 64 ? true : (TM == 128 ? K >= 256 : K >= 128);
     }
     if (p.s2f && TM == 128) wide = false;          // k_gconv_s2f: the 128 x 256 tile would spill (all four fragment sets live)
-    if (wide) return launch_gconv_tp<T, TM, EM, 256, BNR>(p, s);
-    if constexpr (TM != 256) return launch_gconv_tp<T, TM, EM, 128, BNR>(p, s);
+    if (wide) return launch_gconv_tp<T, TM, EM, 256, BNR, XF>(p, s);
+    if constexpr (TM != 256) return launch_gconv_tp<T, TM, EM, 128, BNR, XF>(p, s);
     return AYOLO_EINVAL;
 }
 
 template <typename T, int TM>
 static int launch_gconv(const GConvP& p, hipStream_t s) {
+    if constexpr (TM != 256 && sizeof(T) == 2) {
+        if (p.xf) return p.epi == AYOLO_EPI_HEAD ? launch_gconv_em<T, TM, 3, false, true>(p, s) : launch_gconv_em<T, TM, 0, false, true>(p, s);
+    }
     if constexpr (TM != 256) {
         if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
     }
@@ -2051,7 +2111,7 @@ static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
     if (p.Nout > 128 && p.Nout % 128 == 64 && p.Mtotal <= 65536) tm = 64;
     if (force_tm == 32 || force_tm == 64 || force_tm == 128) tm = force_tm;
     // 256-channel tiles (8 wavefronts, 256 x 256): fp16, per-tap path only (not the row-sharing kernels, not the head)
-    const bool can256 = dtype == AYOLO_F16 && p.Nout >= 256 && !p.row3 && !p.s2f && p.epi != AYOLO_EPI_HEAD;
+    const bool can256 = dtype == AYOLO_F16 && p.Nout >= 256 && !p.row3 && !p.s2f && p.epi != AYOLO_EPI_HEAD && !p.xf;
     if (can256 && force_tm == 256) tm = 256;
     if (dtype == AYOLO_F16) {
         if (tm == 256) return launch_gconv<half_t, 256>(p, s);
@@ -2190,6 +2250,35 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
             int t = i * d->kw + j;
             p.dh[t] = (signed char)(i - d->ph); p.dw[t] = (signed char)(j - d->pw); p.wt[t] = (signed char)t;
         }
+    return dispatch_gconv(d->dtype, p, (hipStream_t)s);
+}
+
+// Forward of a 1x1 / stride-1 conv whose input is VIRTUAL: x = act(z * xscale + xshift) formed on the way to the MFMAs (k_gconv<...,
+// XF>), i.e. the consumer of a Conv-BN-act block reads the block's pre-activation z and the BatchNorm + activation pass that
+// would have written the activation is not launched at all.
+extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const void* z, const float* xscale, const float* xshift, int xact,
+                                 const void* w, void* y, int epilogue, const float* shift, double* stats, int stat_reps, int head_no,
+                                 ayolo_stream s) {
+    int rc = check_desc(d, "conv_fwd_xf");
+    if (rc) return rc;
+    AY_CHECK_ARG(z && xscale && xshift && w && y, "conv_fwd_xf: null pointer");
+    AY_CHECK_ARG(d->dtype == AYOLO_F16 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0,
+                 "conv_fwd_xf: fp16 1x1 / stride 1 / no padding only");
+    AY_CHECK_ARG(epilogue == AYOLO_EPI_NONE || epilogue == AYOLO_EPI_HEAD, "conv_fwd_xf: epilogue %d (plain + statistics, or YOLOHead)", epilogue);
+    AY_CHECK_ARG(epilogue != AYOLO_EPI_HEAD || (head_no > 0 && d->Cout % head_no == 0), "conv_fwd_xf: head_no=%d", head_no);
+    AY_CHECK_ARG(d->Cin <= 4096, "conv_fwd_xf: %d input channels (LDS constants table)", d->Cin);
+    GConvP p{};
+    p.x = z; p.w = w; p.y = y;
+    p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = d->ldx;
+    p.OH = d->Ho; p.OW = d->Wo; p.ish = 1; p.isw = 1;
+    p.YH = d->Ho; p.YW = d->Wo; p.ldy = d->ldy; p.osh = 1; p.osw = 1; p.oah = 0; p.oaw = 0;
+    p.C = d->Cin; p.ntaps = 1; p.K = p.C; p.ldw = p.K; p.Nout = d->Cout;
+    p.epi = epilogue; p.scale = nullptr; p.shift = shift; p.stats = stats; p.head_no = head_no; p.accumulate = 0;
+    p.stat_reps = stat_reps > 0 ? stat_reps : 1;
+    p.y_linear = 1; p.x_linear = 1;
+    p.Mtotal = (long long)d->B * d->Ho * d->Wo;
+    p.dh[0] = 0; p.dw[0] = 0; p.wt[0] = 0;
+    p.xf = 1; p.xf_act = xact ? 1 : 0; p.xf_scale = xscale; p.xf_shift = xshift;
     return dispatch_gconv(d->dtype, p, (hipStream_t)s);
 }
 

@@ -124,6 +124,13 @@ def conv_fwd(desc: ConvDesc, x, w, y, epilogue=_lib.EPI_NONE, scale=None, shift=
          _stream())
 
 
+def conv_fwd_xf(desc: ConvDesc, z, xscale, xshift, xact: int, w, y, epilogue=_lib.EPI_NONE, shift=None, stats=None, head_no=0):
+    """1x1 conv over the VIRTUAL input act(z * xscale + xshift) (ayolo_conv_fwd_xf: transform on load)."""
+    reps = stats.shape[0] if (stats is not None and stats.dim() == 2) else 1
+    call("ayolo_conv_fwd_xf", desc, _ptr(z), _ptr(xscale), _ptr(xshift), int(xact), _ptr(w), _ptr(y), epilogue, _ptr(shift), _ptr(stats),
+         reps, head_no, _stream())
+
+
 def conv_dgrad(desc: ConvDesc, dy, wt, dx, accumulate=False):
     call("ayolo_conv_dgrad", desc, _ptr(dy), _ptr(wt), _ptr(dx), int(accumulate), _stream())
 

@@ -75,7 +75,7 @@ BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
 # layers of a group + one fixed-order reduction of the split-K partials) instead of one launch per layer.  The backward list is
 # cut into this many groups of similar work (the last one is halved AYOLO_WGRAD_TAIL more times: what the final group still has
 # to do when the main stream's backward ends is exposed); 0 = one launch per layer (same kernels, for A/B).
-WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "8"))
+WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "4"))
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
 
 

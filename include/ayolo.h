@@ -101,6 +101,16 @@ typedef struct ayolo_bn_seg {
 int ayolo_conv_dgrad_bn(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
                         const ayolo_bn_seg* segs, int nseg, int act, int sum_reps, ayolo_stream s);
 
+/* Forward of a 1x1 / stride-1 conv whose input is VIRTUAL (transform on load; res/configs/model/yolov5s.yaml:21-33: kindle
+ * `Conv` = conv -> BatchNorm -> SiLU, whose activation has exactly one reader here): x[p][c] = act(z[p][c] * xscale[c] +
+ * xshift[c]) is formed from the producer's pre-activation z on the way to the MFMAs, with the arithmetic of
+ * ayolo_bn_train_act / ayolo_affine_act (fma, sigmoid by v_exp / v_rcp, one fp16 rounding), so the result equals the conv
+ * over the materialised activation bit for bit and that pass is never launched.  fp16; d: the conv's descriptor with ldx =
+ * channel stride of z; epilogue AYOLO_EPI_NONE (+ `stats`) or AYOLO_EPI_HEAD (+ `shift` = bias, head_no). */
+int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const void* z, const float* xscale, const float* xshift, int xact,
+                      const void* w, void* y, int epilogue, const float* shift, double* stats, int stat_reps, int head_no,
+                      ayolo_stream s);
+
 /* Weight gradient (autograd's ConvolutionBackward weight leg behind scripts/train/yolo_trainer.py:329):
  * dw[Cout][kh][kw][Cin] (fp32) += alpha * sum_pixels dy (x) x.  The pixel reduction is split over workgroups; every split
  * STORES its tile sums into its own slot of the caller's workspace `ws` (ayolo_conv_wgrad_workspace(d) bytes, 16-byte

@@ -648,3 +648,53 @@ def test_wgrad_grouped_launch_vs_single_layer_and_bit_reproducible(dt):
         assert float((s1[k].cpu() - want).abs().max()) <= tol * scale, k
         got = g1[k].cpu() - (3.0 if k == 4 else 0.0)                     # layer 4 accumulates onto its old contents
         assert float((got - want).abs().max()) <= tol * scale + (1e-5 if k == 4 else 0.0), k
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 64, 40, 40, 1), (2, 128, 32, 24, 20, 1), (3, 512, 256, 10, 12, 1), (2, 256, 255, 16, 16, 0),
+                                   (1, 48, 160, 33, 7, 1), (8, 32, 64, 64, 64, 1)])
+def test_conv_transform_on_load_equals_materialised_route(shape):
+    """ayolo_conv_fwd_xf (stage A): the 1x1 consumer reads the producer's pre-activation z and forms
+    act(z * scale + shift) on the way to the MFMAs.  Against the two-launch route -- ayolo_affine_act writes the activation,
+    ayolo_conv_fwd reads it -- output AND BatchNorm statistics must agree BIT FOR BIT (same operand bits, same MFMA order);
+    the last case is the YOLOHead epilogue (fp32 logits + bias, Cout 255), one case has a channel-slice input (ld > C)."""
+    from ayolov2_amd import ops, _lib
+    B, Ci, Co, H, W, act = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    head = Co == 255
+    ld = Ci + 32 if Ci == 128 else Ci                                   # channel slice of a wider z buffer
+    zfull = torch.randn(B, ld, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+    z = zfull[:, :Ci]
+    scale = (torch.rand(Ci, device="cuda", generator=g) + 0.5).float()
+    shift = torch.randn(Ci, device="cuda", generator=g).float()
+    cop = (Co + 7) // 8 * 8
+    w = torch.zeros(cop, 1, 1, Ci, device="cuda", dtype=torch.float16)
+    w[:Co] = (torch.randn(Co, 1, 1, Ci, device="cuda", generator=g) / Ci ** 0.5).half()
+    bias = torch.randn(cop, device="cuda", generator=g).float() if head else None
+    d = ops.make_desc(torch.float16, B, H, W, Ci, ld, cop, cop, (1, 1), (1, 1), (0, 0), H, W)
+    a = ops.new_act(B, Ci, H, W, torch.float16, "cuda")
+    ops.affine_act(z, a, scale, shift, act)
+    da = ops.make_desc(torch.float16, B, H, W, Ci, Ci, cop, cop, (1, 1), (1, 1), (0, 0), H, W)
+    outs = []
+    for route in ("materialised", "on_load"):
+        if head:
+            y = torch.zeros((B, H, W, cop), dtype=torch.float32, device="cuda")
+            stats = None
+        else:
+            y = ops.new_act(B, cop, H, W, torch.float16, "cuda")
+            stats = torch.zeros((ops.STAT_REPS, 2 * cop), dtype=torch.float64, device="cuda")
+        epi = _lib.EPI_HEAD if head else _lib.EPI_NONE
+        if route == "materialised":
+            ops.conv_fwd(da, a, w, y, epi, shift=bias, stats=stats, head_no=85 if head else 0)
+        else:
+            ops.conv_fwd_xf(d, z, scale, shift, act, w, y, epi, shift=bias, stats=stats, head_no=85 if head else 0)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), None if stats is None else stats.sum(0).clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if not head:
+        assert torch.equal(outs[0][1], outs[1][1])
+    # and the route is right at all: against torch fp32 on the rounded activation
+    u = z.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref_a = (u * torch.sigmoid(u) if act else u).half().float()
+    ref = F.conv2d(ref_a.cpu(), w[:Co].permute(0, 3, 1, 2).float().cpu(), bias[:Co].cpu() if head else None)
+    got = outs[1][0].permute(0, 3, 1, 2)[:, :Co].float().cpu() if head else outs[1][0][:, :Co].float().cpu()
+    assert _rel_err(got, ref) <= 4e-3
