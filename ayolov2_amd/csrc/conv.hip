@@ -150,12 +150,6 @@ typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
 typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-#ifndef AYOLO_GCONV_MI2
-#define AYOLO_GCONV_MI2 1
-#endif
-#ifndef AYOLO_GCONV_MI2_64
-#define AYOLO_GCONV_MI2_64 0
-#endif
 template <typename T, int TM, int TPX = 128>
 struct GT {
     static constexpr int ES = sizeof(T);
@@ -167,10 +161,7 @@ struct GT {
     // pixels per block tile: 128, or 256 for the narrow channel tiles on multi-step reductions (K >= 128) so that a
     // wave still has 4-8 MFMAs per barrier
     static constexpr int TP = TPX;
-    // wavefronts per workgroup: 4; the 256-channel x 256-pixel fp16 tile (k_gconv only) runs 8 -- 4 (channels) x 2 (pixels) of
-    // the same 64 x 128 wave tile as the 128 x 256 workgroup tile, so that a 32-deep step moves 4 DMA pieces per wave next to
-    // its 16 MFMAs instead of 6 (the L2 -> LDS DMA rate is what bounds the deep-reduction layers)
-    static constexpr int NW = TM == 256 ? 8 : 4;
+    static constexpr int NW = 4;                    // wavefronts per workgroup
     static constexpr int NT = NW * 64;
     static constexpr int PIECE = NW * 1024;         // bytes one DMA instruction of every wave covers
     static constexpr int XSTAGE = TP * ROWB;        // 8-16 KiB / 16-32 KiB
@@ -181,7 +172,7 @@ struct GT {
     static constexpr int LPS = XR + WR;             // DMA instructions per thread per step
     // wave tile: MI x NI MFMA blocks of 32 channels x 32 pixels.  The 128-channel x 256-pixel fp16 tile gives each wave
     // 64 channels x 128 pixels (2 x 4 blocks: 6 LDS fragments per 8 MFMAs) instead of 32 x 256 (1 x 8: 9 per 8).
-    static constexpr int MI = (ES == 2 && TPX == 256 && ((TM >= 128 && AYOLO_GCONV_MI2) || (TM == 64 && AYOLO_GCONV_MI2_64))) ? 2 : 1;
+    static constexpr int MI = (ES == 2 && TPX == 256 && TM >= 128) ? 2 : 1;
     static constexpr int WM = TM / (32 * MI), WP = NW / WM, NI = TP / (32 * WP);
     static constexpr int NACC = MI * NI;            // accumulator blocks per wave
     static constexpr int NST = NACC * 4;            // store instructions per thread per epilogue
@@ -804,9 +795,9 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, in
 }
 
 template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false>
-__global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (TM == 256 ? 1 : (GT<T, TM, TPX>::lds(EM, BNR) > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4))) : 1)) void k_gconv(GConvP p) {
-    static_assert(TM != 256 || (sizeof(T) == 2 && TPX == 256), "the 8-wave tile is fp16 256 x 256 only");
-    static_assert(!XF || (sizeof(T) == 2 && !BNR && TM != 256 && (EM == 0 || EM == 3)), "transform on load: fp16 forward of a 1x1 conv");
+__global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, TPX>::lds(EM, BNR) > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
+    static_assert(TM == 32 || TM == 64 || TM == 128, "output-channel tiles of 32 / 64 / 128");
+    static_assert(!XF || (sizeof(T) == 2 && !BNR && (EM == 0 || EM == 3)), "transform on load: fp16 forward of a 1x1 conv");
     using G = GT<T, TM, TPX>;
     // stores per thread and epilogue (the step loop's vmcnt arithmetic): fp16 tiles leave in 16-byte stores
     constexpr int NSTK = (sizeof(T) == 2 && EM != 3) ? G::NACC * 2 : G::NST;
@@ -1971,7 +1962,7 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     constexpr int bpc_env = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if constexpr (sizeof(T) == 2 && EM != 3 && EM != 1 && TM != 256) {
+    if constexpr (sizeof(T) == 2 && EM != 3 && EM != 1) {
         if (p.s2f) {                         // forward 3x3 / stride 2 with the odd-column taps sharing one row run
             constexpr size_t lds2 = 3 * (size_t)(G::TP + 16) * G::ROWB + 3 * (size_t)(2 * TM * G::ROWB < 4096 ? 4096 : 2 * TM * G::ROWB) +
                                     4 * TM * sizeof(float);
@@ -1988,7 +1979,7 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
             return AYOLO_OK;
         }
     }
-    if constexpr (sizeof(T) == 2 && EM != 3 && TM != 256) {
+    if constexpr (sizeof(T) == 2 && EM != 3) {
         if (p.row3) {                        // 3x3 / stride 1: x rows shared by the three taps of a kernel row (k_gconv3)
             using G3 = GT3<T, TM, TPX>;
             const long long slots3 = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc_env > 0 ? bpc_env : 2).slots;
@@ -2033,7 +2024,6 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     //  * many waves: the wider tile wins through fewer barriers and LDS fragment reads per MFMA when the reduction is
     //    deep enough -- TM 64: always; TM 128: K >= 256 (3x3); TM 32: K >= 128 (stem) -- and loses a few % on one- and
     //    two-step 1x1 layers (lower occupancy).
-    if constexpr (TM == 256) return launch_gconv_tp<T, TM, EM, 256, BNR, XF>(p, s);
     static const int force = getenv("AYOLO_GCONV_TP") ? atoi(getenv("AYOLO_GCONV_TP")) : 0;
     bool wide;
     if (force) wide = force == 256;
@@ -2048,18 +2038,15 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     }
     if (p.s2f && TM == 128) wide = false;          // k_gconv_s2f: the 128 x 256 tile would spill (all four fragment sets live)
     if (wide) return launch_gconv_tp<T, TM, EM, 256, BNR, XF>(p, s);
-    if constexpr (TM != 256) return launch_gconv_tp<T, TM, EM, 128, BNR, XF>(p, s);
-    return AYOLO_EINVAL;
+    return launch_gconv_tp<T, TM, EM, 128, BNR, XF>(p, s);
 }
 
 template <typename T, int TM>
 static int launch_gconv(const GConvP& p, hipStream_t s) {
-    if constexpr (TM != 256 && sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) {
         if (p.xf) return p.epi == AYOLO_EPI_HEAD ? launch_gconv_em<T, TM, 3, false, true>(p, s) : launch_gconv_em<T, TM, 0, false, true>(p, s);
     }
-    if constexpr (TM != 256) {
-        if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
-    }
+    if (p.epi == AYOLO_EPI_HEAD) return launch_gconv_em<T, TM, 3>(p, s);
     if (p.epi == AYOLO_EPI_AFFINE || p.epi == AYOLO_EPI_AFFINE_SILU) return launch_gconv_em<T, TM, 2>(p, s);
     if (p.epi == AYOLO_EPI_AFFINE_RES || p.epi == AYOLO_EPI_AFFINE_SILU_RES) return launch_gconv_em<T, TM, 4>(p, s);
     if constexpr (sizeof(T) == 2) {
@@ -2102,19 +2089,15 @@ static int dispatch_gconv_one(int dtype, const GConvP& p, hipStream_t s) {
     // Output-channel tile: the widest that is not mostly padding.  Measured on the YOLOv5x widths (80 / 160 / 320 / 640 / 1280
     // channels, profiles/r02_conv_tm_sweep_yolov5x.txt): 128-wide tiles beat 64- and 32-wide ones by 1.3-2.5x even where
     // 37 % of the tile is padding (80 or 160 output channels) -- a narrow tile re-reads the pixel tile per channel tile and
-    // halves the MFMAs per barrier -- so padding waste is NOT a reason to go narrower.  AYOLO_GCONV_TM forces a tile.
-    static const int force_tm = getenv("AYOLO_GCONV_TM") ? atoi(getenv("AYOLO_GCONV_TM")) : 0;
+    // halves the MFMAs per barrier -- so padding waste is NOT a reason to go narrower.  (A 256-channel x 256-pixel tile on eight
+    // wavefronts existed in round 3 behind a switch; it measured neutral-to-slower -- profiles/r03_tm256_tile_sweep.txt -- and
+    // was removed in round 4 together with the switch.)
     int tm = p.Nout <= 32 ? 32 : (p.Nout <= 64 ? 64 : 128);
     // ... except where the last 128-wide tile would be half empty (192 / 320 output channels) on a small map: there the
     // 64-wide tiling is exact and the extra pixel-tile reads stay in L2 (YOLOv5x, batch 8 at 1280^2: 320 -> 320 3x3 on 80x80
     // 154 vs 169 us; on the 160x160 maps the 128-wide tiles still win)
     if (p.Nout > 128 && p.Nout % 128 == 64 && p.Mtotal <= 65536) tm = 64;
-    if (force_tm == 32 || force_tm == 64 || force_tm == 128) tm = force_tm;
-    // 256-channel tiles (8 wavefronts, 256 x 256): fp16, per-tap path only (not the row-sharing kernels, not the head)
-    const bool can256 = dtype == AYOLO_F16 && p.Nout >= 256 && !p.row3 && !p.s2f && p.epi != AYOLO_EPI_HEAD && !p.xf;
-    if (can256 && force_tm == 256) tm = 256;
     if (dtype == AYOLO_F16) {
-        if (tm == 256) return launch_gconv<half_t, 256>(p, s);
         if (tm == 32) return launch_gconv<half_t, 32>(p, s);
         if (tm == 64) return launch_gconv<half_t, 64>(p, s);
         return launch_gconv<half_t, 128>(p, s);
@@ -2170,9 +2153,8 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
         p.ncls = 1; p.ctap0[0] = 0; p.cnt[0] = p.ntaps; p.coah[0] = p.oah; p.coaw[0] = p.oaw;
     }
     // 3x3, stride 1, same-size maps (the Bottleneck 3x3 convs and their dgrad): k_gconv3
-    static const int row3_on = getenv("AYOLO_GCONV_ROW3") ? atoi(getenv("AYOLO_GCONV_ROW3")) : 1;
     p.row3 = 0;
-    if (row3_on && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 1 && p.isw == 1 && p.osh == 1 && p.osw == 1 &&
+    if (dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 1 && p.isw == 1 && p.osh == 1 && p.osw == 1 &&
         p.XH == p.OH && p.XW == p.OW && p.YH == p.OH && p.YW == p.OW && p.C >= BK && p.epi != AYOLO_EPI_HEAD &&
         // channels beyond C in the last 32-wide chunk are fetched as zeros (x and W): at most a quarter of the MFMA work
         ((p.C + BK - 1) / BK * BK - p.C) * 4 <= (p.C + BK - 1) / BK * BK) {
@@ -2187,10 +2169,9 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     }
     // forward 3x3 / stride 2 / pad 1 on even maps -> k_gconv_s2f.  Measured on MI355X (profiles/r03_conv_layer_sweep*.txt):
     // 32 -> 64 @ 320^2 177 -> 160 us; the wider layers move by -4 .. +4 us (their step is bound by the W tiles, not by x), so
-    // it is the default for <= 32 input channels only (AYOLO_GCONV_S2F=1: every eligible layer, =0: none)
-    static const int s2f_on = getenv("AYOLO_GCONV_S2F") ? atoi(getenv("AYOLO_GCONV_S2F")) : -1;
+    // it is used for <= 32 input channels only
     p.s2f = 0;
-    if ((s2f_on > 0 || (s2f_on < 0 && p.C <= 32)) && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 2 && p.isw == 2 && p.osh == 1 && p.osw == 1 &&
+    if (p.C <= 32 && dtype == AYOLO_F16 && p.ncls == 1 && p.ntaps == 9 && p.ish == 2 && p.isw == 2 && p.osh == 1 && p.osw == 1 &&
         !p.accumulate && p.XH == 2 * p.OH && p.XW == 2 * p.OW && p.YH == p.OH && p.YW == p.OW && p.C >= BK && p.epi != AYOLO_EPI_HEAD &&
         ((p.C + BK - 1) / BK * BK - p.C) * 4 <= (p.C + BK - 1) / BK * BK && p.Nout <= 128 * 1024) {
         int seen = 0;
@@ -2370,9 +2351,8 @@ static int conv_dgrad_impl(const ayolo_conv_desc* d, const void* dy, const void*
         m.ncls = ncls_all; m.ntaps = mt; m.K = mt * m.C;
         // 3x3 / stride 2 / pad 1 with <= 64 input channels: the nine (class, tap) products read four shifts of the dy tile
         // -> k_dgrad_s2 keeps all four classes' accumulators and loads every dy row group once
-        static const int s2d_on = getenv("AYOLO_DGRAD_S2") ? atoi(getenv("AYOLO_DGRAD_S2")) : 1;
         const int cpad = (m.C + BK - 1) / BK * BK;
-        if (s2d_on && d->dtype == AYOLO_F16 && d->kh == 3 && d->kw == 3 && d->sh == 2 && d->sw == 2 && d->ph == 1 && d->pw == 1 &&
+        if (d->dtype == AYOLO_F16 && d->kh == 3 && d->kw == 3 && d->sh == 2 && d->sw == 2 && d->ph == 1 && d->pw == 1 &&
             d->Cin <= 64 && m.C >= BK && (cpad - m.C) * 4 <= cpad) {
             static const signed char order[9] = {4, 5, 7, 8, 3, 6, 1, 2, 0};
             for (int t = 0; t < 9; ++t) m.s2wt[t] = order[t];

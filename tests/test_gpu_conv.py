@@ -670,10 +670,11 @@ def test_conv_transform_on_load_equals_materialised_route(shape):
     w = torch.zeros(cop, 1, 1, Ci, device="cuda", dtype=torch.float16)
     w[:Co] = (torch.randn(Co, 1, 1, Ci, device="cuda", generator=g) / Ci ** 0.5).half()
     bias = torch.randn(cop, device="cuda", generator=g).float() if head else None
-    d = ops.make_desc(torch.float16, B, H, W, Ci, ld, cop, cop, (1, 1), (1, 1), (0, 0), H, W)
+    cd = Co if head else cop                                            # YOLOHead: Cout = na * no exactly, rows padded to 8
+    d = ops.make_desc(torch.float16, B, H, W, Ci, ld, cd, cop, (1, 1), (1, 1), (0, 0), H, W)
     a = ops.new_act(B, Ci, H, W, torch.float16, "cuda")
     ops.affine_act(z, a, scale, shift, act)
-    da = ops.make_desc(torch.float16, B, H, W, Ci, Ci, cop, cop, (1, 1), (1, 1), (0, 0), H, W)
+    da = ops.make_desc(torch.float16, B, H, W, Ci, Ci, cd, cop, (1, 1), (1, 1), (0, 0), H, W)
     outs = []
     for route in ("materialised", "on_load"):
         if head:

@@ -166,17 +166,6 @@ def test_tucker_launch_forms_fp32(form, monkeypatch):
         assert any(float((a - b).abs().max()) > 1e-6 * float(b.max() - b.min()) for a, b in zip(raws_ref2, raws_ref))   # the update is visible at all
 
 
-def test_wide_channel_tile_opt_in():
-    """The 256-channel x 256-pixel / 8-wavefront k_gconv tile is opt-in (AYOLO_GCONV_TM=256, read once per process: measured
-    neutral-to-slower, profiles/r03_tm256_tile_sweep.txt) -- keep it correct: tools/tm256_check.py in a process of its own."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AYOLO_GCONV_TM="256")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "tm256_check.py")], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().endswith("all ok"), r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_cfg4_tucker_decomposed_yolov5s_fp16_eval():
     """BASELINE cfg 4: decompose_model() (scripts/tensor_decomposition/decomposition.py:237-339, defaults of
     decompose_model.py:63-74 except prune_step 0 to bound the SVD count) on YOLOv5s -- every k > 1 conv incl. the 6x6
