@@ -31,7 +31,7 @@ class BnSeg(ctypes.Structure):
 class WgradJob(ctypes.Structure):
     """ayolo_wgrad_job (include/ayolo.h): one layer's weight gradient inside a grouped launch."""
     _fields_ = [("conv", ConvDesc), ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("alpha", c_float),
-                ("dy_slot", c_int), ("overwrite", c_int), ("reserved", c_int)]
+                ("dy_slot", c_int), ("overwrite", c_int), ("xact", c_int), ("xscale", c_void_p), ("xshift", c_void_p)]
 
 
 class LossLevel(ctypes.Structure):
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "ayolo_sgd_step": [_P, c_int, _P, _P, _P, _P],
     "ayolo_coco_rows": [_P, _P, c_int64, _P, _P, c_int, _P, _P],
     "ayolo_bn_finalize": [_P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
+    "ayolo_bn_finalize_ld": [_P, c_int, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P],
     "ayolo_affine_act": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, c_int, _P],
     "ayolo_bn_train_act": [c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P,
                            _P, _P, c_int, _P, c_int, _P],

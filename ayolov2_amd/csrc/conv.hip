@@ -2387,6 +2387,9 @@ struct WGradP {
     int dy_slot;                   // >= 0: dy is the launch's override pointer of that slot (YOLOHead levels: the loss hands a
                                    // different buffer over each step), else `dy`
     int tm;                        // output-channel tile of this job's launch class: 32 / 64 / 128
+    // transform on load (1x1 / stride-1 consumers of a virtual activation, see ayolo_conv_fwd_xf): x is the producer's
+    // pre-activation z and the operand is act(z * xf_scale[c] + xf_shift[c]); null = plain x
+    const float* xf_scale; const float* xf_shift; int xf_act, xf_pad;
 };
 
 #define TNW 128     // dw columns per block tile
@@ -2553,6 +2556,36 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+    // transform on load: this lane's x chunks are the same 8 dw columns (= input channels of a 1x1 conv) in every step, so its
+    // 2 x 8 constants live in registers for the whole item; the chunks are transformed in place in their LDS stage by the lane
+    // whose DMA wrote them (see k_gconv's xf_transform), one step before they are consumed
+    const bool xf = sizeof(T) == 2 && p.xf_scale != nullptr;
+    float xfa[8], xfb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xfa[e] = 1.0f; xfb[e] = 0.0f; }
+    if (xf && xcol_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xfa[e] = p.xf_scale[xcol + e]; xfb[e] = p.xf_shift[xcol + e]; }     // K = C, C % 8 == 0
+    }
+    const bool xf_act = p.xf_act != 0;
+    auto xf_transform = [&](unsigned so) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int r = 0; r < W::XR; ++r) {
+                half8* q = reinterpret_cast<half8*>(smem_raw + so + (r * 4 + wave) * 1024 + lane * 16);
+                half8 h = *q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float u = __builtin_fmaf((float)h[e], xfa[e], xfb[e]);
+                    if (xf_act) u = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+                    h[e] = (half_t)u;
+                }
+                *q = h;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+
     const int nk = (int)((pend - pbeg + W::BP - 1) / W::BP);
     // DMA of reduction step `st` into the stage at byte offset `so`; steps >= nk lie beyond pend: all rows zero-fill
 #define W_ISSUE(st, so)                                                                                             \
@@ -2581,6 +2614,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     unsigned so0 = 0, so1 = W::STAGE, so2 = 2 * W::STAGE;
     W_ISSUE(0, so0)
     W_ISSUE(1, so1)
+    if (xf) {
+        wait_vm<W::LPS>();                       // step 0's pieces
+        xf_transform(so0);
+    }
     AY_PROBE(1);
     for (int kt = 0; kt < nk; ++kt) {
 #ifdef AYOLO_PROBE
@@ -2667,6 +2704,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
             }
         }
         if constexpr (sizeof(T) == 4) AY_MFMA_PAD("s_nop 15\n\ts_nop 3");   // see k_gconv: MFMA result hazard across the back edge
+        if (xf) {
+            wait_vm<W::LPS>();                   // step kt+1's pieces (behind them only this step's issues)
+            xf_transform(so1);
+        }
 #ifdef AYOLO_PROBE
         AY_PROBE(probe_k); ++probe_k;
 #endif
@@ -3365,6 +3406,10 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
         WGradP p;
         wgrad_fill(&a.conv, a.x, a.dy, p);
         p.dy_slot = a.dy_slot;
+        if (a.xscale || a.xshift) {
+            AY_CHECK_ARG(a.xscale && a.xshift && p.linear && a.conv.dtype == AYOLO_F16, "wgrad_group: job %d: transform on load needs fp16, 1x1 / stride 1", k);
+            p.xf_scale = a.xscale; p.xf_shift = a.xshift; p.xf_act = a.xact ? 1 : 0;
+        }
         const size_t j0 = g.jobs.size();
         rc = wgrad_halves(&a.conv, p, g.jobs);
         if (rc) return rc;

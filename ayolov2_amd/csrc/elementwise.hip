@@ -77,15 +77,15 @@ static unsigned grid_for(long long work_items, int per_block) {
 // ---------------------------------------------------------------------------------------------------
 // BN finalize
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_bn_finalize(const double* stats, int reps, int C, double count, const float* gamma, const float* beta,
+__global__ void k_bn_finalize(const double* stats, int reps, int sld, int C, double count, const float* gamma, const float* beta,
                               float eps, float momentum, float* rmean, float* rvar, float* smean, float* sinv,
                               float* scale, float* shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < reps; ++r) {
-        s1 += stats[(size_t)r * 2 * C + c];
-        s2 += stats[(size_t)r * 2 * C + C + c];
+    for (int r = 0; r < reps; ++r) {               // [reps][2][sld] accumulators; this layer's channels start at `stats`
+        s1 += stats[(size_t)r * 2 * sld + c];
+        s2 += stats[(size_t)r * 2 * sld + sld + c];
     }
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
@@ -104,14 +104,21 @@ __global__ void k_bn_finalize(const double* stats, int reps, int C, double count
     }
 }
 
+extern "C" int ayolo_bn_finalize_ld(const double* stats, int stat_reps, int stat_ld, int C, double count, const float* gamma,
+                                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                    float* save_mean, float* save_invstd, float* scale, float* shift, ayolo_stream s) {
+    AY_CHECK_ARG(stats && scale && shift && C > 0 && count > 0 && stat_ld >= C, "bn_finalize: bad args");
+    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s, stats, stat_reps > 0 ? stat_reps : 1, stat_ld, C, count,
+                       gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
+    AY_CHECK_LAUNCH("k_bn_finalize");
+    return AYOLO_OK;
+}
+
 extern "C" int ayolo_bn_finalize(const double* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
                                  float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                                  float* save_invstd, float* scale, float* shift, ayolo_stream s) {
-    AY_CHECK_ARG(stats && scale && shift && C > 0 && count > 0, "bn_finalize: bad args");
-    hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)s, stats, stat_reps > 0 ? stat_reps : 1, C, count, gamma, beta, eps,
-                       momentum, running_mean, running_var, save_mean, save_invstd, scale, shift);
-    AY_CHECK_LAUNCH("k_bn_finalize");
-    return AYOLO_OK;
+    return ayolo_bn_finalize_ld(stats, stat_reps, C, C, count, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                                save_invstd, scale, shift, s);
 }
 
 __global__ void k_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, const float* cbias,

@@ -156,8 +156,12 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
         case AYOLO_OP_NOP:
             break;
         case AYOLO_OP_CONV_FWD:
-            rc = ayolo_conv_fwd(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const float*)o.p[3], (const float*)o.p[4],
-                                (double*)o.p[5], o.i[1], o.i[2], cs);
+            // p[6] / p[7] / i[3]: transform on load -- p[0] is the producer's pre-activation z, the operand is
+            // act(z * p[6][c] + p[7][c]) with act = i[3] (ayolo_conv_fwd_xf)
+            if (o.p[6]) rc = ayolo_conv_fwd_xf(&o.conv, o.p[0], (const float*)o.p[6], (const float*)o.p[7], o.i[3], o.p[1], o.p[2], o.i[0],
+                                               (const float*)o.p[4], (double*)o.p[5], o.i[1], o.i[2], cs);
+            else rc = ayolo_conv_fwd(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const float*)o.p[3], (const float*)o.p[4],
+                                     (double*)o.p[5], o.i[1], o.i[2], cs);
             break;
         case AYOLO_OP_CONV_DGRAD:
             // i[1] > 0: the BatchNorm-backward sums of the i[1] block(s) that produced dx ride in the epilogue
@@ -179,9 +183,10 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
             rc = ayolo_cast_weights((const ayolo_cast_job*)o.p[0], o.i[0], o.i[1], cs);
             break;
         case AYOLO_OP_BN_FINALIZE:
-            rc = ayolo_bn_finalize((const double*)o.p[0], o.i[0], o.i[1], o.d[0], (const float*)o.p[1], (const float*)o.p[2], o.f[0],
-                                   o.f[1], (float*)o.p[3], (float*)o.p[4], (float*)o.p[5], (float*)o.p[6], (float*)o.p[7],
-                                   (float*)o.p[8], cs);
+            // i[2]: channel stride of the accumulators (0: = C)
+            rc = ayolo_bn_finalize_ld((const double*)o.p[0], o.i[0], o.i[2] > 0 ? o.i[2] : o.i[1], o.i[1], o.d[0], (const float*)o.p[1],
+                                      (const float*)o.p[2], o.f[0], o.f[1], (float*)o.p[3], (float*)o.p[4], (float*)o.p[5], (float*)o.p[6],
+                                      (float*)o.p[7], (float*)o.p[8], cs);
             break;
         case AYOLO_OP_AFFINE_ACT:
             rc = ayolo_affine_act_res(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], o.i[3], (const float*)o.p[2],

@@ -75,6 +75,10 @@ BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
 # layers of a group + one fixed-order reduction of the split-K partials) instead of one launch per layer.  The backward list is
 # cut into this many groups of similar work (the last one is halved AYOLO_WGRAD_TAIL more times: what the final group still has
 # to do when the main stream's backward ends is exposed); 0 = one launch per layer (same kernels, for A/B).
+# Transform on load (ayolo_conv_fwd_xf): the BatchNorm + SiLU pass of a Conv block whose activation has exactly ONE reader, a
+# 1x1 / stride-1 conv, is not launched -- that conv (and its weight gradient) read the block's pre-activation z and form the
+# activation on the way to the MFMAs; the block keeps a tiny finalize launch (batch statistics -> scale / shift, running stats)
+XF_ON_LOAD = _os.environ.get("AYOLO_XF", "1") == "1"
 WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "4"))
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
 
@@ -169,6 +173,9 @@ class TrainPlan:
         self.draw_ops: List[Op] = []
         self._head_dz: Dict[int, Tuple[int, int]] = {}
         self._wjobs: List[dict] = []                        # weight-gradient jobs in backward order (grouped after emission)
+        self._reads: List[tuple] = []                       # (root Act id, c_lo, c_hi, kind, consumer record): who reads which activation
+        self._producers: List[dict] = []                    # Conv-BN-act blocks: candidates for transform on load
+        self.xf_layers = 0                                  # blocks whose BatchNorm + activation pass was folded into the consumer
         self.wgroup_costs: Dict[int, Tuple[float, float, int]] = {}   # backward op index -> (bytes, flop, layers) of a group launch
         self.wgroup_slots: List[Tuple[int, int]] = []       # (backward op index, head level) pairs: dy override pointers to patch
         self.pack_op: Optional[Op] = None
@@ -204,11 +211,11 @@ class TrainPlan:
             return t
         return self.dz_buf[:n]
 
-    def _wgrad_job(self, desc: ConvDesc, x: torch.Tensor, dy: torch.Tensor, off: int, n: int, dy_slot: int = -1) -> None:
+    def _wgrad_job(self, desc: ConvDesc, x: torch.Tensor, dy: torch.Tensor, off: int, n: int, dy_slot: int = -1, xf=None) -> None:
         """One layer's weight gradient: a slot in the backward list now (dz is complete here), the launch later
         (_group_wgrads: the slot of the LAST layer of a group becomes the group's launch, the others stay empty)."""
         self.bwd.append(_op(0))
-        self._wjobs.append(dict(idx=len(self.bwd) - 1, desc=desc, x=x, dy=dy, off=off, n=n, slot=dy_slot))
+        self._wjobs.append(dict(idx=len(self.bwd) - 1, desc=desc, x=x, dy=dy, off=off, n=n, slot=dy_slot, xf=xf))
 
     def _group_wgrads(self) -> None:
         from ._lib import WgradJob
@@ -238,6 +245,7 @@ class TrainPlan:
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
             self.keep.append(ws)
             for j in jobs:
+                assert j["xf"] is None, "transform on load needs the grouped weight-gradient launches"
                 o = _op(OP_CONV_WGRAD | side, f=(1.0,), l=(ws.numel(),), p=(j["x"], j["dy"], ga.view(j["off"], j["n"]), ws), conv=j["desc"])
                 self.bwd[j["idx"]] = o
                 self.grad_done.append((j["idx"], j["off"], j["n"]))
@@ -274,6 +282,8 @@ class TrainPlan:
                 arr[k].x, arr[k].dy = j["x"].data_ptr(), j["dy"].data_ptr()
                 arr[k].dw = ga.view(j["off"], j["n"]).data_ptr()
                 arr[k].alpha, arr[k].dy_slot, arr[k].overwrite = 1.0, j["slot"], 1       # nothing else writes these arena ranges
+                if j["xf"] is not None:
+                    arr[k].xscale, arr[k].xshift, arr[k].xact = j["xf"][0].data_ptr(), j["xf"][1].data_ptr(), j["xf"][2]
             tb, wb = ctypes.c_size_t(0), ctypes.c_size_t(0)
             _lib.check(lib.ayolo_wgrad_group_size(arr, len(js), ctypes.byref(tb), ctypes.byref(wb)), "ayolo_wgrad_group_size")
             host = ctypes.create_string_buffer(tb.value)
@@ -352,6 +362,8 @@ class TrainPlan:
             xk = x.t
         _, _, _, _, ldx = ops.nhwc_info(xk)
         code = ops.dtype_code(dt)
+        # what the weight gradient will read as x (the transform-on-load pass may point it at the producer's z)
+        cx = dict(x=xk, ldx=ldx, xf=None)
         # weights: compute-dtype copy and its transpose, refreshed by a cast op at the start of every forward
         wc = torch.empty((Ct, kh, kw, geo.cin_pad), dtype=dt, device=dev)
         wt = torch.empty((geo.cin_pad, kh, kw, Ct), dtype=dt, device=dev)
@@ -366,6 +378,11 @@ class TrainPlan:
         npix = self.B * geo.Ho * geo.Wo
         op_conv = _op(OP_CONV_FWD, i=(EPI_NONE, R, 0), p=(xk, wc, z.t, None, None, None), conv=geo.desc(dt, ldx, Ct))
         self.fwd.append(op_conv)
+        if not image:
+            pointwise = (kh, kw) == (1, 1) and _pair(convs[0].stride) == (1, 1) and _pair(convs[0].padding) == (0, 0) and geo.Cin_k == Cin
+            self._reads.append((id(x.root), x.c0, x.c0 + x.C, "conv", dict(op=op_conv, cx=cx, pointwise=pointwise, cin=Cin, cout=Ct)))
+            if residual is not None:
+                self._reads.append((id(residual.root), residual.c0, residual.c0 + residual.C, "residual", None))
         self.late.append(lambda: op_conv.p.__setitem__(5, self.stats.view(st_off, R * 2 * Ct).data_ptr()))
         self.fwd_sync.append((op_conv, st_off, R * 2 * Ct))            # sync_bn: all-reduce of the batch statistics
         K = geo.kdims[0] * geo.kdims[1] * geo.Cin_k
@@ -414,6 +431,8 @@ class TrainPlan:
                 assert gw_off == gw_off0 + c0 * K, "merged conv: weight gradients must be adjacent in the arena"
             per.append([bn, act, a, zj, c0, co, sm_off])
             outs.append(a)
+            self._producers.append(dict(a=a, op=op_act, z=zj, ldz=Ct, co=co, sm_off=sm_off, act=act, bn=bn, residual=residual is not None,
+                                        R=R, npix=npix))
         for e in per:
             bn, co = e[0], e[5]
             e.append(self.sums.request(R * 2 * co))
@@ -477,7 +496,7 @@ class TrainPlan:
                 return
             # the weight gradient only needs dz: its slot comes BEFORE the layer's dgrad, so that a (grouped) launch forked
             # here does not wait for that dgrad
-            self._wgrad_job(geo.desc(dt, ldx, Ct), xk, dz, gw_off0, Ct * K)
+            self._wgrad_job(geo.desc(dt, cx["ldx"], Ct), cx["x"], dz, gw_off0, Ct * K, xf=cx["xf"])
             if not image:
                 dx = x_act.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
@@ -487,6 +506,45 @@ class TrainPlan:
 
         self.bwd_emitters.append(emit_bwd)
         return outs
+
+    def _fold_bn_act_into_consumers(self) -> None:
+        """Transform on load (stage A).  A Conv-BN-act block whose activation `a` has exactly one reader -- a
+        1x1 / stride-1 conv (a Conv block, C3's merged cv1 | cv2, a YOLOHead level) over exactly a's channels -- does not
+        materialise `a`: its BatchNorm + activation pass becomes the finalize launch (batch statistics -> scale / shift, saved
+        and running statistics), the reader's forward conv and weight gradient take the block's pre-activation z plus the two
+        per-channel vectors and form act(z * scale + shift) on the way to the MFMAs -- bit for bit the activation the pass
+        would have written.  Blocks with a shortcut added in that pass, readers that also read something else (concat
+        buffers), pools, up-sampling and 3x3 readers keep the materialised activation.  Measured per layer:
+        profiles/r04_xf_forward_sweep.txt (the pair costs 1.2-2.5x the fused launch; it loses only where the channel table
+        and the per-channel-tile repetition of the transform weigh in: Cin x channel tiles > 1024)."""
+        if not XF_ON_LOAD or self.dt != torch.float16 or WGRAD_GROUPS <= 0:
+            return
+        for P in self._producers:
+            a = P["a"]
+            lo, hi = a.c0, a.c0 + a.C
+            reads = [r for r in self._reads if r[0] == id(a.root) and r[1] < hi and r[2] > lo]
+            if len(reads) != 1 or P["residual"]:
+                continue
+            _, rlo, rhi, kind, c = reads[0]
+            if kind != "conv" or (rlo, rhi) != (lo, hi) or not c["pointwise"] or c["cx"]["xf"] is not None:
+                continue
+            if c["cin"] * -(-c["cout"] // 128) > 1024 or c["cin"] % 8:
+                continue
+            co, sm = P["co"], self.small.view(P["sm_off"], 4 * P["co"])
+            scale, shift = sm[2 * co:3 * co], sm[3 * co:4 * co]
+            o, bn = P["op"], P["bn"]
+            stats_ptr, smean, sinv = o.p[2], o.p[7], o.p[8]                # bound by the late closures of _conv_group
+            assert (o.kind & 0xff) == OP_BN_TRAIN_ACT and stats_ptr and smean and sinv
+            new = _op(OP_BN_FINALIZE, i=(P["R"], co, P["ldz"]), d=(float(P["npix"]),), f=(bn.eps, bn.momentum),
+                      p=(stats_ptr, bn.weight, bn.bias, bn.running_mean, bn.running_var, smean, sinv, scale, shift))
+            ctypes.memmove(ctypes.addressof(o), ctypes.addressof(new), ctypes.sizeof(Op))    # in place: self.fwd holds this object
+            rd = c["op"]
+            rd.p[0] = P["z"].data_ptr()
+            rd.conv.ldx = P["ldz"]
+            rd.p[6], rd.p[7] = scale.data_ptr(), shift.data_ptr()
+            rd.i[3] = P["act"]
+            c["cx"].update(x=P["z"], ldx=P["ldz"], xf=(scale, shift, P["act"]))
+            self.xf_layers += 1
 
     def _batched_casts(self) -> List[Op]:
         """All per-layer fp32 -> compute-dtype weight casts (and transposes) as ONE launch: the job table lives in
@@ -531,6 +589,7 @@ class TrainPlan:
         code = ops.dtype_code(self.dt)
         lds, ldd = ops.nhwc_info(src.t)[4], ops.nhwc_info(dst.t)[4]
         self.fwd.append(_op(OP_MAXPOOL_FWD, i=(code, lds, ldd, B, H, W, C, k), p=(src.t, dst.t, arg)))
+        self._reads.append((id(src.root), src.c0, src.c0 + src.C, "pool", None))
 
         def emit():
             dy, dx = dst.grad(), src.grad()
@@ -556,6 +615,7 @@ class TrainPlan:
         out = dst if dst is not None else self._new_act(C, 2 * H, 2 * W)
         code = ops.dtype_code(self.dt)
         self.fwd.append(_op(OP_UPSAMPLE_FWD, i=(code, ops.nhwc_info(x.t)[4], ops.nhwc_info(out.t)[4], B, H, W, C), p=(x.t, out.t)))
+        self._reads.append((id(x.root), x.c0, x.c0 + x.C, "upsample", None))
 
         def emit():
             dy, dx = out.grad(), x.grad()
@@ -585,8 +645,10 @@ class TrainPlan:
             self.keep += [wc, wt, buf]
             self.casts.append(_op(OP_CAST_WEIGHT, i=(Cout, 1, 1, Cin, cp, Cin, ops.dtype_code(dt)), p=(conv.weight, wc, wt)))
             ldx = ops.nhwc_info(x.t)[4]
-            self.fwd.append(_op(OP_CONV_FWD, i=(EPI_HEAD, 1, head.no), p=(x.t, wc, buf, None, conv.bias, None),
-                                conv=geo.desc(dt, ldx, cp)))
+            op_head = _op(OP_CONV_FWD, i=(EPI_HEAD, 1, head.no), p=(x.t, wc, buf, None, conv.bias, None), conv=geo.desc(dt, ldx, cp))
+            self.fwd.append(op_head)
+            cx = dict(x=x.t, ldx=ldx, xf=None)
+            self._reads.append((id(x.root), x.c0, x.c0 + x.C, "conv", dict(op=op_head, cx=cx, pointwise=True, cin=Cin, cout=cp)))
             gw_off = self._register_param(conv.weight, cp * Cin, lambda b, Cout=Cout, Cin=Cin: b.view(-1, Cin)[:Cout].view(Cout, Cin, 1, 1))
             gb_off = self._register_param(conv.bias, Cout, lambda b: b) if conv.bias is not None else None
             self.raw_specs.append((buf, (B, head.na, H, W, head.no), (H * W * cp, head.no, W * cp, cp, 1), gb_off, Cout))
@@ -594,7 +656,7 @@ class TrainPlan:
             self.dz_elems = max(self.dz_elems, npix * cp)
             code = ops.dtype_code(dt)
 
-            def emit(x=x, geo=geo, wt=wt, cp=cp, Cin=Cin, Cout=Cout, B=B, H=H, W=W, gw_off=gw_off, gb_off=gb_off, ldx=ldx, npix=npix, lvl=lvl):
+            def emit(x=x, geo=geo, wt=wt, cp=cp, Cin=Cin, Cout=Cout, B=B, H=H, W=W, gw_off=gw_off, gb_off=gb_off, ldx=ldx, npix=npix, lvl=lvl, cx=cx):
                 ga = self.gradarena
                 dz = self._dz(npix * cp)
                 op = _op(OP_HEAD_GRAD_PACK, i=(B, head.na, H, W, head.no, code, cp),
@@ -607,7 +669,7 @@ class TrainPlan:
                 self._gw(x, True)
                 x.mark_init()
                 # dy of a head level changes from step to step (the fused loss hands its own buffer over): override slot = level
-                self._wgrad_job(geo.desc(dt, ldx, cp, cout=cp), x.t, dz, gw_off, cp * Cin, dy_slot=lvl)
+                self._wgrad_job(geo.desc(dt, cx["ldx"], cp, cout=cp), cx["x"], dz, gw_off, cp * Cin, dy_slot=lvl, xf=cx["xf"])
                 self._wrote(gb_off, Cout, at=0)          # bias gradient: pack op, or the fused loss before the list runs
 
             self.bwd_emitters.append(emit)
@@ -695,6 +757,7 @@ class TrainPlan:
         self.dz_buf = torch.empty(max(self.dz_elems, 8), dtype=self.dt, device=dev)
         for fn in self.late:
             fn()
+        self._fold_bn_act_into_consumers()
         # all accumulators are zeroed at the START OF THE FORWARD (one fill each): the gradient arena too, because the
         # fused loss adds the head bias gradients into it before the backward list runs
         head_ops = [_op(OP_MEMSET, l=(self.stats.buf.numel() * 8,), p=(self.stats.buf,)),
@@ -903,6 +966,8 @@ class TrainPlan:
                 out.append(("conv_wgrad", es * (xin + 2 * yout) + 4 * wts, 2.0 * macs))
             elif kind == OP_BN_TRAIN_ACT:
                 out.append(("bn_act_fwd", es * o.l[0] * o.i[3] * (3 if o.p[9] else 2), 0.0))
+            elif kind == OP_BN_FINALIZE:
+                out.append(("bn_finalize", 8.0 * o.i[0] * 2 * o.i[1] + 4.0 * 6 * o.i[1], 0.0))
             elif kind == OP_BN_BWD_REDUCE:
                 out.append(("bn_bwd_reduce", es * o.l[0] * o.i[3] * 2, 0.0))
             elif kind == OP_BN_BWD_APPLY:

@@ -125,13 +125,16 @@ int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const void* dy, fl
  * the per-XCD item queues) happens ONCE: _size reports the bytes of the group table and of the split-K workspace, _build
  * fills the table in HOST memory, the caller keeps that copy and uploads another to the device; _run launches from both.
  * dy_slot >= 0: the job's dy is dy_override[dy_slot] of the run call (YOLOHead levels: the loss hands over a different buffer
- * each step); overwrite: dw = alpha * sum instead of dw += alpha * sum.  Workspaces of groups that run on the same stream may
+ * each step); overwrite: dw = alpha * sum instead of dw += alpha * sum; xscale / xshift / xact: transform on load.  Workspaces of groups that run on the same stream may
  * be shared.  The packed stem is not a group job (ayolo_conv_wgrad / ayolo_stem_bn_wgrad). */
 typedef struct ayolo_wgrad_job {
     ayolo_conv_desc conv;     /* the forward conv's descriptor with ldy = channel stride of dy */
     const void* x; const void* dy; float* dw;
     float alpha;
-    int dy_slot, overwrite, reserved;
+    int dy_slot, overwrite;
+    int xact;                 /* transform on load (1x1 / stride-1 consumers of a virtual activation, see ayolo_conv_fwd_xf): */
+    const float* xscale;      /* x is the producer's pre-activation z, the operand is act(z * xscale[c] + xshift[c]);         */
+    const float* xshift;      /* both NULL: plain x                                                                           */
 } ayolo_wgrad_job;
 int ayolo_wgrad_group_size(const ayolo_wgrad_job* jobs, int njobs, size_t* table_bytes, size_t* ws_bytes);
 int ayolo_wgrad_group_build(const ayolo_wgrad_job* jobs, int njobs, void* table_host, size_t table_bytes);
@@ -199,6 +202,12 @@ int ayolo_cast_weights(const ayolo_cast_job* jobs_dev, int njobs, int dtype, ayo
 int ayolo_bn_finalize(const double* stats, int stat_reps, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                       float* save_invstd, float* scale, float* shift, ayolo_stream s);
+/* the same over a channel slice of wider accumulators ([reps][2][stat_ld], this layer's channels first at `stats`: C3's
+ * cv1 | cv2 run as one conv) -- what ayolo_bn_train_act's prologue does, as a launch of its own for layers whose activation is
+ * never materialised (ayolo_conv_fwd_xf) */
+int ayolo_bn_finalize_ld(const double* stats, int stat_reps, int stat_ld, int C, double count, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         float* save_mean, float* save_invstd, float* scale, float* shift, ayolo_stream s);
 /* ayolo_bn_finalize + ayolo_affine_act(_res) in one pass over z: a = act(batchnorm_train(z)) (+ residual), running
  * statistics updated and save_mean / save_invstd written (all four nullable) by the kernel itself.
  * stats: double[stat_reps][2][stat_ld] as accumulated by ayolo_conv_fwd, pointing at this layer's first channel;

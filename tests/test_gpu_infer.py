@@ -355,12 +355,16 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
         m.load_state_dict(sd)
         m.__dict__.pop("_plans", None)
         m.use_plan = kw.get("use_plan", True)
-        old = P.BN_REDUCE_IN_DGRAD
+        old, old_xf = P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD
         P.BN_REDUCE_IN_DGRAD = kw.get("bnr", True)
+        P.XF_ON_LOAD = kw.get("xf", True)
         try:
             loss, _, g = _train_step(m, x, t, amp=True)
+            if kw.get("use_plan", True):
+                pl = [v for v in m._plans.values() if v][0]
+                assert (pl.xf_layers >= 10) == kw.get("xf", True), pl.xf_layers
         finally:
-            P.BN_REDUCE_IN_DGRAD = old
+            P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD = old, old_xf
             m.use_plan = True
         last.append(g)
         return loss, _flat(g)
@@ -377,6 +381,14 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
     assert len(conv_w) >= 59
     not_equal = [k for k in conv_w if not torch.equal(last[0][k], last[1][k])]
     assert not not_equal, not_equal
+    # transform on load (11 blocks whose BatchNorm + SiLU pass is folded into their 1x1 reader) against the materialised route:
+    # the reader forms the SAME activation bits on the way to the MFMAs, in the forward conv and in its weight gradient, so the
+    # loss and every conv weight gradient of the step are bit-identical with the switch off
+    l4, g4 = run(xf=False)
+    assert l4 == l0, (l4, l0)
+    not_equal = [k for k in conv_w if not torch.equal(last[0][k], last[-1][k])]
+    assert not not_equal, not_equal
+    assert _cos(g0, g4) >= 1.0 - 1e-9
     l2, g2 = run(bnr=False)
     l3, g3 = run(use_plan=False)
     print("fp16 step: same route twice cos %.9f; epilogue sums vs reduce pass cos %.9f; plan vs module path cos %.9f"
