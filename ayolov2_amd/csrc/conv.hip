@@ -2463,8 +2463,8 @@ __device__ __forceinline__ half8 tr_frag_sw(const unsigned char* tile, int k0, i
 typedef const __attribute__((address_space(4))) WGradP* wjob_cptr_t;
 
 template <typename T, int TM>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP pv, const WGradP* jobs, const WItem* items, float* ws,
-                                                                            WOvr ovr) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP pv, const WGradP* jobs, const WItem* items, unsigned nitems,
+                                                                            float* ws, WOvr ovr) {
     using W = WT<T, TM>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2482,13 +2482,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
 #endif
     // ---- which (job, dw tile, pixel split): from the item list of a grouped launch, or -- single job, passed by value -- from
     // the block index: split zz on XCD zz % 8 with its gx * gy tiles consecutive there
+    // A grouped launch may run FEWER workgroups than items (grid = a few per CU, a multiple of 8): workgroup b then walks items b,
+    // b + grid, b + 2 grid, ... -- it keeps its XCD, and the launch never holds more than its share of the CUs' workgroup slots
+    // (resident workgroups are not preempted: an uncapped group kernel that filled every slot made the next main-stream kernels
+    // wait for a whole item, +0.5-1 ms of backward's critical path, profiles/r04_op_table_in_situ_xf.txt).
     typedef __attribute__((address_space(4))) const char* kcptr_t;
+    for (unsigned itx = blockIdx.x;; itx += gridDim.x) {
     wjob_cptr_t pj;
     unsigned tile, zz;
     if (items != nullptr) {
-        const WItem it = items[blockIdx.x];
+        if (itx >= nitems) break;
+        const WItem it = items[itx];
         const unsigned job = (unsigned)__builtin_amdgcn_readfirstlane((int)it.job);
-        if (job == 0xffffffffu) return;
+        if (job == 0xffffffffu) continue;
         pj = (wjob_cptr_t)(unsigned long long)(jobs + job);
         tile = (unsigned)__builtin_amdgcn_readfirstlane((int)it.tile);
         zz = (unsigned)__builtin_amdgcn_readfirstlane((int)it.zz);
@@ -2498,7 +2504,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
         const unsigned ntile = pj->gx * pj->gy;
         tile = local % ntile;
         zz = (local / ntile) * 8u + xcd;
-        if (zz >= pj->splits) return;
+        if (zz >= pj->splits) break;
     }
 #define p (*pj)
 #define WFD(f_) FastDiv{pj->f_.m, pj->f_.s1, pj->f_.s2}     /* member-wise: an address-space-4 struct has no copy constructor */
@@ -2733,6 +2739,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     }
 #undef p
 #undef WFD
+    if (items == nullptr) break;
+    __syncthreads();                             // every wave is done with the LDS stages before the next item's DMA lands in them
+    }
 #ifdef AYOLO_PROBE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AY_PROBE(AY_PROBE_N - 1);
@@ -3543,7 +3552,8 @@ extern "C" int ayolo_wgrad_group_item(const void* table_host, int cls, long long
 }
 
 template <typename T, int TM>
-static int launch_wgrad_k(const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned blocks, float* ws, const WOvr& ovr, hipStream_t s) {
+static int launch_wgrad_k(const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned nitems, unsigned blocks, float* ws, const WOvr& ovr,
+                          hipStream_t s) {
     using W = WT<T, TM>;
     static bool attr_set[16] = {false};
     int dev = 0;
@@ -3552,25 +3562,25 @@ static int launch_wgrad_k(const WGradP& pv, const WGradP* jobs, const WItem* ite
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_wgrad<T, TM>), dim3(blocks), dim3(256), W::LDS, s, pv, jobs, items, ws, ovr);
+    hipLaunchKernelGGL((k_wgrad<T, TM>), dim3(blocks), dim3(256), W::LDS, s, pv, jobs, items, nitems, ws, ovr);
     AY_CHECK_LAUNCH("k_wgrad");
     return AYOLO_OK;
 }
 
-static int launch_wgrad_any(int dtype, int tm, const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned blocks, float* ws,
-                            const WOvr& ovr, hipStream_t s) {
+static int launch_wgrad_any(int dtype, int tm, const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned nitems, unsigned blocks,
+                            float* ws, const WOvr& ovr, hipStream_t s) {
     if (dtype == AYOLO_F16) {
-        if (tm == 32) return launch_wgrad_k<half_t, 32>(pv, jobs, items, blocks, ws, ovr, s);
-        if (tm == 64) return launch_wgrad_k<half_t, 64>(pv, jobs, items, blocks, ws, ovr, s);
-        return launch_wgrad_k<half_t, 128>(pv, jobs, items, blocks, ws, ovr, s);
+        if (tm == 32) return launch_wgrad_k<half_t, 32>(pv, jobs, items, nitems, blocks, ws, ovr, s);
+        if (tm == 64) return launch_wgrad_k<half_t, 64>(pv, jobs, items, nitems, blocks, ws, ovr, s);
+        return launch_wgrad_k<half_t, 128>(pv, jobs, items, nitems, blocks, ws, ovr, s);
     }
-    if (tm == 32) return launch_wgrad_k<float, 32>(pv, jobs, items, blocks, ws, ovr, s);
-    if (tm == 64) return launch_wgrad_k<float, 64>(pv, jobs, items, blocks, ws, ovr, s);
-    return launch_wgrad_k<float, 128>(pv, jobs, items, blocks, ws, ovr, s);
+    if (tm == 32) return launch_wgrad_k<float, 32>(pv, jobs, items, nitems, blocks, ws, ovr, s);
+    if (tm == 64) return launch_wgrad_k<float, 64>(pv, jobs, items, nitems, blocks, ws, ovr, s);
+    return launch_wgrad_k<float, 128>(pv, jobs, items, nitems, blocks, ws, ovr, s);
 }
 
 extern "C" int ayolo_wgrad_group_run(const void* table_host, const void* table_dev, void* ws, size_t ws_bytes,
-                                     const void* const* dy_override, int n_override, ayolo_stream s) {
+                                     const void* const* dy_override, int n_override, int wg_per_cu, ayolo_stream s) {
     AY_CHECK_ARG(table_host && table_dev && ws, "wgrad_group_run: null pointer");
     const WGroupHdr& h = *(const WGroupHdr*)table_host;
     AY_CHECK_ARG(h.magic == WGROUP_MAGIC, "wgrad_group_run: not a group table");
@@ -3586,9 +3596,21 @@ extern "C" int ayolo_wgrad_group_run(const void* table_host, const void* table_d
     const unsigned char* td = (const unsigned char*)table_dev;
     const WGradP* djobs = (const WGradP*)(td + h.off_jobs);
     const WGradP none{};
+    // wg_per_cu > 0: at most that many workgroups per CU for the whole group (shared by its tile classes in proportion to their
+    // items); the rest of the CUs' slots stays free for whatever runs beside it
+    unsigned all_items = h.n_items[0] + h.n_items[1] + h.n_items[2];
+    const unsigned long long cap = wg_per_cu > 0 ? (unsigned long long)wg_per_cu * (unsigned)num_cus() : 0ull;
     for (int c = 0; c < 3; ++c) {
         if (!h.n_items[c]) continue;
-        int rc = launch_wgrad_any((int)h.dtype, 32 << c, none, djobs, (const WItem*)(td + h.off_items[c]), h.n_items[c], (float*)ws, ovr, (hipStream_t)s);
+        unsigned blocks = h.n_items[c];
+        if (cap && all_items > cap) {
+            unsigned long long b = (cap * h.n_items[c] + all_items - 1) / all_items;
+            b = (b + 7) / 8 * 8;
+            if (b < 8) b = 8;
+            if (b < blocks) blocks = (unsigned)b;
+        }
+        int rc = launch_wgrad_any((int)h.dtype, 32 << c, none, djobs, (const WItem*)(td + h.off_items[c]), h.n_items[c], blocks, (float*)ws, ovr,
+                                  (hipStream_t)s);
         if (rc) return rc;
     }
     if (h.n_red) {
@@ -3655,7 +3677,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
     for (const WGradP& j : jobs) {
         const long long blocks = (long long)j.gx * j.gy * ((j.splits + 7) / 8 * 8);
         AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
-        rc = launch_wgrad_any(d->dtype, j.tm, j, nullptr, nullptr, (unsigned)blocks, (float*)ws, ovr, (hipStream_t)s);
+        rc = launch_wgrad_any(d->dtype, j.tm, j, nullptr, nullptr, 0u, (unsigned)blocks, (float*)ws, ovr, (hipStream_t)s);
         if (rc) return rc;
         S += j.splits;
     }

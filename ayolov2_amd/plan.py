@@ -81,6 +81,9 @@ BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
 XF_ON_LOAD = _os.environ.get("AYOLO_XF", "1") == "1"
 WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "4"))
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
+# resident workgroups per CU of a grouped launch (it runs beside backward's dependent chain and must leave that chain its
+# slots; the LAST group has nothing left to run beside and is not capped); 0 = no cap
+WGRAD_BPC = int(_os.environ.get("AYOLO_WGRAD_BPC", "1"))
 
 
 class PlanUnsupported(Exception):
@@ -299,7 +302,8 @@ class TrainPlan:
             idx = js[-1]["idx"]                           # the group launches where its LAST layer's dz is complete
             slots = sorted({j["slot"] for j in js if j["slot"] >= 0})
             nov = (max(slots) + 1) if slots else 0
-            o = _op(OP_WGRAD_GROUP | side, i=(nov,), l=(ws.numel(),), p=(ctypes.addressof(host), dev, ws))
+            last = js is built[-1][0]
+            o = _op(OP_WGRAD_GROUP | side, i=(nov, 0 if last else WGRAD_BPC), l=(ws.numel(),), p=(ctypes.addressof(host), dev, ws))
             for j in js:
                 if j["slot"] >= 0:
                     o.p[3 + j["slot"]] = j["dy"].data_ptr()
