@@ -625,10 +625,85 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const T* x, int ldx, T* y, 
     }
 }
 
+// The SPPF window (5 x 5) in strips: a thread owns PSW adjacent output pixels of one row and one 16-byte channel group, loads
+// each of the PSW + 4 input columns of a window row ONCE (the per-pixel kernel above loads every input 25 times: 20 M 16-byte
+// loads for the 13 MB tensor of YOLOv5s at batch 64, 40 us at 0.8 TB/s) and scans the taps of every output in the same row-major
+// order, so the recorded first maximum is the same.  The PSW x VE window positions leave as ONE 8- (4-) byte store per pixel.
+#define PSW 4
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool5_fwd(const T* x, int ldx, T* y, int ldy, unsigned char* idx, int B, int H, int W, int C) {
+    constexpr int VE = VecT<T>::VE, K = 5, PAD = 2, NC = PSW + K - 1;
+    const int CG = C / VE, NS = (W + PSW - 1) / PSW;
+    const long long total = (long long)B * H * NS * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int cg = (int)(t % CG);
+        long long r = t / CG;
+        const int w0 = (int)(r % NS) * PSW;
+        r /= NS;
+        const int h = (int)(r % H);
+        const long long n = r / H;
+        float best[PSW][VE];
+        int bi[PSW][VE];
+#pragma unroll
+        for (int j = 0; j < PSW; ++j)
+#pragma unroll
+            for (int i = 0; i < VE; ++i) { best[j][i] = -INFINITY; bi[j][i] = 0; }
+        for (int dy = 0; dy < K; ++dy) {
+            const int hh = h + dy - PAD;
+            if (hh < 0 || hh >= H) continue;
+            float v[NC][VE];
+            const T* row = x + ((n * H + hh) * W) * (long long)ldx + cg * VE;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ww = w0 + c - PAD;
+                if (ww >= 0 && ww < W) load_vec<T>(row + (long long)ww * ldx, v[c]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) v[c][i] = -INFINITY;       // never beats the initial best: same as skipping the tap
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PSW; ++j)
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    const int ww = w0 + j + dx - PAD;
+                    if (ww < 0 || ww >= W) continue;
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) {
+                        const float val = v[j + dx][i];
+                        if (val > best[j][i] || val != val) { best[j][i] = val; bi[j][i] = dy * K + dx; }
+                    }
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < PSW; ++j) {
+            if (w0 + j >= W) break;
+            const long long pix = (n * H + h) * W + w0 + j;
+            store_vec<T>(y + pix * ldy + cg * VE, best[j]);
+            if (idx) {
+                unsigned wd[VE / 4];
+#pragma unroll
+                for (int q = 0; q < VE / 4; ++q)
+                    wd[q] = (unsigned)bi[j][4 * q] | ((unsigned)bi[j][4 * q + 1] << 8) | ((unsigned)bi[j][4 * q + 2] << 16) | ((unsigned)bi[j][4 * q + 3] << 24);
+                unsigned* dst = reinterpret_cast<unsigned*>(idx + pix * C + cg * VE);       // C % VE == 0: VE-byte aligned
+                if constexpr (VE == 8) *reinterpret_cast<uint2*>(dst) = make_uint2(wd[0], wd[1]);
+                else dst[0] = wd[0];
+            }
+        }
+    }
+}
+
 extern "C" int ayolo_maxpool_fwd(int dtype, const void* x, int ldx, void* y, int ldy, unsigned char* argmax, int B, int H,
                                  int W, int C, int k, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
     AY_CHECK_ARG(x && y && C % ve == 0 && ldx % ve == 0 && ldy % ve == 0 && k > 0 && k <= 15 && (k & 1), "maxpool_fwd: bad args");
+    if (k == 5 && (argmax == nullptr || ((uintptr_t)argmax % 8) == 0)) {
+        const long long strips = (long long)B * H * ((W + PSW - 1) / PSW) * (C / ve);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool5_fwd<T>, dim3(grid_for(strips, 256)), dim3(256), 0, (hipStream_t)s,
+                                             (const T*)x, ldx, (T*)y, ldy, argmax, B, H, W, C);)
+        AY_CHECK_LAUNCH("k_maxpool5_fwd");
+        return AYOLO_OK;
+    }
     long long total = (long long)B * H * W * (C / ve);
     DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_fwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s,
                                          (const T*)x, ldx, (T*)y, ldy, argmax, B, H, W, C, k);)
@@ -677,10 +752,75 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const unsigned char* idx, c
     }
 }
 
+// backward of the 5 x 5 window in the same strips: the PSW input pixels of a thread are taps of the outputs in columns
+// w0 - 2 .. w0 + PSW + 1 of five rows; every output's gradient vector and its VE window positions (one 8- / 4-byte word) are
+// loaded once and matched against the PSW pixels (the per-pixel kernel: 25 x (VE byte loads + 1 vector load) per input pixel).
+// Taps are visited in the per-pixel kernel's order (dyy ascending, dxx ascending), so the sums round identically.
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool5_bwd(const unsigned char* idx, const T* dy, int lddy, T* dx, int lddx, int B, int H, int W,
+                                                      int C, int accumulate) {
+    constexpr int VE = VecT<T>::VE, K = 5, PAD = 2, NC = PSW + K - 1;
+    const int CG = C / VE, NS = (W + PSW - 1) / PSW;
+    const long long total = (long long)B * H * NS * CG;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int cg = (int)(t % CG);
+        long long r = t / CG;
+        const int w0 = (int)(r % NS) * PSW;
+        r /= NS;
+        const int h = (int)(r % H);
+        const long long n = r / H;
+        float g[PSW][VE];
+#pragma unroll
+        for (int j = 0; j < PSW; ++j) {
+            if (accumulate && w0 + j < W) load_vec<T>(dx + ((n * H + h) * W + w0 + j) * (long long)lddx + cg * VE, g[j]);
+            else {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) g[j][i] = 0.0f;
+            }
+        }
+        for (int dyy = 0; dyy < K; ++dyy) {
+            const int oh = h - dyy + PAD;
+            if (oh < 0 || oh >= H) continue;
+            const long long orow = (n * H + oh) * W;
+            // input pixel w0 + j is tap dxx of output column w0 + j - dxx + PAD: dxx ascending = output column descending
+#pragma unroll
+            for (int c = NC - 1; c >= 0; --c) {
+                const int ow = w0 + c - PAD;
+                if (ow < 0 || ow >= W) continue;
+                float dv[VE];
+                load_vec<T>(dy + (orow + ow) * lddy + cg * VE, dv);
+                unsigned wd[VE / 4];
+                const unsigned* ip = reinterpret_cast<const unsigned*>(idx + (orow + ow) * C + cg * VE);
+                if constexpr (VE == 8) { const uint2 u = *reinterpret_cast<const uint2*>(ip); wd[0] = u.x; wd[1] = u.y; }
+                else wd[0] = ip[0];
+#pragma unroll
+                for (int j = 0; j < PSW; ++j) {
+                    const int dxx = j - c + 2 * PAD;           // (w0 + j) - ow + PAD
+                    if (dxx < 0 || dxx >= K) continue;
+                    const unsigned me = (unsigned)(dyy * K + dxx);
+#pragma unroll
+                    for (int i = 0; i < VE; ++i)
+                        if (((wd[i >> 2] >> (8 * (i & 3))) & 0xffu) == me) g[j][i] += dv[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PSW; ++j)
+            if (w0 + j < W) store_vec<T>(dx + ((n * H + h) * W + w0 + j) * (long long)lddx + cg * VE, g[j]);
+    }
+}
+
 extern "C" int ayolo_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, int lddy, void* dx, int lddx, int B,
                                  int H, int W, int C, int k, int accumulate, ayolo_stream s) {
     const int ve = dtype == AYOLO_F16 ? 8 : 4;
     AY_CHECK_ARG(argmax && dy && dx && C % ve == 0 && lddy % ve == 0 && lddx % ve == 0, "maxpool_bwd: bad args");
+    if (k == 5 && ((uintptr_t)argmax % 8) == 0) {
+        const long long strips = (long long)B * H * ((W + PSW - 1) / PSW) * (C / ve);
+        DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool5_bwd<T>, dim3(grid_for(strips, 256)), dim3(256), 0, (hipStream_t)s, argmax,
+                                             (const T*)dy, lddy, (T*)dx, lddx, B, H, W, C, accumulate);)
+        AY_CHECK_LAUNCH("k_maxpool5_bwd");
+        return AYOLO_OK;
+    }
     long long total = (long long)B * H * W * (C / ve);
     DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool_bwd<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)s, argmax,
                                          (const T*)dy, lddy, (T*)dx, lddx, B, H, W, C, k, accumulate);)

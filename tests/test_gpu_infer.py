@@ -402,14 +402,17 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
     assert abs(l3 - l0) <= 1e-4 * abs(l0) and _cos(g0, g3) >= 0.999, (l3, l0, _cos(g0, g3))
 
 
-def test_fp16_train_step_well_conditioned_vs_oracle():
+@pytest.mark.parametrize("name,size,thr", [("s", 320, (0.997, 0.99)), ("l", 256, (0.99, 0.95))])
+def test_fp16_train_step_well_conditioned_vs_oracle(name, size, thr):
     """The bench's model and dtype against the CPU oracle where the comparison is decided by the kernels and not by the
     conditioning of a random-init BatchNorm network: BatchNorm gains of 0.3 (a trained net's are well below the 1.0 of
     the default initialisation; with them a 3e-4 perturbation of the input moves the exact-fp32 gradient by cosine 0.9995
-    instead of 0.988) and reproducible statistics.  Whole-gradient cosine >= 0.997 (measured 0.9986 against the fp32
-    mode), every conv weight >= 0.99, loss within 2e-4."""
+    instead of 0.988) and reproducible statistics.  YOLOv5s: whole-gradient cosine >= 0.997 (measured 0.9986 against the
+    fp32 mode), every conv weight >= 0.99, loss within 2e-4.  YOLOv5l (BASELINE cfg 3's model, VERDICT r3 item 9 -- until
+    round 4 it was held only to an in-test conditioning calibration): the same check on the deeper net, thresholds 0.99 /
+    0.95 (fp16 storage rounds ~3x as many layers)."""
     from ayolov2_amd.losses import ComputeLoss
-    m, r = _pair("s", seed=39)
+    m, r = _pair(name, seed=39)
     with torch.no_grad():
         for mod in m.modules():
             if isinstance(mod, torch.nn.BatchNorm2d):
@@ -418,17 +421,17 @@ def test_fp16_train_step_well_conditioned_vs_oracle():
     for mod in (m, r):
         mod.hyp, mod.gr, mod.nc = dict(HYP), 1.0, 80
     m, r = m.cuda().train(), r.train()
-    x, t = torch.rand(4, 3, 320, 320), _targets(4, 40)
+    x, t = torch.rand(4, 3, size, size), _targets(4, 40)
     loss_r, _ = ComputeLoss(r)(r(x), t)
     loss_r.backward()
     gr = {k: p.grad.detach() for k, p in r.named_parameters()}
     l16, _, g16 = _train_step(m, x.cuda(), t.cuda(), amp=True)
-    assert abs(l16 - float(loss_r.detach())) <= 2e-4 * abs(float(loss_r.detach())), (l16, float(loss_r.detach()))
+    assert abs(l16 - float(loss_r.detach())) <= (2e-4 if name == "s" else 1e-3) * abs(float(loss_r.detach())), (l16, float(loss_r.detach()))
     glob = _cos(_flat({k: v.cpu() for k, v in g16.items()}), _flat(gr))
     worst = min((_cos(g16[k].cpu().flatten().double(), gr[k].flatten().double()), k) for k in gr if gr[k].dim() == 4)
-    print("yolov5s fp16 (BN gain 0.3) vs oracle: whole-gradient cosine %.5f, worst conv weight %.5f (%s)" % (glob, worst[0], worst[1]))
-    assert glob >= 0.997, glob
-    assert worst[0] >= 0.99, worst
+    print("yolov5%s fp16 (BN gain 0.3) vs oracle: whole-gradient cosine %.5f, worst conv weight %.5f (%s)" % (name, glob, worst[0], worst[1]))
+    assert glob >= thr[0], glob
+    assert worst[0] >= thr[1], worst
 
 
 @pytest.mark.parametrize("name,batch,thr", [("s", 64, (0.975, 0.96, 0.93)), ("l", 16, None)])
