@@ -402,15 +402,15 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
     assert abs(l3 - l0) <= 1e-4 * abs(l0) and _cos(g0, g3) >= 0.999, (l3, l0, _cos(g0, g3))
 
 
-@pytest.mark.parametrize("name,size,thr", [("s", 320, (0.997, 0.99)), ("l", 256, (0.99, 0.95))])
+@pytest.mark.parametrize("name,size,thr", [("s", 320, (0.997, 0.99)), ("l", 256, (0.997, 0.99))])
 def test_fp16_train_step_well_conditioned_vs_oracle(name, size, thr):
     """The bench's model and dtype against the CPU oracle where the comparison is decided by the kernels and not by the
     conditioning of a random-init BatchNorm network: BatchNorm gains of 0.3 (a trained net's are well below the 1.0 of
     the default initialisation; with them a 3e-4 perturbation of the input moves the exact-fp32 gradient by cosine 0.9995
     instead of 0.988) and reproducible statistics.  YOLOv5s: whole-gradient cosine >= 0.997 (measured 0.9986 against the
     fp32 mode), every conv weight >= 0.99, loss within 2e-4.  YOLOv5l (BASELINE cfg 3's model, VERDICT r3 item 9 -- until
-    round 4 it was held only to an in-test conditioning calibration): the same check on the deeper net, thresholds 0.99 /
-    0.95 (fp16 storage rounds ~3x as many layers)."""
+    round 4 it was held only to an in-test conditioning calibration): the same check and thresholds on the deeper net (measured
+    0.9993 / 0.9990)."""
     from ayolov2_amd.losses import ComputeLoss
     m, r = _pair(name, seed=39)
     with torch.no_grad():
