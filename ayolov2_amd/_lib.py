@@ -31,7 +31,12 @@ class BnSeg(ctypes.Structure):
 class WgradJob(ctypes.Structure):
     """ayolo_wgrad_job (include/ayolo.h): one layer's weight gradient inside a grouped launch."""
     _fields_ = [("conv", ConvDesc), ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("alpha", c_float),
-                ("dy_slot", c_int), ("overwrite", c_int), ("xact", c_int), ("xscale", c_void_p), ("xshift", c_void_p)]
+                ("dy_slot", c_int), ("overwrite", c_int), ("xact", c_int), ("xscale", c_void_p), ("xshift", c_void_p), ("dw_ld", c_int), ("reserved", c_int)]
+
+
+class XfSeg(ctypes.Structure):
+    """ayolo_xf_seg (include/ayolo.h): one input segment of a transform-on-load conv."""
+    _fields_ = [("x", c_void_p), ("ld", c_int), ("C", c_int), ("act", c_int), ("virt", c_int)]
 
 
 class LossLevel(ctypes.Structure):
@@ -51,7 +56,7 @@ _P = c_void_p
 # name -> argtypes (restype is int unless noted).  Mirrors include/ayolo.h one to one.
 _SIGNATURES = {
     "ayolo_conv_fwd": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, _P],
-    "ayolo_conv_fwd_xf": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P],
+    "ayolo_conv_fwd_xf": [POINTER(ConvDesc), POINTER(XfSeg), c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P],
     "ayolo_conv_dgrad": [POINTER(ConvDesc), _P, _P, _P, c_int, _P],
     "ayolo_conv_dgrad_bn": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P],
     "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P, c_size_t, _P],

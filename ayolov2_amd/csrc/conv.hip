@@ -72,8 +72,12 @@ struct GConvP {
     unsigned z_bytes[2];
     // XF kernels (transform on load, ayolo_conv_fwd_xf): x is the producer's pre-activation z; the operand the MFMAs see is
     // act(z * xf_scale[c] + xf_shift[c]) -- the BatchNorm + SiLU pass that would have materialised it does not exist
-    int xf, xf_act;
+    // Up to TWO input segments side by side in the conv's channels (C3's cv3 reads [last Bottleneck output | cv2 half]): segment
+    // 1 = channels [xs_split, C) from `x2` (channel stride ldx2); each segment is virtual (transformed, activation xf_act bit) or a
+    // plain materialised activation (xf_virt bit clear: copied as it lies)
+    int xf, xf_act, xf_virt;         // bit 0: segment 0, bit 1: segment 1
     const float* xf_scale; const float* xf_shift;
+    const void* x2; int ldx2, xs_split; unsigned x2_bytes;
 };
 
 template <typename T> struct Tr;
@@ -910,6 +914,9 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
     const int kc = slotc ^ lsw;
 
     int xoff[G::XR], xh0[G::XR], xw0[G::XR];
+    // XF (1x1 / stride 1 only): the loader needs no pixel decode -- a row's byte offset in segment 0 (xoff) and in segment 1 (xoff2),
+    // out of range for rows beyond the tensor
+    unsigned xoff2[XF ? G::XR : 1];
     unsigned woff[G::WR];
 #pragma unroll
     for (int r = 0; r < G::WR; ++r) {
@@ -946,11 +953,49 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
     // s_waitcnt round trips in EVERY step
     int ld_tap0 = p.ctap0[0], ld_ntap = p.cnt[0];
     bool ld_valid = true;
-    g_setup_rows<T, TM, TPX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
+    const v4i32 rsX2 = XF ? make_srd(p.x2 ? p.x2 : p.x, p.x2 ? p.x2_bytes : p.x_bytes) : rsX;
+    const unsigned xf_ldb0 = (unsigned)p.ldx * G::ES, xf_ldb1 = (unsigned)p.ldx2 * G::ES;
+    auto xf_setup_rows = [&](unsigned tile, bool valid) {
+        if constexpr (XF) {
+#pragma unroll
+            for (int r = 0; r < G::XR; ++r) {
+                const unsigned mu = tile * G::TP + (unsigned)((r * G::NW + wave) * G::RW + rowin);
+                const bool ok = valid & (mu < (unsigned)p.Mtotal);
+                xoff[r] = ok ? (int)(mu * xf_ldb0) : (int)G_OOB;
+                xoff2[r] = ok ? mu * xf_ldb1 : G_OOB;
+            }
+        }
+    };
+    // per-piece offsets of k step kt (XF): the step lies in ONE segment (xs_split % 32 == 0); channels beyond C are K padding
+    auto xf_prep = [&](int kt, unsigned (&offs)[G::LPS]) -> bool {
+        const unsigned k0 = (unsigned)(kt * BK + kc * G::CE);
+        const bool s1 = (unsigned)(kt * BK) >= (unsigned)p.xs_split;
+        const bool kin = k0 < (unsigned)p.C;
+        const unsigned cb = (k0 - (s1 ? (unsigned)p.xs_split : 0u)) * G::ES;
+        if constexpr (XF) {
+#pragma unroll
+            for (int r = 0; r < G::XR; ++r) {
+                const unsigned base = s1 ? xoff2[r] : (unsigned)xoff[r];
+                offs[r] = (kin && base != G_OOB) ? base + cb : G_OOB;
+            }
+#pragma unroll
+            for (int r = 0; r < G::WR; ++r) offs[G::XR + r] = (kin && woff[r] != G_OOB) ? woff[r] + k0 * G::ES : G_OOB;
+        }
+        return s1;
+    };
+    if constexpr (XF) xf_setup_rows(ld_tile, true);
+    else g_setup_rows<T, TM, TPX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
     AY_PROBE(AY_PROBE_N - 5);
     __syncthreads();                          // tap table visible
     AY_PROBE(AY_PROBE_N - 6);
-#define G_ISSUE(so) g_issue<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, lds_tiles, so, rsX, rsW, wave, kc);
+#define G_ISSUE(so)                                                                                                                  \
+    if constexpr (XF) {                                                                                                              \
+        unsigned offs_[G::LPS];                                                                                                      \
+        const bool s1_ = xf_prep(ld_kt, offs_);                                                                                      \
+        const v4i32 rs_ = s1_ ? rsX2 : rsX;                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < G::XR; ++r) glds16(rs_, lds_tiles + (so) + (r * G::NW + wave) * 1024, offs_[r]);       \
+        _Pragma("unroll") for (int r = 0; r < G::WR; ++r) glds16(rsW, lds_tiles + (so) + G::XSTAGE + (r * G::NW + wave) * 1024, offs_[G::XR + r]); \
+    } else g_issue<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, lds_tiles, so, rsX, rsW, wave, kc);
 #define G_ADVANCE()                                                                           \
     {                                                                                         \
         if (++ld_kt == ld_nk) {                                                               \
@@ -959,7 +1004,8 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
                 ld_cls = 0;                                                                   \
                 ld_tile += lstride;                                                           \
                 ld_valid = ld_valid && ld_tile < ntiles;                                      \
-                g_setup_rows<T, TM, TPX>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);   \
+                if constexpr (XF) xf_setup_rows(ld_tile, ld_valid);                           \
+                else g_setup_rows<T, TM, TPX>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);   \
             }                                                                                 \
             ld_nk = G_NK(ld_cls);                                                             \
             ld_tap0 = p.ctap0[ld_cls]; ld_ntap = p.cnt[ld_cls];                               \
@@ -981,7 +1027,9 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
             const int c0 = kt * BK + kc * G::CE;
             const float4v a0 = *reinterpret_cast<const float4v*>(sXf + c0), a1 = *reinterpret_cast<const float4v*>(sXf + c0 + 4);
             const float4v b0 = *reinterpret_cast<const float4v*>(sXf + xf_cp + c0), b1 = *reinterpret_cast<const float4v*>(sXf + xf_cp + c0 + 4);
-            const bool act = p.xf_act != 0;
+            const int sg = (kt * BK) >= p.xs_split ? 1 : 0;
+            if (!((p.xf_virt >> sg) & 1)) return;                       // a plain segment: the DMA already delivered the activation
+            const bool act = ((p.xf_act >> sg) & 1) != 0;
 #pragma unroll
             for (int r = 0; r < G::XR; ++r) {
                 half8* q = reinterpret_cast<half8*>(sTiles + so + (r * G::NW + wave) * 1024 + lane * 16);
@@ -1025,9 +1073,11 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
             __builtin_amdgcn_sched_barrier(0);
             // address work of step s+2 (covers the LDS latency of the fetch), its DMA pieces one per MFMA of the first half
             unsigned offs[G::LPS];
-            g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
+            v4i32 rsXs = rsX;
+            if constexpr (XF) { if (xf_prep(ld_kt, offs)) rsXs = rsX2; }
+            else g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
             __builtin_amdgcn_sched_barrier(0);
-            g_mma_k_issue<T, TM, TPX>(f0, acc, offs, lds_tiles, so2, rsX, rsW, wave);   // -> the stage step s-1 used
+            g_mma_k_issue<T, TM, TPX>(f0, acc, offs, lds_tiles, so2, rsXs, rsW, wave);   // -> the stage step s-1 used
             g_fetch_k<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, 1, f1);
             __builtin_amdgcn_sched_barrier(0);
             G_ADVANCE()
@@ -1038,9 +1088,11 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
             g_fetch_frags<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, fr);
             __builtin_amdgcn_sched_barrier(0);
             unsigned offs[G::LPS];
-            g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
+            v4i32 rsXs = rsX;
+            if constexpr (XF) { if (xf_prep(ld_kt, offs)) rsXs = rsX2; }
+            else g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
             __builtin_amdgcn_sched_barrier(0);
-            g_mma_frags_issue<T, TM, TPX>(fr, acc, offs, lds_tiles, so2, rsX, rsW, wave);   // step s+2 -> the stage step s-1 used
+            g_mma_frags_issue<T, TM, TPX>(fr, acc, offs, lds_tiles, so2, rsXs, rsW, wave);   // step s+2 -> the stage step s-1 used
             G_ADVANCE()
         } else {
             G_ISSUE(so2)
@@ -2127,13 +2179,16 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
         z_img_max = z_img > z_img_max ? z_img : z_img_max;
     }
     AY_CHECK_ARG(z_img_max < LIM, "conv: a single image of z (%lld bytes) unsupported", z_img_max);
-    if (x_img * p.B >= LIM || y_img * p.B >= LIM || z_img_max * p.B >= LIM) {
+    const long long x2_img = p.x2 ? (long long)p.XH * p.XW * p.ldx2 * es : 0;
+    AY_CHECK_ARG(x2_img < LIM, "conv: a single image of the second input segment (%lld bytes) unsupported", x2_img);
+    if (x_img * p.B >= LIM || y_img * p.B >= LIM || z_img_max * p.B >= LIM || x2_img * p.B >= LIM) {
         AY_CHECK_ARG(p.B > 1, "conv: one image exceeds the 2 GiB descriptor range");
         GConvP a = p, b = p;
         a.B = p.B / 2; b.B = p.B - a.B;
         a.Mtotal = (long long)a.B * p.OH * p.OW; b.Mtotal = (long long)b.B * p.OH * p.OW;
         b.x = (const char*)p.x + x_img * a.B;
         b.y = (char*)p.y + y_img * a.B;
+        if (p.x2) b.x2 = (const char*)p.x2 + (long long)p.XH * p.XW * p.ldx2 * es * a.B;
         for (int k = 0; k < p.bnr; ++k)
             b.bseg[k].z = (const char*)p.bseg[k].z + (long long)p.YH * p.YW * p.bseg[k].ldz * 2 * a.B;
         int rc = dispatch_gconv(dtype, a, s);
@@ -2146,6 +2201,7 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
                      "conv: fp16 outputs leave in 16-byte stores: Cout=%d / channel stride %d must be multiples of 8", p.Nout, p.ldy);
     }
     p.x_bytes = (unsigned)(x_img * p.B);
+    p.x2_bytes = (unsigned)(x2_img * p.B);
     p.y_bytes = (unsigned)(y_img * p.B);
     p.w_bytes = (unsigned)w_bytes;
     p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)(p.C > 0 ? p.C : 1));
@@ -2234,23 +2290,31 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
     return dispatch_gconv(d->dtype, p, (hipStream_t)s);
 }
 
-// Forward of a 1x1 / stride-1 conv whose input is VIRTUAL: x = act(z * xscale + xshift) formed on the way to the MFMAs (k_gconv<...,
-// XF>), i.e. the consumer of a Conv-BN-act block reads the block's pre-activation z and the BatchNorm + activation pass that
-// would have written the activation is not launched at all.
-extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const void* z, const float* xscale, const float* xshift, int xact,
+// Forward of a 1x1 / stride-1 conv whose input is (partly) VIRTUAL: a segment's operand is act(z * xscale + xshift) formed on the
+// way to the MFMAs (k_gconv<..., XF>), i.e. the consumer of a Conv-BN-act block reads the block's pre-activation z and the
+// BatchNorm + activation pass that would have written the activation is not launched at all.
+extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* segs, int nseg, const float* xscale, const float* xshift,
                                  const void* w, void* y, int epilogue, const float* shift, double* stats, int stat_reps, int head_no,
                                  ayolo_stream s) {
     int rc = check_desc(d, "conv_fwd_xf");
     if (rc) return rc;
-    AY_CHECK_ARG(z && xscale && xshift && w && y, "conv_fwd_xf: null pointer");
+    AY_CHECK_ARG(segs && (nseg == 1 || nseg == 2) && xscale && xshift && w && y, "conv_fwd_xf: null pointer / %d segments", nseg);
     AY_CHECK_ARG(d->dtype == AYOLO_F16 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0,
                  "conv_fwd_xf: fp16 1x1 / stride 1 / no padding only");
     AY_CHECK_ARG(epilogue == AYOLO_EPI_NONE || epilogue == AYOLO_EPI_HEAD, "conv_fwd_xf: epilogue %d (plain + statistics, or YOLOHead)", epilogue);
     AY_CHECK_ARG(epilogue != AYOLO_EPI_HEAD || (head_no > 0 && d->Cout % head_no == 0), "conv_fwd_xf: head_no=%d", head_no);
     AY_CHECK_ARG(d->Cin <= 4096, "conv_fwd_xf: %d input channels (LDS constants table)", d->Cin);
+    int c = 0;
+    for (int k = 0; k < nseg; ++k) {
+        AY_CHECK_ARG(segs[k].x && segs[k].C > 0 && segs[k].C % 8 == 0 && segs[k].ld % 8 == 0 && segs[k].ld >= segs[k].C,
+                     "conv_fwd_xf: segment %d: C=%d ld=%d", k, segs[k].C, segs[k].ld);
+        c += segs[k].C;
+    }
+    AY_CHECK_ARG(c == d->Cin && (nseg == 1 || segs[0].C % BK == 0), "conv_fwd_xf: segments cover %d of %d channels; the first must end on a multiple of %d",
+                 c, d->Cin, BK);
     GConvP p{};
-    p.x = z; p.w = w; p.y = y;
-    p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = d->ldx;
+    p.x = segs[0].x; p.w = w; p.y = y;
+    p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = segs[0].ld;
     p.OH = d->Ho; p.OW = d->Wo; p.ish = 1; p.isw = 1;
     p.YH = d->Ho; p.YW = d->Wo; p.ldy = d->ldy; p.osh = 1; p.osw = 1; p.oah = 0; p.oaw = 0;
     p.C = d->Cin; p.ntaps = 1; p.K = p.C; p.ldw = p.K; p.Nout = d->Cout;
@@ -2259,7 +2323,11 @@ extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const void* z, const 
     p.y_linear = 1; p.x_linear = 1;
     p.Mtotal = (long long)d->B * d->Ho * d->Wo;
     p.dh[0] = 0; p.dw[0] = 0; p.wt[0] = 0;
-    p.xf = 1; p.xf_act = xact ? 1 : 0; p.xf_scale = xscale; p.xf_shift = xshift;
+    p.xf = 1; p.xf_scale = xscale; p.xf_shift = xshift;
+    p.xf_act = (segs[0].act ? 1 : 0) | ((nseg > 1 && segs[1].act) ? 2 : 0);
+    p.xf_virt = (segs[0].virt ? 1 : 0) | ((nseg > 1 && segs[1].virt) ? 2 : 0);
+    p.xs_split = nseg > 1 ? segs[0].C : (d->Cin + BK - 1) / BK * BK;          // one segment: no step ever reaches the split
+    if (nseg > 1) { p.x2 = segs[1].x; p.ldx2 = segs[1].ld; }
     return dispatch_gconv(d->dtype, p, (hipStream_t)s);
 }
 
@@ -2400,7 +2468,10 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 struct WItem { unsigned job, tile, zz, pad; };
 // one block of the reduction: n <= WRED_N consecutive elements of one layer's dw, S partials `stride` floats apart
 #define WRED_N 2048
-struct WRed { unsigned long long ws_off, stride; float* dst; unsigned n, S; float alpha; int overwrite; };
+// (cols, ldd): the layer's dw is a column block of a wider matrix -- element e of the dense N x cols partials goes to
+// dst[(e / cols) * ldd + e % cols] (the two input segments of a transform-on-load conv are two jobs over one weight matrix);
+// e0 = index of the block's first element, ldd == cols: dense
+struct WRed { unsigned long long ws_off, stride; float* dst; unsigned n, S; float alpha; int overwrite; unsigned cols, ldd; unsigned long long e0; };
 struct WOvr { const void* q[4]; };           // dy override pointers of a launch (WGradP::dy_slot)
 
 // A/B fragments for v_mfma_f32_32x32x16_f16 come out of the pixel-major LDS tiles t[pixel][channel] through the gfx950
@@ -2763,8 +2834,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WRed rv, const WRed* red, 
         const unsigned long long left = (unsigned long long)rv.n > o ? (unsigned long long)rv.n - o : 0ull;     // rv.n: all elements
         r.n = (unsigned)(left < WRED_N ? left : WRED_N);
         r.ws_off += o;
-        r.dst += o;
+        r.e0 = o;
     }
+    const bool dense = r.ldd == r.cols;
     for (unsigned i = threadIdx.x * 4; i < r.n; i += 1024) {
         const float* src = ws + r.ws_off + i;
         float4v a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
@@ -2777,7 +2849,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WRed rv, const WRed* red, 
         }
         for (; s < r.S; ++s) a0 += *reinterpret_cast<const float4v*>(src + (unsigned long long)s * r.stride);
         float4v v = ((a0 + a1) + (a2 + a3)) * r.alpha;
-        float4v* d = reinterpret_cast<float4v*>(r.dst + i);
+        const unsigned long long e = r.e0 + i;                 // cols % 4 == 0: the four elements share a row
+        float4v* d = reinterpret_cast<float4v*>(r.dst + (dense ? e : (e / r.cols) * r.ldd + e % r.cols));
         if (!r.overwrite) v += *d;
         *d = v;
     }
@@ -3399,7 +3472,7 @@ struct WGroupPlan {
 static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
     AY_CHECK_ARG(jj && njobs > 0 && njobs < 4096, "wgrad_group: %d jobs", njobs);
     g.dtype = jj[0].conv.dtype;
-    struct Layer { size_t j0, j1; float* dw; float alpha; int overwrite; };
+    struct Layer { size_t j0, j1; float* dw; float alpha; int overwrite; unsigned ldd; };
     std::vector<Layer> layers;
     for (int k = 0; k < njobs; ++k) {
         const ayolo_wgrad_job& a = jj[k];
@@ -3422,7 +3495,9 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
         const size_t j0 = g.jobs.size();
         rc = wgrad_halves(&a.conv, p, g.jobs);
         if (rc) return rc;
-        layers.push_back({j0, g.jobs.size(), a.dw, a.alpha, a.overwrite});
+        const int kj = a.conv.kh * a.conv.kw * a.conv.Cin;
+        AY_CHECK_ARG(a.dw_ld == 0 || (a.dw_ld >= kj && a.dw_ld % 4 == 0 && kj % 4 == 0), "wgrad_group: job %d: dw_ld=%d for %d columns", k, a.dw_ld, kj);
+        layers.push_back({j0, g.jobs.size(), a.dw, a.alpha, a.overwrite, (unsigned)(a.dw_ld > 0 ? a.dw_ld : kj)});
     }
     // ---- item length.  All items of the group together should fill the chip's workgroup slots a few times over (so that the
     // tail of the launch is short against its body) without cutting a layer finer than ~AYOLO_WGRAD_MINQ steps per item
@@ -3444,8 +3519,8 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
         for (size_t j = L.j0; j < L.j1; ++j) { g.jobs[j].ws_off = off; g.jobs[j].zz0 = S; S += g.jobs[j].splits; }
         for (unsigned long long e = 0; e < nk; e += WRED_N) {
             WRed r{};
-            r.ws_off = off + e; r.stride = nk; r.dst = L.dw + e; r.n = (unsigned)(nk - e < WRED_N ? nk - e : WRED_N); r.S = S;
-            r.alpha = L.alpha; r.overwrite = L.overwrite;
+            r.ws_off = off + e; r.stride = nk; r.dst = L.dw; r.e0 = e; r.n = (unsigned)(nk - e < WRED_N ? nk - e : WRED_N); r.S = S;
+            r.alpha = L.alpha; r.overwrite = L.overwrite; r.cols = (unsigned)g.jobs[L.j0].K; r.ldd = L.ldd;
             g.red.push_back(r);
         }
         off += (unsigned long long)S * nk;
@@ -3682,7 +3757,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
         S += j.splits;
     }
     WRed r{};
-    r.ws_off = 0; r.stride = nk; r.dst = dw; r.S = S; r.alpha = alpha; r.overwrite = 0;
+    r.ws_off = 0; r.stride = nk; r.dst = dw; r.S = S; r.alpha = alpha; r.overwrite = 0; r.cols = r.ldd = (unsigned)jobs[0].K; r.e0 = 0;
     AY_CHECK_ARG(nk < (1ull << 32), "conv_wgrad: dw of %llu elements", nk);
     r.n = (unsigned)nk;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nk + WRED_N - 1) / WRED_N)), dim3(256), 0, (hipStream_t)s, r, (const WRed*)nullptr, (const float*)ws);

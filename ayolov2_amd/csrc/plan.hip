@@ -156,10 +156,17 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
         case AYOLO_OP_NOP:
             break;
         case AYOLO_OP_CONV_FWD:
-            // p[6] / p[7] / i[3]: transform on load -- p[0] is the producer's pre-activation z, the operand is
-            // act(z * p[6][c] + p[7][c]) with act = i[3] (ayolo_conv_fwd_xf)
-            if (o.p[6]) rc = ayolo_conv_fwd_xf(&o.conv, o.p[0], (const float*)o.p[6], (const float*)o.p[7], o.i[3], o.p[1], o.p[2], o.i[0],
-                                               (const float*)o.p[4], (double*)o.p[5], o.i[1], o.i[2], cs);
+            // p[6] / p[7]: transform on load (ayolo_conv_fwd_xf) -- p[0] is segment 0 (channel stride conv.ldx, i[5] channels, or all
+            // of them when there is no second segment), p[8] / i[4] segment 1 and its channel stride; i[3] bits: 0 act of segment 0,
+            // 1 segment 0 is virtual (the producer's z), 2 / 3 the same for segment 1
+            if (o.p[6]) {
+                ayolo_xf_seg sg[2];
+                const int two = o.p[8] != nullptr;
+                sg[0].x = o.p[0]; sg[0].ld = o.conv.ldx; sg[0].C = two ? o.i[5] : o.conv.Cin; sg[0].act = o.i[3] & 1; sg[0].virt = (o.i[3] >> 1) & 1;
+                sg[1].x = o.p[8]; sg[1].ld = o.i[4]; sg[1].C = o.conv.Cin - sg[0].C; sg[1].act = (o.i[3] >> 2) & 1; sg[1].virt = (o.i[3] >> 3) & 1;
+                rc = ayolo_conv_fwd_xf(&o.conv, sg, two ? 2 : 1, (const float*)o.p[6], (const float*)o.p[7], o.p[1], o.p[2], o.i[0],
+                                       (const float*)o.p[4], (double*)o.p[5], o.i[1], o.i[2], cs);
+            }
             else rc = ayolo_conv_fwd(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const float*)o.p[3], (const float*)o.p[4],
                                      (double*)o.p[5], o.i[1], o.i[2], cs);
             break;

@@ -215,11 +215,23 @@ class TrainPlan:
             return t
         return self.dz_buf[:n]
 
-    def _wgrad_job(self, desc: ConvDesc, x: torch.Tensor, dy: torch.Tensor, off: int, n: int, dy_slot: int = -1, xf=None) -> None:
+    def _wgrad_jobs_of(self, cx: dict, desc: ConvDesc, dy: torch.Tensor, off: int, n: int, dy_slot: int = -1) -> None:
+        """The weight-gradient job(s) of a conv whose x the transform-on-load pass may have redirected: one job over the plain
+        input, one over the producer's z, or -- two input segments -- one job per segment, each writing its column block of dw."""
+        if not cx["segs"]:
+            return self._wgrad_job(desc, cx["x"], dy, off, n, dy_slot=dy_slot)
+        K = desc.kh * desc.kw * desc.Cin
+        for t, ld, c0, C, xf in cx["segs"]:
+            d = ConvDesc.from_buffer_copy(desc)
+            d.Cin, d.ldx = C, ld
+            self._wgrad_job(d, t, dy, off, n, dy_slot=dy_slot, xf=xf, col0=c0, dw_ld=(K if len(cx["segs"]) > 1 else 0))
+
+    def _wgrad_job(self, desc: ConvDesc, x: torch.Tensor, dy: torch.Tensor, off: int, n: int, dy_slot: int = -1, xf=None, col0: int = 0,
+                   dw_ld: int = 0) -> None:
         """One layer's weight gradient: a slot in the backward list now (dz is complete here), the launch later
         (_group_wgrads: the slot of the LAST layer of a group becomes the group's launch, the others stay empty)."""
         self.bwd.append(_op(0))
-        self._wjobs.append(dict(idx=len(self.bwd) - 1, desc=desc, x=x, dy=dy, off=off, n=n, slot=dy_slot, xf=xf))
+        self._wjobs.append(dict(idx=len(self.bwd) - 1, desc=desc, x=x, dy=dy, off=off, n=n, slot=dy_slot, xf=xf, col0=col0, dw_ld=dw_ld))
 
     def _group_wgrads(self) -> None:
         from ._lib import WgradJob
@@ -239,9 +251,9 @@ class TrainPlan:
 
         def account(js):
             by = sum(es * (j["desc"].B * j["desc"].H * j["desc"].W * j["desc"].Cin + j["desc"].B * j["desc"].Ho * j["desc"].Wo * j["desc"].Cout)
-                     + 4 * j["n"] for j in js)
+                     + 4 * j["desc"].Cout * j["desc"].kh * j["desc"].kw * j["desc"].Cin for j in js)
             fl = sum(2.0 * j["desc"].B * j["desc"].Ho * j["desc"].Wo * j["desc"].Cout * j["desc"].kh * j["desc"].kw * j["desc"].Cin for j in js)
-            return float(by), fl, len(js)
+            return float(by), fl, len({j["off"] for j in js})       # layers (a two-segment conv is two jobs over one weight)
 
         if WGRAD_GROUPS <= 0:
             # one launch per layer (A/B against the grouped launches): the same kernels, a shared split-K workspace
@@ -249,7 +261,7 @@ class TrainPlan:
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
             self.keep.append(ws)
             for j in jobs:
-                assert j["xf"] is None, "transform on load needs the grouped weight-gradient launches"
+                assert j["xf"] is None and not j["dw_ld"], "transform on load needs the grouped weight-gradient launches"
                 o = _op(OP_CONV_WGRAD | side, f=(1.0,), l=(ws.numel(),), p=(j["x"], j["dy"], ga.view(j["off"], j["n"]), ws), conv=j["desc"])
                 self.bwd[j["idx"]] = o
                 self.grad_done.append((j["idx"], j["off"], j["n"]))
@@ -284,7 +296,8 @@ class TrainPlan:
             for k, j in enumerate(js):
                 arr[k].conv = j["desc"]
                 arr[k].x, arr[k].dy = j["x"].data_ptr(), j["dy"].data_ptr()
-                arr[k].dw = ga.view(j["off"], j["n"]).data_ptr()
+                arr[k].dw = ga.view(j["off"], j["n"]).data_ptr() + 4 * j["col0"]
+                arr[k].dw_ld = j["dw_ld"]
                 arr[k].alpha, arr[k].dy_slot, arr[k].overwrite = 1.0, j["slot"], 1       # nothing else writes these arena ranges
                 if j["xf"] is not None:
                     arr[k].xscale, arr[k].xshift, arr[k].xact = j["xf"][0].data_ptr(), j["xf"][1].data_ptr(), j["xf"][2]
@@ -367,7 +380,7 @@ class TrainPlan:
         _, _, _, _, ldx = ops.nhwc_info(xk)
         code = ops.dtype_code(dt)
         # what the weight gradient will read as x (the transform-on-load pass may point it at the producer's z)
-        cx = dict(x=xk, ldx=ldx, xf=None)
+        cx = dict(x=xk, ldx=ldx, xf=None, segs=None, xs_off=None)
         # weights: compute-dtype copy and its transpose, refreshed by a cast op at the start of every forward
         wc = torch.empty((Ct, kh, kw, geo.cin_pad), dtype=dt, device=dev)
         wt = torch.empty((geo.cin_pad, kh, kw, Ct), dtype=dt, device=dev)
@@ -384,7 +397,9 @@ class TrainPlan:
         self.fwd.append(op_conv)
         if not image:
             pointwise = (kh, kw) == (1, 1) and _pair(convs[0].stride) == (1, 1) and _pair(convs[0].padding) == (0, 0) and geo.Cin_k == Cin
-            self._reads.append((id(x.root), x.c0, x.c0 + x.C, "conv", dict(op=op_conv, cx=cx, pointwise=pointwise, cin=Cin, cout=Ct)))
+            if pointwise:
+                cx["xs_off"] = self.small.request(2 * Cin)           # scale | shift over the conv's input channels (transform on load)
+            self._reads.append((id(x.root), x.c0, x.c0 + x.C, "conv", dict(op=op_conv, cx=cx, pointwise=pointwise, cin=Cin, cout=Ct, x=x)))
             if residual is not None:
                 self._reads.append((id(residual.root), residual.c0, residual.c0 + residual.C, "residual", None))
         self.late.append(lambda: op_conv.p.__setitem__(5, self.stats.view(st_off, R * 2 * Ct).data_ptr()))
@@ -500,7 +515,7 @@ class TrainPlan:
                 return
             # the weight gradient only needs dz: its slot comes BEFORE the layer's dgrad, so that a (grouped) launch forked
             # here does not wait for that dgrad
-            self._wgrad_job(geo.desc(dt, cx["ldx"], Ct), cx["x"], dz, gw_off0, Ct * K, xf=cx["xf"])
+            self._wgrad_jobs_of(cx, geo.desc(dt, ldx, Ct), dz, gw_off0, Ct * K)
             if not image:
                 dx = x_act.grad()
                 self.bwd.append(_op(OP_CONV_DGRAD, i=(int(x_act.is_init()),), p=(dz, wt, dx),
@@ -513,42 +528,91 @@ class TrainPlan:
 
     def _fold_bn_act_into_consumers(self) -> None:
         """Transform on load (stage A).  A Conv-BN-act block whose activation `a` has exactly one reader -- a
-        1x1 / stride-1 conv (a Conv block, C3's merged cv1 | cv2, a YOLOHead level) over exactly a's channels -- does not
-        materialise `a`: its BatchNorm + activation pass becomes the finalize launch (batch statistics -> scale / shift, saved
-        and running statistics), the reader's forward conv and weight gradient take the block's pre-activation z plus the two
-        per-channel vectors and form act(z * scale + shift) on the way to the MFMAs -- bit for bit the activation the pass
-        would have written.  Blocks with a shortcut added in that pass, readers that also read something else (concat
-        buffers), pools, up-sampling and 3x3 readers keep the materialised activation.  Measured per layer:
-        profiles/r04_xf_forward_sweep.txt (the pair costs 1.2-2.5x the fused launch; it loses only where the channel table
-        and the per-channel-tile repetition of the transform weigh in: Cin x channel tiles > 1024)."""
+        1x1 / stride-1 conv (a Conv block, C3's merged cv1 | cv2, C3's cv3 over its two-part concat, a YOLOHead level) -- does
+        not materialise `a`: its BatchNorm + activation pass becomes the finalize launch (batch statistics -> scale / shift,
+        saved and running statistics), the reader's forward conv and weight gradient take the block's pre-activation z plus the
+        two per-channel vectors and form act(z * scale + shift) on the way to the MFMAs -- bit for bit the activation the pass
+        would have written.  The reader's input channels are one or two SEGMENTS (ayolo_xf_seg): each a virtual block output or
+        a plain activation as it lies in the concat buffer (a Bottleneck output with its shortcut added, an up-sampled map).
+        Blocks with a shortcut added in their pass, activations that are also read by a pool, an up-sampling, a 3x3 conv or a
+        shortcut keep the materialised pass.  Measured per layer: profiles/r04_xf_forward_sweep.txt (the pair of launches costs
+        1.2-2.5x the fused one; it loses only where the channel table and the per-channel-tile repetition of the transform
+        weigh in: Cin x channel tiles > 1024)."""
         if not XF_ON_LOAD or self.dt != torch.float16 or WGRAD_GROUPS <= 0:
             return
-        for P in self._producers:
-            a = P["a"]
-            lo, hi = a.c0, a.c0 + a.C
-            reads = [r for r in self._reads if r[0] == id(a.root) and r[1] < hi and r[2] > lo]
-            if len(reads) != 1 or P["residual"]:
+        for rd in self._reads:
+            root, rlo, rhi, kind, c = rd
+            if kind != "conv" or not c["pointwise"] or c["cx"]["segs"] is not None:
                 continue
-            _, rlo, rhi, kind, c = reads[0]
-            if kind != "conv" or (rlo, rhi) != (lo, hi) or not c["pointwise"] or c["cx"]["xf"] is not None:
+            if c["cin"] * -(-c["cout"] // 128) > 1024 or c["cin"] % 8 or c["cx"]["xs_off"] is None:
                 continue
-            if c["cin"] * -(-c["cout"] // 128) > 1024 or c["cin"] % 8:
+            prods = sorted((P for P in self._producers if id(P["a"].root) == root and rlo <= P["a"].c0 and P["a"].c0 + P["a"].C <= rhi),
+                           key=lambda P: P["a"].c0)
+            # segments of [rlo, rhi): (lo, hi, producer or None = plain)
+            segs, cur = [], rlo
+            for P in prods:
+                lo, hi = P["a"].c0, P["a"].c0 + P["a"].C
+                if lo < cur:
+                    segs = None
+                    break
+                only = [r for r in self._reads if r[0] == root and r[1] < hi and r[2] > lo]
+                virt = (not P["residual"]) and len(only) == 1 and only[0] is rd
+                if lo > cur:
+                    segs.append([cur, lo, None])
+                segs.append([lo, hi, P if virt else None])
+                cur = hi
+            if segs is None:
                 continue
-            co, sm = P["co"], self.small.view(P["sm_off"], 4 * P["co"])
-            scale, shift = sm[2 * co:3 * co], sm[3 * co:4 * co]
-            o, bn = P["op"], P["bn"]
-            stats_ptr, smean, sinv = o.p[2], o.p[7], o.p[8]                # bound by the late closures of _conv_group
-            assert (o.kind & 0xff) == OP_BN_TRAIN_ACT and stats_ptr and smean and sinv
-            new = _op(OP_BN_FINALIZE, i=(P["R"], co, P["ldz"]), d=(float(P["npix"]),), f=(bn.eps, bn.momentum),
-                      p=(stats_ptr, bn.weight, bn.bias, bn.running_mean, bn.running_var, smean, sinv, scale, shift))
-            ctypes.memmove(ctypes.addressof(o), ctypes.addressof(new), ctypes.sizeof(Op))    # in place: self.fwd holds this object
-            rd = c["op"]
-            rd.p[0] = P["z"].data_ptr()
-            rd.conv.ldx = P["ldz"]
-            rd.p[6], rd.p[7] = scale.data_ptr(), shift.data_ptr()
-            rd.i[3] = P["act"]
-            c["cx"].update(x=P["z"], ldx=P["ldz"], xf=(scale, shift, P["act"]))
-            self.xf_layers += 1
+            if cur < rhi:
+                segs.append([cur, rhi, None])
+            merged = []
+            for sg in segs:                                   # adjacent plain pieces are one plain segment
+                if merged and merged[-1][2] is None and sg[2] is None:
+                    merged[-1][1] = sg[1]
+                else:
+                    merged.append(sg)
+            if len(merged) > 2 or not any(sg[2] is not None for sg in merged):
+                continue
+            if len(merged) == 2 and (merged[0][1] - rlo) % 32:
+                continue
+            if any((hi - lo) % 8 for lo, hi, _ in merged):
+                continue
+            cin = c["cin"]
+            xs = self.small.view(c["cx"]["xs_off"], 2 * cin)
+            scale_all, shift_all = xs[:cin], xs[cin:]
+            xin = c["x"]                                      # the consumer's materialised input (for plain segments)
+            ld_plain = ops.nhwc_info(xin.t)[4]
+            wsegs, bits, ptrs = [], 0, []
+            for k, (lo, hi, P) in enumerate(merged):
+                c0, C = lo - rlo, hi - lo
+                if P is None:
+                    t = xin.t[:, c0:c0 + C]
+                    wsegs.append((t, ld_plain, c0, C, None))
+                    ptrs.append((t, ld_plain, C))
+                    continue
+                co = P["co"]
+                assert co == C
+                sm = self.small.view(P["sm_off"], 4 * co)
+                scale, shift = scale_all[c0:c0 + C], shift_all[c0:c0 + C]
+                o, bn = P["op"], P["bn"]
+                stats_ptr, smean, sinv = o.p[2], o.p[7], o.p[8]            # bound by the late closures of _conv_group
+                assert (o.kind & 0xff) == OP_BN_TRAIN_ACT and stats_ptr and smean and sinv
+                new = _op(OP_BN_FINALIZE, i=(P["R"], co, P["ldz"]), d=(float(P["npix"]),), f=(bn.eps, bn.momentum),
+                          p=(stats_ptr, bn.weight, bn.bias, bn.running_mean, bn.running_var, smean, sinv, scale, shift))
+                ctypes.memmove(ctypes.addressof(o), ctypes.addressof(new), ctypes.sizeof(Op))    # in place: self.fwd holds this object
+                bits |= ((1 if P["act"] else 0) | 2) << (2 * k)
+                wsegs.append((P["z"], P["ldz"], c0, C, (scale, shift, P["act"])))
+                ptrs.append((P["z"], P["ldz"], C))
+                self.xf_layers += 1
+            op = c["op"]
+            op.p[0] = ptrs[0][0].data_ptr()
+            op.conv.ldx = ptrs[0][1]
+            op.p[6], op.p[7] = scale_all.data_ptr(), shift_all.data_ptr()
+            op.i[3] = bits
+            if len(ptrs) > 1:
+                op.p[8] = ptrs[1][0].data_ptr()
+                op.i[4], op.i[5] = ptrs[1][1], ptrs[0][2]
+            c["cx"]["segs"] = wsegs
 
     def _batched_casts(self) -> List[Op]:
         """All per-layer fp32 -> compute-dtype weight casts (and transposes) as ONE launch: the job table lives in
@@ -651,8 +715,8 @@ class TrainPlan:
             ldx = ops.nhwc_info(x.t)[4]
             op_head = _op(OP_CONV_FWD, i=(EPI_HEAD, 1, head.no), p=(x.t, wc, buf, None, conv.bias, None), conv=geo.desc(dt, ldx, cp))
             self.fwd.append(op_head)
-            cx = dict(x=x.t, ldx=ldx, xf=None)
-            self._reads.append((id(x.root), x.c0, x.c0 + x.C, "conv", dict(op=op_head, cx=cx, pointwise=True, cin=Cin, cout=cp)))
+            cx = dict(x=x.t, ldx=ldx, xf=None, segs=None, xs_off=self.small.request(2 * Cin))
+            self._reads.append((id(x.root), x.c0, x.c0 + x.C, "conv", dict(op=op_head, cx=cx, pointwise=True, cin=Cin, cout=cp, x=x)))
             gw_off = self._register_param(conv.weight, cp * Cin, lambda b, Cout=Cout, Cin=Cin: b.view(-1, Cin)[:Cout].view(Cout, Cin, 1, 1))
             gb_off = self._register_param(conv.bias, Cout, lambda b: b) if conv.bias is not None else None
             self.raw_specs.append((buf, (B, head.na, H, W, head.no), (H * W * cp, head.no, W * cp, cp, 1), gb_off, Cout))
@@ -673,7 +737,7 @@ class TrainPlan:
                 self._gw(x, True)
                 x.mark_init()
                 # dy of a head level changes from step to step (the fused loss hands its own buffer over): override slot = level
-                self._wgrad_job(geo.desc(dt, cx["ldx"], cp, cout=cp), cx["x"], dz, gw_off, cp * Cin, dy_slot=lvl, xf=cx["xf"])
+                self._wgrad_jobs_of(cx, geo.desc(dt, ldx, cp, cout=cp), dz, gw_off, cp * Cin, dy_slot=lvl)
                 self._wrote(gb_off, Cout, at=0)          # bias gradient: pack op, or the fused loss before the list runs
 
             self.bwd_emitters.append(emit)

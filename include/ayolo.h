@@ -101,13 +101,20 @@ typedef struct ayolo_bn_seg {
 int ayolo_conv_dgrad_bn(const ayolo_conv_desc* d, const void* dy, const void* wt, void* dx, int accumulate,
                         const ayolo_bn_seg* segs, int nseg, int act, int sum_reps, ayolo_stream s);
 
-/* Forward of a 1x1 / stride-1 conv whose input is VIRTUAL (transform on load; res/configs/model/yolov5s.yaml:21-33: kindle
- * `Conv` = conv -> BatchNorm -> SiLU, whose activation has exactly one reader here): x[p][c] = act(z[p][c] * xscale[c] +
- * xshift[c]) is formed from the producer's pre-activation z on the way to the MFMAs, with the arithmetic of
- * ayolo_bn_train_act / ayolo_affine_act (fma, sigmoid by v_exp / v_rcp, one fp16 rounding), so the result equals the conv
- * over the materialised activation bit for bit and that pass is never launched.  fp16; d: the conv's descriptor with ldx =
- * channel stride of z; epilogue AYOLO_EPI_NONE (+ `stats`) or AYOLO_EPI_HEAD (+ `shift` = bias, head_no). */
-int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const void* z, const float* xscale, const float* xshift, int xact,
+/* Forward of a 1x1 / stride-1 conv whose input is (partly) VIRTUAL (transform on load; res/configs/model/yolov5s.yaml:21-33:
+ * kindle `Conv` = conv -> BatchNorm -> SiLU, whose activation has exactly one reader here).  The conv's input channels are one or
+ * two SEGMENTS side by side (two: C3's cv3 over [last Bottleneck output | cv2 half]); a `virt` segment is the producing
+ * block's pre-activation z and its operand act(z[p][c] * xscale[c] + xshift[c]) is formed on the way to the MFMAs, with the
+ * arithmetic of ayolo_bn_train_act / ayolo_affine_act (fma, sigmoid by v_exp / v_rcp, one fp16 rounding) -- the result equals
+ * the conv over the materialised activation bit for bit and that pass is never launched; a plain segment is an activation as
+ * it lies.  xscale / xshift: float[Cin] over the conv's input channels (ignored for plain segments).  fp16; the first of two
+ * segments must end on a multiple of 32 channels; epilogue AYOLO_EPI_NONE (+ `stats`) or AYOLO_EPI_HEAD (+ `shift` = bias). */
+typedef struct ayolo_xf_seg {
+    const void* x;            /* first channel of the segment at pixel 0 */
+    int ld, C;                /* channel stride of its buffer, channels */
+    int act, virt;            /* SiLU on / off; 1: transform (x is z), 0: plain activation */
+} ayolo_xf_seg;
+int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* segs, int nseg, const float* xscale, const float* xshift,
                       const void* w, void* y, int epilogue, const float* shift, double* stats, int stat_reps, int head_no,
                       ayolo_stream s);
 
@@ -135,6 +142,8 @@ typedef struct ayolo_wgrad_job {
     int xact;                 /* transform on load (1x1 / stride-1 consumers of a virtual activation, see ayolo_conv_fwd_xf): */
     const float* xscale;      /* x is the producer's pre-activation z, the operand is act(z * xscale[c] + xshift[c]);         */
     const float* xshift;      /* both NULL: plain x                                                                           */
+    int dw_ld, reserved;      /* > 0: dw is a column block of a wider matrix with this row stride (the input segments of a
+                               * two-segment transform-on-load conv are two jobs over one weight); 0: dense                   */
 } ayolo_wgrad_job;
 int ayolo_wgrad_group_size(const ayolo_wgrad_job* jobs, int njobs, size_t* table_bytes, size_t* ws_bytes);
 int ayolo_wgrad_group_build(const ayolo_wgrad_job* jobs, int njobs, void* table_host, size_t table_bytes);

@@ -699,3 +699,67 @@ def test_conv_transform_on_load_equals_materialised_route(shape):
     ref = F.conv2d(ref_a.cpu(), w[:Co].permute(0, 3, 1, 2).float().cpu(), bias[:Co].cpu() if head else None)
     got = outs[1][0].permute(0, 3, 1, 2)[:, :Co].float().cpu() if head else outs[1][0][:, :Co].float().cpu()
     assert _rel_err(got, ref) <= 4e-3
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, 128, 40, 40, (1, 1), (True, True)), (2, 32, 96, 64, 24, 20, (1, 0), (True, False)),
+                                  (3, 128, 128, 256, 10, 12, (0, 1), (False, True)), (2, 64, 32, 48, 33, 7, (1, 1), (True, True))])
+def test_conv_transform_on_load_two_segments(case):
+    """C3's cv3 reads [last Bottleneck output | cv2 half]: two input segments from two buffers with their own channel strides,
+    each virtual (the producer's z, transformed on load) or a plain activation.  Forward vs the conv over the materialised concat
+    -- bit for bit, statistics included -- and the weight gradient as two grouped jobs writing the column blocks of one dw
+    against the single-layer weight gradient over the materialised concat (bit for bit: same operand bits, same split-K order
+    per column block is NOT guaranteed, so 1e-6 relative)."""
+    import ctypes
+    from ayolov2_amd import ops, _lib
+    from ayolov2_amd._lib import WgradJob
+    B, C0, C1, Co, H, W, acts, virt = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case[:7]) + 5)
+    Ci = C0 + C1
+    z0full = torch.randn(B, C0 + 16, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+    z1full = torch.randn(B, 2 * C1, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+    z0, z1 = z0full[:, :C0], z1full[:, C1:]                              # channel slices of wider buffers
+    scale = (torch.rand(Ci, device="cuda", generator=g) + 0.5).float()
+    shift = torch.randn(Ci, device="cuda", generator=g).float()
+    cat = ops.new_act(B, Ci, H, W, torch.float16, "cuda")
+    for zz, c0, C, act, v in ((z0, 0, C0, acts[0], virt[0]), (z1, C0, C1, acts[1], virt[1])):
+        if v:
+            ops.affine_act(zz, cat[:, c0:c0 + C], scale[c0:c0 + C].contiguous(), shift[c0:c0 + C].contiguous(), act)
+        else:
+            cat[:, c0:c0 + C] = zz                                       # a plain segment IS the activation
+    w = (torch.randn(Co, 1, 1, Ci, device="cuda", generator=g) / Ci ** 0.5).half()
+    d = ops.make_desc(torch.float16, B, H, W, Ci, Ci, Co, Co, (1, 1), (1, 1), (0, 0), H, W)
+    outs = []
+    for route in ("materialised", "on_load"):
+        y = ops.new_act(B, Co, H, W, torch.float16, "cuda")
+        stats = torch.zeros((ops.STAT_REPS, 2 * Co), dtype=torch.float64, device="cuda")
+        if route == "materialised":
+            ops.conv_fwd(d, cat, w, y, _lib.EPI_NONE, stats=stats)
+        else:
+            ops.conv_fwd_xf(d, [(z0, acts[0], virt[0]), (z1, acts[1], virt[1])], scale, shift, 0, w, y, _lib.EPI_NONE, stats=stats)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), stats.sum(0).clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # weight gradient: two jobs, one per segment, into the column blocks of one [Co][Ci] matrix
+    dy = torch.randn(B, Co, H, W, device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last)
+    dw_ref = torch.zeros((Co, 1, 1, Ci), dtype=torch.float32, device="cuda")
+    ops.conv_wgrad(d, cat, dy, dw_ref)
+    dw = torch.full((Co, 1, 1, Ci), 7.0, dtype=torch.float32, device="cuda")
+    lib = _lib.lib()
+    arr = (WgradJob * 2)()
+    for k, (zz, c0, C, act, v) in enumerate(((z0, 0, C0, acts[0], virt[0]), (z1, C0, C1, acts[1], virt[1]))):
+        arr[k].conv = ops.make_desc(torch.float16, B, H, W, C, ops.nhwc_info(zz)[4], Co, Co, (1, 1), (1, 1), (0, 0), H, W)
+        arr[k].x, arr[k].dy, arr[k].dw = zz.data_ptr(), dy.data_ptr(), dw.data_ptr() + 4 * c0
+        arr[k].alpha, arr[k].dy_slot, arr[k].overwrite, arr[k].dw_ld = 1.0, -1, 1, Ci
+        if v:
+            sc, sh = scale[c0:c0 + C], shift[c0:c0 + C]
+            arr[k].xscale, arr[k].xshift, arr[k].xact = sc.data_ptr(), sh.data_ptr(), act
+    tb, wb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _lib.check(lib.ayolo_wgrad_group_size(arr, 2, ctypes.byref(tb), ctypes.byref(wb)), "size")
+    host = ctypes.create_string_buffer(tb.value)
+    _lib.check(lib.ayolo_wgrad_group_build(arr, 2, host, tb.value), "build")
+    dev = torch.frombuffer(host, dtype=torch.uint8).clone().cuda()
+    ws = torch.empty(max(wb.value, 16), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ayolo_wgrad_group_run(ctypes.addressof(host), dev.data_ptr(), ws.data_ptr(), ws.numel(), None, 0, 0,
+                                        torch.cuda.current_stream().cuda_stream), "run")
+    torch.cuda.synchronize()
+    assert float((dw - dw_ref).abs().max()) <= 1e-5 * float(dw_ref.abs().max())

@@ -344,11 +344,16 @@ def test_plan_gradient_buckets_cover_the_arena():
     kinds = Counter(o.kind & 0xff for o in pl.bwd)
     # weight gradients: 51 layers in <= 12 grouped launches (23) + the stem's fused BN-backward + weight gradient (22)
     assert kinds[3] == 0 and kinds[2] == 51 and kinds[22] == 1 and 4 <= kinds[23] <= 12
-    assert sum(v[2] for v in pl.wgroup_costs.values()) == 51 and len(pl.wgroup_costs) == kinds[23]
+    assert 51 <= sum(v[2] for v in pl.wgroup_costs.values()) <= 51 + kinds[23] and len(pl.wgroup_costs) == kinds[23]
     gidx = sorted(pl.wgroup_costs)
     assert all((pl.bwd[k].kind & 0xff) == 23 for k in gidx)
     # the tail of backward is cut finer than its body (what the last group still has to do after the main stream is exposed)
     assert pl.wgroup_costs[gidx[-1]][1] < 0.6 * max(v[1] for v in pl.wgroup_costs.values())
+    # transform on load: 21 of the 57 BatchNorm + SiLU passes are folded into their single 1x1 reader (18 convs, 7 of them over two
+    # input segments); the blocks keep a finalize launch
+    fk = Counter(o.kind & 0xff for o in pl.fwd)
+    assert pl.xf_layers == 21 and fk[18] == 36 and fk[5] == 21
+    assert sum(1 for o in pl.fwd if (o.kind & 0xff) == 1 and o.p[6]) == 18 and sum(1 for o in pl.fwd if (o.kind & 0xff) == 1 and o.p[8]) == 7
     # sync_bn cut points: one per conv launch (forward), one per BatchNorm layer (backward)
     assert len(pl.fwd_sync_idx) == 49 and len(pl.bwd_sync) == 57
     # fp16 plans fold the BatchNorm-backward sums of every layer whose output gradient is last written by a conv dgrad into
