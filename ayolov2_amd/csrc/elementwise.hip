@@ -648,30 +648,39 @@ __global__ __launch_bounds__(256) void k_maxpool5_fwd(const T* x, int ldx, T* y,
         for (int j = 0; j < PSW; ++j)
 #pragma unroll
             for (int i = 0; i < VE; ++i) { best[j][i] = -INFINITY; bi[j][i] = 0; }
+        // BRANCH-FREE on purpose: hipcc turns a conditional load into a branch + s_waitcnt vmcnt(0), i.e. one memory round trip per
+        // tap (what bounds the per-pixel kernel).  Out-of-image taps load a clamped address and become -inf, which never beats the
+        // running best (strict >) -- the same as skipping the tap; the NC loads of a window row are in flight together.
+#pragma unroll 1
         for (int dy = 0; dy < K; ++dy) {
             const int hh = h + dy - PAD;
-            if (hh < 0 || hh >= H) continue;
+            const bool rok = hh >= 0 && hh < H;
+            const int hc = hh < 0 ? 0 : (hh >= H ? H - 1 : hh);
             float v[NC][VE];
-            const T* row = x + ((n * H + hh) * W) * (long long)ldx + cg * VE;
+            const T* row = x + ((n * H + hc) * W) * (long long)ldx + cg * VE;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int ww = w0 + c - PAD;
-                if (ww >= 0 && ww < W) load_vec<T>(row + (long long)ww * ldx, v[c]);
-                else {
+                const int wc = ww < 0 ? 0 : (ww >= W ? W - 1 : ww);
+                load_vec<T>(row + (long long)wc * ldx, v[c]);
+            }
 #pragma unroll
-                    for (int i = 0; i < VE; ++i) v[c][i] = -INFINITY;       // never beats the initial best: same as skipping the tap
-                }
+            for (int c = 0; c < NC; ++c) {
+                const int ww = w0 + c - PAD;
+                const bool ok = rok && ww >= 0 && ww < W;
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[c][i] = ok ? v[c][i] : -INFINITY;
             }
 #pragma unroll
             for (int j = 0; j < PSW; ++j)
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
-                    const int ww = w0 + j + dx - PAD;
-                    if (ww < 0 || ww >= W) continue;
 #pragma unroll
                     for (int i = 0; i < VE; ++i) {
                         const float val = v[j + dx][i];
-                        if (val > best[j][i] || val != val) { best[j][i] = val; bi[j][i] = dy * K + dx; }
+                        const bool take = val > best[j][i] || val != val;
+                        best[j][i] = take ? val : best[j][i];
+                        bi[j][i] = take ? dy * K + dx : bi[j][i];
                     }
                 }
         }
@@ -778,21 +787,36 @@ __global__ __launch_bounds__(256) void k_maxpool5_bwd(const unsigned char* idx, 
                 for (int i = 0; i < VE; ++i) g[j][i] = 0.0f;
             }
         }
+#pragma unroll 1
         for (int dyy = 0; dyy < K; ++dyy) {
             const int oh = h - dyy + PAD;
-            if (oh < 0 || oh >= H) continue;
-            const long long orow = (n * H + oh) * W;
+            const bool rok = oh >= 0 && oh < H;
+            const int ohc = oh < 0 ? 0 : (oh >= H ? H - 1 : oh);
+            const long long orow = (n * H + ohc) * W;
+            // branch-free (see k_maxpool5_fwd): an output outside the image is loaded from a clamped address and its window
+            // positions are replaced by 0xff, which matches no tap
+            float dvs[NC][VE];
+            unsigned wds[NC][VE / 4];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int ow = w0 + c - PAD;
+                const int owc = ow < 0 ? 0 : (ow >= W ? W - 1 : ow);
+                load_vec<T>(dy + (orow + owc) * lddy + cg * VE, dvs[c]);
+                const unsigned* ip = reinterpret_cast<const unsigned*>(idx + (orow + owc) * C + cg * VE);
+                if constexpr (VE == 8) { const uint2 u = *reinterpret_cast<const uint2*>(ip); wds[c][0] = u.x; wds[c][1] = u.y; }
+                else wds[c][0] = ip[0];
+            }
             // input pixel w0 + j is tap dxx of output column w0 + j - dxx + PAD: dxx ascending = output column descending
 #pragma unroll
             for (int c = NC - 1; c >= 0; --c) {
                 const int ow = w0 + c - PAD;
-                if (ow < 0 || ow >= W) continue;
+                const bool ok = rok && ow >= 0 && ow < W;
                 float dv[VE];
-                load_vec<T>(dy + (orow + ow) * lddy + cg * VE, dv);
                 unsigned wd[VE / 4];
-                const unsigned* ip = reinterpret_cast<const unsigned*>(idx + (orow + ow) * C + cg * VE);
-                if constexpr (VE == 8) { const uint2 u = *reinterpret_cast<const uint2*>(ip); wd[0] = u.x; wd[1] = u.y; }
-                else wd[0] = ip[0];
+#pragma unroll
+                for (int i = 0; i < VE; ++i) dv[i] = dvs[c][i];
+#pragma unroll
+                for (int q = 0; q < VE / 4; ++q) wd[q] = ok ? wds[c][q] : 0xffffffffu;
 #pragma unroll
                 for (int j = 0; j < PSW; ++j) {
                     const int dxx = j - c + 2 * PAD;           // (w0 + j) - ow + PAD
