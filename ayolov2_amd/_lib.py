@@ -39,6 +39,13 @@ class XfSeg(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("ld", c_int), ("C", c_int), ("act", c_int), ("virt", c_int)]
 
 
+class XfFin(ctypes.Structure):
+    """ayolo_xf_fin (include/ayolo.h): BatchNorm finalize of one virtual input segment inside the consumer's launch."""
+    _fields_ = [("stats", c_void_p), ("reps", c_int), ("sld", c_int), ("C", c_int), ("c0", c_int), ("count", c_double),
+                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("momentum", c_float),
+                ("running_mean", c_void_p), ("running_var", c_void_p), ("save_mean", c_void_p), ("save_invstd", c_void_p)]
+
+
 class LossLevel(ctypes.Structure):
     _fields_ = ([("pred", c_void_p)] + [(n, c_int64) for n in ("sb", "sa", "sy", "sx")]
                 + [(n, c_int) for n in ("B", "na", "ny", "nx", "no", "n")]
@@ -56,7 +63,7 @@ _P = c_void_p
 # name -> argtypes (restype is int unless noted).  Mirrors include/ayolo.h one to one.
 _SIGNATURES = {
     "ayolo_conv_fwd": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, _P],
-    "ayolo_conv_fwd_xf": [POINTER(ConvDesc), POINTER(XfSeg), c_int, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P],
+    "ayolo_conv_fwd_xf": [POINTER(ConvDesc), POINTER(XfSeg), c_int, _P, _P, POINTER(XfFin), c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P],
     "ayolo_conv_dgrad": [POINTER(ConvDesc), _P, _P, _P, c_int, _P],
     "ayolo_conv_dgrad_bn": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P],
     "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P, c_size_t, _P],

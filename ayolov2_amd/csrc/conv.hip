@@ -78,6 +78,11 @@ struct GConvP {
     int xf, xf_act, xf_virt;         // bit 0: segment 0, bit 1: segment 1
     const float* xf_scale; const float* xf_shift;
     const void* x2; int ldx2, xs_split; unsigned x2_bytes;
+    // the virtual segments' BatchNorm finalize inside this kernel (nfin > 0): every workgroup derives scale / shift of the channels
+    // from the producer's batch statistics (the expression sequence of k_bn_finalize), workgroup 0 also writes them to
+    // xf_scale / xf_shift (the weight gradient reads them later) and the saved / running statistics
+    int nfin;
+    ayolo_xf_fin fin[2];
 };
 
 template <typename T> struct Tr;
@@ -890,9 +895,47 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
     float* sXf = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sStat) + G::tail(EM, BNR));
     const int xf_cp = (p.C + BK - 1) / BK * BK;
     if constexpr (XF) {
-        for (int i = tid; i < xf_cp; i += (int)blockDim.x) {
-            sXf[i] = i < p.C ? p.xf_scale[i] : 0.0f;
-            sXf[xf_cp + i] = i < p.C ? p.xf_shift[i] : 0.0f;
+        if (p.nfin > 0) {
+            for (int i = tid; i < 2 * xf_cp; i += (int)blockDim.x) sXf[i] = 0.0f;
+            __syncthreads();
+            float* gsc = const_cast<float*>(p.xf_scale);
+            float* gsh = const_cast<float*>(p.xf_shift);
+            for (int f = 0; f < p.nfin; ++f) {
+                const ayolo_xf_fin& q = p.fin[f];
+                for (int c = tid; c < q.C; c += (int)blockDim.x) {
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int r = 0; r < q.reps; ++r) {
+                        s1 += q.stats[(size_t)r * 2 * q.sld + c];
+                        s2 += q.stats[(size_t)r * 2 * q.sld + q.sld + c];
+                    }
+                    // the SAME expression sequence as k_bn_finalize / k_bn_train_act's prologue: bit-identical scale / shift
+                    const double mean = s1 / q.count;
+                    double var = s2 / q.count - mean * mean;
+                    if (var < 0) var = 0;
+                    const float invstd = (float)(1.0 / sqrt(var + (double)q.eps));
+                    const float g = q.gamma ? q.gamma[c] : 1.0f, b = q.beta ? q.beta[c] : 0.0f;
+                    const float sc = g * invstd;
+                    const float sh = b - (float)mean * sc;
+                    sXf[q.c0 + c] = sc;
+                    sXf[xf_cp + q.c0 + c] = sh;
+                    if (Lb == 0) {
+                        gsc[q.c0 + c] = sc;
+                        gsh[q.c0 + c] = sh;
+                        if (q.save_mean) q.save_mean[c] = (float)mean;
+                        if (q.save_invstd) q.save_invstd[c] = invstd;
+                        if (q.running_mean) q.running_mean[c] = (1.0f - q.momentum) * q.running_mean[c] + q.momentum * (float)mean;
+                        if (q.running_var) {
+                            const double unb = q.count > 1.0 ? var * q.count / (q.count - 1.0) : var;
+                            q.running_var[c] = (1.0f - q.momentum) * q.running_var[c] + q.momentum * (float)unb;
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int i = tid; i < xf_cp; i += (int)blockDim.x) {
+                sXf[i] = i < p.C ? p.xf_scale[i] : 0.0f;
+                sXf[xf_cp + i] = i < p.C ? p.xf_shift[i] : 0.0f;
+            }
         }
     }
     constexpr bool TILE_RED = BNR && TM >= 128;
@@ -2293,9 +2336,9 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
 // Forward of a 1x1 / stride-1 conv whose input is (partly) VIRTUAL: a segment's operand is act(z * xscale + xshift) formed on the
 // way to the MFMAs (k_gconv<..., XF>), i.e. the consumer of a Conv-BN-act block reads the block's pre-activation z and the
 // BatchNorm + activation pass that would have written the activation is not launched at all.
-extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* segs, int nseg, const float* xscale, const float* xshift,
-                                 const void* w, void* y, int epilogue, const float* shift, double* stats, int stat_reps, int head_no,
-                                 ayolo_stream s) {
+extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* segs, int nseg, float* xscale, float* xshift,
+                                 const ayolo_xf_fin* fin, int nfin, const void* w, void* y, int epilogue, const float* shift, double* stats,
+                                 int stat_reps, int head_no, ayolo_stream s) {
     int rc = check_desc(d, "conv_fwd_xf");
     if (rc) return rc;
     AY_CHECK_ARG(segs && (nseg == 1 || nseg == 2) && xscale && xshift && w && y, "conv_fwd_xf: null pointer / %d segments", nseg);
@@ -2328,6 +2371,17 @@ extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* s
     p.xf_virt = (segs[0].virt ? 1 : 0) | ((nseg > 1 && segs[1].virt) ? 2 : 0);
     p.xs_split = nseg > 1 ? segs[0].C : (d->Cin + BK - 1) / BK * BK;          // one segment: no step ever reaches the split
     if (nseg > 1) { p.x2 = segs[1].x; p.ldx2 = segs[1].ld; }
+    AY_CHECK_ARG(nfin >= 0 && nfin <= 2 && (nfin == 0 || fin), "conv_fwd_xf: %d finalize records", nfin);
+    for (int k = 0; k < nfin; ++k) {
+        AY_CHECK_ARG(fin[k].stats && fin[k].C > 0 && fin[k].c0 >= 0 && fin[k].c0 + fin[k].C <= d->Cin && fin[k].sld >= fin[k].C && fin[k].reps >= 1 &&
+                     fin[k].count > 0, "conv_fwd_xf: finalize record %d", k);
+        p.fin[k] = fin[k];
+    }
+    p.nfin = nfin;
+    // the running statistics are updated by workgroup 0 of ONE launch: a conv that has to be cut into batch halves cannot carry them
+    AY_CHECK_ARG(nfin == 0 || ((long long)d->B * d->H * d->W * (segs[0].ld > d->ldy ? segs[0].ld : d->ldy) * 4 < (1ll << 31) - 4096 &&
+                               (nseg < 2 || (long long)d->B * d->H * d->W * segs[1].ld * 2 < (1ll << 31) - 4096)),
+                 "conv_fwd_xf: tensors of 2 GiB need the separate finalize launch");
     return dispatch_gconv(d->dtype, p, (hipStream_t)s);
 }
 

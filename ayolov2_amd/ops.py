@@ -135,8 +135,8 @@ def conv_fwd_xf(desc: ConvDesc, z, xscale, xshift, xact, w, y, epilogue=_lib.EPI
         _, C, _, _, ld = nhwc_info(t)
         arr[k].x, arr[k].ld, arr[k].C, arr[k].act, arr[k].virt = t.data_ptr(), ld, C, int(act), int(bool(virt))
     reps = stats.shape[0] if (stats is not None and stats.dim() == 2) else 1
-    call("ayolo_conv_fwd_xf", desc, arr, len(segs), _ptr(xscale), _ptr(xshift), _ptr(w), _ptr(y), epilogue, _ptr(shift), _ptr(stats),
-         reps, head_no, _stream())
+    call("ayolo_conv_fwd_xf", desc, arr, len(segs), _ptr(xscale), _ptr(xshift), None, 0, _ptr(w), _ptr(y), epilogue, _ptr(shift),
+         _ptr(stats), reps, head_no, _stream())
 
 
 def conv_dgrad(desc: ConvDesc, dy, wt, dx, accumulate=False):

@@ -79,6 +79,7 @@ BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
 # 1x1 / stride-1 conv, is not launched -- that conv (and its weight gradient) read the block's pre-activation z and form the
 # activation on the way to the MFMAs; the block keeps a tiny finalize launch (batch statistics -> scale / shift, running stats)
 XF_ON_LOAD = _os.environ.get("AYOLO_XF", "1") == "1"
+XF_FINALIZE_IN_READER = _os.environ.get("AYOLO_XF_FIN", "1") == "1"      # the folded blocks' finalize inside the reader's launch
 WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "4"))
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
 # (A cap on a group's resident workgroups per CU -- so that the kernels of backward's dependent chain forked behind it find free
@@ -582,7 +583,7 @@ class TrainPlan:
             scale_all, shift_all = xs[:cin], xs[cin:]
             xin = c["x"]                                      # the consumer's materialised input (for plain segments)
             ld_plain = ops.nhwc_info(xin.t)[4]
-            wsegs, bits, ptrs = [], 0, []
+            wsegs, bits, ptrs, fins = [], 0, [], []
             for k, (lo, hi, P) in enumerate(merged):
                 c0, C = lo - rlo, hi - lo
                 if P is None:
@@ -597,14 +598,40 @@ class TrainPlan:
                 o, bn = P["op"], P["bn"]
                 stats_ptr, smean, sinv = o.p[2], o.p[7], o.p[8]            # bound by the late closures of _conv_group
                 assert (o.kind & 0xff) == OP_BN_TRAIN_ACT and stats_ptr and smean and sinv
-                new = _op(OP_BN_FINALIZE, i=(P["R"], co, P["ldz"]), d=(float(P["npix"]),), f=(bn.eps, bn.momentum),
-                          p=(stats_ptr, bn.weight, bn.bias, bn.running_mean, bn.running_var, smean, sinv, scale, shift))
-                ctypes.memmove(ctypes.addressof(o), ctypes.addressof(new), ctypes.sizeof(Op))    # in place: self.fwd holds this object
+                fins.append(dict(stats=stats_ptr, reps=P["R"], sld=P["ldz"], C=co, c0=c0, count=float(P["npix"]), bn=bn, smean=smean, sinv=sinv,
+                                 op=o, scale=scale, shift=shift))
                 bits |= ((1 if P["act"] else 0) | 2) << (2 * k)
                 wsegs.append((P["z"], P["ldz"], c0, C, (scale, shift, P["act"])))
                 ptrs.append((P["z"], P["ldz"], C))
                 self.xf_layers += 1
             op = c["op"]
+            # the finalize of the folded blocks: inside the reader's launch (every workgroup derives scale / shift in its prologue,
+            # workgroup 0 writes the vectors and the saved / running statistics) unless the reader may have to be cut into batch
+            # halves (2 GiB tensors): then each block keeps a finalize launch of its own
+            B_, _, H_, W_ = xin.t.shape
+            small_enough = B_ * H_ * W_ * max(max(pt[1] for pt in ptrs), c["cout"]) * 4 < (1 << 31) - 4096
+            if XF_FINALIZE_IN_READER and small_enough:
+                from ._lib import XfFin
+                farr = (XfFin * len(fins))()
+                for k, f in enumerate(fins):
+                    bn = f["bn"]
+                    farr[k].stats, farr[k].reps, farr[k].sld, farr[k].C, farr[k].c0, farr[k].count = f["stats"], f["reps"], f["sld"], f["C"], f["c0"], f["count"]
+                    farr[k].gamma = bn.weight.data_ptr() if bn.weight is not None else None
+                    farr[k].beta = bn.bias.data_ptr() if bn.bias is not None else None
+                    farr[k].eps, farr[k].momentum = bn.eps, bn.momentum
+                    farr[k].running_mean = bn.running_mean.data_ptr() if bn.running_mean is not None else None
+                    farr[k].running_var = bn.running_var.data_ptr() if bn.running_var is not None else None
+                    farr[k].save_mean, farr[k].save_invstd = f["smean"], f["sinv"]
+                    f["op"].kind = 0                             # no launch of its own
+                self.keep.append(farr)
+                op.p[9] = ctypes.addressof(farr)
+                op.i[6] = len(fins)
+            else:
+                for f in fins:
+                    bn = f["bn"]
+                    new = _op(OP_BN_FINALIZE, i=(f["reps"], f["C"], f["sld"]), d=(f["count"],), f=(bn.eps, bn.momentum),
+                              p=(f["stats"], bn.weight, bn.bias, bn.running_mean, bn.running_var, f["smean"], f["sinv"], f["scale"], f["shift"]))
+                    ctypes.memmove(ctypes.addressof(f["op"]), ctypes.addressof(new), ctypes.sizeof(Op))    # in place: self.fwd holds this object
             op.p[0] = ptrs[0][0].data_ptr()
             op.conv.ldx = ptrs[0][1]
             op.p[6], op.p[7] = scale_all.data_ptr(), shift_all.data_ptr()

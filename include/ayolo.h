@@ -114,9 +114,21 @@ typedef struct ayolo_xf_seg {
     int ld, C;                /* channel stride of its buffer, channels */
     int act, virt;            /* SiLU on / off; 1: transform (x is z), 0: plain activation */
 } ayolo_xf_seg;
-int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* segs, int nseg, const float* xscale, const float* xshift,
-                      const void* w, void* y, int epilogue, const float* shift, double* stats, int stat_reps, int head_no,
-                      ayolo_stream s);
+/* nfin > 0: the BatchNorm FINALIZE of the virtual segments happens inside this launch too (what ayolo_bn_finalize_ld computes, from
+ * the producing conv's batch statistics): every workgroup derives the scale / shift of channels [c0, c0 + C) of the conv's input,
+ * workgroup 0 writes them to xscale / xshift (the weight gradient reads them later) and updates the saved / running statistics
+ * -- a block whose activation is read on load then costs no launch of its own at all.  nfin == 0: xscale / xshift are inputs. */
+typedef struct ayolo_xf_fin {
+    const double* stats;      /* [reps][2][sld] accumulators of the producing conv, this block's channels first */
+    int reps, sld, C, c0;     /* replicas, accumulator channel stride, channels, first input channel of the consumer */
+    double count;             /* pixels per channel */
+    const float* gamma; const float* beta;
+    float eps, momentum;
+    float* running_mean; float* running_var; float* save_mean; float* save_invstd;   /* each nullable */
+} ayolo_xf_fin;
+int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* segs, int nseg, float* xscale, float* xshift,
+                      const ayolo_xf_fin* fin, int nfin, const void* w, void* y, int epilogue, const float* shift, double* stats,
+                      int stat_reps, int head_no, ayolo_stream s);
 
 /* Weight gradient (autograd's ConvolutionBackward weight leg behind scripts/train/yolo_trainer.py:329):
  * dw[Cout][kh][kw][Cin] (fp32) += alpha * sum_pixels dy (x) x.  The pixel reduction is split over workgroups; every split
