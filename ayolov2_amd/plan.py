@@ -574,7 +574,10 @@ class TrainPlan:
                     merged.append(sg)
             if len(merged) > 2 or not any(sg[2] is not None for sg in merged):
                 continue
-            if len(merged) == 2 and (merged[0][1] - rlo) % 32:
+            # two segments: the weight gradient runs as one job per segment over 128-column dw tiles -- a segment that is not a
+            # whole number of tiles would spend up to half of its MFMA / DMA work on padding (measured: folding the 32- / 64-channel
+            # halves of the early C3 blocks cost the step what the saved passes bought, profiles/r04_ab_xf_two_segments.txt)
+            if len(merged) == 2 and any((hi - lo) % 128 for lo, hi, _ in merged):
                 continue
             if any((hi - lo) % 8 for lo, hi, _ in merged):
                 continue
