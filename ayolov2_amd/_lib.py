@@ -63,7 +63,7 @@ _P = c_void_p
 # name -> argtypes (restype is int unless noted).  Mirrors include/ayolo.h one to one.
 _SIGNATURES = {
     "ayolo_conv_fwd": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, _P],
-    "ayolo_conv_fwd_xf": [POINTER(ConvDesc), POINTER(XfSeg), c_int, _P, _P, POINTER(XfFin), c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P],
+    "ayolo_conv_fwd_xf": [POINTER(ConvDesc), POINTER(XfSeg), c_int, _P, _P, POINTER(XfFin), c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P],
     "ayolo_conv_dgrad": [POINTER(ConvDesc), _P, _P, _P, c_int, _P],
     "ayolo_conv_dgrad_bn": [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P],
     "ayolo_conv_wgrad": [POINTER(ConvDesc), _P, _P, _P, c_float, _P, c_size_t, _P],

@@ -78,6 +78,9 @@ struct GConvP {
     int xf, xf_act, xf_virt;         // bit 0: segment 0, bit 1: segment 1
     const float* xf_scale; const float* xf_shift;
     const void* x2; int ldx2, xs_split; unsigned x2_bytes;
+    // store-back: the workgroups of channel tile 0 also WRITE the transformed chunks to the materialised activation `xa` (channel
+    // stride ldxa, the conv's input channels side by side) -- the weight gradient then reads a plain operand
+    void* xa; int ldxa; unsigned xa_bytes;
     // the virtual segments' BatchNorm finalize inside this kernel (nfin > 0): every workgroup derives scale / shift of the channels
     // from the producer's batch statistics (the expression sequence of k_bn_finalize), workgroup 0 also writes them to
     // xf_scale / xf_shift (the weight gradient reads them later) and the saved / running statistics
@@ -1065,7 +1068,9 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
     // so its own counted vmcnt is all the ordering the read needs (no barrier between landing and transform), and the step's
     // barrier publishes the result.  Same arithmetic as k_bn_train_act (fma, v_exp / v_rcp sigmoid, one fp16 rounding): the
     // operand bits equal the materialised activation's.
-    auto xf_transform = [&](unsigned so, int kt) {
+    const bool xst = XF && p.xa != nullptr && nt == 0;               // this workgroup also stores the activation it forms
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(XF ? p.xa : nullptr, 0, XF ? p.xa_bytes : 0, 0x00020000);
+    auto xf_transform = [&](unsigned so, int kt, unsigned tile) {
         if constexpr (XF) {
             const int c0 = kt * BK + kc * G::CE;
             const float4v a0 = *reinterpret_cast<const float4v*>(sXf + c0), a1 = *reinterpret_cast<const float4v*>(sXf + c0 + 4);
@@ -1084,13 +1089,26 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
                     h[e] = (half_t)u;
                 }
                 *q = h;
+                if (xst) {
+                    // exactly XR stores per transform of a virtual segment (rows beyond the tensor / K padding: out-of-range offset,
+                    // dropped by the hardware), so that the step loop's counted waits stay exact
+                    const unsigned mu = tile * G::TP + (unsigned)((r * G::NW + wave) * G::RW + rowin);
+                    const bool ok = (tile < ntiles) & (mu < (unsigned)p.Mtotal) & (c0 < p.C);
+                    const unsigned off = ok ? mu * ((unsigned)p.ldxa * G::ES) + (unsigned)c0 * G::ES : G_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, h), rsA, off, 0, 0);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // written before this wave reaches the next barrier
         }
     };
+    // VMEM operations the transform of a step leaves behind (the counted waits of the loop skip over them): XR stores when this
+    // workgroup stores back AND the step's segment is virtual
+    auto xf_stores = [&](int kt) -> bool { return xst && ((p.xf_virt >> (((kt * BK) >= p.xs_split) ? 1 : 0)) & 1); };
+    bool xf_prev_st = false;                                        // did the LAST transform issue stores?
     if constexpr (XF) {
         wait_vm<G::LPS>();                                          // step 0's pieces (the older half of the two issues)
-        xf_transform(so0, 0);
+        xf_transform(so0, 0, cur_tile);
+        xf_prev_st = xf_stores(0);
     }
 
     bool after_epi = false;
@@ -1101,7 +1119,13 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
         AY_PROBE(probe_k); ++probe_k;
 #endif
         const bool prev_epi = after_epi;
-        if (after_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
+        if constexpr (XF) {
+            // behind step s's pieces: step s+1's pieces, the stores of the last transform (if it stored), an epilogue's stores
+            if (xf_prev_st) { if (after_epi) wait_vm<G::LPS + G::XR + NSTK>(); else wait_vm<G::LPS + G::XR>(); }
+            else { if (after_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>(); }
+        } else {
+            if (after_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
+        }
 #ifdef AYOLO_PROBE
         AY_PROBE(probe_k); ++probe_k;
 #endif
@@ -1150,8 +1174,12 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
         if constexpr (XF) {
             // step s+1's x pieces (issued during step s-1; behind them only the stores of an epilogue of step s-1 and this
             // step's issues): transform them now, in the shadow of the other waves' MFMAs
-            if (prev_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>();
-            xf_transform(so1, cur_kt + 1 == cur_nk ? 0 : cur_kt + 1);
+            if (xf_prev_st) { if (prev_epi) wait_vm<G::LPS + G::XR + NSTK>(); else wait_vm<G::LPS + G::XR>(); }
+            else { if (prev_epi) wait_vm<G::LPS + NSTK>(); else wait_vm<G::LPS>(); }
+            const bool wrap = cur_kt + 1 == cur_nk;
+            const int nkt = wrap ? 0 : cur_kt + 1;
+            xf_transform(so1, nkt, wrap ? cur_tile + lstride : cur_tile);
+            xf_prev_st = xf_stores(nkt);
         }
 #ifdef AYOLO_PROBE
         AY_PROBE(probe_k); ++probe_k;
@@ -2226,6 +2254,7 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     AY_CHECK_ARG(x2_img < LIM, "conv: a single image of the second input segment (%lld bytes) unsupported", x2_img);
     if (x_img * p.B >= LIM || y_img * p.B >= LIM || z_img_max * p.B >= LIM || x2_img * p.B >= LIM) {
         AY_CHECK_ARG(p.B > 1, "conv: one image exceeds the 2 GiB descriptor range");
+        AY_CHECK_ARG(p.xa == nullptr && p.nfin == 0, "conv_fwd_xf: store-back / in-launch finalize need tensors below 2 GiB");
         GConvP a = p, b = p;
         a.B = p.B / 2; b.B = p.B - a.B;
         a.Mtotal = (long long)a.B * p.OH * p.OW; b.Mtotal = (long long)b.B * p.OH * p.OW;
@@ -2337,8 +2366,8 @@ extern "C" int ayolo_conv_fwd(const ayolo_conv_desc* d, const void* x, const voi
 // way to the MFMAs (k_gconv<..., XF>), i.e. the consumer of a Conv-BN-act block reads the block's pre-activation z and the
 // BatchNorm + activation pass that would have written the activation is not launched at all.
 extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* segs, int nseg, float* xscale, float* xshift,
-                                 const ayolo_xf_fin* fin, int nfin, const void* w, void* y, int epilogue, const float* shift, double* stats,
-                                 int stat_reps, int head_no, ayolo_stream s) {
+                                 const ayolo_xf_fin* fin, int nfin, void* xa, int ldxa, const void* w, void* y, int epilogue, const float* shift,
+                                 double* stats, int stat_reps, int head_no, ayolo_stream s) {
     int rc = check_desc(d, "conv_fwd_xf");
     if (rc) return rc;
     AY_CHECK_ARG(segs && (nseg == 1 || nseg == 2) && xscale && xshift && w && y, "conv_fwd_xf: null pointer / %d segments", nseg);
@@ -2378,6 +2407,9 @@ extern "C" int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* s
         p.fin[k] = fin[k];
     }
     p.nfin = nfin;
+    AY_CHECK_ARG(xa == nullptr || (ldxa % 8 == 0 && ldxa >= d->Cin && (long long)d->B * d->H * d->W * ldxa * 2 < (1ll << 31) - 4096),
+                 "conv_fwd_xf: store-back buffer: ld=%d (< 2 GiB)", ldxa);
+    p.xa = xa; p.ldxa = ldxa; p.xa_bytes = xa ? (unsigned)((long long)d->B * d->H * d->W * ldxa * 2) : 0u;
     // the running statistics are updated by workgroup 0 of ONE launch: a conv that has to be cut into batch halves cannot carry them
     AY_CHECK_ARG(nfin == 0 || ((long long)d->B * d->H * d->W * (segs[0].ld > d->ldy ? segs[0].ld : d->ldy) * 4 < (1ll << 31) - 4096 &&
                                (nseg < 2 || (long long)d->B * d->H * d->W * segs[1].ld * 2 < (1ll << 31) - 4096)),

@@ -165,8 +165,9 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
                 sg[0].x = o.p[0]; sg[0].ld = o.conv.ldx; sg[0].C = two ? o.i[5] : o.conv.Cin; sg[0].act = o.i[3] & 1; sg[0].virt = (o.i[3] >> 1) & 1;
                 sg[1].x = o.p[8]; sg[1].ld = o.i[4]; sg[1].C = o.conv.Cin - sg[0].C; sg[1].act = (o.i[3] >> 2) & 1; sg[1].virt = (o.i[3] >> 3) & 1;
                 // p[9] / i[6]: host array of ayolo_xf_fin -- the producers' BatchNorm finalize inside this launch
-                rc = ayolo_conv_fwd_xf(&o.conv, sg, two ? 2 : 1, (float*)o.p[6], (float*)o.p[7], (const ayolo_xf_fin*)o.p[9], o.i[6], o.p[1], o.p[2],
-                                       o.i[0], (const float*)o.p[4], (double*)o.p[5], o.i[1], o.i[2], cs);
+                // p[10] / i[7]: store-back buffer (the materialised activation) and its channel stride
+                rc = ayolo_conv_fwd_xf(&o.conv, sg, two ? 2 : 1, (float*)o.p[6], (float*)o.p[7], (const ayolo_xf_fin*)o.p[9], o.i[6], o.p[10], o.i[7],
+                                       o.p[1], o.p[2], o.i[0], (const float*)o.p[4], (double*)o.p[5], o.i[1], o.i[2], cs);
             }
             else rc = ayolo_conv_fwd(&o.conv, o.p[0], o.p[1], o.p[2], o.i[0], (const float*)o.p[3], (const float*)o.p[4],
                                      (double*)o.p[5], o.i[1], o.i[2], cs);

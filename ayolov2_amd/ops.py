@@ -124,7 +124,7 @@ def conv_fwd(desc: ConvDesc, x, w, y, epilogue=_lib.EPI_NONE, scale=None, shift=
          _stream())
 
 
-def conv_fwd_xf(desc: ConvDesc, z, xscale, xshift, xact, w, y, epilogue=_lib.EPI_NONE, shift=None, stats=None, head_no=0):
+def conv_fwd_xf(desc: ConvDesc, z, xscale, xshift, xact, w, y, epilogue=_lib.EPI_NONE, shift=None, stats=None, head_no=0, store=None):
     """1x1 conv over a (partly) VIRTUAL input (ayolo_conv_fwd_xf: transform on load).  One segment: `z` is the producer's
     pre-activation, the operand is act(z * xscale + xshift).  Two segments: z = [(tensor, act, virt), (tensor, act, virt)] --
     channel slices side by side in the conv's input channels; virt = False marks a plain (materialised) activation."""
@@ -135,8 +135,9 @@ def conv_fwd_xf(desc: ConvDesc, z, xscale, xshift, xact, w, y, epilogue=_lib.EPI
         _, C, _, _, ld = nhwc_info(t)
         arr[k].x, arr[k].ld, arr[k].C, arr[k].act, arr[k].virt = t.data_ptr(), ld, C, int(act), int(bool(virt))
     reps = stats.shape[0] if (stats is not None and stats.dim() == 2) else 1
-    call("ayolo_conv_fwd_xf", desc, arr, len(segs), _ptr(xscale), _ptr(xshift), None, 0, _ptr(w), _ptr(y), epilogue, _ptr(shift),
-         _ptr(stats), reps, head_no, _stream())
+    lds = nhwc_info(store)[4] if store is not None else 0      # store: the materialised activation the first channel tile writes back
+    call("ayolo_conv_fwd_xf", desc, arr, len(segs), _ptr(xscale), _ptr(xshift), None, 0, _ptr(store), lds, _ptr(w), _ptr(y), epilogue,
+         _ptr(shift), _ptr(stats), reps, head_no, _stream())
 
 
 def conv_dgrad(desc: ConvDesc, dy, wt, dx, accumulate=False):

@@ -80,6 +80,11 @@ BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
 # activation on the way to the MFMAs; the block keeps a tiny finalize launch (batch statistics -> scale / shift, running stats)
 XF_ON_LOAD = _os.environ.get("AYOLO_XF", "1") == "1"
 XF_FINALIZE_IN_READER = _os.environ.get("AYOLO_XF_FIN", "1") == "1"      # the folded blocks' finalize inside the reader's launch
+# What the reader's WEIGHT GRADIENT reads: 0 (default) = the materialised activation, which the reader's forward launch writes back
+# from its first channel tile ("store-back": the pass and its z read are still gone, the write stays); 1 = the pre-activation z,
+# transformed on load in k_wgrad too (no write at all, but the transform then runs on the weight-gradient stream, where it cost
+# the step more than the write does: same-box A/B, profiles/r04_ab_xf_*)
+XF_WGRAD_ON_LOAD = _os.environ.get("AYOLO_XF_WGRAD", "0") == "1"
 WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "4"))
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
 # (A cap on a group's resident workgroups per CU -- so that the kernels of backward's dependent chain forked behind it find free
@@ -577,7 +582,7 @@ class TrainPlan:
             # two segments: the weight gradient runs as one job per segment over 128-column dw tiles -- a segment that is not a
             # whole number of tiles would spend up to half of its MFMA / DMA work on padding (measured: folding the 32- / 64-channel
             # halves of the early C3 blocks cost the step what the saved passes bought, profiles/r04_ab_xf_two_segments.txt)
-            if len(merged) == 2 and any((hi - lo) % 128 for lo, hi, _ in merged):
+            if len(merged) == 2 and ((merged[0][1] - rlo) % 32 or (XF_WGRAD_ON_LOAD and any((hi - lo) % 128 for lo, hi, _ in merged))):
                 continue
             if any((hi - lo) % 8 for lo, hi, _ in merged):
                 continue
@@ -606,13 +611,15 @@ class TrainPlan:
                 bits |= ((1 if P["act"] else 0) | 2) << (2 * k)
                 wsegs.append((P["z"], P["ldz"], c0, C, (scale, shift, P["act"])))
                 ptrs.append((P["z"], P["ldz"], C))
-                self.xf_layers += 1
             op = c["op"]
             # the finalize of the folded blocks: inside the reader's launch (every workgroup derives scale / shift in its prologue,
             # workgroup 0 writes the vectors and the saved / running statistics) unless the reader may have to be cut into batch
             # halves (2 GiB tensors): then each block keeps a finalize launch of its own
             B_, _, H_, W_ = xin.t.shape
             small_enough = B_ * H_ * W_ * max(max(pt[1] for pt in ptrs), c["cout"]) * 4 < (1 << 31) - 4096
+            if not XF_WGRAD_ON_LOAD and not small_enough:
+                continue                                      # (store-back cannot follow a batch split; nothing was modified yet)
+            self.xf_layers += len(fins)
             if XF_FINALIZE_IN_READER and small_enough:
                 from ._lib import XfFin
                 farr = (XfFin * len(fins))()
@@ -642,7 +649,12 @@ class TrainPlan:
             if len(ptrs) > 1:
                 op.p[8] = ptrs[1][0].data_ptr()
                 op.i[4], op.i[5] = ptrs[1][1], ptrs[0][2]
-            c["cx"]["segs"] = wsegs
+            if XF_WGRAD_ON_LOAD:
+                c["cx"]["segs"] = wsegs
+            else:
+                op.p[10] = xin.t.data_ptr()                   # store-back: the first channel tile writes the activation it forms
+                op.i[7] = ld_plain
+                c["cx"]["segs"] = []                          # (marks the consumer as folded; the weight gradient reads xin as before)
 
     def _batched_casts(self) -> List[Op]:
         """All per-layer fp32 -> compute-dtype weight casts (and transposes) as ONE launch: the job table lives in

@@ -126,9 +126,13 @@ typedef struct ayolo_xf_fin {
     float eps, momentum;
     float* running_mean; float* running_var; float* save_mean; float* save_invstd;   /* each nullable */
 } ayolo_xf_fin;
+/* xa != NULL (store-back): the workgroups of the first output-channel tile also WRITE the activation they form to xa[p][c]
+ * (channel stride ldxa, the conv's input channels side by side; plain segments are not touched) -- exactly the tensor the
+ * BatchNorm + activation pass would have written, for later readers that want it materialised (the conv's weight gradient:
+ * transforming on load there too costs more on the weight-gradient stream than the write costs here, profiles/r04_ab_xf_*). */
 int ayolo_conv_fwd_xf(const ayolo_conv_desc* d, const ayolo_xf_seg* segs, int nseg, float* xscale, float* xshift,
-                      const ayolo_xf_fin* fin, int nfin, const void* w, void* y, int epilogue, const float* shift, double* stats,
-                      int stat_reps, int head_no, ayolo_stream s);
+                      const ayolo_xf_fin* fin, int nfin, void* xa, int ldxa, const void* w, void* y, int epilogue, const float* shift,
+                      double* stats, int stat_reps, int head_no, ayolo_stream s);
 
 /* Weight gradient (autograd's ConvolutionBackward weight leg behind scripts/train/yolo_trainer.py:329):
  * dw[Cout][kh][kw][Cin] (fp32) += alpha * sum_pixels dy (x) x.  The pixel reduction is split over workgroups; every split

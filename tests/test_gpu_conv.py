@@ -687,7 +687,11 @@ def test_conv_transform_on_load_equals_materialised_route(shape):
         if route == "materialised":
             ops.conv_fwd(da, a, w, y, epi, shift=bias, stats=stats, head_no=85 if head else 0)
         else:
-            ops.conv_fwd_xf(d, z, scale, shift, act, w, y, epi, shift=bias, stats=stats, head_no=85 if head else 0)
+            # store-back: the first channel tile also writes the activation it forms -- it must BE the pass's output
+            back = torch.full_like(a, float("nan"))
+            ops.conv_fwd_xf(d, z, scale, shift, act, w, y, epi, shift=bias, stats=stats, head_no=85 if head else 0, store=back)
+            torch.cuda.synchronize()
+            assert torch.equal(back, a), "store-back differs from the materialised activation"
         torch.cuda.synchronize()
         outs.append((y.clone(), None if stats is None else stats.sum(0).clone()))
     assert torch.equal(outs[0][0], outs[1][0])
@@ -735,7 +739,13 @@ def test_conv_transform_on_load_two_segments(case):
         if route == "materialised":
             ops.conv_fwd(d, cat, w, y, _lib.EPI_NONE, stats=stats)
         else:
-            ops.conv_fwd_xf(d, [(z0, acts[0], virt[0]), (z1, acts[1], virt[1])], scale, shift, 0, w, y, _lib.EPI_NONE, stats=stats)
+            back = cat.clone()
+            for c0, C, v in ((0, C0, virt[0]), (C0, C1, virt[1])):
+                if v:
+                    back[:, c0:c0 + C] = float("nan")                     # virtual segments are written back, plain ones are left alone
+            ops.conv_fwd_xf(d, [(z0, acts[0], virt[0]), (z1, acts[1], virt[1])], scale, shift, 0, w, y, _lib.EPI_NONE, stats=stats, store=back)
+            torch.cuda.synchronize()
+            assert torch.equal(back, cat), "store-back differs from the materialised concat"
         torch.cuda.synchronize()
         outs.append((y.clone(), stats.sum(0).clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

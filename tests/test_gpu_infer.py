@@ -355,16 +355,17 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
         m.load_state_dict(sd)
         m.__dict__.pop("_plans", None)
         m.use_plan = kw.get("use_plan", True)
-        old, old_xf = P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD
+        old, old_xf, old_xw = P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD, P.XF_WGRAD_ON_LOAD
         P.BN_REDUCE_IN_DGRAD = kw.get("bnr", True)
         P.XF_ON_LOAD = kw.get("xf", True)
+        P.XF_WGRAD_ON_LOAD = kw.get("xf_wgrad", False)
         try:
             loss, _, g = _train_step(m, x, t, amp=True)
             if kw.get("use_plan", True):
                 pl = [v for v in m._plans.values() if v][0]
                 assert (pl.xf_layers >= 10) == kw.get("xf", True), pl.xf_layers
         finally:
-            P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD = old, old_xf
+            P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD, P.XF_WGRAD_ON_LOAD = old, old_xf, old_xw
             m.use_plan = True
         last.append(g)
         return loss, _flat(g)
@@ -389,6 +390,12 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
     not_equal = [k for k in conv_w if not torch.equal(last[0][k], last[-1][k])]
     assert not not_equal, not_equal
     assert _cos(g0, g4) >= 1.0 - 1e-9
+    # ... and with the weight gradients transforming on load as well (k_wgrad reads z; one job per input segment)
+    l5, g5 = run(xf_wgrad=True)
+    assert l5 == l0, (l5, l0)
+    assert _cos(g0, g5) >= 1.0 - 1e-9
+    bad = [k for k in conv_w if float((last[0][k] - last[-1][k]).abs().max()) > 1e-6 * float(last[0][k].abs().max())]
+    assert not bad, bad
     l2, g2 = run(bnr=False)
     l3, g3 = run(use_plan=False)
     print("fp16 step: same route twice cos %.9f; epilogue sums vs reduce pass cos %.9f; plan vs module path cos %.9f"

@@ -349,12 +349,14 @@ def test_plan_gradient_buckets_cover_the_arena():
     assert all((pl.bwd[k].kind & 0xff) == 23 for k in gidx)
     # the tail of backward is cut finer than its body (what the last group still has to do after the main stream is exposed)
     assert pl.wgroup_costs[gidx[-1]][1] < 0.6 * max(v[1] for v in pl.wgroup_costs.values())
-    # transform on load: 17 of the 57 BatchNorm + SiLU passes are folded into their single 1x1 reader (15 convs, 4 of them over two
-    # input segments of whole 128-column weight-gradient tiles); their finalize rides in the reader's launch (p[9])
+    # transform on load: 21 of the 57 BatchNorm + SiLU passes are folded into their single 1x1 reader (18 convs, 7 of them over two
+    # input segments); their finalize rides in the reader's launch (p[9]) and the reader's first channel tile writes the activation
+    # back for the weight gradient (p[10]), which therefore stays one plain job per layer
     fk = Counter(o.kind & 0xff for o in pl.fwd)
-    assert pl.xf_layers == 17 and fk[18] == 40 and fk[5] == 0
+    assert pl.xf_layers == 21 and fk[18] == 36 and fk[5] == 0
     xfc = [o for o in pl.fwd if (o.kind & 0xff) == 1 and o.p[6]]
-    assert len(xfc) == 15 and sum(1 for o in xfc if o.p[8]) == 4 and all(o.p[9] for o in xfc)
+    assert len(xfc) == 18 and sum(1 for o in xfc if o.p[8]) == 7 and all(o.p[9] and o.p[10] for o in xfc)
+    assert len(pl._wjobs) == 51 and not any(j["xf"] for j in pl._wjobs)
     # sync_bn cut points: one per conv launch (forward), one per BatchNorm layer (backward)
     assert len(pl.fwd_sync_idx) == 49 and len(pl.bwd_sync) == 57
     # fp16 plans fold the BatchNorm-backward sums of every layer whose output gradient is last written by a conv dgrad into
