@@ -161,6 +161,9 @@ def in_situ_roofline(model, one_step, ms_per_step, batch):
                      "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
                      "basis": f"{FWD_BWD_GFLOP_PER_IMG} GFLOP per image (conv MACs fwd + bwd, SURVEY.md 8d) x {img_s:.0f} img/s, wall time of the step"},
             "bn_layers_folded_into_dgrad": plan.bn_in_dgrad,
+            # round 4: BatchNorm + SiLU passes folded into their single 1x1 reader (transform on load), grouped weight-gradient launches
+            "bn_act_passes_folded_into_reader": getattr(plan, "xf_layers", 0),
+            "wgrad_group_launches": len(getattr(plan, "wgroup_costs", {})),
             "families_in_situ": fams,
             "whole_step": {"algorithmic_gb": round(step_gb, 2), "ms_per_step": round(ms_per_step, 3),
                            "achieved_gb_per_s": round(step_gb / ms_per_step * 1e3, 1),
