@@ -1062,7 +1062,12 @@ class TrainPlan:
             xin, yout, wts = d.B * d.H * d.W * d.Cin, d.B * d.Ho * d.Wo * d.Cout, d.Cout * d.kh * d.kw * d.Cin
             if kind == OP_CONV_FWD:
                 yes = 4 if o.i[0] == EPI_HEAD else es
-                out.append(("conv_fwd", es * (xin + wts) + yes * yout, 2.0 * macs))
+                back = 0
+                if o.p[6] and o.p[10]:               # transform on load with store-back: the virtual segments' activation is written once
+                    c_first = o.i[5] if o.p[8] else d.Cin
+                    cv = (c_first if (o.i[3] >> 1) & 1 else 0) + ((d.Cin - c_first) if (o.i[3] >> 3) & 1 else 0)
+                    back = es * d.B * d.H * d.W * cv
+                out.append(("conv_fwd", es * (xin + wts) + yes * yout + back, 2.0 * macs))
             elif kind == OP_CONV_DGRAD:
                 zb = 0
                 if o.i[1] > 0:                      # BatchNorm-backward sums in the epilogue: z of the served layers read once
