@@ -249,7 +249,8 @@ def test_conv_epilogue_statistics_fp16(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 64, 40, 40), (1, 64, 32, 8, 6), (2, 32, 80, 10, 12), (1, 48, 64, 34, 2), (3, 16, 32, 6, 6),
-                                   (2, 64, 128, 64, 48), (1, 8, 96, 18, 66), (4, 32, 64, 2, 2)])
+                                   (2, 64, 128, 64, 48), (1, 8, 96, 18, 66), (4, 32, 64, 2, 2), (2, 128, 64, 24, 16), (1, 256, 128, 12, 20),
+                                   (2, 192, 96, 10, 10)])
 def test_dgrad_stride2_all_classes(shape):
     """k_dgrad_s2 (data gradient of 3x3 / stride 2 / pad 1 convs with <= 64 input channels: the four residue classes share
     the dy rows and their accumulators live in one workgroup) against torch's conv_transpose-style reference, fp16 with
