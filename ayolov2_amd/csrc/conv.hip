@@ -2506,7 +2506,10 @@ static int conv_dgrad_impl(const ayolo_conv_desc* d, const void* dy, const void*
         // 3x3 / stride 2 / pad 1 with <= 64 input channels: the nine (class, tap) products read four shifts of the dy tile
         // -> k_dgrad_s2 keeps all four classes' accumulators and loads every dy row group once
         const int cpad = (m.C + BK - 1) / BK * BK;
-        static const int dgrad_s2_maxc = getenv("AYOLO_DGRAD_S2_MAXC") ? atoi(getenv("AYOLO_DGRAD_S2_MAXC")) : 64;
+        // channel limit: round 3 took this kernel for <= 64 input channels only; measured in round 4 (tools/s2_sweep.py) it also wins on
+        // 128 and 256 (128 -> 256 @ 80^2: 105 -> 84 us, 256 -> 512 @ 40^2: 94 -> 86 us; train step -0.09 ms) with 64-channel tiles
+        // re-reading the dy rows from L2
+        constexpr int dgrad_s2_maxc = 256;
         if (d->dtype == AYOLO_F16 && d->kh == 3 && d->kw == 3 && d->sh == 2 && d->sw == 2 && d->ph == 1 && d->pw == 1 &&
             d->Cin <= dgrad_s2_maxc && m.C >= BK && (cpad - m.C) * 4 <= cpad) {
             static const signed char order[9] = {4, 5, 7, 8, 3, 6, 1, 2, 0};
@@ -2620,9 +2623,9 @@ __device__ __forceinline__ half8 tr_frag_sw(const unsigned char* tile, int k0, i
 
 typedef const __attribute__((address_space(4))) WGradP* wjob_cptr_t;
 
-template <typename T, int TM>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP pv, const WGradP* jobs, const WItem* items, unsigned nitems,
-                                                                            float* ws, WOvr ovr) {
+template <typename T, int TM, bool XFW = false>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP pv, const WGradP* jobs, const WItem* items, float* ws,
+                                                                            WOvr ovr) {
     using W = WT<T, TM>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2640,19 +2643,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
 #endif
     // ---- which (job, dw tile, pixel split): from the item list of a grouped launch, or -- single job, passed by value -- from
     // the block index: split zz on XCD zz % 8 with its gx * gy tiles consecutive there
-    // A grouped launch may run FEWER workgroups than items (grid = a few per CU, a multiple of 8): workgroup b then walks items b,
-    // b + grid, b + 2 grid, ... -- it keeps its XCD, and the launch never holds more than its share of the CUs' workgroup slots
-    // (resident workgroups are not preempted: an uncapped group kernel that filled every slot made the next main-stream kernels
-    // wait for a whole item, +0.5-1 ms of backward's critical path, profiles/r04_op_table_in_situ_xf.txt).
     typedef __attribute__((address_space(4))) const char* kcptr_t;
-    for (unsigned itx = blockIdx.x;; itx += gridDim.x) {
     wjob_cptr_t pj;
     unsigned tile, zz;
     if (items != nullptr) {
-        if (itx >= nitems) break;
-        const WItem it = items[itx];
+        const WItem it = items[blockIdx.x];
         const unsigned job = (unsigned)__builtin_amdgcn_readfirstlane((int)it.job);
-        if (job == 0xffffffffu) continue;
+        if (job == 0xffffffffu) return;
         pj = (wjob_cptr_t)(unsigned long long)(jobs + job);
         tile = (unsigned)__builtin_amdgcn_readfirstlane((int)it.tile);
         zz = (unsigned)__builtin_amdgcn_readfirstlane((int)it.zz);
@@ -2662,7 +2659,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
         const unsigned ntile = pj->gx * pj->gy;
         tile = local % ntile;
         zz = (local / ntile) * 8u + xcd;
-        if (zz >= pj->splits) break;
+        if (zz >= pj->splits) return;
     }
 #define p (*pj)
 #define WFD(f_) FastDiv{pj->f_.m, pj->f_.s1, pj->f_.s2}     /* member-wise: an address-space-4 struct has no copy constructor */
@@ -2723,17 +2720,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     // transform on load: this lane's x chunks are the same 8 dw columns (= input channels of a 1x1 conv) in every step, so its
     // 2 x 8 constants live in registers for the whole item; the chunks are transformed in place in their LDS stage by the lane
     // whose DMA wrote them (see k_gconv's xf_transform), one step before they are consumed
-    const bool xf = sizeof(T) == 2 && p.xf_scale != nullptr;
-    float xfa[8], xfb[8];
+    // (XFW instantiations only: the constants and the branch cost 15-40 registers, i.e. a wavefront per SIMD on the narrow tiles)
+    const bool xf = XFW && sizeof(T) == 2 && p.xf_scale != nullptr;
+    float xfa[XFW ? 8 : 1], xfb[XFW ? 8 : 1];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { xfa[e] = 1.0f; xfb[e] = 0.0f; }
-    if (xf && xcol_ok) {
+    for (int e = 0; e < (XFW ? 8 : 1); ++e) { xfa[e] = 1.0f; xfb[e] = 0.0f; }
+    if constexpr (XFW) if (xf && xcol_ok) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { xfa[e] = p.xf_scale[xcol + e]; xfb[e] = p.xf_shift[xcol + e]; }     // K = C, C % 8 == 0
     }
     const bool xf_act = p.xf_act != 0;
     auto xf_transform = [&](unsigned so) {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(T) == 2 && XFW) {
 #pragma unroll
             for (int r = 0; r < W::XR; ++r) {
                 half8* q = reinterpret_cast<half8*>(smem_raw + so + (r * 4 + wave) * 1024 + lane * 16);
@@ -2897,9 +2895,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     }
 #undef p
 #undef WFD
-    if (items == nullptr) break;
-    __syncthreads();                             // every wave is done with the LDS stages before the next item's DMA lands in them
-    }
 #ifdef AYOLO_PROBE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AY_PROBE(AY_PROBE_N - 1);
@@ -3713,36 +3708,40 @@ extern "C" int ayolo_wgrad_group_item(const void* table_host, int cls, long long
     return AYOLO_OK;
 }
 
-template <typename T, int TM>
-static int launch_wgrad_k(const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned nitems, unsigned blocks, float* ws, const WOvr& ovr,
-                          hipStream_t s) {
+template <typename T, int TM, bool XFW>
+static int launch_wgrad_k(const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned blocks, float* ws, const WOvr& ovr, hipStream_t s) {
     using W = WT<T, TM>;
     static bool attr_set[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM, XFW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_wgrad<T, TM>), dim3(blocks), dim3(256), W::LDS, s, pv, jobs, items, nitems, ws, ovr);
+    hipLaunchKernelGGL((k_wgrad<T, TM, XFW>), dim3(blocks), dim3(256), W::LDS, s, pv, jobs, items, ws, ovr);
     AY_CHECK_LAUNCH("k_wgrad");
     return AYOLO_OK;
 }
 
-static int launch_wgrad_any(int dtype, int tm, const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned nitems, unsigned blocks,
-                            float* ws, const WOvr& ovr, hipStream_t s) {
+static int launch_wgrad_any(int dtype, int tm, bool xfw, const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned blocks, float* ws,
+                            const WOvr& ovr, hipStream_t s) {
     if (dtype == AYOLO_F16) {
-        if (tm == 32) return launch_wgrad_k<half_t, 32>(pv, jobs, items, nitems, blocks, ws, ovr, s);
-        if (tm == 64) return launch_wgrad_k<half_t, 64>(pv, jobs, items, nitems, blocks, ws, ovr, s);
-        return launch_wgrad_k<half_t, 128>(pv, jobs, items, nitems, blocks, ws, ovr, s);
+        if (xfw) {                           // some job of the launch transforms x on load
+            if (tm == 32) return launch_wgrad_k<half_t, 32, true>(pv, jobs, items, blocks, ws, ovr, s);
+            if (tm == 64) return launch_wgrad_k<half_t, 64, true>(pv, jobs, items, blocks, ws, ovr, s);
+            return launch_wgrad_k<half_t, 128, true>(pv, jobs, items, blocks, ws, ovr, s);
+        }
+        if (tm == 32) return launch_wgrad_k<half_t, 32, false>(pv, jobs, items, blocks, ws, ovr, s);
+        if (tm == 64) return launch_wgrad_k<half_t, 64, false>(pv, jobs, items, blocks, ws, ovr, s);
+        return launch_wgrad_k<half_t, 128, false>(pv, jobs, items, blocks, ws, ovr, s);
     }
-    if (tm == 32) return launch_wgrad_k<float, 32>(pv, jobs, items, nitems, blocks, ws, ovr, s);
-    if (tm == 64) return launch_wgrad_k<float, 64>(pv, jobs, items, nitems, blocks, ws, ovr, s);
-    return launch_wgrad_k<float, 128>(pv, jobs, items, nitems, blocks, ws, ovr, s);
+    if (tm == 32) return launch_wgrad_k<float, 32, false>(pv, jobs, items, blocks, ws, ovr, s);
+    if (tm == 64) return launch_wgrad_k<float, 64, false>(pv, jobs, items, blocks, ws, ovr, s);
+    return launch_wgrad_k<float, 128, false>(pv, jobs, items, blocks, ws, ovr, s);
 }
 
 extern "C" int ayolo_wgrad_group_run(const void* table_host, const void* table_dev, void* ws, size_t ws_bytes,
-                                     const void* const* dy_override, int n_override, int wg_per_cu, ayolo_stream s) {
+                                     const void* const* dy_override, int n_override, ayolo_stream s) {
     AY_CHECK_ARG(table_host && table_dev && ws, "wgrad_group_run: null pointer");
     const WGroupHdr& h = *(const WGroupHdr*)table_host;
     AY_CHECK_ARG(h.magic == WGROUP_MAGIC, "wgrad_group_run: not a group table");
@@ -3758,21 +3757,13 @@ extern "C" int ayolo_wgrad_group_run(const void* table_host, const void* table_d
     const unsigned char* td = (const unsigned char*)table_dev;
     const WGradP* djobs = (const WGradP*)(td + h.off_jobs);
     const WGradP none{};
-    // wg_per_cu > 0: at most that many workgroups per CU for the whole group (shared by its tile classes in proportion to their
-    // items); the rest of the CUs' slots stays free for whatever runs beside it
-    unsigned all_items = h.n_items[0] + h.n_items[1] + h.n_items[2];
-    const unsigned long long cap = wg_per_cu > 0 ? (unsigned long long)wg_per_cu * (unsigned)num_cus() : 0ull;
+    // (A cap on the group's resident workgroups per CU -- workgroups walking the item list with a grid stride -- was measured in
+    // round 4 and removed: 13.58 ms uncapped, 14.45 / 16.3 ms with two / one workgroup per CU, and the loop cost 20+ registers.)
     for (int c = 0; c < 3; ++c) {
         if (!h.n_items[c]) continue;
-        unsigned blocks = h.n_items[c];
-        if (cap && all_items > cap) {
-            unsigned long long b = (cap * h.n_items[c] + all_items - 1) / all_items;
-            b = (b + 7) / 8 * 8;
-            if (b < 8) b = 8;
-            if (b < blocks) blocks = (unsigned)b;
-        }
-        int rc = launch_wgrad_any((int)h.dtype, 32 << c, none, djobs, (const WItem*)(td + h.off_items[c]), h.n_items[c], blocks, (float*)ws, ovr,
-                                  (hipStream_t)s);
+        bool xfw = false;
+        for (unsigned j = 0; j < h.njobs; ++j) xfw = xfw || (hjobs[j].tm == (32 << c) && hjobs[j].xf_scale != nullptr);
+        int rc = launch_wgrad_any((int)h.dtype, 32 << c, xfw, none, djobs, (const WItem*)(td + h.off_items[c]), h.n_items[c], (float*)ws, ovr, (hipStream_t)s);
         if (rc) return rc;
     }
     if (h.n_red) {
@@ -3839,7 +3830,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
     for (const WGradP& j : jobs) {
         const long long blocks = (long long)j.gx * j.gy * ((j.splits + 7) / 8 * 8);
         AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
-        rc = launch_wgrad_any(d->dtype, j.tm, j, nullptr, nullptr, 0u, (unsigned)blocks, (float*)ws, ovr, (hipStream_t)s);
+        rc = launch_wgrad_any(d->dtype, j.tm, false, j, nullptr, nullptr, (unsigned)blocks, (float*)ws, ovr, (hipStream_t)s);
         if (rc) return rc;
         S += j.splits;
     }

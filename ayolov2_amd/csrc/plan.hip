@@ -183,7 +183,7 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
             rc = ayolo_conv_wgrad(&o.conv, o.p[0], o.p[1], (float*)o.p[2], o.f[0], o.p[3], (size_t)o.l[0], cs);
             break;
         case AYOLO_OP_WGRAD_GROUP:
-            rc = ayolo_wgrad_group_run(o.p[0], o.p[1], o.p[2], (size_t)o.l[0], (const void* const*)&o.p[3], o.i[0], o.i[1], cs);
+            rc = ayolo_wgrad_group_run(o.p[0], o.p[1], o.p[2], (size_t)o.l[0], (const void* const*)&o.p[3], o.i[0], cs);
             break;
         case AYOLO_OP_CAST_WEIGHT:
             rc = ayolo_cast_weight((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.p[1], o.p[2], cs);

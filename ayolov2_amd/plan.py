@@ -89,8 +89,7 @@ WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "4"))
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
 # (A cap on a group's resident workgroups per CU -- so that the kernels of backward's dependent chain forked behind it find free
 # slots at once -- was measured and lost: 13.58 ms uncapped, 14.45 with two workgroups per CU, 16.3 with one; the weight
-# gradients are latency-bound per workgroup and need every slot they can get, profiles/r04_ab_wgrad_cap.txt.  The C entry
-# keeps the parameter; the plan passes 0.)
+# gradients are latency-bound per workgroup and need every slot they can get, profiles/r04_ab_wgrad_cap.txt; code removed.)
 
 
 class PlanUnsupported(Exception):
@@ -322,7 +321,7 @@ class TrainPlan:
             idx = js[-1]["idx"]                           # the group launches where its LAST layer's dz is complete
             slots = sorted({j["slot"] for j in js if j["slot"] >= 0})
             nov = (max(slots) + 1) if slots else 0
-            o = _op(OP_WGRAD_GROUP | side, i=(nov, 0), l=(ws.numel(),), p=(ctypes.addressof(host), dev, ws))
+            o = _op(OP_WGRAD_GROUP | side, i=(nov,), l=(ws.numel(),), p=(ctypes.addressof(host), dev, ws))
             for j in js:
                 if j["slot"] >= 0:
                     o.p[3 + j["slot"]] = j["dy"].data_ptr()

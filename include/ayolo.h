@@ -164,8 +164,7 @@ typedef struct ayolo_wgrad_job {
 int ayolo_wgrad_group_size(const ayolo_wgrad_job* jobs, int njobs, size_t* table_bytes, size_t* ws_bytes);
 int ayolo_wgrad_group_build(const ayolo_wgrad_job* jobs, int njobs, void* table_host, size_t table_bytes);
 int ayolo_wgrad_group_run(const void* table_host, const void* table_dev, void* ws, size_t ws_bytes,
-                          const void* const* dy_override, int n_override, int wg_per_cu /* > 0: cap on the group's resident
-                          workgroups per CU (it runs BESIDE a dependent chain on another stream), 0: none */, ayolo_stream s);
+                          const void* const* dy_override, int n_override, ayolo_stream s);
 /* introspection of a host table (tests / tools): out[0..5] = jobs (batch halves count as jobs), items of tile class 32 / 64 /
  * 128, reduction blocks, workspace floats; job >= 0: out[6..11] = its tile class, column tiles, channel tiles, pixel splits,
  * pixels per split, first workspace slot.  _item: {job or -1 (queue padding), tile, split} of item i of a tile class;
@@ -499,7 +498,7 @@ enum {
     AYOLO_OP_JOIN_SIDE,         /* the caller's stream waits for everything enqueued so far on the side stream */
     AYOLO_OP_STEM_BN_WGRAD,     /* ayolo_stem_bn_wgrad */
     AYOLO_OP_WGRAD_GROUP        /* ayolo_wgrad_group_run: p[0] table (host), p[1] table (device), p[2] workspace, l[0] its bytes,
-                                 * p[3..6] dy overrides, i[0] their count, i[1] workgroups per CU (0: uncapped) */
+                                 * p[3..6] dy overrides, i[0] their count */
 };
 typedef struct ayolo_op {
     int kind;

@@ -620,7 +620,7 @@ def test_wgrad_grouped_launch_vs_single_layer_and_bit_reproducible(dt):
     lib = _lib.lib()
     base = [torch.full((d.Cout, d.kh, d.kw, d.Cin), 3.0, dtype=torch.float32, device="cuda") for d, _, _ in ops_]
 
-    def grouped(cap=0):
+    def grouped():
         dws = [b.clone() for b in base]
         arr = (WgradJob * n)()
         for k, ((d, x, dy), dw) in enumerate(zip(ops_, dws)):
@@ -635,12 +635,12 @@ def test_wgrad_grouped_launch_vs_single_layer_and_bit_reproducible(dt):
         dev = torch.frombuffer(host, dtype=torch.uint8).clone().cuda()
         ws = torch.empty(max(wb.value, 16), dtype=torch.uint8, device="cuda")
         ovr = (ctypes.c_void_p * 2)(None, ops_[2][2].data_ptr())
-        _lib.check(lib.ayolo_wgrad_group_run(ctypes.addressof(host), dev.data_ptr(), ws.data_ptr(), ws.numel(), ovr, 2, cap,
+        _lib.check(lib.ayolo_wgrad_group_run(ctypes.addressof(host), dev.data_ptr(), ws.data_ptr(), ws.numel(), ovr, 2,
                                             torch.cuda.current_stream().cuda_stream), "run")
         torch.cuda.synchronize()
         return dws
 
-    s1, s2, g1, g2 = single(), single(), grouped(), grouped(cap=1)     # cap: one workgroup per CU walks several items
+    s1, s2, g1, g2 = single(), single(), grouped(), grouped()
     tol = 1e-4 if dt == torch.float32 else 2e-3
     for k in range(n):
         assert torch.equal(s1[k], s2[k]) and torch.equal(g1[k], g2[k]), f"layer {k}: not bit-reproducible"
@@ -770,7 +770,7 @@ def test_conv_transform_on_load_two_segments(case):
     _lib.check(lib.ayolo_wgrad_group_build(arr, 2, host, tb.value), "build")
     dev = torch.frombuffer(host, dtype=torch.uint8).clone().cuda()
     ws = torch.empty(max(wb.value, 16), dtype=torch.uint8, device="cuda")
-    _lib.check(lib.ayolo_wgrad_group_run(ctypes.addressof(host), dev.data_ptr(), ws.data_ptr(), ws.numel(), None, 0, 0,
+    _lib.check(lib.ayolo_wgrad_group_run(ctypes.addressof(host), dev.data_ptr(), ws.data_ptr(), ws.numel(), None, 0,
                                         torch.cuda.current_stream().cuda_stream), "run")
     torch.cuda.synchronize()
     assert float((dw - dw_ref).abs().max()) <= 1e-5 * float(dw_ref.abs().max())
