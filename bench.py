@@ -104,6 +104,47 @@ def pmc_traffic(families):
     return (round(tot, 3) if tot else None), src
 
 
+def pmc_traffic_live(families, steps=3, warm=2, timeout=150):
+    """HBM bytes per step of a kernel family measured IN THIS RUN: two child runs of this file (train step only) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no other trace domain), summed per kernel,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if rocprofv3 is not on the box, a pass fails or
+    AYOLO_BENCH_PMC=0 -- the caller then reports the newest committed summary instead."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("AYOLO_BENCH_PMC", "1") != "1" or shutil.which("rocprofv3") is None:
+        return None
+    tot, launches = 0.0, 0
+    try:
+        for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            d = tempfile.mkdtemp(prefix="ayolo_pmc_")
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                     "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK")
+                   and not k.startswith("TORCHELASTIC_")}
+            env.update(TMPDIR="/tmp", AYOLO_BENCH_PMC="0")
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--no-extras", "--steps", str(steps), "--warmup", str(warm)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                shutil.rmtree(d, ignore_errors=True)
+                return None
+            n = 0
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") == counter and any(f in row["Kernel_Name"] for f in families):
+                    tot += float(row["Counter_Value"]) * 1024.0 * mult
+                    n += 1
+            launches = max(launches, n)
+            shutil.rmtree(d, ignore_errors=True)
+    except Exception:
+        return None
+    nsteps = steps + warm
+    return {"gb_per_step": round(tot / nsteps / 1e9, 3), "launches_per_step": round(launches / nsteps, 1),
+            "how": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over {nsteps} train steps of a child run of this file, FETCH_SIZE x2 (gfx950)"}
+
+
 def in_situ_roofline(model, one_step, ms_per_step, batch):
     """Roofline of the dominant kernel family measured INSIDE the real train step: the plan executor re-runs a few steps in
     its measurement mode (ayolo_run_ops_timed: a HIP event before and after every op on the stream the op runs on, so cold
@@ -134,7 +175,10 @@ def in_situ_roofline(model, one_step, ms_per_step, batch):
         tf = sum(fam[n][2] for n in names if n in fam) / 1e12
         return ms, gb, tf
     ms, gb, tf = view(("conv_fwd", "conv_dgrad"))
+    live = pmc_traffic_live(("k_gconv", "k_dgrad_s2"))
     traffic, src = pmc_traffic(("k_gconv", "k_dgrad_s2"))
+    if live is not None:
+        traffic, src = live["gb_per_step"], "measured in this run: " + live["how"]
     fams = {n: {"launches": v[3], "ms_per_step": round(v[0], 3), "algorithmic_gb": round(v[1] / 1e9, 3),
                 "gb_per_s": round(v[1] / 1e6 / v[0], 1) if v[0] > 0 else None,
                 **({"tflops": round(v[2] / 1e9 / v[0], 1)} if v[2] else {})}
