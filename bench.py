@@ -83,8 +83,8 @@ def build_train_objects(model_name, device, world_size):
 
 def pmc_traffic(families):
     """HBM bytes per step of a kernel family from the newest committed PMC summary (tools/profile_round.sh: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950).  Counters cannot be collected inside this
-    run, so the committed measurement is reported together with the file and commit it comes from."""
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950).  The fallback of pmc_traffic_live (no
+    rocprofv3 on the box, a pass failed, AYOLO_BENCH_PMC=0): reported together with the file and commit it comes from."""
     import glob
     import subprocess
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
@@ -112,6 +112,7 @@ def pmc_traffic_live(families, steps=3, warm=2, timeout=150):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     if os.environ.get("AYOLO_BENCH_PMC", "1") != "1" or shutil.which("rocprofv3") is None:
@@ -126,9 +127,16 @@ def pmc_traffic_live(families, steps=3, warm=2, timeout=150):
             env.update(TMPDIR="/tmp", AYOLO_BENCH_PMC="0")
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--no-extras", "--steps", str(steps), "--warmup", str(warm)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            # own process group: a pass that outlives its limit is ended together with the python it started (by that exact pgid)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                rc = -1
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 shutil.rmtree(d, ignore_errors=True)
                 return None
             n = 0
