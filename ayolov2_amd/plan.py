@@ -85,7 +85,11 @@ XF_FINALIZE_IN_READER = _os.environ.get("AYOLO_XF_FIN", "1") == "1"      # the f
 # transformed on load in k_wgrad too (no write at all, but the transform then runs on the weight-gradient stream, where it cost
 # the step more than the write does: same-box A/B, profiles/r04_ab_xf_*)
 XF_WGRAD_ON_LOAD = _os.environ.get("AYOLO_XF_WGRAD", "0") == "1"
-WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "4"))
+# The group count follows the weight gradients' total work (32-pixel steps x dw tiles, `cost` below): one group per ~0.36 M
+# tile-steps, between 4 and 8 -- YOLOv5s at batch 64 (1.45 M) is fastest with 4 (profiles/r04_ab_wgrad_sweep.txt), YOLOv5l at
+# batch 32 (3.56 M) with 8 (profiles/r04_cfg3_ab.txt); AYOLO_WGRAD_GROUPS pins it (0 = one launch per layer, for A/B).
+WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "-1"))
+WGRAD_GROUP_WORK = 0.36e6
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
 # (A cap on a group's resident workgroups per CU -- so that the kernels of backward's dependent chain forked behind it find free
 # slots at once -- was measured and lost: 13.58 ms uncapped, 14.45 with two workgroups per CU, 16.3 with one; the weight
@@ -214,7 +218,7 @@ class TrainPlan:
     def _dz(self, n: int) -> torch.Tensor:
         """Backward operand dz of one layer: a slice of the shared scratch buffer, or -- when weight gradients run on the
         side stream and therefore outlive the layer's turn -- a buffer of its own."""
-        if WGRAD_SIDE_STREAM or WGRAD_GROUPS > 0:           # grouped launches also read dz long after the layer's turn
+        if WGRAD_SIDE_STREAM or WGRAD_GROUPS != 0:           # grouped launches also read dz long after the layer's turn
             t = torch.empty(n, dtype=self.dt, device=self.device)
             self.keep.append(t)
             return t
@@ -260,7 +264,7 @@ class TrainPlan:
             fl = sum(2.0 * j["desc"].B * j["desc"].Ho * j["desc"].Wo * j["desc"].Cout * j["desc"].kh * j["desc"].kw * j["desc"].Cin for j in js)
             return float(by), fl, len({j["off"] for j in js})       # layers (a two-segment conv is two jobs over one weight)
 
-        if WGRAD_GROUPS <= 0:
+        if WGRAD_GROUPS == 0:
             # one launch per layer (A/B against the grouped launches): the same kernels, a shared split-K workspace
             need = max(int(lib.ayolo_conv_wgrad_workspace(j["desc"])) for j in jobs)
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
@@ -278,8 +282,9 @@ class TrainPlan:
         # ---- cut the jobs (backward order) into groups of similar work; the tail is cut finer
         costs = [cost(j) for j in jobs]
         total = float(sum(costs))
-        targets = [total / WGRAD_GROUPS] * max(WGRAD_GROUPS - 1, 0)
-        rest = total / WGRAD_GROUPS
+        ngroups = WGRAD_GROUPS if WGRAD_GROUPS > 0 else min(8, max(4, int(round(total / WGRAD_GROUP_WORK))))
+        targets = [total / ngroups] * max(ngroups - 1, 0)
+        rest = total / ngroups
         for _ in range(max(WGRAD_TAIL, 0)):
             rest /= 2
             targets.append(rest)
@@ -543,7 +548,7 @@ class TrainPlan:
         shortcut keep the materialised pass.  Measured per layer: profiles/r04_xf_forward_sweep.txt (the pair of launches costs
         1.2-2.5x the fused one; it loses only where the channel table and the per-channel-tile repetition of the transform
         weigh in: Cin x channel tiles > 1024)."""
-        if not XF_ON_LOAD or self.dt != torch.float16 or WGRAD_GROUPS <= 0:
+        if not XF_ON_LOAD or self.dt != torch.float16 or WGRAD_GROUPS == 0:
             return
         for rd in self._reads:
             root, rlo, rhi, kind, c = rd
