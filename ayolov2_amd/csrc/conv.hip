@@ -2966,6 +2966,7 @@ struct StemWP {
     const half_t* z; int ldz; unsigned z_bytes;
     const float* mean; const float* invstd; const float* gamma; const float* beta;
     const double* sums; int reps, act;
+    int NS;                                // channel count of the sums' layout [reps][2][NS] (a launch may cover a slice of them)
     float* dgamma; float* dbeta; float grad_scale;
 };
 #define STEM_TR 4                          // output rows per tile = wavefronts
@@ -3006,7 +3007,7 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p)
             float A = 0.0f, Bc = 0.0f, P = 0.0f, R2 = 0.0f, Q2 = 0.0f;
             if (c < p.N) {
                 double d1 = 0.0, d2 = 0.0;
-                for (int r = 0; r < p.reps; ++r) { d1 += p.sums[(size_t)r * 2 * p.N + c]; d2 += p.sums[(size_t)r * 2 * p.N + p.N + c]; }
+                for (int r = 0; r < p.reps; ++r) { d1 += p.sums[(size_t)r * 2 * p.NS + c]; d2 += p.sums[(size_t)r * 2 * p.NS + p.NS + c]; }
                 const float s1 = (float)d1, s2 = (float)d2;
                 const float mu = p.mean[c], is = p.invstd[c], ga = p.gamma ? p.gamma[c] : 1.0f, be = p.beta ? p.beta[c] : 0.0f;
                 const float m1 = s1 * invn, m2 = s2 * invn;
@@ -3224,6 +3225,32 @@ static int launch_stem_wgrad(StemWP p, hipStream_t s) {
     if (grid > p.ntiles) grid = p.ntiles;
     hipLaunchKernelGGL((k_stem_wgrad<MB, BN>), dim3((unsigned)grid), dim3(256), lds, s, p);
     AY_CHECK_LAUNCH("k_stem_wgrad");
+    return AYOLO_OK;
+}
+
+// More than 32 output channels (YOLOv5m / l: 48 / 64): one launch per 32-channel slice.  The 64-channel instance
+// (k_stem_wgrad<2>: 192 accumulators next to three register-staged tile sets) does not fit the register file -- the compiler
+// parks accumulators in scratch BETWEEN the MFMAs of the tile loop (896 bytes per lane): 2.2 ms for YOLOv5l's stem at batch
+// 32, against 2 x ~0.12 ms for two slices that each re-read the (small) image.
+template <bool BN>
+static int launch_stem_wgrad_sliced(StemWP p, hipStream_t s) {
+    const int total = p.N;
+    p.NS = total;
+    for (int c0 = 0; c0 < total; c0 += 32) {
+        StemWP q = p;
+        q.N = total - c0 < 32 ? total - c0 : 32;
+        q.dy = p.dy + c0; q.y_bytes = p.y_bytes - (unsigned)c0 * 2u;
+        q.dw = p.dw + (size_t)c0 * p.K;
+        if constexpr (BN) {
+            q.z = p.z + c0; q.z_bytes = p.z_bytes - (unsigned)c0 * 2u;
+            q.mean = p.mean + c0; q.invstd = p.invstd + c0;
+            q.gamma = p.gamma ? p.gamma + c0 : nullptr; q.beta = p.beta ? p.beta + c0 : nullptr;
+            q.sums = p.sums + c0;
+            q.dgamma = p.dgamma ? p.dgamma + c0 : nullptr; q.dbeta = p.dbeta ? p.dbeta + c0 : nullptr;
+        }
+        const int rc = launch_stem_wgrad<1, BN>(q, s);
+        if (rc) return rc;
+    }
     return AYOLO_OK;
 }
 
@@ -3815,7 +3842,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
         q.tw = (d->Wo + STEM_TC - 1) / STEM_TC; q.th = (d->Ho + STEM_TR - 1) / STEM_TR;
         q.ntiles = (long long)d->B * q.tw * q.th;
         q.x_bytes = (unsigned)((long long)d->B * d->H * d->W * 16); q.y_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * d->ldy * 2);
-        return d->Cout <= 32 ? launch_stem_wgrad<1, false>(q, (hipStream_t)s) : launch_stem_wgrad<2, false>(q, (hipStream_t)s);
+        return launch_stem_wgrad_sliced<false>(q, (hipStream_t)s);
     }
     std::vector<WGradP> jobs;
     unsigned long long wf = 0;
@@ -3864,7 +3891,7 @@ extern "C" int ayolo_stem_bn_wgrad(const ayolo_conv_desc* d, const void* x, cons
     q.z = (const half_t*)z; q.ldz = ldz; q.z_bytes = (unsigned)((long long)d->B * d->Ho * d->Wo * ldz * 2);
     q.mean = save_mean; q.invstd = save_invstd; q.gamma = gamma; q.beta = beta; q.sums = sums; q.reps = sum_reps; q.act = act ? 1 : 0;
     q.dgamma = dgamma; q.dbeta = dbeta; q.grad_scale = grad_scale;
-    return d->Cout <= 32 ? launch_stem_wgrad<1, true>(q, (hipStream_t)s) : launch_stem_wgrad<2, true>(q, (hipStream_t)s);
+    return launch_stem_wgrad_sliced<true>(q, (hipStream_t)s);
 }
 
 // ---------------------------------------------------------------------------------------------------

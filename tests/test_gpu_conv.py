@@ -519,7 +519,7 @@ def test_stem_forward_kernel_and_statistics(shape):
     np.testing.assert_allclose(tot[Cout:].numpy(), (yf * yf).sum((0, 2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-6 * P)
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 64, 96), (3, 16, 70, 100), (2, 64, 24, 40)])
+@pytest.mark.parametrize("shape", [(2, 32, 64, 96), (3, 16, 70, 100), (2, 64, 24, 40), (1, 48, 38, 132)])
 @pytest.mark.parametrize("act", [1, 0])
 def test_stem_backward_in_one_launch(shape, act):
     """ayolo_stem_bn_wgrad: BatchNorm + SiLU backward of the stem's output gradient and the weight gradient of its conv in one
