@@ -3947,26 +3947,53 @@ __global__ __launch_bounds__(256) void k_cast_weights_t(const ayolo_cast_job* jo
         const int tap = tl % J.taps;
         const int rest = tl / J.taps;
         const int c0 = (rest % nc) * TS, co0 = (rest / nc) * TS;
+        // interior tiles of layers whose rows are 16-byte aligned in all three arrays: one 16-byte load and one 4-element store
+        // per thread and row instead of four scalar loads and four 2-byte stores (YOLOv5l: 372 MB in 249 us = 1.5 TB/s before)
+        const bool vec = sizeof(T) == 2 && (J.Cin & 3) == 0 && (J.Cin_pad & 3) == 0 && (wt_ld & 3) == 0 && c0 + TS <= J.Cin &&
+                         co0 + TS <= J.Cout && (((uintptr_t)J.w32 | (uintptr_t)w | (uintptr_t)wt) & 15) == 0;
+        if (vec) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = co0 + tr + 16 * i;
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + tr + 16 * i;
+                const float4 v = *reinterpret_cast<const float4*>(J.w32 + ((size_t)co * J.taps + tap) * J.Cin + c0 + tc4);
+                T h[4] = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = c0 + tc4 + j;
-                const float v = (c < J.Cin && co < J.Cout) ? J.w32[((size_t)co * J.taps + tap) * J.Cin + c] : 0.0f;
-                tile[tr + 16 * i][tc4 + j] = (T)v;
-                if (w && co < J.Cout_pad && c < J.Cin_pad) w[((size_t)co * J.taps + tap) * J.Cin_pad + c] = (T)v;
+                for (int j = 0; j < 4; ++j) tile[tr + 16 * i][tc4 + j] = h[j];
+                if (w) *reinterpret_cast<uint2*>(w + ((size_t)co * J.taps + tap) * J.Cin_pad + c0 + tc4) = *reinterpret_cast<const uint2*>(h);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + tr + 16 * i;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + tc4 + j;
+                    const float v = (c < J.Cin && co < J.Cout) ? J.w32[((size_t)co * J.taps + tap) * J.Cin + c] : 0.0f;
+                    tile[tr + 16 * i][tc4 + j] = (T)v;
+                    if (w && co < J.Cout_pad && c < J.Cin_pad) w[((size_t)co * J.taps + tap) * J.Cin_pad + c] = (T)v;
+                }
             }
         }
         __syncthreads();
         if (wt) {
+            if (vec) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = c0 + tr + 16 * i;
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + tr + 16 * i;
+                    T h[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int co = co0 + tc4 + j;
-                    if (c < J.Cin_pad && co < J.Cout_pad) wt[((size_t)c * J.taps + tap) * wt_ld + co] = tile[tc4 + j][tr + 16 * i];
+                    for (int j = 0; j < 4; ++j) h[j] = tile[tc4 + j][tr + 16 * i];
+                    *reinterpret_cast<uint2*>(wt + ((size_t)c * J.taps + tap) * wt_ld + co0 + tc4) = *reinterpret_cast<const uint2*>(h);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + tr + 16 * i;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = co0 + tc4 + j;
+                        if (c < J.Cin_pad && co < J.Cout_pad) wt[((size_t)c * J.taps + tap) * wt_ld + co] = tile[tc4 + j][tr + 16 * i];
+                    }
                 }
             }
         }

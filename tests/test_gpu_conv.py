@@ -774,3 +774,40 @@ def test_conv_transform_on_load_two_segments(case):
                                         torch.cuda.current_stream().cuda_stream), "run")
     torch.cuda.synchronize()
     assert float((dw - dw_ref).abs().max()) <= 1e-5 * float(dw_ref.abs().max())
+
+
+def test_batched_weight_cast_equals_per_layer_cast():
+    """ayolo_cast_weights (all layers of a plan in one launch, 64 x 64 tiles with an LDS transpose, 16-byte rows on interior
+    tiles) against ayolo_cast_weight (one thread per element): both copies bit-identical, for layers that take the vector
+    path (multiples of 64), ragged ones (3 input channels, 255 outputs, padded rows), a 3x3 layer and a transposed copy that
+    is a column slice of a wider matrix."""
+    from ayolov2_amd import ops
+    from ayolov2_amd._lib import call
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    cases = [(64, 1, 64, 64, 64, 0), (128, 9, 192, 128, 192, 0), (255, 1, 128, 256, 128, 0), (32, 18, 8, 32, 8, 0), (80, 9, 3, 96, 32, 0),
+             (64, 1, 128, 64, 128, 256), (48, 1, 100, 64, 104, 0)]
+    job_t = np.dtype([("w32", "<u8"), ("w", "<u8"), ("wt", "<u8"), ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"),
+                      ("Cout_pad", "<i4"), ("Cin_pad", "<i4"), ("wt_ld", "<i4")])
+    jobs = np.zeros(len(cases), dtype=job_t)
+    keep, want = [], []
+    for k, (co, taps, ci, cop, cip, ld) in enumerate(cases):
+        w32 = torch.randn(co, taps, ci, generator=g).to(dev)
+        w = torch.full((cop, taps, cip), 7.0, dtype=torch.float16, device=dev)
+        wide = torch.full((cip, taps, ld or cop), 7.0, dtype=torch.float16, device=dev)
+        wt = wide[:, :, 64:64 + cop] if ld else wide
+        rw = torch.empty(cop, taps, cip, dtype=torch.float16, device=dev)
+        rt = torch.empty(cip, taps, cop, dtype=torch.float16, device=dev)
+        call("ayolo_cast_weight", w32.data_ptr(), co, taps, 1, ci, cop, cip, ops.dtype_code(torch.float16), rw.data_ptr(), rt.data_ptr(),
+             torch.cuda.current_stream().cuda_stream)
+        jobs[k] = (w32.data_ptr(), w.data_ptr(), wt.data_ptr(), co, taps, ci, cop, cip, ld)
+        keep.append((w32, w, wide, wt))
+        want.append((rw, rt))
+    tab = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+    call("ayolo_cast_weights", tab.data_ptr(), len(cases), ops.dtype_code(torch.float16), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for (w32, w, wide, wt), (rw, rt), case in zip(keep, want, cases):
+        assert torch.equal(w, rw), case
+        assert torch.equal(wt, rt), case
+        if case[5]:
+            assert bool((wide[:, :, :64] == 7.0).all()) and bool((wide[:, :, 64 + case[3]:] == 7.0).all()), case
