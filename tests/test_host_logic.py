@@ -491,3 +491,22 @@ def test_tucker_block_merge_algebra_and_launch_form_cpu():
     assert form(32, 16, 16, 32, 3, 1, 160, 160) == "dense"                         # large map, ranks C/2: HBM-bound either way
     assert form(256, 64, 64, 256, 3, 1, 20, 20) in ("first", "last", "factors")     # small map, ranks C/4: the factors pay
     assert form(3, 2, 8, 32, 6, 2, 640, 640, image=True) in ("first", "dense")      # the stem
+
+
+def test_weight_gradient_group_count_follows_the_work():
+    """The number of grouped weight-gradient launches is chosen from the layers' total work (32-pixel steps x dw tiles): four
+    groups (+ the finer tail) for the benchmark's YOLOv5s at batch 64, eight for YOLOv5l at batch 32 (cfg 3), never fewer than
+    four for a toy shape; AYOLO_WGRAD_GROUPS is not set in the test environment."""
+    import torch
+    from collections import Counter
+    from ayolov2_amd import YOLOModel
+    from ayolov2_amd import plan as P
+    if P.WGRAD_GROUPS > 0:
+        pytest.skip("AYOLO_WGRAD_GROUPS pins the count")
+    want = {("yolov5s", 64, 640): (4, 7), ("yolov5l", 32, 640): (8, 11), ("yolov5s", 2, 64): (4, 7)}
+    for (name, batch, size), (lo, hi) in want.items():
+        m = YOLOModel(os.path.join(ROOT, "ayolov2_amd", "configs", f"{name}.yaml")).train()
+        pl = P.TrainPlan(m, (batch, 3, size, size), torch.float16, torch.device("cpu"))
+        n = Counter(o.kind & 0xff for o in pl.bwd)[P.OP_WGRAD_GROUP]
+        assert lo <= n <= hi, (name, batch, n)
+        assert sum(v[2] for v in pl.wgroup_costs.values()) >= len({j["off"] for j in pl._wjobs})
