@@ -2561,7 +2561,19 @@ struct WItem { unsigned job, tile, zz, pad; };
 // (cols, ldd): the layer's dw is a column block of a wider matrix -- element e of the dense N x cols partials goes to
 // dst[(e / cols) * ldd + e % cols] (the two input segments of a transform-on-load conv are two jobs over one weight matrix);
 // e0 = index of the block's first element, ldd == cols: dense
-struct WRed { unsigned long long ws_off, stride; float* dst; unsigned n, S; float alpha; int overwrite; unsigned cols, ldd; unsigned long long e0; };
+// tpc (1, 2, 4 .. 64): threads that share one 16-byte column of a block and split its S partials between them (thread slice
+// sl adds partials sl, sl + tpc, ..; the slices are then added in slice order through LDS: still a fixed order).  A layer with a
+// tiny dw and a huge map (64 x 64 weights, 1.6 M pixels: S = 2 133 partials of 16 KB) otherwise has two blocks whose threads
+// each walk all 2 133 partials one memory round trip after the other: 250 us for 35 MB.  A block covers wred_chunk(tpc) elements.
+struct WRed { unsigned long long ws_off, stride; float* dst; unsigned n, S; float alpha; int overwrite; unsigned cols, ldd; unsigned long long e0; unsigned tpc, pad; };
+static inline unsigned wred_tpc(unsigned S) {
+    static const bool off = getenv("AYOLO_WRED_SERIAL") != nullptr;     // A/B: every column's partials added by one thread
+    if (off) return 1;
+    unsigned t = 1;
+    while (t < 64 && S > 32 * t) t *= 2;                       // <= 32 partials per thread (16 .. 48 measured alike, 8 / 96 worse)
+    return t;
+}
+__host__ __device__ static inline unsigned wred_chunk(unsigned tpc) { return tpc > 1 ? 1024u / tpc : (unsigned)WRED_N; }
 struct WOvr { const void* q[4]; };           // dy override pointers of a launch (WGradP::dy_slot)
 
 // A/B fragments for v_mfma_f32_32x32x16_f16 come out of the pixel-major LDS tiles t[pixel][channel] through the gfx950
@@ -2912,13 +2924,44 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WRed rv, const WRed* red, 
     if (red != nullptr) r = red[blockIdx.x];
     else {
         r = rv;
-        const unsigned long long o = (unsigned long long)blockIdx.x * WRED_N;
+        const unsigned chunk = wred_chunk(rv.tpc);
+        const unsigned long long o = (unsigned long long)blockIdx.x * chunk;
         const unsigned long long left = (unsigned long long)rv.n > o ? (unsigned long long)rv.n - o : 0ull;     // rv.n: all elements
-        r.n = (unsigned)(left < WRED_N ? left : WRED_N);
+        r.n = (unsigned)(left < chunk ? left : chunk);
         r.ws_off += o;
         r.e0 = o;
     }
     const bool dense = r.ldd == r.cols;
+    if (r.tpc > 1) {
+        __shared__ float4v part[256];
+        const unsigned ncol = 256u / r.tpc;                    // 16-byte columns of this block (n <= 4 * ncol)
+        const unsigned col = threadIdx.x % ncol, sl = threadIdx.x / ncol;
+        const unsigned i = col * 4;
+        float4v a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+        if (i < r.n) {
+            const float* src = ws + r.ws_off + i;
+            unsigned q = sl;
+            for (; q + 3 * r.tpc < r.S; q += 4 * r.tpc) {
+                a0 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(q) * r.stride);
+                a1 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(q + r.tpc) * r.stride);
+                a2 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(q + 2 * r.tpc) * r.stride);
+                a3 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(q + 3 * r.tpc) * r.stride);
+            }
+            for (; q < r.S; q += r.tpc) a0 += *reinterpret_cast<const float4v*>(src + (unsigned long long)q * r.stride);
+        }
+        part[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (sl == 0 && i < r.n) {
+            float4v v = part[col];
+            for (unsigned t = 1; t < r.tpc; ++t) v += part[t * ncol + col];
+            v *= r.alpha;
+            const unsigned long long e = r.e0 + i;
+            float4v* d = reinterpret_cast<float4v*>(r.dst + (dense ? e : (e / r.cols) * r.ldd + e % r.cols));
+            if (!r.overwrite) v += *d;
+            *d = v;
+        }
+        return;
+    }
     for (unsigned i = threadIdx.x * 4; i < r.n; i += 1024) {
         const float* src = ws + r.ws_off + i;
         float4v a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
@@ -3626,9 +3669,11 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
         unsigned S = 0;
         const unsigned long long nk = (unsigned long long)g.jobs[L.j0].N * (unsigned long long)g.jobs[L.j0].K;
         for (size_t j = L.j0; j < L.j1; ++j) { g.jobs[j].ws_off = off; g.jobs[j].zz0 = S; S += g.jobs[j].splits; }
-        for (unsigned long long e = 0; e < nk; e += WRED_N) {
+        const unsigned tpc = wred_tpc(S), chunk = wred_chunk(tpc);
+        for (unsigned long long e = 0; e < nk; e += chunk) {
             WRed r{};
-            r.ws_off = off + e; r.stride = nk; r.dst = L.dw; r.e0 = e; r.n = (unsigned)(nk - e < WRED_N ? nk - e : WRED_N); r.S = S;
+            r.tpc = tpc;
+            r.ws_off = off + e; r.stride = nk; r.dst = L.dw; r.e0 = e; r.n = (unsigned)(nk - e < chunk ? nk - e : chunk); r.S = S;
             r.alpha = L.alpha; r.overwrite = L.overwrite; r.cols = (unsigned)g.jobs[L.j0].K; r.ldd = L.ldd;
             g.red.push_back(r);
         }
@@ -3865,7 +3910,9 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
     r.ws_off = 0; r.stride = nk; r.dst = dw; r.S = S; r.alpha = alpha; r.overwrite = 0; r.cols = r.ldd = (unsigned)jobs[0].K; r.e0 = 0;
     AY_CHECK_ARG(nk < (1ull << 32), "conv_wgrad: dw of %llu elements", nk);
     r.n = (unsigned)nk;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nk + WRED_N - 1) / WRED_N)), dim3(256), 0, (hipStream_t)s, r, (const WRed*)nullptr, (const float*)ws);
+    r.tpc = wred_tpc(S);
+    const unsigned rchunk = wred_chunk(r.tpc);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nk + rchunk - 1) / rchunk)), dim3(256), 0, (hipStream_t)s, r, (const WRed*)nullptr, (const float*)ws);
     AY_CHECK_LAUNCH("k_wgrad_reduce");
     return AYOLO_OK;
 }

@@ -416,7 +416,17 @@ def test_wgrad_group_tables_cover_every_tile_once():
             assert len({i % 8 for i in idxs}) == 1                          # one XCD
             assert [i // 8 for i in idxs] == list(range(idxs[0] // 8, idxs[0] // 8 + len(idxs)))   # back to back in its queue
     assert len(seen) == sum(j["gx"] * j["gy"] * j["splits"] for j in jobs)
-    assert n_red == sum(-(-(Co * kk * kk * Ci) // 2048) for (_, _, _, Ci, Co, kk, _) in shapes)
+    # reduction blocks: a layer's S partials are split between tpc threads per 16-byte column when S is large (tpc doubles while
+    # S > 32 * tpc, up to 64), and a block then covers 1024 / tpc elements instead of 2048
+    def red_blocks(nk, S):
+        tpc = 1
+        while tpc < 64 and S > 32 * tpc:
+            tpc *= 2
+        chunk = 1024 // tpc if tpc > 1 else 2048
+        return -(-nk // chunk)
+    layer_S = [j["splits"] for j in jobs[:len(shapes) - 1]] + [jobs[-2]["splits"] + jobs[-1]["splits"]]
+    assert n_red == sum(red_blocks(Co * kk * kk * Ci, S) for (_, _, _, Ci, Co, kk, _), S in zip(shapes, layer_S))
+    assert max(layer_S) > 32                                                    # the case the split reduction exists for
 
 
 def test_model_ema_follows_reassigned_tensors_cpu():
