@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256) void k_loss_rowbox(LossP P, const float* grad_
 // A group's value is computed by loss_group() from the cells of BOTH anchors it may span, so every group is written whole
 // and exactly once; the bias gradient is accumulated from the same fp32 values.
 template <typename T>
-__device__ __forceinline__ void loss_group(const LossP& P, const ayolo_loss_level& L, long long pix, int cg, float k_obj, float k_cls,
-                                           float* sb) {
+__device__ __forceinline__ void loss_group_values(const LossP& P, const ayolo_loss_level& L, long long pix, int cg, float k_obj, float k_cls,
+                                                  float* sb, T (&out)[8]) {
     const unsigned hw = (unsigned)(L.ny * L.nx), nx = (unsigned)L.nx;
     const int no = L.no, nc = no - 5, Cc = L.na * no, ldz = L.ldz;
     const unsigned pu = (unsigned)pix;
@@ -300,14 +300,21 @@ __device__ __forceinline__ void loss_group(const LossP& P, const ayolo_loss_leve
         }
         if (sb && v[i] != 0.0f) atomicAdd(&sb[c], v[i]);
     }
-    T out[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) out[i] = (T)v[i];
-    T* dst = reinterpret_cast<T*>(L.dz) + pix * ldz + c0;
+}
+
+template <typename T>
+__device__ __forceinline__ void loss_group(const LossP& P, const ayolo_loss_level& L, long long pix, int cg, float k_obj, float k_cls,
+                                           float* sb) {
+    T out[8];
+    loss_group_values<T>(P, L, pix, cg, k_obj, k_cls, sb, out);
+    T* dst = reinterpret_cast<T*>(L.dz) + pix * L.ldz + cg * 8;
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
     if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(out + 4);
 }
 
+#define LOSS_PB 64                        // pixels per pass of the full-row writer (MODE 3): 64 * na <= 256 threads for na <= 4
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_loss_grad_packed(LossP P, const float* grad_out) {
     const int l = blockIdx.y;
@@ -325,7 +332,38 @@ __global__ __launch_bounds__(256) void k_loss_grad_packed(LossP P, const float* 
         __syncthreads();
     }
     float* acc = L.dbias ? sb : nullptr;
-    if (MODE == 1) {
+    if (MODE == 3) {
+        // stages 1 + 2 in one pass of FULL rows: a workgroup takes LOSS_PB pixels at a time, computes their na objectness groups
+        // (one thread per (pixel, anchor)) into LDS and then writes the pixels' whole dz rows -- those groups in place, zeros
+        // everywhere else -- in consecutive 16-byte pieces.  The zero fill (275 MB at HBM speed) plus the scattered 16-byte
+        // writes of stage 2 into it (one per 512-byte row and anchor) were 65 + 127 us of the step's serial head.
+        constexpr int PB = LOSS_PB;
+        __shared__ T sg[PB * 4][8];                                    // [pixel][anchor (na <= 4)][8 channels]
+        const int gpr = L.ldz / 8;                                     // groups per row
+        const long long nblk = (npix + PB - 1) / PB;
+        for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+            const long long p0 = blk * PB;
+            const int t = threadIdx.x;
+            if (t < PB * L.na) {
+                const int pl = t / L.na, a = t - pl * L.na;
+                if (p0 + pl < npix) loss_group_values<T>(P, L, p0 + pl, (a * no + 4) / 8, k_obj, k_cls, acc, sg[pl * 4 + a]);
+            }
+            __syncthreads();
+            const int cpg = (int)(8 * sizeof(T) / 16);                  // 16-byte pieces per group: 1 (fp16) or 2 (fp32)
+            const int total = PB * gpr * cpg;
+            for (int q = t; q < total; q += 256) {
+                const int pl = q / (gpr * cpg), r = q - pl * gpr * cpg;
+                if (p0 + pl >= npix) break;
+                const int cg = r / cpg, half = r - cg * cpg;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                // is cg the objectness group of an anchor?  (a * no + 4) / 8 == cg  <=>  a in [ceil((8 cg - 4) / no), (8 cg + 3) / no]
+                const int a = (8 * cg + 3) / no;
+                if (a < L.na && (a * no + 4) / 8 == cg) v = reinterpret_cast<const uint4*>(sg[pl * 4 + a])[half];
+                reinterpret_cast<uint4*>(reinterpret_cast<T*>(L.dz) + (p0 + pl) * L.ldz)[r] = v;
+            }
+            __syncthreads();
+        }
+    } else if (MODE == 1) {
         // (pixel, anchor) -> the group of that anchor's objectness channel; two anchors never share one (no >= 8)
         const long long total = npix * L.na;
         for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < total; w += (long long)gridDim.x * 256) {
@@ -441,13 +479,20 @@ extern "C" int ayolo_yolo_loss_bwd_packed(const ayolo_loss_level* lv, int nl, fl
         AY_CHECK_LAUNCH("k_loss_rowbox");
     }
     const size_t es = dt == AYOLO_F16 ? 2 : 4;
-    for (int l = 0; l < nl; ++l) {
-        const ayolo_loss_level& L = lv[l];
-        rc = ayolo_fill_zero(L.dz, (size_t)L.B * L.ny * L.nx * L.ldz * es, s);
-        if (rc) return rc;
+    bool rows = getenv("AYOLO_LOSS_ROWS") == nullptr || atoi(getenv("AYOLO_LOSS_ROWS")) != 0;
+    for (int l = 0; l < nl; ++l) rows = rows && lv[l].na <= 4;
+    if (rows) {                                  // zero fill + objectness groups as one pass of whole rows (MODE 3)
+        if (dt == AYOLO_F16) hipLaunchKernelGGL((k_loss_grad_packed<half_t, 3>), dim3(2048, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+        else hipLaunchKernelGGL((k_loss_grad_packed<float, 3>), dim3(2048, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+    } else {
+        for (int l = 0; l < nl; ++l) {
+            const ayolo_loss_level& L = lv[l];
+            rc = ayolo_fill_zero(L.dz, (size_t)L.B * L.ny * L.nx * L.ldz * es, s);
+            if (rc) return rc;
+        }
+        if (dt == AYOLO_F16) hipLaunchKernelGGL((k_loss_grad_packed<half_t, 1>), dim3(1024, (unsigned)nl), dim3(256), 0, st, P, grad_out);
+        else hipLaunchKernelGGL((k_loss_grad_packed<float, 1>), dim3(1024, (unsigned)nl), dim3(256), 0, st, P, grad_out);
     }
-    if (dt == AYOLO_F16) hipLaunchKernelGGL((k_loss_grad_packed<half_t, 1>), dim3(1024, (unsigned)nl), dim3(256), 0, st, P, grad_out);
-    else hipLaunchKernelGGL((k_loss_grad_packed<float, 1>), dim3(1024, (unsigned)nl), dim3(256), 0, st, P, grad_out);
     if (max_n > 0) {
         const unsigned gr_ = (unsigned)(((long long)max_n * 13 + 255) / 256);
         if (dt == AYOLO_F16) hipLaunchKernelGGL((k_loss_grad_packed<half_t, 2>), dim3(gr_ < 2048 ? gr_ : 2048, (unsigned)nl), dim3(256), 0, st, P, grad_out);
