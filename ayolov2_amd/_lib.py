@@ -72,6 +72,7 @@ _SIGNATURES = {
     "ayolo_wgrad_group_run": [_P, _P, _P, c_size_t, POINTER(c_void_p), c_int, _P],
     "ayolo_wgrad_group_info": [_P, c_int, POINTER(c_int64), c_int],
     "ayolo_wgrad_group_item": [_P, c_int, c_int64, POINTER(c_int64)],
+    "ayolo_wgrad3_geometry": [POINTER(ConvDesc), POINTER(c_int64), c_int],
     "ayolo_stem_bn_wgrad": [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, c_float, c_float, _P],
     "ayolo_cast_weight": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "ayolo_ema_update": [_P, c_int, c_float, _P],

@@ -15,6 +15,8 @@
 // Replaces kindle Conv/YOLOHead.conv forward (yolov5s.yaml:21-57) and the autograd backward torch/cuDNN ran
 // (scripts/train/yolo_trainer.py:329).
 #include "common.h"
+#include "gfx950_dma.h"
+#include "wgrad3.h"
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
@@ -23,19 +25,6 @@
 
 #define MAX_TAPS 36
 #define BK 32
-
-// exact unsigned division by a runtime constant (Granlund-Montgomery round-up form), all 32-bit numerators
-struct FastDiv { unsigned m, s1, s2; };
-static FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    unsigned l = 0;
-    if (d < 1) d = 1;
-    while ((1ull << l) < d) ++l;
-    f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.s1 = l < 1 ? l : 1;
-    f.s2 = l > 0 ? l - 1 : 0;
-    return f;
-}
 
 struct GConvP {
     const void* x; const void* w; void* y;
@@ -156,12 +145,6 @@ extern "C" int ayolo_probe_read(void* dst, unsigned long long bytes) {
 #else
 #define AY_PROBE(k_) do { } while (0)
 #endif
-#define G_OOB 0x80000000u          // buffer offset beyond any descriptor (tensors are < 2 GiB, checked on the host)
-
-typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
-typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
 template <typename T, int TM, int TPX = 128>
 struct GT {
     static constexpr int ES = sizeof(T);
@@ -210,40 +193,6 @@ struct GT {
         asm volatile(asm_nops ::: "memory");           \
         __builtin_amdgcn_sched_barrier(0);             \
     } while (0)
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Buffer descriptor (raw, stride 0, `bytes` records) held in 4 SGPRs, and the LDS-DMA load itself.  The DMA is issued
-// from inline asm on purpose: hipcc (ROCm 7.2) orders every LDS read behind ALL LDS-DMA it knows to be in flight with a
-// vmcnt(0), which would drain the two-steps-ahead pipeline at each step; hidden from its scoreboard, completion is
-// tracked by the counted wait_vm<N>() + s_barrier of the step loop alone.  (The compiler's own vmcnt for its loads and
-// stores stays correct: completion is in order, so extra younger operations only make its counts conservative.)
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4i32 make_srd(const void* ptr, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)ptr;
-    v4i32 r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-    r.w = 0x00020000;
-    return r;
-}
-// 64 lanes x 16 B: global (srd base + voff, zero when voff is beyond the descriptor) -> LDS [lds_addr + lane*16, +16)
-__device__ __forceinline__ void glds16(v4i32 srd, unsigned lds_addr, unsigned voff) {
-    unsigned keep;
-    // s_nop 2: (a) one wait state between the M0 write and the LDS-DMA; (b) with the two s_mov it makes five wait states
-    // between any VALU that wrote a descriptor SGPR just before this statement (v_readlane of a spilled SGPR) and the
-    // VMEM instruction reading it -- hipcc does not look inside the string
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(lds_addr), "s"(srd)
-                 : "memory");
-}
-
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
-    const unsigned t = __umulhi(f.m, n);
-    return (t + ((n - t) >> f.s1)) >> f.s2;
-}
 
 // pixel decode of the loader's rows for pixel tile `tile` (invalid tile / rows beyond Mtotal -> never in range).
 // Branch-free on purpose (selects only): see the header comment.
@@ -2554,8 +2503,7 @@ struct WGradP {
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-// one unit of work of a grouped weight-gradient launch: (job, dw tile, pixel split); job == ~0u: padding of an XCD queue
-struct WItem { unsigned job, tile, zz, pad; };
+// (WItem -- one unit of work of a grouped launch: (job, dw tile, pixel split) -- lives in wgrad3.h, shared with k_wgrad3)
 // one block of the reduction: n <= WRED_N consecutive elements of one layer's dw, S partials `stride` floats apart
 #define WRED_N 2048
 // (cols, ldd): the layer's dw is a column block of a wider matrix -- element e of the dense N x cols partials goes to
@@ -3604,27 +3552,52 @@ static void wgrad_split(WGradP& p, double q) {
 }
 
 // A group table (one contiguous blob; the caller keeps a host copy and a device copy):
-//   WGroupHdr | WGradP jobs[njobs] | WItem items[class 0] | items[class 1] | items[class 2] | WRed red[n_red]
+//   WGroupHdr | WGradP jobs[njobs] | W3P jobs3[njobs3] | WItem items[class 0] | .. | items[class 3] | WRed red[n_red]
+// Classes 0 .. 2: k_wgrad with 32 / 64 / 128 output channels per tile; class 3: the 3x3 layers of k_wgrad3 (their jobs are the
+// W3P array; in the introspection entries they are jobs njobs .. njobs + njobs3 - 1).
 struct WGroupHdr {
     unsigned magic, dtype, njobs, n_red;
-    unsigned n_items[3];               // item count per tile class (TM 32 / 64 / 128), each a multiple of 8
-    unsigned off_jobs, off_items[3], off_red;
+    unsigned n_items[4];               // item count per class, each a multiple of 8
+    unsigned off_jobs, off_items[4], off_red;
+    unsigned njobs3, off_jobs3, lds3, pad;
     unsigned long long ws_floats, table_bytes;
 };
-#define WGROUP_MAGIC 0x57475234u
+#define WGROUP_MAGIC 0x57475235u
 
 struct WGroupPlan {
     std::vector<WGradP> jobs;
-    std::vector<WItem> items[3];
+    std::vector<W3P> jobs3;
+    std::vector<WItem> items[4];
+    size_t lds3 = 0;
     std::vector<WRed> red;
     unsigned long long ws_floats = 0;
     int dtype = AYOLO_F16;
 };
 
+// modelled cycles of one k_wgrad3 step of job p (a wavefront's MFMAs + the workgroup's DMA pieces): the unit item lengths are
+// balanced in (w3_fill picks the step geometry by the same model)
+static double w3_step_cost(const W3P& p) {
+    return 288.0 * ((p.nsub + p.SL - 1) / p.SL) + 25.0 * (p.nrows * p.ppr + p.NB * p.nsub);
+}
+// Steps per item of a k_wgrad3 job.  `q`: the launch's common item length (in steps of THIS job).  Every (strip, row range) is
+// one more N x K slot to store and to add: a deep layer on a small map (256 -> 256 at 20 x 20: 2.4 MB per slot for 6.5 MB of
+// operands) is cut no finer than what keeps that traffic under about half of the layer's own compute / operand time.
+static void w3_split_job(W3P& p, double q) {
+    const double nk = (double)p.N * p.K;
+    const double px = (double)p.B * p.OH * p.OW;
+    const double t_layer = 2.0 * px * nk / 1.0e15 + 2.0 * ((double)p.B * p.XH * p.XW * p.C + px * p.N) / 4.5e12;
+    double smax = 0.5 * t_layer * 4.5e12 / (nk * 8.0);
+    if (smax < 1.0) smax = 1.0;
+    const double steps = (double)((p.NU + p.RPS - 1) / p.RPS);
+    const double per_strip = smax / p.strips < 1.0 ? 1.0 : smax / p.strips;
+    const double qmin = steps / per_strip;
+    w3_split(p, q > qmin ? q : qmin);
+}
+
 static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
     AY_CHECK_ARG(jj && njobs > 0 && njobs < 4096, "wgrad_group: %d jobs", njobs);
     g.dtype = jj[0].conv.dtype;
-    struct Layer { size_t j0, j1; float* dw; float alpha; int overwrite; unsigned ldd; };
+    struct Layer { size_t j0, j1; float* dw; float alpha; int overwrite; unsigned ldd; bool w3; };
     std::vector<Layer> layers;
     for (int k = 0; k < njobs; ++k) {
         const ayolo_wgrad_job& a = jj[k];
@@ -3637,6 +3610,14 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
         AY_CHECK_ARG(!is_packed_stem(&a.conv), "wgrad_group: job %d is the packed stem (ayolo_conv_wgrad / ayolo_stem_bn_wgrad)", k);
         AY_CHECK_ARG(((uintptr_t)a.dw % 16) == 0 && ((long long)a.conv.Cout * a.conv.kh * a.conv.kw * a.conv.Cin) % 4 == 0,
                      "wgrad_group: job %d: dw must be 16-byte aligned with a multiple of 4 elements", k);
+        const int kj = a.conv.kh * a.conv.kw * a.conv.Cin;
+        AY_CHECK_ARG(a.dw_ld == 0 || (a.dw_ld >= kj && a.dw_ld % 4 == 0 && kj % 4 == 0), "wgrad_group: job %d: dw_ld=%d for %d columns", k, a.dw_ld, kj);
+        W3P p3;
+        if (a.dy_slot < 0 && !a.xscale && !a.xshift && w3_fill(&a.conv, a.x, a.dy, p3) == 0) {      // a 3x3 layer of k_wgrad3
+            g.jobs3.push_back(p3);
+            layers.push_back({g.jobs3.size() - 1, g.jobs3.size(), a.dw, a.alpha, a.overwrite, (unsigned)(a.dw_ld > 0 ? a.dw_ld : kj), true});
+            continue;
+        }
         WGradP p;
         wgrad_fill(&a.conv, a.x, a.dy, p);
         p.dy_slot = a.dy_slot;
@@ -3647,9 +3628,7 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
         const size_t j0 = g.jobs.size();
         rc = wgrad_halves(&a.conv, p, g.jobs);
         if (rc) return rc;
-        const int kj = a.conv.kh * a.conv.kw * a.conv.Cin;
-        AY_CHECK_ARG(a.dw_ld == 0 || (a.dw_ld >= kj && a.dw_ld % 4 == 0 && kj % 4 == 0), "wgrad_group: job %d: dw_ld=%d for %d columns", k, a.dw_ld, kj);
-        layers.push_back({j0, g.jobs.size(), a.dw, a.alpha, a.overwrite, (unsigned)(a.dw_ld > 0 ? a.dw_ld : kj)});
+        layers.push_back({j0, g.jobs.size(), a.dw, a.alpha, a.overwrite, (unsigned)(a.dw_ld > 0 ? a.dw_ld : kj), false});
     }
     // ---- item length.  All items of the group together should fill the chip's workgroup slots a few times over (so that the
     // tail of the launch is short against its body) without cutting a layer finer than ~AYOLO_WGRAD_MINQ steps per item
@@ -3663,36 +3642,69 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
     double q = total / (slots * waves);
     if (q < minq) q = minq;
     for (WGradP& p : g.jobs) wgrad_split(p, q);
+    // k_wgrad3's launch: two workgroups per CU, items of equal modelled time
+    if (!g.jobs3.empty()) {
+        const double slots3 = (double)num_cus() * 2.0;
+        const double waves3 = (double)wgrad_env("AYOLO_WGRAD3_WAVES", 2);
+        const double minq3 = (double)wgrad_env("AYOLO_WGRAD3_MINQ", 6);
+        double total3 = 0.0;
+        for (const W3P& p : g.jobs3) total3 += (double)w3_tiles(p) * p.strips * (double)((p.NU + p.RPS - 1) / p.RPS) * w3_step_cost(p);
+        const double t_item = total3 / (slots3 * waves3);
+        for (W3P& p : g.jobs3) {
+            double q3 = t_item / w3_step_cost(p);
+            if (q3 < minq3) q3 = minq3;
+            w3_split_job(p, q3);
+            const size_t l = w3_lds_bytes(p);
+            g.lds3 = l > g.lds3 ? l : g.lds3;
+        }
+    }
     // ---- workspace slots + reduction blocks, layer by layer
     unsigned long long off = 0;
     for (const Layer& L : layers) {
         unsigned S = 0;
-        const unsigned long long nk = (unsigned long long)g.jobs[L.j0].N * (unsigned long long)g.jobs[L.j0].K;
-        for (size_t j = L.j0; j < L.j1; ++j) { g.jobs[j].ws_off = off; g.jobs[j].zz0 = S; S += g.jobs[j].splits; }
+        unsigned long long nk;
+        unsigned cols;
+        if (L.w3) {
+            W3P& p = g.jobs3[L.j0];
+            nk = (unsigned long long)p.N * (unsigned long long)p.K; cols = (unsigned)p.K;
+            p.ws_off = off; p.zz0 = 0; S = w3_splits(p);
+        } else {
+            nk = (unsigned long long)g.jobs[L.j0].N * (unsigned long long)g.jobs[L.j0].K; cols = (unsigned)g.jobs[L.j0].K;
+            for (size_t j = L.j0; j < L.j1; ++j) { g.jobs[j].ws_off = off; g.jobs[j].zz0 = S; S += g.jobs[j].splits; }
+        }
         const unsigned tpc = wred_tpc(S), chunk = wred_chunk(tpc);
         for (unsigned long long e = 0; e < nk; e += chunk) {
             WRed r{};
             r.tpc = tpc;
             r.ws_off = off + e; r.stride = nk; r.dst = L.dw; r.e0 = e; r.n = (unsigned)(nk - e < chunk ? nk - e : chunk); r.S = S;
-            r.alpha = L.alpha; r.overwrite = L.overwrite; r.cols = (unsigned)g.jobs[L.j0].K; r.ldd = L.ldd;
+            r.alpha = L.alpha; r.overwrite = L.overwrite; r.cols = cols; r.ldd = L.ldd;
             g.red.push_back(r);
         }
         off += (unsigned long long)S * nk;
         off = (off + 63) / 64 * 64;
     }
     g.ws_floats = off;
-    // ---- items: per tile class, (job, split) groups -- the gx * gy tiles of one pixel split, back to back on one XCD -- dealt
-    // longest first to the XCD queue with the least work so far; queues padded to equal length, interleaved block % 8 = XCD
-    for (int c = 0; c < 3; ++c) {
+    // ---- items: per class, (job, split) groups -- the tiles of one pixel split, back to back on one XCD -- dealt longest first
+    // to the XCD queue with the least work so far; queues padded to equal length, interleaved block % 8 = XCD
+    for (int c = 0; c < 4; ++c) {
         const int tm = 32 << c;
-        struct Grp { unsigned job, zz; double cost; };
+        struct Grp { unsigned job, zz, nt; double cost; };
         std::vector<Grp> grps;
-        for (size_t j = 0; j < g.jobs.size(); ++j) {
-            const WGradP& p = g.jobs[j];
-            if (p.tm != tm) continue;
-            for (unsigned z = 0; z < p.splits; ++z) {
-                const long long pb = (long long)z * p.chunk, pe = pb + p.chunk < p.P ? pb + p.chunk : p.P;
-                grps.push_back({(unsigned)j, z, (double)((pe - pb + 31) / 32)});
+        if (c < 3) {
+            for (size_t j = 0; j < g.jobs.size(); ++j) {
+                const WGradP& p = g.jobs[j];
+                if (p.tm != tm) continue;
+                for (unsigned z = 0; z < p.splits; ++z) {
+                    const long long pb = (long long)z * p.chunk, pe = pb + p.chunk < p.P ? pb + p.chunk : p.P;
+                    grps.push_back({(unsigned)j, z, p.gx * p.gy, (double)((pe - pb + 31) / 32)});
+                }
+            }
+        } else {
+            for (size_t j = 0; j < g.jobs3.size(); ++j) {
+                const W3P& p = g.jobs3[j];
+                const double sc = w3_step_cost(p);
+                for (unsigned z = 0; z < w3_splits(p); ++z)
+                    grps.push_back({(unsigned)j, z, w3_tiles(p), (double)w3_item_steps(p, z / (unsigned)p.strips) * sc});
             }
         }
         if (grps.empty()) continue;
@@ -3703,10 +3715,8 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
             int best = 0;
             for (int x = 1; x < 8; ++x)
                 if (load[x] < load[best]) best = x;
-            const WGradP& p = g.jobs[gr.job];
-            const unsigned nt = p.gx * p.gy;
-            for (unsigned t = 0; t < nt; ++t) qs[best].push_back({gr.job, t, gr.zz, 0u});
-            load[best] += gr.cost * nt;
+            for (unsigned t = 0; t < gr.nt; ++t) qs[best].push_back({gr.job, t, gr.zz, 0u});
+            load[best] += gr.cost * gr.nt;
         }
         size_t len = 0;
         for (int x = 0; x < 8; ++x) len = qs[x].size() > len ? qs[x].size() : len;
@@ -3721,9 +3731,11 @@ static size_t wgroup_bytes(const WGroupPlan& g, WGroupHdr* h) {
     WGroupHdr t{};
     size_t o = (sizeof(WGroupHdr) + 63) / 64 * 64;
     t.off_jobs = (unsigned)o; o += (g.jobs.size() * sizeof(WGradP) + 63) / 64 * 64;
-    for (int c = 0; c < 3; ++c) { t.off_items[c] = (unsigned)o; t.n_items[c] = (unsigned)g.items[c].size(); o += (g.items[c].size() * sizeof(WItem) + 63) / 64 * 64; }
+    t.off_jobs3 = (unsigned)o; o += (g.jobs3.size() * sizeof(W3P) + 63) / 64 * 64;
+    for (int c = 0; c < 4; ++c) { t.off_items[c] = (unsigned)o; t.n_items[c] = (unsigned)g.items[c].size(); o += (g.items[c].size() * sizeof(WItem) + 63) / 64 * 64; }
     t.off_red = (unsigned)o; o += (g.red.size() * sizeof(WRed) + 63) / 64 * 64;
     t.magic = WGROUP_MAGIC; t.dtype = (unsigned)g.dtype; t.njobs = (unsigned)g.jobs.size(); t.n_red = (unsigned)g.red.size();
+    t.njobs3 = (unsigned)g.jobs3.size(); t.lds3 = (unsigned)g.lds3;
     t.ws_floats = g.ws_floats; t.table_bytes = o;
     if (h) *h = t;
     return o;
@@ -3750,7 +3762,8 @@ extern "C" int ayolo_wgrad_group_build(const ayolo_wgrad_job* jobs, int njobs, v
     memset(t, 0, (size_t)h.table_bytes);
     memcpy(t, &h, sizeof(h));
     memcpy(t + h.off_jobs, g.jobs.data(), g.jobs.size() * sizeof(WGradP));
-    for (int c = 0; c < 3; ++c)
+    if (!g.jobs3.empty()) memcpy(t + h.off_jobs3, g.jobs3.data(), g.jobs3.size() * sizeof(W3P));
+    for (int c = 0; c < 4; ++c)
         if (!g.items[c].empty()) memcpy(t + h.off_items[c], g.items[c].data(), g.items[c].size() * sizeof(WItem));
     memcpy(t + h.off_red, g.red.data(), g.red.size() * sizeof(WRed));
     return AYOLO_OK;
@@ -3762,21 +3775,31 @@ extern "C" int ayolo_wgrad_group_info(const void* table_host, int job, long long
     const WGroupHdr& h = *(const WGroupHdr*)table_host;
     AY_CHECK_ARG(h.magic == WGROUP_MAGIC, "wgrad_group_info: not a group table");
     out[0] = h.njobs; out[1] = h.n_items[0]; out[2] = h.n_items[1]; out[3] = h.n_items[2]; out[4] = h.n_red; out[5] = (long long)h.ws_floats;
-    for (int k = 6; k < 12; ++k) out[k] = 0;
+    for (int k = 6; k < nout; ++k) out[k] = 0;
+    if (nout >= 14) { out[12] = h.n_items[3]; out[13] = h.njobs3; }
     if (job >= 0) {
-        AY_CHECK_ARG((unsigned)job < h.njobs, "wgrad_group_info: job %d of %u", job, h.njobs);
-        const WGradP& p = ((const WGradP*)((const unsigned char*)table_host + h.off_jobs))[job];
-        out[6] = p.tm; out[7] = p.gx; out[8] = p.gy; out[9] = p.splits; out[10] = p.chunk; out[11] = p.zz0;
+        AY_CHECK_ARG((unsigned)job < h.njobs + h.njobs3, "wgrad_group_info: job %d of %u", job, h.njobs + h.njobs3);
+        if ((unsigned)job < h.njobs) {
+            const WGradP& p = ((const WGradP*)((const unsigned char*)table_host + h.off_jobs))[job];
+            out[6] = p.tm; out[7] = p.gx; out[8] = p.gy; out[9] = p.splits; out[10] = p.chunk; out[11] = p.zz0;
+        } else {
+            // a k_wgrad3 job: "tile class" 0 (none of 32 / 64 / 128), tiles along C / along N, (strip, row range) splits, virtual
+            // rows per item
+            const W3P& p = ((const W3P*)((const unsigned char*)table_host + h.off_jobs3))[(unsigned)job - h.njobs];
+            out[6] = 0; out[7] = p.tc; out[8] = p.tn; out[9] = w3_splits(p); out[10] = p.uch; out[11] = p.zz0;
+            if (nout >= 20) { out[14] = p.TC; out[15] = p.RPS; out[16] = p.strips; out[17] = p.NB; out[18] = p.CB; out[19] = p.stage; }
+        }
     }
     return AYOLO_OK;
 }
-/* item `i` of tile class `cls` (0: 32, 1: 64, 2: 128 output channels per tile): out = {job or -1, tile, split} */
+/* item `i` of class `cls` (0: 32, 1: 64, 2: 128 output channels per tile of k_wgrad; 3: k_wgrad3, job numbers continue behind
+ * k_wgrad's): out = {job or -1, tile, split} */
 extern "C" int ayolo_wgrad_group_item(const void* table_host, int cls, long long i, long long* out) {
-    AY_CHECK_ARG(table_host && out && cls >= 0 && cls < 3, "wgrad_group_item: bad args");
+    AY_CHECK_ARG(table_host && out && cls >= 0 && cls < 4, "wgrad_group_item: bad args");
     const WGroupHdr& h = *(const WGroupHdr*)table_host;
     AY_CHECK_ARG(h.magic == WGROUP_MAGIC && i >= 0 && i < (long long)h.n_items[cls], "wgrad_group_item: index %lld", i);
     const WItem& it = ((const WItem*)((const unsigned char*)table_host + h.off_items[cls]))[i];
-    out[0] = it.job == 0xffffffffu ? -1 : (long long)it.job; out[1] = it.tile; out[2] = it.zz;
+    out[0] = it.job == 0xffffffffu ? -1 : (long long)it.job + (cls == 3 ? (long long)h.njobs : 0); out[1] = it.tile; out[2] = it.zz;
     return AYOLO_OK;
 }
 
@@ -3838,6 +3861,11 @@ extern "C" int ayolo_wgrad_group_run(const void* table_host, const void* table_d
         int rc = launch_wgrad_any((int)h.dtype, 32 << c, xfw, none, djobs, (const WItem*)(td + h.off_items[c]), h.n_items[c], (float*)ws, ovr, (hipStream_t)s);
         if (rc) return rc;
     }
+    if (h.n_items[3]) {
+        const W3P none3{};
+        int rc = w3_launch(none3, (const W3P*)(td + h.off_jobs3), (const WItem*)(td + h.off_items[3]), h.n_items[3], h.lds3, (float*)ws, (hipStream_t)s);
+        if (rc) return rc;
+    }
     if (h.n_red) {
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(h.n_red), dim3(256), 0, (hipStream_t)s, WRed{}, (const WRed*)(td + h.off_red), (const float*)ws);
         AY_CHECK_LAUNCH("k_wgrad_reduce");
@@ -3865,8 +3893,24 @@ static int wgrad_single_plan(const ayolo_conv_desc* d, const void* x, const void
     return AYOLO_OK;
 }
 
+// single 3x3 layer on k_wgrad3: items for the chip to itself (two workgroups per CU, about two rounds of them)
+static bool w3_single_plan(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
+    if (w3_fill(d, x, dy, p) != 0) return false;
+    const double steps = (double)((p.NU + p.RPS - 1) / p.RPS);
+    const double want = (double)num_cus() * 2.0 * 2.0 / ((double)w3_tiles(p) * p.strips);       // row ranges per (tile, strip)
+    double q = steps / (want < 1.0 ? 1.0 : want);
+    const double minq = (double)wgrad_env("AYOLO_WGRAD3_MINQ", 6);
+    w3_split_job(p, q < minq ? minq : q);
+    p.ws_off = 0; p.zz0 = 0;
+    return true;
+}
+
 extern "C" size_t ayolo_conv_wgrad_workspace(const ayolo_conv_desc* d) {
     if (!d || check_desc(d, "conv_wgrad_workspace") != AYOLO_OK || is_packed_stem(d)) return 0;
+    {
+        W3P p3;
+        if (w3_single_plan(d, d, d, p3)) return (size_t)w3_splits(p3) * (size_t)p3.N * (size_t)p3.K * sizeof(float);
+    }
     std::vector<WGradP> jobs;
     unsigned long long wf = 0;
     if (wgrad_single_plan(d, d, d, jobs, &wf) != AYOLO_OK) return 0;      // pointers are not looked at by the sizing
@@ -3891,14 +3935,26 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
     }
     std::vector<WGradP> jobs;
     unsigned long long wf = 0;
-    rc = wgrad_single_plan(d, x, dy, jobs, &wf);
-    if (rc) return rc;
+    W3P p3;
+    const bool use3 = w3_single_plan(d, x, dy, p3);
+    if (use3) wf = (unsigned long long)w3_splits(p3) * (unsigned long long)p3.N * (unsigned long long)p3.K;
+    else {
+        rc = wgrad_single_plan(d, x, dy, jobs, &wf);
+        if (rc) return rc;
+    }
     AY_CHECK_ARG(ws && ((uintptr_t)ws % 16) == 0 && (size_t)wf * 4 <= ws_bytes,
                  "conv_wgrad: split-K workspace of %zu bytes, %llu needed (ayolo_conv_wgrad_workspace; 16-byte aligned)", ws_bytes, wf * 4);
-    const unsigned long long nk = (unsigned long long)jobs[0].N * (unsigned long long)jobs[0].K;
+    const unsigned long long nk = (unsigned long long)d->Cout * (unsigned long long)(d->kh * d->kw * d->Cin);
     AY_CHECK_ARG(((uintptr_t)dw % 16) == 0 && nk % 4 == 0, "conv_wgrad: dw must be 16-byte aligned with a multiple of 4 elements");
     unsigned S = 0;
     const WOvr ovr{};
+    if (use3) {
+        S = w3_splits(p3);
+        const long long blocks = (long long)w3_tiles(p3) * ((S + 7) / 8 * 8);
+        AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
+        rc = w3_launch(p3, nullptr, nullptr, (unsigned)blocks, w3_lds_bytes(p3), (float*)ws, (hipStream_t)s);
+        if (rc) return rc;
+    }
     for (const WGradP& j : jobs) {
         const long long blocks = (long long)j.gx * j.gy * ((j.splits + 7) / 8 * 8);
         AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
@@ -3907,7 +3963,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
         S += j.splits;
     }
     WRed r{};
-    r.ws_off = 0; r.stride = nk; r.dst = dw; r.S = S; r.alpha = alpha; r.overwrite = 0; r.cols = r.ldd = (unsigned)jobs[0].K; r.e0 = 0;
+    r.ws_off = 0; r.stride = nk; r.dst = dw; r.S = S; r.alpha = alpha; r.overwrite = 0; r.cols = r.ldd = (unsigned)(d->kh * d->kw * d->Cin); r.e0 = 0;
     AY_CHECK_ARG(nk < (1ull << 32), "conv_wgrad: dw of %llu elements", nk);
     r.n = (unsigned)nk;
     r.tpc = wred_tpc(S);

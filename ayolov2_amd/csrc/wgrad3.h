@@ -1,0 +1,50 @@
+// Patch-staged weight gradient of the 3x3 convs (wgrad3.hip), shared with the planner / launcher in conv.hip.
+#pragma once
+#include "gfx950_dma.h"
+
+// one unit of work of a grouped weight-gradient launch: (job, dw tile, pixel split); job == ~0u: padding of an XCD queue
+struct WItem { unsigned job, tile, zz, pad; };
+
+// One job of k_wgrad3 = the weight gradient of one 3x3 / pad 1 / stride 1 or 2 conv (fp16 operands, fp32 partial sums).
+// The output rows of all images form ONE list of "virtual rows" u = n * UP + oh with UP = OH + 2 (stride 1) or OH + 1 (stride 2):
+// the rows oh >= OH of an image do not exist (their dy is fetched as zeros), which makes the padded input rows an output row
+// needs simply V = s * u + {0, 1, 2} with V = n * XP + (ih + 1), XP = s * UP -- no image-boundary case anywhere in the kernel.
+struct W3P {
+    const void* x; const void* dy;
+    int B, XH, XW, ldx, C;         // x: input activations (NHWC, channel stride ldx)
+    int OH, OW, ldy, N;            // dy: output gradient, N = Cout
+    int s, K;                      // stride; K = 9 * C (row length of dw)
+    int UP, XP;                    // virtual rows per image: output rows / padded input rows
+    unsigned NU;                   // B * UP
+    // step geometry: a step = RPS output rows x TC columns of a column strip (PX = RPS * TC pixels in nsub 16-pixel sub-steps)
+    int TC, RPS, PX, nsub, strips;
+    // workgroup tile of dw: NB x CB blocks of (32 output channels) x (32 input channels x 9 taps); NP = NB * CB of the four
+    // wavefronts own one block each, SL = 4 / NP wavefronts share a block and split the sub-steps (summed through LDS at the end)
+    int NB, CB, NP, SL;
+    int tn, tc;                    // tiles along N / along C
+    // x window of a step: nrows padded input rows, each ppr DMA pieces (1 KiB) = [c-block][column planes][pixel][32 channels]
+    int nrows, ppr, rowpitch;
+    int plo, ple;                  // bytes of a c-block's column planes: stride 1: plo = (TC + 2) * 64, ple = 0;
+                                   // stride 2: odd input columns (TC + 1 pixels) then even input columns (TC pixels)
+    int xstage, stage;             // bytes of the x window / of one LDS stage (x window + NB dy planes of nsub * 1024 bytes)
+    unsigned x_bytes, y_bytes;     // buffer descriptor extents (< 1 GiB each: the loader adds a row base and a lane offset
+                                   // that may each be "out of range" on their own)
+    unsigned uch, uranges;         // virtual rows per item (a multiple of RPS), items per (tile, strip)
+    unsigned long long ws_off;     // split-K workspace of this layer, in floats
+    unsigned zz0;                  // first partial slot of this job
+    FastDiv dXP, dUP, dTC;
+};
+
+/* 0 = `d` is a conv k_wgrad3 runs (fills the geometry of `p`, not its split); != 0: use the generic kernel */
+int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p);
+/* cut the job into items of about `steps` steps each (at least one item); p.uch / p.uranges */
+void w3_split(W3P& p, double steps);
+static inline unsigned w3_splits(const W3P& p) { return (unsigned)p.strips * p.uranges; }
+static inline unsigned w3_tiles(const W3P& p) { return (unsigned)(p.tn * p.tc); }
+static inline unsigned long long w3_item_steps(const W3P& p, unsigned ur) {
+    const unsigned u0 = ur * p.uch, u1 = u0 + p.uch < p.NU ? u0 + p.uch : p.NU;
+    return (u1 - u0 + (unsigned)p.RPS - 1) / (unsigned)p.RPS;
+}
+size_t w3_lds_bytes(const W3P& p);
+/* grouped launch (jobs / items in device memory, pv ignored) or single job by value (items == nullptr: blocks = tiles * splits) */
+int w3_launch(const W3P& pv, const W3P* jobs, const WItem* items, unsigned blocks, size_t lds, float* ws, hipStream_t s);

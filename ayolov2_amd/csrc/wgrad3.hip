@@ -1,0 +1,377 @@
+// k_wgrad3: weight gradient of the 3x3 / pad 1 convs (stride 1 and 2), fp16 operands, on a once-staged input patch.
+//
+//   dw[n][(dh, dw) * C + c] = sum over output pixels of dy[pixel][n] * x[pixel * s + (dh, dw) - 1][c]
+//
+// Replaces, for these layers, the autograd weight-gradient launches behind scripts/train/yolo_trainer.py:329 (the 3x3 Conv rows of
+// res/configs/model/yolov5s.yaml:22,25,28,31,46,50 and the Bottleneck 3x3 convs inside every C3).
+//
+// The generic k_wgrad (conv.hip) treats the nine taps as nine gathers: a 32-pixel step DMAs the x tile once per tap and the dy
+// tile once per 128-column tile of dw, 3-6 LDS-DMA pieces next to 4-8 MFMAs, and a 3x3 layer runs at 250-350 TFLOP/s whatever
+// its size (profiles/r03_conv_layer_sweep*.txt).  Here a step stages the input PATCH of RPS output rows x TC columns once -- the
+// padded input rows as they lie, 64 bytes (one 32-channel block) per pixel -- and every tap is the SAME patch read at a shifted
+// LDS address by the transposing fragment read (ds_read_b64_tr_b16: each lane supplies its own pixel-row address, so a stride-2
+// pixel walk and a two-row step cost nothing).  A wavefront owns one (32 output channels) x (32 input channels) block of dw for
+// ALL nine taps -- 9 accumulator blocks, 144 registers -- so one dy fragment and nine x fragments feed nine MFMAs (2.2 LDS reads
+// per MFMA instead of 2.5-3), a step of 80 pixels is 45 MFMAs per wavefront behind ONE barrier, and the DMA traffic per MFMA
+// drops from 0.4-0.75 pieces to 0.1-0.25.  Planes of [pixel][32 channels] are 64-byte rows: any four consecutive pixels are 256
+// contiguous bytes = every LDS bank once, shifted or not, so the fragment reads are conflict-free without a swizzle (stride 2
+// keeps odd and even input columns in separate planes for the same reason).
+// Partial sums leave through the split-K workspace of k_wgrad (plain stores, fixed-order k_wgrad_reduce): bit-reproducible.
+#include "wgrad3.h"
+#include <stdlib.h>
+#include <string.h>
+
+typedef __fp16 w3_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef const __attribute__((address_space(4))) W3P* w3job_cptr_t;
+
+#define W3_XOOB 0x40000000u     // a lane offset that is out of range on its own AND on top of any row base (tensors < 1 GiB)
+#define W3_MAXK 3               // x pieces of one window row per wavefront (ppr <= 12)
+#define W3_MAXD 6               // dy pieces per wavefront (NB * nsub <= 24)
+#define W3_MAXI 6               // sub-steps per wavefront (nsub <= 6)
+#define W3_STAGE_MAX 40960      // two stages of two workgroups fill the CU's 160 KiB exactly
+#define W3_RED_BYTES 36864      // cross-wavefront reduction: up to 3 wavefronts x 3 blocks x 16 registers x 64 lanes x 4 bytes
+
+// 16 pixels x this lane's channel out of a [pixel][32 channel] plane: lane supplies the row address of pixel (q >> 2) (+ 4 for the
+// second read), channels (q & 3) * 4 .. of its 16-channel half, and receives channel q of the 4 + 4 rows (see tr_frag_sw in conv.hip)
+__device__ __forceinline__ half8 w3_frag(const unsigned char* lo_, const unsigned char* hi_) {
+    const w3_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) w3_fp16x4*)(lo_));
+    const w3_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) w3_fp16x4*)(hi_));
+    half8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, const WItem* items, float* ws) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    typedef __attribute__((address_space(4))) const char* kcptr_t;
+    w3job_cptr_t pj;
+    unsigned tile, zz;
+    if (items != nullptr) {
+        const WItem it = items[blockIdx.x];
+        const unsigned job = (unsigned)__builtin_amdgcn_readfirstlane((int)it.job);
+        if (job == 0xffffffffu) return;
+        pj = (w3job_cptr_t)(unsigned long long)(jobs + job);
+        tile = (unsigned)__builtin_amdgcn_readfirstlane((int)it.tile);
+        zz = (unsigned)__builtin_amdgcn_readfirstlane((int)it.zz);
+    } else {
+        // single job, passed by value: split zz on XCD zz % 8 with its tiles consecutive there (they re-read the same x / dy)
+        pj = (w3job_cptr_t)((kcptr_t)__builtin_amdgcn_kernarg_segment_ptr());
+        const unsigned Lb = blockIdx.x, xcd = Lb & 7u, local = Lb >> 3;
+        const unsigned ntile = (unsigned)(pj->tn * pj->tc);
+        tile = local % ntile;
+        zz = (local / ntile) * 8u + xcd;
+        if (zz >= (unsigned)pj->strips * pj->uranges) return;
+    }
+#define p (*pj)
+#define W3FD(f_) FastDiv{pj->f_.m, pj->f_.s1, pj->f_.s2}
+    const int s = p.s, TC = p.TC, RPS = p.RPS, PX = p.PX, nsub = p.nsub;
+    const int NB = p.NB, CB = p.CB, NP = p.NP, SL = p.SL;
+    const int nrows = p.nrows, ppr = p.ppr, rowpitch = p.rowpitch, plo = p.plo, ple = p.ple, xstage = p.xstage;
+    const unsigned XP = (unsigned)p.XP, UP = (unsigned)p.UP;
+    const int tni = (int)(tile / (unsigned)p.tc), tci = (int)(tile - (unsigned)tni * (unsigned)p.tc);
+    const int nb0 = tni * NB, cb0 = tci * CB;
+    const unsigned strip = zz % (unsigned)p.strips, ur = zz / (unsigned)p.strips;
+    const int c0 = (int)strip * TC;
+    const unsigned u0 = ur * p.uch;
+    const unsigned u1 = u0 + p.uch < p.NU ? u0 + p.uch : p.NU;
+    const int nsteps = (int)((u1 - u0 + (unsigned)RPS - 1) / (unsigned)RPS);
+    // this wavefront: block `pair` of the tile, slice `slice` of the sub-steps
+    const int pair = wave & (NP - 1);
+    const int slice = NP == 1 ? wave : (NP == 2 ? wave >> 1 : 0);
+    const int nb = CB == 2 ? pair >> 1 : pair, cb = CB == 2 ? pair & 1 : 0;
+
+    const v4i32 rsX = make_srd(p.x, p.x_bytes), rsY = make_srd(p.dy, p.y_bytes);
+    const unsigned lds_tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)smem_raw);
+
+    // ---- x loader: this wavefront issues pieces j = wave, wave + 4, .. of every window row; lane l of piece j fetches the
+    // 16-byte chunk ci = j * 64 + l of the row image [c-block][odd / all columns | even columns][pixel][4 chunks]
+    unsigned XC[W3_MAXK];
+    {
+        const int cbsz = (plo + ple) >> 4;               // chunks per c-block
+#pragma unroll
+        for (int k = 0; k < W3_MAXK; ++k) {
+            const int j = wave + 4 * k;
+            const int ci = j * 64 + lane;
+            const int cbi = ci >= cbsz ? 1 : 0;
+            const int rem = ci - cbi * cbsz;
+            const bool even = rem >= (plo >> 4);             // stride 2 only (ple == 0 otherwise: rem < plo / 16 for every live chunk)
+            const int rem2 = even ? rem - (plo >> 4) : rem;
+            const int q = rem2 >> 2, ch = rem2 & 3;
+            const int ic = s == 1 ? c0 - 1 + q : (even ? 2 * (c0 + q) : 2 * (c0 + q) - 1);
+            const int chan = (cb0 + cbi) * 32 + ch * 8;
+            const bool ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < p.XW) & (chan < p.C);
+            XC[k] = ok ? (unsigned)((ic * p.ldx + chan) * 2) : W3_XOOB;
+        }
+    }
+    // ---- dy loader: pieces e = wave, wave + 4, .. of the NB * nsub pieces [n-block][sub-step]; lane l fetches chunk (l & 3) of
+    // pixel sub * 16 + (l >> 2) of the step = (row pp / TC, column pp % TC); the row index rides in the low bits of the offset
+    unsigned DC[W3_MAXD];
+#pragma unroll
+    for (int k = 0; k < W3_MAXD; ++k) {
+        const int e = wave + 4 * k;
+        int nbk = 0, sub = e;
+        while (sub >= nsub) { sub -= nsub; ++nbk; }
+        const unsigned pp = (unsigned)(sub * 16 + (lane >> 2));
+        const unsigned row = fdiv(pp, W3FD(dTC));
+        const int col = (int)(pp - row * (unsigned)TC);
+        const int chan = (nb0 + nbk) * 32 + (lane & 3) * 8;
+        const bool ok = (e < NB * nsub) & (pp < (unsigned)PX) & (c0 + col < p.OW) & (chan < p.N);
+        DC[k] = ok ? ((unsigned)((col * p.ldy + chan) * 2) | row) : W3_XOOB;
+    }
+    // ---- fragment geometry.  Sub-step `sub`, half h of its 16 pixels: this lane's pixel is 4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl
+    // (TC % 4 == 0: the four pixels of a read lie in one output row); pixels beyond the step are clamped (their dy is zero, the
+    // x they meet only has to be finite)
+    const int q16 = lane & 15, rowl = q16 >> 2;
+    const unsigned chanb = (unsigned)(((q16 & 3) * 4 + ((lane >> 4) & 1) * 16) * 2);
+    unsigned XO[W3_MAXI][2];
+#pragma unroll
+    for (int i = 0; i < W3_MAXI; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sub = slice + SL * i;
+            unsigned pp = (unsigned)(4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl);
+            pp = pp < (unsigned)PX ? pp : (unsigned)(PX - 1);
+            const unsigned row = fdiv(pp, W3FD(dTC));
+            const unsigned col = pp - row * (unsigned)TC;
+            XO[i][h] = row * (unsigned)(s * rowpitch) + col * 64u + chanb;
+        }
+    const unsigned DYL = (unsigned)(((lane >> 5) * 8 + rowl) * 64) + chanb + (unsigned)(nb * nsub * 1024);
+    // tap (dh, dw) -> byte offset inside the window, for this wavefront's c-block
+    unsigned tapo[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dh = t / 3, dw = t % 3;
+        const int colo = s == 1 ? dw * 64 : (dw == 1 ? plo : (dw == 2 ? 64 : 0));
+        tapo[t] = (unsigned)(dh * rowpitch + cb * (plo + ple) + colo);
+    }
+
+    float16v acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // DMA of step `st` into the stage at byte offset `sb`: the window's padded input rows V = s * u .. + nrows - 1 (row base
+    // uniform per row: out of range for padding rows), then the dy rows of the step's RPS virtual output rows
+    auto issue = [&](int st, unsigned sb) {
+        const unsigned us = u0 + (unsigned)(st * RPS);
+        const unsigned V0 = (unsigned)s * us;
+        const unsigned n0 = fdiv(V0, W3FD(dXP));
+        const unsigned vi0 = V0 - n0 * XP;
+        for (int r = 0; r < nrows; ++r) {
+            unsigned vi = vi0 + (unsigned)r, n = n0;
+            if (vi >= XP) { vi -= XP; ++n; }
+            const unsigned ih = vi - 1u;                              // vi == 0: the top padding row -> wraps to out of range
+            const bool ok = (ih < (unsigned)p.XH) & (n < (unsigned)p.B);
+            const unsigned rb = ok ? ((n * (unsigned)p.XH + ih) * (unsigned)p.XW) * (unsigned)p.ldx * 2u : G_OOB;
+            const unsigned la = lds_tiles + sb + (unsigned)(r * rowpitch + wave * 1024);
+#pragma unroll
+            for (int k = 0; k < W3_MAXK; ++k)
+                if (wave + 4 * k < ppr) glds16(rsX, la + (unsigned)(k * 4096), rb + XC[k]);
+        }
+        unsigned dyb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned u = us + (unsigned)r;
+            const unsigned n = fdiv(u, W3FD(dUP));
+            const unsigned oh = u - n * UP;
+            const bool ok = (r < RPS) & (oh < (unsigned)p.OH) & (u < u1);
+            dyb[r] = ok ? ((n * (unsigned)p.OH + oh) * (unsigned)p.OW + (unsigned)c0) * (unsigned)p.ldy * 2u : G_OOB;
+        }
+        const unsigned ly = lds_tiles + sb + (unsigned)(xstage + wave * 1024);
+#pragma unroll
+        for (int k = 0; k < W3_MAXD; ++k)
+            if (wave + 4 * k < NB * nsub) {
+                const unsigned row = DC[k] & 3u;
+                const unsigned b = row == 0 ? dyb[0] : (row == 1 ? dyb[1] : (row == 2 ? dyb[2] : dyb[3]));
+                glds16(rsY, ly + (unsigned)(k * 4096), b + (DC[k] & ~3u));
+            }
+    };
+    // the wavefront's sub-steps of the stage at `sb`: one dy fragment, nine shifted x fragments, nine MFMAs each
+    auto compute = [&](unsigned sb) {
+        const unsigned char* sx = smem_raw + sb;
+        const unsigned char* sy = smem_raw + sb + xstage + DYL;
+#pragma unroll
+        for (int i = 0; i < W3_MAXI; ++i) {
+            const int sub = slice + SL * i;
+            if (sub < nsub) {
+                const half8 a = w3_frag(sy + sub * 1024, sy + sub * 1024 + 256);
+                half8 b[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) b[t] = w3_frag(sx + (XO[i][0] + tapo[t]), sx + (XO[i][1] + tapo[t]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    const unsigned stage = (unsigned)p.stage;
+    issue(0, 0u);
+    for (int st = 0; st < nsteps; ++st) {
+        const unsigned sb = (st & 1) ? stage : 0u;
+        wait_vm<0>();                            // step st landed (this wavefront's pieces) ...
+        __builtin_amdgcn_s_barrier();            // ... everyone's pieces landed, everyone finished reading step st - 1
+        if (st + 1 < nsteps) issue(st + 1, stage - sb);
+        compute(sb);
+    }
+    // the accumulators are read below: MFMA result hazard (see AY_MFMA_PAD in conv.hip)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 11" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                             // the stages are free
+    // ---- wavefronts that share a block: slices 1 .. SL - 1 hand their sums to slice 0 through LDS, three taps per round, added in
+    // slice order (a fixed order: the partial is bit-reproducible)
+    if (SL > 1) {
+        float* red = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            if (slice > 0) {
+                float* dst = red + (size_t)((slice - 1) * NP + pair) * (48 * 64) + lane;
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(tt * 16 + r) * 64] = acc[3 * g + tt][r];
+            }
+            __syncthreads();
+            if (slice == 0) {
+                for (int sl = 1; sl < SL; ++sl) {
+                    const float* src = red + (size_t)((sl - 1) * NP + pair) * (48 * 64) + lane;
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[3 * g + tt][r] += src[(tt * 16 + r) * 64];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- acc[t][r]: output channel (nb0 + nb) * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), column t * C + (cb0 + cb) * 32 + (lane & 31)
+    // -> this split's slot of the workspace: lanes 0 .. 31 of a store cover 128 contiguous bytes of one dw row
+    if (slice == 0) {
+        float* slotp = ws + p.ws_off + (unsigned long long)(p.zz0 + zz) * ((unsigned long long)p.N * (unsigned long long)p.K);
+        const int K = p.K, N = p.N, C = p.C;
+        const int cc = (cb0 + cb) * 32 + (lane & 31);
+        const int rbase = (nb0 + nb) * 32 + 4 * (lane >> 5);
+        if (cc < C) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + 8 * (r >> 2) + (r & 3);
+                    if (row < N) slotp[(long long)row * K + t * C + cc] = acc[t][r];
+                }
+        }
+    }
+#undef p
+#undef W3FD
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static int w3_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+size_t w3_lds_bytes(const W3P& p) {
+    const size_t a = 2 * (size_t)p.stage;
+    return p.SL > 1 && a < W3_RED_BYTES ? (size_t)W3_RED_BYTES : a;
+}
+
+int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
+    static const int on = w3_env("AYOLO_WGRAD3", 1);
+    if (!on) return 1;
+    if (d->dtype != AYOLO_F16 || d->kh != 3 || d->kw != 3 || d->ph != 1 || d->pw != 1 || d->sh != d->sw || (d->sh != 1 && d->sh != 2)) return 1;
+    if (d->Cin % 8 || d->Cout % 8 || d->ldx % 8 || d->ldy % 8 || d->Cin < 16 || d->Cout < 16) return 1;
+    const int s = d->sh;
+    if (d->Ho != (d->H + 2 - 3) / s + 1 || d->Wo != (d->W + 2 - 3) / s + 1) return 1;
+    const long long xb = (long long)d->B * d->H * d->W * d->ldx * 2, yb = (long long)d->B * d->Ho * d->Wo * d->ldy * 2;
+    if (xb >= (1ll << 30) || yb >= (1ll << 30)) return 1;
+    p = W3P{};
+    p.x = x; p.dy = dy;
+    p.B = d->B; p.XH = d->H; p.XW = d->W; p.ldx = d->ldx; p.C = d->Cin;
+    p.OH = d->Ho; p.OW = d->Wo; p.ldy = d->ldy; p.N = d->Cout;
+    p.s = s; p.K = 9 * p.C;
+    p.UP = p.OH + (s == 1 ? 2 : 1); p.XP = s * p.UP;
+    if ((long long)d->B * p.XP >= (1ll << 30)) return 1;
+    p.NU = (unsigned)(d->B * p.UP);
+    p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
+    const int NBt = (p.N + 31) / 32, CBt = (p.C + 31) / 32;
+    if (CBt >= 2 && NBt >= 2) { p.NB = 2; p.CB = 2; }
+    else if (CBt == 1) { p.CB = 1; p.NB = NBt >= 3 ? 4 : NBt; }
+    else { p.NB = 1; p.CB = 2; }
+    p.NP = p.NB * p.CB; p.SL = 4 / p.NP;
+    p.tn = (NBt + p.NB - 1) / p.NB; p.tc = (CBt + p.CB - 1) / p.CB;
+    // step geometry: the (TC, RPS) with the least modelled time per output pixel -- MFMA cycles of a wavefront's sub-steps (a
+    // 16-pixel sub-step costs its 9 MFMAs whether its pixels are live or not) + ~25 cycles per DMA piece of the workgroup
+    double best = 1e30;
+    for (int TC = 4; TC <= 96; TC += 4)
+        for (int RPS = 1; RPS <= 4; ++RPS) {
+            const int PX = TC * RPS;
+            if (PX > 96 || (TC > p.OW + 3 && TC > 4)) continue;
+            const int nsub = (PX + 15) / 16;
+            const int pw = s == 1 ? TC + 2 : 2 * TC + 1;
+            const int ppr = (p.CB * pw * 4 + 63) / 64;
+            const int nrows = s * (RPS - 1) + 3;
+            if (ppr > 4 * W3_MAXK || nrows > p.XP || p.NB * nsub > 4 * W3_MAXD) continue;
+            const int stage = nrows * ppr * 1024 + p.NB * nsub * 1024;
+            if (stage > W3_STAGE_MAX) continue;
+            const int strips = (p.OW + TC - 1) / TC;
+            const int wsub = (nsub + p.SL - 1) / p.SL;
+            const double t = (double)strips * (288.0 * wsub + 25.0 * (nrows * ppr + p.NB * nsub)) / ((double)RPS * p.OW);
+            if (t < best - 1e-9) {
+                best = t;
+                p.TC = TC; p.RPS = RPS; p.PX = PX; p.nsub = nsub; p.strips = strips;
+                p.nrows = nrows; p.ppr = ppr; p.rowpitch = ppr * 1024;
+                p.plo = (s == 1 ? TC + 2 : TC + 1) * 64; p.ple = s == 1 ? 0 : TC * 64;
+                p.xstage = nrows * ppr * 1024; p.stage = stage;
+            }
+        }
+    if (best > 1e29) return 1;
+    p.dXP = make_fastdiv((unsigned)p.XP); p.dUP = make_fastdiv((unsigned)p.UP); p.dTC = make_fastdiv((unsigned)p.TC);
+    p.uch = (unsigned)p.RPS; p.uranges = (p.NU + p.uch - 1) / p.uch;
+    return 0;
+}
+
+void w3_split(W3P& p, double steps) {
+    const unsigned total = (p.NU + (unsigned)p.RPS - 1) / (unsigned)p.RPS;        // steps of one (tile, strip)
+    double q = steps < 2.0 ? 2.0 : steps;
+    unsigned n = (unsigned)((double)total / q + 0.5);
+    if (n < 1) n = 1;
+    unsigned per = (total + n - 1) / n;
+    p.uch = per * (unsigned)p.RPS;
+    p.uranges = (p.NU + p.uch - 1) / p.uch;
+}
+
+int w3_launch(const W3P& pv, const W3P* jobs, const WItem* items, unsigned blocks, size_t lds, float* ws, hipStream_t s) {
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W3_STAGE_MAX);
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(k_wgrad3, dim3(blocks), dim3(256), lds, s, pv, jobs, items, ws);
+    AY_CHECK_LAUNCH("k_wgrad3");
+    return AYOLO_OK;
+}
+
+/* introspection (tests/test_kernel_math.py restates the kernel's index algebra on the CPU from these numbers): the step
+ * geometry w3_fill chooses for `d`; returns AYOLO_EINVAL when the layer is not k_wgrad3's */
+extern "C" int ayolo_wgrad3_geometry(const ayolo_conv_desc* d, long long* out, int nout) {
+    AY_CHECK_ARG(d && out && nout >= 24, "wgrad3_geometry: out[24]");
+    W3P p;
+    AY_CHECK_ARG(w3_fill(d, d, d, p) == 0, "wgrad3_geometry: not a fp16 3x3 / pad 1 / stride 1 or 2 layer of k_wgrad3");
+    const long long v[24] = {p.TC, p.RPS, p.PX, p.nsub, p.strips, p.NB, p.CB, p.NP, p.SL, p.tn, p.tc, p.nrows, p.ppr, p.rowpitch,
+                             p.plo, p.ple, p.xstage, p.stage, p.UP, p.XP, (long long)p.NU, (long long)p.x_bytes, (long long)p.y_bytes,
+                             (long long)w3_lds_bytes(p)};
+    for (int i = 0; i < 24; ++i) out[i] = v[i];
+    return AYOLO_OK;
+}

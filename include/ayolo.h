@@ -165,12 +165,21 @@ int ayolo_wgrad_group_size(const ayolo_wgrad_job* jobs, int njobs, size_t* table
 int ayolo_wgrad_group_build(const ayolo_wgrad_job* jobs, int njobs, void* table_host, size_t table_bytes);
 int ayolo_wgrad_group_run(const void* table_host, const void* table_dev, void* ws, size_t ws_bytes,
                           const void* const* dy_override, int n_override, ayolo_stream s);
-/* introspection of a host table (tests / tools): out[0..5] = jobs (batch halves count as jobs), items of tile class 32 / 64 /
+/* introspection of a host table (tests / tools): out[0..5] = k_wgrad jobs (batch halves count as jobs), items of tile class 32 / 64 /
  * 128, reduction blocks, workspace floats; job >= 0: out[6..11] = its tile class, column tiles, channel tiles, pixel splits,
  * pixels per split, first workspace slot.  _item: {job or -1 (queue padding), tile, split} of item i of a tile class;
  * block i of a class's launch runs on XCD i % 8. */
 int ayolo_wgrad_group_info(const void* table_host, int job, long long* out, int nout);
 int ayolo_wgrad_group_item(const void* table_host, int cls, long long i, long long* out);
+/* The fp16 3x3 / pad 1 / stride 1 or 2 layers (the Conv rows res/configs/model/yolov5s.yaml:22,25,28,31,46,50 and every Bottleneck's
+ * 3x3 conv) run a dedicated kernel behind both entries above: the input patch of a step is staged once and all nine taps read it
+ * at shifted LDS addresses (csrc/wgrad3.hip).  In a group table they are item class 3 and jobs `out[0]` .. `out[0] + out[13] - 1`
+ * (nout >= 14: out[12] = items of class 3, out[13] = such jobs; job fields: tile class 0, tiles along C, tiles along N, splits,
+ * virtual rows per split, first slot; nout >= 20: out[14..19] = strip width, rows per step, strips, n-blocks and c-blocks per
+ * workgroup tile, LDS bytes per stage).  ayolo_wgrad3_geometry: the step geometry chosen for a layer (tests restate the kernel's
+ * index algebra from it), out[0..23] = TC, RPS, PX, nsub, strips, NB, CB, NP, SL, tn, tc, nrows, ppr, rowpitch, plo, ple, xstage,
+ * stage, UP, XP, NU, x_bytes, y_bytes, LDS bytes; AYOLO_EINVAL for any other layer. */
+int ayolo_wgrad3_geometry(const ayolo_conv_desc* d, long long* out, int nout);
 /* Backward of the STEM block (kindle Conv row 0, res/configs/model/yolov5s.yaml:21: Conv-BN-SiLU on the image) in one launch:
  * the BatchNorm + activation backward of its output gradient da and the weight gradient of its conv.  The stem has no input
  * gradient, so its dz has no other reader: the kernel forms dz = bn_act_backward(da, z; sums) on the way from HBM to LDS

@@ -83,3 +83,214 @@ def test_four_shift_decomposition_of_stride2_dgrad(shape):
         shifted[:, :, :Ho - dh, :Wo - dw] = dy[:, :, dh:, dw:]            # rows / columns beyond the dy map are zero
         dx[:, :, a::2, b::2] += np.einsum("bohw,oc->bchw", shifted, w[:, :, tap // 3, tap % 3].numpy())
     np.testing.assert_allclose(dx, x.grad.numpy(), rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------
+# k_wgrad3 (csrc/wgrad3.hip): the kernel's data movement restated lane by lane.  The step geometry comes from the library
+# (ayolo_wgrad3_geometry: host code, no GPU); everything the GPU does with it -- which 16 bytes every DMA lane fetches and where
+# they land in LDS, which LDS addresses every lane hands to the transposing fragment read, which accumulator element ends up
+# in which dw element, how the slices of a block are summed -- is followed here with the kernel's own expressions, on an LDS
+# image that starts as NaN (a fragment read that touches bytes no DMA wrote poisons the result, as it could on the GPU).
+# ---------------------------------------------------------------------------------------------------
+def _w3_geometry(B, C, N, H, W, s, ldx, ldy):
+    import ctypes
+    from ayolov2_amd import _lib, ops
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    d = ops.make_desc(torch.float16, B, H, W, C, ldx, N, ldy, (3, 3), (s, s), (1, 1), Ho, Wo)
+    out = (ctypes.c_int64 * 24)()
+    _lib.check(_lib.lib().ayolo_wgrad3_geometry(d, out, 24), "ayolo_wgrad3_geometry")
+    names = "TC RPS PX nsub strips NB CB NP SL tn tc nrows ppr rowpitch plo ple xstage stage UP XP NU x_bytes y_bytes lds".split()
+    return dict(zip(names, [int(v) for v in out])), Ho, Wo
+
+
+def _w3_emulate(x, dy, g, s, steps_per_item):
+    """x: (B, XH, XW, ldx) float16 NHWC, dy: (B, OH, OW, ldy) float16 -> dw (N, 9 * C) float64, plus the number of workspace slots."""
+    B, XH, XW, ldx = x.shape
+    _, OH, OW, ldy = dy.shape
+    C, N = g["C"], g["N"]
+    TC, RPS, PX, nsub, strips = g["TC"], g["RPS"], g["PX"], g["nsub"], g["strips"]
+    NB, CB, NP, SL, tn, tc = g["NB"], g["CB"], g["NP"], g["SL"], g["tn"], g["tc"]
+    nrows, ppr, rowpitch, plo, ple, xstage, stage = g["nrows"], g["ppr"], g["rowpitch"], g["plo"], g["ple"], g["xstage"], g["stage"]
+    UP, XP, NU = g["UP"], g["XP"], g["NU"]
+    K = 9 * C
+    G_OOB, XOOB, M32 = 0x80000000, 0x40000000, 0xFFFFFFFF
+    xf, yf = x.reshape(-1), dy.reshape(-1)
+    lane = np.arange(64)
+    uch = RPS * steps_per_item
+    uranges = -(-NU // uch)
+    slots = np.zeros((strips * uranges, N, K))
+    written = np.zeros((strips * uranges, N, K), dtype=np.int32)
+
+    def dma(lds, dst, buf, nbytes, off):
+        """one LDS-DMA piece: lane l moves 16 bytes from byte offset off[l] (zeros beyond the descriptor) to LDS dst + 16 l"""
+        off = off & M32
+        ok = off < nbytes
+        idx = np.where(ok, off, 0)[:, None] // 2 + np.arange(8)
+        vals = np.where(ok[:, None], buf[np.minimum(idx, buf.size - 1)], 0).astype(np.float16)
+        lds[(dst // 2 + lane * 8)[:, None] + np.arange(8)] = vals
+
+    def frag(lds, lo, hi):
+        """ds_read_b64_tr_b16 x 2 -> [16 pixels][32 channels]: lane supplies the address of pixel (q >> 2) (+ 4), 4 channels"""
+        F = np.zeros((16, 32))
+        q = lane & 15
+        for h, a in ((0, lo), (1, hi)):
+            px = (lane >> 5) * 8 + h * 4 + (q >> 2)
+            ch = ((lane >> 4) & 1) * 16 + (q & 3) * 4
+            F[px[:, None], ch[:, None] + np.arange(4)] = lds[(a // 2)[:, None] + np.arange(4)]
+        return F
+
+    for tile in range(tn * tc):
+        for zz in range(strips * uranges):
+            tni, tci = tile // tc, tile % tc
+            nb0, cb0 = tni * NB, tci * CB
+            strip, ur = zz % strips, zz // strips
+            c0 = strip * TC
+            u0 = ur * uch
+            u1 = min(u0 + uch, NU)
+            nsteps = -(-(u1 - u0) // RPS)
+            lds = np.full(max(g["lds"], 2 * stage) // 2, np.nan, dtype=np.float16)
+            acc = np.zeros((4, 9, 32, 32))
+            # per-wave constants
+            wc = []
+            for wave in range(4):
+                pair = wave & (NP - 1)
+                slice_ = wave if NP == 1 else (wave >> 1 if NP == 2 else 0)
+                nb, cb = (pair >> 1, pair & 1) if CB == 2 else (pair, 0)
+                cbsz = (plo + ple) >> 4
+                XC = []
+                for k in range(3):
+                    j = wave + 4 * k
+                    ci = j * 64 + lane
+                    cbi = (ci >= cbsz).astype(int)
+                    rem = ci - cbi * cbsz
+                    even = rem >= (plo >> 4)
+                    rem2 = np.where(even, rem - (plo >> 4), rem)
+                    q, ch = rem2 >> 2, rem2 & 3
+                    ic = c0 - 1 + q if s == 1 else np.where(even, 2 * (c0 + q), 2 * (c0 + q) - 1)
+                    chan = (cb0 + cbi) * 32 + ch * 8
+                    ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < C)
+                    XC.append(np.where(ok, (ic * ldx + chan) * 2, XOOB))
+                DC = []
+                for k in range(6):
+                    e = wave + 4 * k
+                    nbk, sub = 0, e
+                    while sub >= nsub:
+                        sub -= nsub
+                        nbk += 1
+                    pp = sub * 16 + (lane >> 2)
+                    row, col = pp // TC, pp % TC
+                    chan = (nb0 + nbk) * 32 + (lane & 3) * 8
+                    ok = (e < NB * nsub) & (pp < PX) & (c0 + col < OW) & (chan < N)
+                    DC.append(np.where(ok, ((col * ldy + chan) * 2) | row, XOOB))
+                q16 = lane & 15
+                rowl = q16 >> 2
+                chanb = ((q16 & 3) * 4 + ((lane >> 4) & 1) * 16) * 2
+                XO = {}
+                for i in range(6):
+                    for h in range(2):
+                        sub = slice_ + SL * i
+                        pp = np.minimum(4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl, PX - 1)
+                        XO[i, h] = (pp // TC) * (s * rowpitch) + (pp % TC) * 64 + chanb
+                DYL = ((lane >> 5) * 8 + rowl) * 64 + chanb + nb * nsub * 1024
+                tapo = []
+                for t in range(9):
+                    dh, dw = t // 3, t % 3
+                    colo = dw * 64 if s == 1 else (plo if dw == 1 else (64 if dw == 2 else 0))
+                    tapo.append(dh * rowpitch + cb * (plo + ple) + colo)
+                wc.append(dict(pair=pair, slice=slice_, nb=nb, cb=cb, XC=XC, DC=DC, XO=XO, DYL=DYL, tapo=tapo))
+
+            def issue(st, sb):
+                us = u0 + st * RPS
+                V0 = s * us
+                n0, vi0 = V0 // XP, V0 % XP
+                for wave in range(4):
+                    w = wc[wave]
+                    for r in range(nrows):
+                        vi, n = vi0 + r, n0
+                        if vi >= XP:
+                            vi -= XP
+                            n += 1
+                        ih = (vi - 1) & M32
+                        ok = ih < XH and n < B
+                        rb = ((n * XH + ih) * XW) * ldx * 2 if ok else G_OOB
+                        for k in range(3):
+                            if wave + 4 * k < ppr:
+                                dma(lds, sb + r * rowpitch + wave * 1024 + k * 4096, xf, g["x_bytes"], rb + w["XC"][k])
+                    dyb = []
+                    for r in range(4):
+                        u = us + r
+                        n, oh = u // UP, u % UP
+                        ok = r < RPS and oh < OH and u < u1
+                        dyb.append(((n * OH + oh) * OW + c0) * ldy * 2 if ok else G_OOB)
+                    for k in range(6):
+                        if wave + 4 * k < NB * nsub:
+                            row = w["DC"][k] & 3
+                            b = np.choose(row, dyb)
+                            dma(lds, sb + xstage + wave * 1024 + k * 4096, yf, g["y_bytes"], b + (w["DC"][k] & ~3))
+
+            def compute(sb):
+                for wave in range(4):
+                    w = wc[wave]
+                    for i in range(6):
+                        sub = w["slice"] + SL * i
+                        if sub < nsub:
+                            ya = sb + xstage + w["DYL"] + sub * 1024
+                            A = frag(lds, ya, ya + 256)
+                            for t in range(9):
+                                Bf = frag(lds, sb + w["XO"][i, 0] + w["tapo"][t], sb + w["XO"][i, 1] + w["tapo"][t])
+                                acc[wave, t] += A.T @ Bf
+
+            issue(0, 0)
+            for st in range(nsteps):
+                sb = stage if st & 1 else 0
+                if st + 1 < nsteps:
+                    issue(st + 1, stage - sb)
+                compute(sb)
+            # slices of a block summed in slice order by slice 0, which stores the block
+            for wave in range(4):
+                w = wc[wave]
+                if w["slice"] != 0:
+                    continue
+                tot = acc[wave].copy()
+                for sl in range(1, SL):
+                    other = next(v for v in range(4) if wc[v]["pair"] == w["pair"] and wc[v]["slice"] == sl)
+                    tot += acc[other]
+                for t in range(9):
+                    for m in range(32):
+                        row = (nb0 + w["nb"]) * 32 + m
+                        for c in range(32):
+                            cc = (cb0 + w["cb"]) * 32 + c
+                            if cc < C and row < N:
+                                slots[zz, row, t * C + cc] = tot[t, m, c]
+                                written[zz, row, t * C + cc] += 1
+    assert (written == 1).all(), "every element of every workspace slot is stored exactly once"
+    return slots.sum(0), strips * uranges
+
+
+@pytest.mark.parametrize("case", [
+    (2, 32, 32, 8, 16, 1, 0, 3),       # one block: four wavefronts split the sub-steps
+    (2, 32, 64, 12, 24, 2, 0, 2),      # stride 2, two n-blocks x two slices
+    (1, 64, 64, 8, 20, 1, 8, 4),       # 2 x 2 blocks, x a channel slice of a wider buffer
+    (2, 40, 72, 10, 12, 2, 0, 1),      # ragged channel blocks, two tiles along N
+    (1, 96, 32, 6, 8, 1, 0, 2),        # one n-block x two c-blocks, two tiles along C
+    (2, 32, 128, 9, 13, 2, 0, 3),      # odd map (bottom padding row, strip wider than the map), four n-blocks
+    (3, 64, 64, 5, 4, 1, 0, 2),        # tiny map: steps straddle images
+])
+def test_wgrad3_patch_index_math(case):
+    B, C, N, H, W, s, xpad, spi = case
+    ldx, ldy = C + xpad, N
+    geo, Ho, Wo = _w3_geometry(B, C, N, H, W, s, ldx, ldy)
+    geo.update(C=C, N=N)
+    gen = torch.Generator().manual_seed(sum(case))
+    xt = torch.randn(B, C, H, W, generator=gen).half()
+    dyt = torch.randn(B, N, Ho, Wo, generator=gen).half()
+    x = np.full((B, H, W, ldx), 7.0, dtype=np.float16)               # the other channels of the wider buffer must never be read
+    x[..., :C] = xt.permute(0, 2, 3, 1).numpy()
+    dy = dyt.permute(0, 2, 3, 1).contiguous().numpy()
+    dw, nslots = _w3_emulate(x, dy, geo, s, spi)
+    xr = xt.double().requires_grad_(False)
+    w = torch.zeros(N, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w, None, s, 1).backward(dyt.double())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(N, 9 * C).numpy()      # [n][(dh, dw)][c]
+    assert nslots >= 1
+    np.testing.assert_allclose(dw, ref, rtol=1e-9, atol=1e-9)
