@@ -2515,8 +2515,6 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 // each walk all 2 133 partials one memory round trip after the other: 250 us for 35 MB.  A block covers wred_chunk(tpc) elements.
 struct WRed { unsigned long long ws_off, stride; float* dst; unsigned n, S; float alpha; int overwrite; unsigned cols, ldd; unsigned long long e0; unsigned tpc, pad; };
 static inline unsigned wred_tpc(unsigned S) {
-    static const bool off = getenv("AYOLO_WRED_SERIAL") != nullptr;     // A/B: every column's partials added by one thread
-    if (off) return 1;
     unsigned t = 1;
     while (t < 64 && S > 32 * t) t *= 2;                       // <= 32 partials per thread (16 .. 48 measured alike, 8 / 96 worse)
     return t;
@@ -3577,20 +3575,19 @@ struct WGroupPlan {
 // modelled cycles of one k_wgrad3 step of job p (a wavefront's MFMAs + the workgroup's DMA pieces): the unit item lengths are
 // balanced in (w3_fill picks the step geometry by the same model)
 static double w3_step_cost(const W3P& p) {
-    return 288.0 * ((p.nsub + p.SL - 1) / p.SL) + 25.0 * (p.nrows * p.ppr + p.NB * p.nsub);
+    return 600.0 + 405.0 * ((p.nsub + p.SL - 1) / p.SL) + 100.0 * ((p.nrows * p.ppr + p.NB * p.nsub + 3) / 4);
 }
-// Steps per item of a k_wgrad3 job.  `q`: the launch's common item length (in steps of THIS job).  Every (strip, row range) is
-// one more N x K slot to store and to add: a deep layer on a small map (256 -> 256 at 20 x 20: 2.4 MB per slot for 6.5 MB of
-// operands) is cut no finer than what keeps that traffic under about half of the layer's own compute / operand time.
+// Steps per item of a k_wgrad3 job.  `q`: the launch's common item length (in steps of THIS job).  Every row range is one more
+// N x K slot to store and to add: a deep layer on a small map (256 -> 256 at 20 x 20: 2.4 MB per slot for 6.5 MB of operands)
+// is cut no finer than what keeps that traffic under about a third of the layer's own compute / operand time.
 static void w3_split_job(W3P& p, double q) {
     const double nk = (double)p.N * p.K;
     const double px = (double)p.B * p.OH * p.OW;
     const double t_layer = 2.0 * px * nk / 1.0e15 + 2.0 * ((double)p.B * p.XH * p.XW * p.C + px * p.N) / 4.5e12;
-    double smax = 0.5 * t_layer * 4.5e12 / (nk * 8.0);
+    double smax = 0.3 * t_layer * 4.5e12 / (nk * 8.0);
     if (smax < 1.0) smax = 1.0;
-    const double steps = (double)((p.NU + p.RPS - 1) / p.RPS);
-    const double per_strip = smax / p.strips < 1.0 ? 1.0 : smax / p.strips;
-    const double qmin = steps / per_strip;
+    const double steps = (double)p.strips * (double)((p.NU + p.RPS - 1) / p.RPS);
+    const double qmin = steps / smax;
     w3_split(p, q > qmin ? q : qmin);
 }
 
@@ -3704,7 +3701,7 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
                 const W3P& p = g.jobs3[j];
                 const double sc = w3_step_cost(p);
                 for (unsigned z = 0; z < w3_splits(p); ++z)
-                    grps.push_back({(unsigned)j, z, w3_tiles(p), (double)w3_item_steps(p, z / (unsigned)p.strips) * sc});
+                    grps.push_back({(unsigned)j, z, w3_tiles(p), (double)w3_item_steps(p, z) * sc});
             }
         }
         if (grps.empty()) continue;
@@ -3896,8 +3893,8 @@ static int wgrad_single_plan(const ayolo_conv_desc* d, const void* x, const void
 // single 3x3 layer on k_wgrad3: items for the chip to itself (two workgroups per CU, about two rounds of them)
 static bool w3_single_plan(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
     if (w3_fill(d, x, dy, p) != 0) return false;
-    const double steps = (double)((p.NU + p.RPS - 1) / p.RPS);
-    const double want = (double)num_cus() * 2.0 * 2.0 / ((double)w3_tiles(p) * p.strips);       // row ranges per (tile, strip)
+    const double steps = (double)p.strips * (double)((p.NU + p.RPS - 1) / p.RPS);
+    const double want = (double)num_cus() * 2.0 * 2.0 / (double)w3_tiles(p);                    // row ranges per tile
     double q = steps / (want < 1.0 ? 1.0 : want);
     const double minq = (double)wgrad_env("AYOLO_WGRAD3_MINQ", 6);
     w3_split_job(p, q < minq ? minq : q);

@@ -1072,8 +1072,8 @@ static int head_decode_launch(bool aug, const float* raw, const int64_t* raw_str
     if (raw_strides) { sb = raw_strides[0]; sa = raw_strides[1]; sy = raw_strides[2]; sx = raw_strides[3]; }
     if (total == 0) return AYOLO_OK;
     const unsigned long long plane_n = (unsigned long long)ny * nx * no, plane_px = (unsigned long long)ny * nx;
-    static const bool flat = getenv("AYOLO_DECODE_FLAT") != nullptr;         // A/B: the element kernel with 64-bit index arithmetic
-    if (!flat && plane_n * (unsigned)no < (1ull << 32) && plane_px * (unsigned)nx < (1ull << 32) && (long long)B * na < 65536 && no > 1 && nx > 1) {
+    // (the element kernel with 64-bit index arithmetic below only takes what these 32-bit magic divisions cannot index)
+    if (plane_n * (unsigned)no < (1ull << 32) && plane_px * (unsigned)nx < (1ull << 32) && (long long)B * na < 65536 && no > 1 && nx > 1) {
         const unsigned m_no = (unsigned)(((1ull << 32) + (unsigned)no - 1) / (unsigned)no);
         const unsigned m_nx = (unsigned)(((1ull << 32) + (unsigned)nx - 1) / (unsigned)nx);
         unsigned gx = (unsigned)((plane_n + 256 * 4 - 1) / (256 * 4));

@@ -51,6 +51,17 @@ __device__ __forceinline__ void glds16(v4i32 srd, unsigned lds_addr, unsigned vo
                  : "memory");
 }
 
+// The same statement with a different text.  Two glds16 calls in the arms of an if / else are otherwise MERGED by hipcc into one
+// statement behind the join, its descriptor / LDS address operands selected per arm -- through VGPRs, which the "s" constraints
+// then reject ("invalid operand for instruction").  Use this one in the second arm.
+__device__ __forceinline__ void glds16_b(v4i32 srd, unsigned lds_addr, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0 ; arm b"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd)
+                 : "memory");
+}
+
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
     const unsigned t = __umulhi(f.m, n);
     return (t + ((n - t) >> f.s1)) >> f.s2;

@@ -479,7 +479,7 @@ extern "C" int ayolo_yolo_loss_bwd_packed(const ayolo_loss_level* lv, int nl, fl
         AY_CHECK_LAUNCH("k_loss_rowbox");
     }
     const size_t es = dt == AYOLO_F16 ? 2 : 4;
-    bool rows = getenv("AYOLO_LOSS_ROWS") == nullptr || atoi(getenv("AYOLO_LOSS_ROWS")) != 0;
+    bool rows = true;                            // (more than four anchors per cell: the fill + scatter route below)
     for (int l = 0; l < nl; ++l) rows = rows && lv[l].na <= 4;
     if (rows) {                                  // zero fill + objectness groups as one pass of whole rows (MODE 3)
         if (dt == AYOLO_F16) hipLaunchKernelGGL((k_loss_grad_packed<half_t, 3>), dim3(2048, (unsigned)nl), dim3(256), 0, st, P, grad_out);

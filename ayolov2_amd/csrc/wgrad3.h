@@ -29,7 +29,7 @@ struct W3P {
     int xstage, stage;             // bytes of the x window / of one LDS stage (x window + NB dy planes of nsub * 1024 bytes)
     unsigned x_bytes, y_bytes;     // buffer descriptor extents (< 1 GiB each: the loader adds a row base and a lane offset
                                    // that may each be "out of range" on their own)
-    unsigned uch, uranges;         // virtual rows per item (a multiple of RPS), items per (tile, strip)
+    unsigned uch, uranges;         // virtual rows per item (a multiple of RPS; an item walks them once per column strip), items per tile
     unsigned long long ws_off;     // split-K workspace of this layer, in floats
     unsigned zz0;                  // first partial slot of this job
     FastDiv dXP, dUP, dTC;
@@ -37,13 +37,13 @@ struct W3P {
 
 /* 0 = `d` is a conv k_wgrad3 runs (fills the geometry of `p`, not its split); != 0: use the generic kernel */
 int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p);
-/* cut the job into items of about `steps` steps each (at least one item); p.uch / p.uranges */
+/* cut the job into items of about `steps` steps each (all strips of a row range together; at least one item); p.uch / p.uranges */
 void w3_split(W3P& p, double steps);
-static inline unsigned w3_splits(const W3P& p) { return (unsigned)p.strips * p.uranges; }
+static inline unsigned w3_splits(const W3P& p) { return p.uranges; }
 static inline unsigned w3_tiles(const W3P& p) { return (unsigned)(p.tn * p.tc); }
 static inline unsigned long long w3_item_steps(const W3P& p, unsigned ur) {
     const unsigned u0 = ur * p.uch, u1 = u0 + p.uch < p.NU ? u0 + p.uch : p.NU;
-    return (u1 - u0 + (unsigned)p.RPS - 1) / (unsigned)p.RPS;
+    return (unsigned long long)p.strips * ((u1 - u0 + (unsigned)p.RPS - 1) / (unsigned)p.RPS);
 }
 size_t w3_lds_bytes(const W3P& p);
 /* grouped launch (jobs / items in device memory, pv ignored) or single job by value (items == nullptr: blocks = tiles * splits) */

@@ -28,7 +28,7 @@ typedef const __attribute__((address_space(4))) W3P* w3job_cptr_t;
 #define W3_MAXK 3               // x pieces of one window row per wavefront (ppr <= 12)
 #define W3_MAXD 6               // dy pieces per wavefront (NB * nsub <= 24)
 #define W3_MAXI 6               // sub-steps per wavefront (nsub <= 6)
-#define W3_STAGE_MAX 40960      // two stages of two workgroups fill the CU's 160 KiB exactly
+#define W3_STAGE_MAX 81920      // two stages of ONE workgroup fill the CU's 160 KiB exactly (<= 40 KiB: two workgroups per CU)
 #define W3_RED_BYTES 36864      // cross-wavefront reduction: up to 3 wavefronts x 3 blocks x 16 registers x 64 lanes x 4 bytes
 
 // 16 pixels x this lane's channel out of a [pixel][32 channel] plane: lane supplies the row address of pixel (q >> 2) (+ 4 for the
@@ -42,10 +42,37 @@ __device__ __forceinline__ half8 w3_frag(const unsigned char* lo_, const unsigne
     return r;
 }
 
+// Timeline probe (tools/w3_probe.py; -DAYOLO_PROBE builds only, never the product library): wave 0 of the first 512 workgroups
+// records s_memtime at the marks of its step loop
+#ifdef AYOLO_PROBE
+#define W3_PROBE_N 128
+__device__ unsigned long long g_probe3[512 * W3_PROBE_N];
+extern "C" int ayolo_probe3_read(void* dst, unsigned long long bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_probe3), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#define W3_MARK()                                                                                      \
+    do {                                                                                               \
+        if (blockIdx.x < 512 && probe_k < W3_PROBE_N) {                                                \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+            if (threadIdx.x == 0) s_probe[probe_k] = t_;                                               \
+        }                                                                                              \
+        ++probe_k;                                                                                     \
+    } while (0)
+#else
+#define W3_MARK() do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, const WItem* items, float* ws) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef AYOLO_PROBE
+    __shared__ unsigned long long s_probe[W3_PROBE_N];
+    int probe_k = 0;
+    if (threadIdx.x < W3_PROBE_N) s_probe[threadIdx.x] = 0;
+    __syncthreads();
+    W3_MARK();                                   // 0: start
+#endif
 
     typedef __attribute__((address_space(4))) const char* kcptr_t;
     w3job_cptr_t pj;
@@ -64,21 +91,33 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
         const unsigned ntile = (unsigned)(pj->tn * pj->tc);
         tile = local % ntile;
         zz = (local / ntile) * 8u + xcd;
-        if (zz >= (unsigned)pj->strips * pj->uranges) return;
+        if (zz >= pj->uranges) return;
     }
 #define p (*pj)
 #define W3FD(f_) FastDiv{pj->f_.m, pj->f_.s1, pj->f_.s2}
-    const int s = p.s, TC = p.TC, RPS = p.RPS, PX = p.PX, nsub = p.nsub;
-    const int NB = p.NB, CB = p.CB, NP = p.NP, SL = p.SL;
-    const int nrows = p.nrows, ppr = p.ppr, rowpitch = p.rowpitch, plo = p.plo, ple = p.ple, xstage = p.xstage;
-    const unsigned XP = (unsigned)p.XP, UP = (unsigned)p.UP;
+    // Everything the step loop needs lives in registers from here on.  Left to itself hipcc RE-LOADS fields of the job (constant
+    // address space) inside the loader's row loop -- an s_load + s_waitcnt lgkmcnt(0) round trip per window row: the first probe
+    // of this kernel showed 3 200 cycles of "issue" per step for seven DMA pieces per wavefront (profiles/r05_w3_probe_v1.txt).
+    // The asm statements pin the values (no rematerialisation from memory); what does not fit the SGPR file is spilled to VGPR lanes.
+    int s = p.s, TC = p.TC, RPS = p.RPS, PX = p.PX, nsub = p.nsub;
+    int NB = p.NB, CB = p.CB, NP = p.NP, SL = p.SL;
+    int nrows = p.nrows, ppr = p.ppr, rowpitch = p.rowpitch, plo = p.plo, ple = p.ple, xstage = p.xstage;
+    unsigned XP = (unsigned)p.XP, UP = (unsigned)p.UP, XH = (unsigned)p.XH, OH = (unsigned)p.OH, Bn = (unsigned)p.B;
+    unsigned xrowb = (unsigned)p.XW * (unsigned)p.ldx * 2u, yrowb = (unsigned)p.OW * (unsigned)p.ldy * 2u, ypixb = (unsigned)p.ldy * 2u;
+    unsigned stage = (unsigned)p.stage;
+    int nstrips = p.strips, ndy = NB * nsub;
+    const FastDiv fXP = W3FD(dXP), fUP = W3FD(dUP);
+    unsigned fxm = fXP.m, fxs1 = fXP.s1, fxs2 = fXP.s2, fum = fUP.m, fus1 = fUP.s1, fus2 = fUP.s2;
+    asm volatile("" : "+s"(s), "+s"(RPS), "+s"(nsub), "+s"(nrows), "+s"(ppr), "+s"(rowpitch), "+s"(xstage), "+s"(stage));
+    asm volatile("" : "+s"(XP), "+s"(UP), "+s"(XH), "+s"(OH), "+s"(Bn), "+s"(xrowb), "+s"(yrowb), "+s"(ypixb), "+s"(ndy), "+s"(nstrips));
+    asm volatile("" : "+s"(fxm), "+s"(fxs1), "+s"(fxs2), "+s"(fum), "+s"(fus1), "+s"(fus2));
     const int tni = (int)(tile / (unsigned)p.tc), tci = (int)(tile - (unsigned)tni * (unsigned)p.tc);
     const int nb0 = tni * NB, cb0 = tci * CB;
-    const unsigned strip = zz % (unsigned)p.strips, ur = zz / (unsigned)p.strips;
-    const int c0 = (int)strip * TC;
-    const unsigned u0 = ur * p.uch;
-    const unsigned u1 = u0 + p.uch < p.NU ? u0 + p.uch : p.NU;
+    // item = (tile, row range zz): the virtual output rows [u0, u1) of EVERY column strip, strip after strip
+    unsigned u0 = zz * p.uch;
+    unsigned u1 = u0 + p.uch < p.NU ? u0 + p.uch : p.NU;
     const int nsteps = (int)((u1 - u0 + (unsigned)RPS - 1) / (unsigned)RPS);
+    asm volatile("" : "+s"(u0), "+s"(u1));
     // this wavefront: block `pair` of the tile, slice `slice` of the sub-steps
     const int pair = wave & (NP - 1);
     const int slice = NP == 1 ? wave : (NP == 2 ? wave >> 1 : 0);
@@ -86,12 +125,20 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsY = make_srd(p.dy, p.y_bytes);
     const unsigned lds_tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)smem_raw);
+    const int XW = p.XW, OW = p.OW, Cc = p.C, Nn = p.N, ldx = p.ldx, ldy = p.ldy;
+    const FastDiv fTC = W3FD(dTC);
 
-    // ---- x loader: this wavefront issues pieces j = wave, wave + 4, .. of every window row; lane l of piece j fetches the
-    // 16-byte chunk ci = j * 64 + l of the row image [c-block][odd / all columns | even columns][pixel][4 chunks]
-    unsigned XC[W3_MAXK];
-    {
+    // ---- loader lanes of column strip c0.  x: this wavefront issues pieces j = wave, wave + 4, .. of every window row; lane l of
+    // piece j fetches the 16-byte chunk ci = j * 64 + l of the row image [c-block][odd / all columns | even columns][pixel][4 chunks].
+    // dy: pieces e = wave, wave + 4, .. of the NB * nsub pieces [n-block][sub-step]; lane l fetches chunk (l & 3) of pixel
+    // sub * 16 + (l >> 2) of the step = (row pp / TC, column pp % TC); the row index rides in the low bits of the offset
+    // (separate scalars, not an array: the piece cursor picks one by a uniform index, and an array indexed at run time goes to
+    // scratch memory -- a scratch load per DMA piece whose s_waitcnt vmcnt would also wait for every DMA in flight)
+    unsigned XC0 = 0, XC1 = 0, XC2 = 0;
+    int c0_ld = 0;                                            // first output column of the loader's strip
+    auto setup_strip = [&](int c0) __attribute__((always_inline)) {
         const int cbsz = (plo + ple) >> 4;               // chunks per c-block
+        unsigned XC[W3_MAXK];
 #pragma unroll
         for (int k = 0; k < W3_MAXK; ++k) {
             const int j = wave + 4 * k;
@@ -103,42 +150,24 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
             const int q = rem2 >> 2, ch = rem2 & 3;
             const int ic = s == 1 ? c0 - 1 + q : (even ? 2 * (c0 + q) : 2 * (c0 + q) - 1);
             const int chan = (cb0 + cbi) * 32 + ch * 8;
-            const bool ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < p.XW) & (chan < p.C);
-            XC[k] = ok ? (unsigned)((ic * p.ldx + chan) * 2) : W3_XOOB;
+            const bool ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < Cc);
+            XC[k] = ok ? (unsigned)((ic * ldx + chan) * 2) : W3_XOOB;
         }
-    }
-    // ---- dy loader: pieces e = wave, wave + 4, .. of the NB * nsub pieces [n-block][sub-step]; lane l fetches chunk (l & 3) of
-    // pixel sub * 16 + (l >> 2) of the step = (row pp / TC, column pp % TC); the row index rides in the low bits of the offset
-    unsigned DC[W3_MAXD];
-#pragma unroll
-    for (int k = 0; k < W3_MAXD; ++k) {
-        const int e = wave + 4 * k;
-        int nbk = 0, sub = e;
-        while (sub >= nsub) { sub -= nsub; ++nbk; }
-        const unsigned pp = (unsigned)(sub * 16 + (lane >> 2));
-        const unsigned row = fdiv(pp, W3FD(dTC));
-        const int col = (int)(pp - row * (unsigned)TC);
-        const int chan = (nb0 + nbk) * 32 + (lane & 3) * 8;
-        const bool ok = (e < NB * nsub) & (pp < (unsigned)PX) & (c0 + col < p.OW) & (chan < p.N);
-        DC[k] = ok ? ((unsigned)((col * p.ldy + chan) * 2) | row) : W3_XOOB;
-    }
+        XC0 = XC[0]; XC1 = XC[1]; XC2 = XC[2];
+        c0_ld = c0;
+    };
     // ---- fragment geometry.  Sub-step `sub`, half h of its 16 pixels: this lane's pixel is 4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl
     // (TC % 4 == 0: the four pixels of a read lie in one output row); pixels beyond the step are clamped (their dy is zero, the
-    // x they meet only has to be finite)
+    // x they meet only has to be finite).  xoff(pp): byte offset of step pixel pp in the window (tap (0, 0), c-block 0).
     const int q16 = lane & 15, rowl = q16 >> 2;
     const unsigned chanb = (unsigned)(((q16 & 3) * 4 + ((lane >> 4) & 1) * 16) * 2);
-    unsigned XO[W3_MAXI][2];
-#pragma unroll
-    for (int i = 0; i < W3_MAXI; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int sub = slice + SL * i;
-            unsigned pp = (unsigned)(4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl);
-            pp = pp < (unsigned)PX ? pp : (unsigned)(PX - 1);
-            const unsigned row = fdiv(pp, W3FD(dTC));
-            const unsigned col = pp - row * (unsigned)TC;
-            XO[i][h] = row * (unsigned)(s * rowpitch) + col * 64u + chanb;
-        }
+    const unsigned srp = (unsigned)(s * rowpitch);
+    auto xoff = [&](unsigned pp) __attribute__((always_inline)) -> unsigned {
+        pp = pp < (unsigned)PX ? pp : (unsigned)(PX - 1);
+        const unsigned row = fdiv(pp, fTC);
+        return row * srp + (pp - row * (unsigned)TC) * 64u + chanb;
+    };
+    const unsigned pp_lane = (unsigned)(8 * (lane >> 5) + rowl);      // + 16 * sub + 4 * h
     const unsigned DYL = (unsigned)(((lane >> 5) * 8 + rowl) * 64) + chanb + (unsigned)(nb * nsub * 1024);
     // tap (dh, dw) -> byte offset inside the window, for this wavefront's c-block
     unsigned tapo[9];
@@ -155,71 +184,143 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    // DMA of step `st` into the stage at byte offset `sb`: the window's padded input rows V = s * u .. + nrows - 1 (row base
-    // uniform per row: out of range for padding rows), then the dy rows of the step's RPS virtual output rows
-    auto issue = [&](int st, unsigned sb) {
-        const unsigned us = u0 + (unsigned)(st * RPS);
-        const unsigned V0 = (unsigned)s * us;
-        const unsigned n0 = fdiv(V0, W3FD(dXP));
-        const unsigned vi0 = V0 - n0 * XP;
-        for (int r = 0; r < nrows; ++r) {
-            unsigned vi = vi0 + (unsigned)r, n = n0;
-            if (vi >= XP) { vi -= XP; ++n; }
-            const unsigned ih = vi - 1u;                              // vi == 0: the top padding row -> wraps to out of range
-            const bool ok = (ih < (unsigned)p.XH) & (n < (unsigned)p.B);
-            const unsigned rb = ok ? ((n * (unsigned)p.XH + ih) * (unsigned)p.XW) * (unsigned)p.ldx * 2u : G_OOB;
-            const unsigned la = lds_tiles + sb + (unsigned)(r * rowpitch + wave * 1024);
-#pragma unroll
-            for (int k = 0; k < W3_MAXK; ++k)
-                if (wave + 4 * k < ppr) glds16(rsX, la + (unsigned)(k * 4096), rb + XC[k]);
-        }
-        unsigned dyb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned u = us + (unsigned)r;
-            const unsigned n = fdiv(u, W3FD(dUP));
-            const unsigned oh = u - n * UP;
-            const bool ok = (r < RPS) & (oh < (unsigned)p.OH) & (u < u1);
-            dyb[r] = ok ? ((n * (unsigned)p.OH + oh) * (unsigned)p.OW + (unsigned)c0) * (unsigned)p.ldy * 2u : G_OOB;
-        }
-        const unsigned ly = lds_tiles + sb + (unsigned)(xstage + wave * 1024);
-#pragma unroll
-        for (int k = 0; k < W3_MAXD; ++k)
-            if (wave + 4 * k < NB * nsub) {
-                const unsigned row = DC[k] & 3u;
-                const unsigned b = row == 0 ? dyb[0] : (row == 1 ? dyb[1] : (row == 2 ? dyb[2] : dyb[3]));
-                glds16(rsY, ly + (unsigned)(k * 4096), b + (DC[k] & ~3u));
-            }
-    };
-    // the wavefront's sub-steps of the stage at `sb`: one dy fragment, nine shifted x fragments, nine MFMAs each
-    auto compute = [&](unsigned sb) {
-        const unsigned char* sx = smem_raw + sb;
-        const unsigned char* sy = smem_raw + sb + xstage + DYL;
-#pragma unroll
-        for (int i = 0; i < W3_MAXI; ++i) {
-            const int sub = slice + SL * i;
-            if (sub < nsub) {
-                const half8 a = w3_frag(sy + sub * 1024, sy + sub * 1024 + 256);
-                half8 b[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) b[t] = w3_frag(sx + (XO[i][0] + tapo[t]), sx + (XO[i][1] + tapo[t]));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    const unsigned stage = (unsigned)p.stage;
-    issue(0, 0u);
-    for (int st = 0; st < nsteps; ++st) {
-        const unsigned sb = (st & 1) ? stage : 0u;
-        wait_vm<0>();                            // step st landed (this wavefront's pieces) ...
-        __builtin_amdgcn_s_barrier();            // ... everyone's pieces landed, everyone finished reading step st - 1
-        if (st + 1 < nsteps) issue(st + 1, stage - sb);
-        compute(sb);
+    // ---- loader cursor: the step whose DMA is issued next.  (xn, xvi): image and padded row of the window's first row
+    // V = s * u; (yn, yoh, yu): image, row and virtual row of the step's first output row.  Both advance by a step without a division.
+    // (Macros over plain locals, not lambdas: with the mutable cursor captured by reference in nested lambdas hipcc kept the
+    // closure in memory -- every uniform counter became a scratch load in divergent control flow.)
+    unsigned xn = 0, xvi = 0, yn = 0, yoh = 0, yu = 0;
+#define W3_CURSOR_RESET()                                                    \
+    {                                                                        \
+        const unsigned V0_ = (unsigned)s * u0;                               \
+        const unsigned tq_ = __umulhi(fxm, V0_);                             \
+        xn = (tq_ + ((V0_ - tq_) >> fxs1)) >> fxs2;                          \
+        xvi = V0_ - xn * XP;                                                 \
+        const unsigned tu_ = __umulhi(fum, u0);                              \
+        yn = (tu_ + ((u0 - tu_) >> fus1)) >> fus2;                           \
+        yoh = u0 - yn * UP;                                                  \
+        yu = u0;                                                             \
     }
+#define W3_CURSOR_STEP()                                                     \
+    {                                                                        \
+        xvi += (unsigned)(s * RPS);                                          \
+        if (xvi >= XP) { xvi -= XP; ++xn; }                                  \
+        yoh += (unsigned)RPS; yu += (unsigned)RPS;                           \
+        if (yoh >= UP) { yoh -= UP; ++yn; }                                  \
+    }
+    // ---- DMA of the cursor's step into the stage at byte offset sb_: the window's padded input rows (row base uniform per row:
+    // out of range for padding rows), then the dy rows of the step's RPS virtual output rows: piece e = wave + 4 k of the NB * nsub
+    // pieces [n-block][sub-step]; lane l fetches chunk (l & 3) of pixel sub * 16 + (l >> 2) of the step = (row pp / TC, column
+    // pp % TC).  The row index is per lane, the four row bases are uniform: masks, not selects -- hipcc turns a chain of per-lane
+    // selects between SGPR values into divergent branches and then duplicates the DMA statement into them (its SGPR operands
+    // become VGPR phis: "invalid operand for instruction").
+    // Issued as one burst behind the barrier, in front of the step's MFMAs.  One piece behind every MFMA (k_gconv's schedule)
+    // was built and dropped: the piece cursor's branches between the MFMAs cost hipcc's register allocator the accumulators
+    // (16-byte spills around every MFMA, 540 bytes of scratch per lane).
+    // vi == 0: the top padding row -> vi - 1 wraps to out of range
+#define W3_ROW_BASE(vi_, n_) (((((vi_) - 1u) < XH) & ((n_) < Bn)) ? ((n_) * XH + ((vi_) - 1u)) * xrowb : G_OOB)
+#define W3_ISSUE(sb_)                                                                                \
+    {                                                                                                \
+        unsigned vi_ = xvi, n_ = xn;                                                                 \
+        unsigned la_ = lds_tiles + (sb_) + (unsigned)(wave * 1024);                                  \
+        for (int r_ = 0; r_ < nrows; ++r_) {                                                         \
+            const unsigned rb_ = W3_ROW_BASE(vi_, n_);                                               \
+            if (wave < ppr) glds16(rsX, la_, rb_ + XC0);                                             \
+            if (wave + 4 < ppr) glds16(rsX, la_ + 4096u, rb_ + XC1);                                 \
+            if (wave + 8 < ppr) glds16(rsX, la_ + 8192u, rb_ + XC2);                                 \
+            la_ += (unsigned)rowpitch;                                                               \
+            if (++vi_ >= XP) { vi_ = 0; ++n_; }                                                      \
+        }                                                                                            \
+        unsigned oh_ = yoh, n2_ = yn, u_ = yu;                                                       \
+        const unsigned dyb0 = ((oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;           \
+        ++u_; if (++oh_ >= UP) { oh_ = 0; ++n2_; }                                                   \
+        const unsigned dyb1 = ((1 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;   \
+        ++u_; if (++oh_ >= UP) { oh_ = 0; ++n2_; }                                                   \
+        const unsigned dyb2 = ((2 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;   \
+        ++u_; if (++oh_ >= UP) { oh_ = 0; ++n2_; }                                                   \
+        const unsigned dyb3 = ((3 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;   \
+        unsigned ly_ = lds_tiles + (sb_) + (unsigned)(xstage + wave * 1024);                         \
+        int nbk_ = 0, sub_ = wave;                                                                   \
+        for (int e_ = wave; e_ < ndy; e_ += 4) {                                                     \
+            while (sub_ >= nsub) { sub_ -= nsub; ++nbk_; }                                           \
+            const unsigned pp_ = (unsigned)(sub_ * 16 + (lane >> 2));                                \
+            unsigned row_ = fdiv(pp_, fTC);                                                          \
+            const int col_ = (int)(pp_ - row_ * (unsigned)TC);                                       \
+            const int chan_ = (nb0 + nbk_) * 32 + (lane & 3) * 8;                                    \
+            const bool okd_ = (pp_ < (unsigned)PX) & (c0_ld + col_ < OW) & (chan_ < Nn);             \
+            const unsigned dc_ = okd_ ? (unsigned)(((c0_ld + col_) * ldy + chan_) * 2) : W3_XOOB;    \
+            asm volatile("" : "+v"(row_));                                                           \
+            const unsigned bb_ = (dyb0 & (0u - (unsigned)(row_ == 0))) | (dyb1 & (0u - (unsigned)(row_ == 1))) |   \
+                                 (dyb2 & (0u - (unsigned)(row_ == 2))) | (dyb3 & (0u - (unsigned)(row_ == 3)));    \
+            glds16_b(rsY, ly_, bb_ + dc_);                                                           \
+            ly_ += 4096u; sub_ += 4;                                                                 \
+        }                                                                                            \
+    }
+
+    W3_MARK();                                   // 1: prologue done
+    const int G = nstrips * nsteps;              // steps of the item, strip after strip
+    int strip_ld = 0, st_ld = 0;
+    setup_strip(0);
+    W3_CURSOR_RESET()
+    W3_ISSUE(0u)
+    W3_MARK();                                   // 2: first issue done
+    const unsigned char* sy0 = smem_raw + xstage + DYL;
+    for (int g = 0; g < G; ++g) {
+        const unsigned sb = (g & 1) ? stage : 0u;
+        wait_vm<0>();                            // step g landed (this wavefront's pieces) ...
+        W3_MARK();                               // 3 + 4 g: DMA waited for
+        __builtin_amdgcn_s_barrier();            // ... everyone's pieces landed, everyone finished reading step g - 1
+        W3_MARK();                               // 4 + 4 g: barrier passed
+        if (g + 1 < G) {
+            if (++st_ld == nsteps) {
+                st_ld = 0; ++strip_ld;
+                setup_strip(strip_ld * TC);
+                W3_CURSOR_RESET()
+            } else W3_CURSOR_STEP()
+            W3_ISSUE(stage - sb)
+        }
+        W3_MARK();                               // 5 + 4 g: next step issued
+        // The wavefront's sub-steps of the stage at `sb`: one dy fragment and nine shifted x fragments feed nine MFMAs.  Software
+        // pipeline: the fragments of the NEXT sub-step are fetched behind the MFMAs of this one that read the registers they
+        // replace (x fragment t right after MFMA t, the dy fragment into a second register set), so the LDS latency and the
+        // address adds run in the matrix pipe's shadow -- a wavefront alone on its SIMD otherwise alternates ~400 cycles of
+        // fetch with 288 of MFMA (first probe: 60 cycles per MFMA).
+        if (slice < nsub) {
+            const unsigned char* sx = smem_raw + sb;
+            const unsigned char* sy = sy0 + sb;
+            int sub = slice;
+            unsigned ppc = pp_lane + (unsigned)(16 * sub);
+            unsigned xo0 = xoff(ppc), xo1 = xoff(ppc + 4u);
+            half8 a = w3_frag(sy + sub * 1024, sy + sub * 1024 + 256);
+            half8 b[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) b[t] = w3_frag(sx + (xo0 + tapo[t]), sx + (xo1 + tapo[t]));
+            __builtin_amdgcn_sched_barrier(0);
+            while (true) {
+                const int subn = sub + SL;
+                if (subn >= nsub) break;
+                ppc += (unsigned)(16 * SL);
+                xo0 = xoff(ppc); xo1 = xoff(ppc + 4u);
+                const half8 an = w3_frag(sy + subn * 1024, sy + subn * 1024 + 256);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
+                    b[t] = w3_frag(sx + (xo0 + tapo[t]), sx + (xo1 + tapo[t]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                a = an;
+                sub = subn;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        W3_MARK();                               // 6 + 4 g: MFMAs issued
+    }
+#undef W3_CURSOR_RESET
+#undef W3_CURSOR_STEP
+#undef W3_ROW_BASE
+#undef W3_ISSUE
     // the accumulators are read below: MFMA result hazard (see AY_MFMA_PAD in conv.hip)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 11" ::: "memory");
@@ -270,6 +371,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
     }
 #undef p
 #undef W3FD
+#ifdef AYOLO_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) { s_probe[W3_PROBE_N - 1] = t_; s_probe[W3_PROBE_N - 2] = (unsigned long long)probe_k; }
+    }
+    __syncthreads();
+    if (blockIdx.x < 512 && threadIdx.x < W3_PROBE_N) g_probe3[blockIdx.x * W3_PROBE_N + threadIdx.x] = s_probe[threadIdx.x];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -309,8 +419,10 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
     else { p.NB = 1; p.CB = 2; }
     p.NP = p.NB * p.CB; p.SL = 4 / p.NP;
     p.tn = (NBt + p.NB - 1) / p.NB; p.tc = (CBt + p.CB - 1) / p.CB;
-    // step geometry: the (TC, RPS) with the least modelled time per output pixel -- MFMA cycles of a wavefront's sub-steps (a
-    // 16-pixel sub-step costs its 9 MFMAs whether its pixels are live or not) + ~25 cycles per DMA piece of the workgroup
+    // step geometry: the (TC, RPS) with the least modelled time per output pixel.  A step costs ~600 cycles of barrier / waits /
+    // cursor work, ~100 cycles per DMA piece of a wavefront (interleaved with the MFMAs) and ~45 per MFMA with the fragment fetch
+    // pipelined behind it -- a 16-pixel sub-step costs its 9 MFMAs whether its pixels are live or not; a stage over 40 KiB means
+    // one workgroup per CU instead of two (tools/w3_probe.py prints the marks these numbers come from)
     double best = 1e30;
     for (int TC = 4; TC <= 96; TC += 4)
         for (int RPS = 1; RPS <= 4; ++RPS) {
@@ -325,7 +437,9 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
             if (stage > W3_STAGE_MAX) continue;
             const int strips = (p.OW + TC - 1) / TC;
             const int wsub = (nsub + p.SL - 1) / p.SL;
-            const double t = (double)strips * (288.0 * wsub + 25.0 * (nrows * ppr + p.NB * nsub)) / ((double)RPS * p.OW);
+            const double pieces = (double)((nrows * ppr + p.NB * nsub + 3) / 4);
+            double t = (double)strips * (600.0 + 405.0 * wsub + 100.0 * pieces) / ((double)RPS * p.OW);
+            if (stage > W3_STAGE_MAX / 2) t *= 1.15;
             if (t < best - 1e-9) {
                 best = t;
                 p.TC = TC; p.RPS = RPS; p.PX = PX; p.nsub = nsub; p.strips = strips;
@@ -341,8 +455,8 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
 }
 
 void w3_split(W3P& p, double steps) {
-    const unsigned total = (p.NU + (unsigned)p.RPS - 1) / (unsigned)p.RPS;        // steps of one (tile, strip)
-    double q = steps < 2.0 ? 2.0 : steps;
+    const unsigned total = (p.NU + (unsigned)p.RPS - 1) / (unsigned)p.RPS;        // steps of one strip over all rows
+    double q = steps / p.strips < 2.0 ? 2.0 : steps / p.strips;                   // an item walks its rows once per strip
     unsigned n = (unsigned)((double)total / q + 0.5);
     if (n < 1) n = 1;
     unsigned per = (total + n - 1) / n;

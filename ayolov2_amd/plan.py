@@ -74,7 +74,7 @@ BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
 # Weight gradients run as a few GROUPED launches (ayolo_wgrad_group_run: one launch per tile class over the item list of all
 # layers of a group + one fixed-order reduction of the split-K partials) instead of one launch per layer.  The backward list is
 # cut into this many groups of similar work (the last one is halved AYOLO_WGRAD_TAIL more times: what the final group still has
-# to do when the main stream's backward ends is exposed); 0 = one launch per layer (same kernels, for A/B).
+# to do when the main stream's backward ends is exposed).
 # Transform on load (ayolo_conv_fwd_xf): the BatchNorm + SiLU pass of a Conv block whose activation has exactly ONE reader, a
 # 1x1 / stride-1 conv, is not launched -- that conv (and its weight gradient) read the block's pre-activation z and form the
 # activation on the way to the MFMAs; the block keeps a tiny finalize launch (batch statistics -> scale / shift, running stats)
@@ -84,10 +84,12 @@ XF_FINALIZE_IN_READER = _os.environ.get("AYOLO_XF_FIN", "1") == "1"      # the f
 # from its first channel tile ("store-back": the pass and its z read are still gone, the write stays); 1 = the pre-activation z,
 # transformed on load in k_wgrad too (no write at all, but the transform then runs on the weight-gradient stream, where it cost
 # the step more than the write does: same-box A/B, profiles/r04_ab_xf_*)
-XF_WGRAD_ON_LOAD = _os.environ.get("AYOLO_XF_WGRAD", "0") == "1"
+# (no environment switch since round 5: the on-load route lost its A/B; tests flip this attribute to pin it against the default)
+XF_WGRAD_ON_LOAD = False
 # The group count follows the weight gradients' total work (32-pixel steps x dw tiles, `cost` below): one group per ~0.36 M
 # tile-steps, between 4 and 8 -- YOLOv5s at batch 64 (1.45 M) is fastest with 4 (profiles/r04_ab_wgrad_sweep.txt), YOLOv5l at
-# batch 32 (3.56 M) with 8 (profiles/r04_cfg3_ab.txt); AYOLO_WGRAD_GROUPS pins it (0 = one launch per layer, for A/B).
+# batch 32 (3.56 M) with 8 (profiles/r04_cfg3_ab.txt); AYOLO_WGRAD_GROUPS=n pins it (the one-launch-per-layer
+# route of round 4's A/B -- +0.67 ms, profiles/r04_ab_wgrad_groups.txt -- is gone).
 WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "-1"))
 WGRAD_GROUP_WORK = 0.36e6
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
@@ -187,6 +189,7 @@ class TrainPlan:
         self._head_dz: Dict[int, Tuple[int, int]] = {}
         self._wjobs: List[dict] = []                        # weight-gradient jobs in backward order (grouped after emission)
         self._reads: List[tuple] = []                       # (root Act id, c_lo, c_hi, kind, consumer record): who reads which activation
+        self._reads_at: set = set()                         # forward-list lengths at which a read was registered (see _read)
         self._producers: List[dict] = []                    # Conv-BN-act blocks: candidates for transform on load
         self.xf_layers = 0                                  # blocks whose BatchNorm + activation pass was folded into the consumer
         self.wgroup_costs: Dict[int, Tuple[float, float, int]] = {}   # backward op index -> (bytes, flop, layers) of a group launch
@@ -211,6 +214,13 @@ class TrainPlan:
         if off is not None:
             self.grad_done.append((len(self.bwd) - 1 if at is None else at, off, n))
 
+    def _read(self, act: "Act", kind: str, consumer: Optional[dict] = None) -> None:
+        """EVERY forward emitter registers the activations its op reads here (the transform-on-load pass decides from
+        this list whether an activation has exactly one 1x1 reader and may stay virtual -- a reader that is not registered
+        would see an unmaterialised activation).  _emit_fwd checks that no forward op was appended without a registration."""
+        self._reads.append((id(act.root), act.c0, act.c0 + act.C, kind, consumer))
+        self._reads_at.add(len(self.fwd))
+
     def _gw(self, act: "Act", is_dgrad: bool) -> None:
         """The backward op just appended writes (or accumulates into) the gradient of `act`."""
         self._gwrites.append((len(self.bwd) - 1, id(act.root), act.c0, act.c0 + act.C, is_dgrad))
@@ -218,7 +228,7 @@ class TrainPlan:
     def _dz(self, n: int) -> torch.Tensor:
         """Backward operand dz of one layer: a slice of the shared scratch buffer, or -- when weight gradients run on the
         side stream and therefore outlive the layer's turn -- a buffer of its own."""
-        if WGRAD_SIDE_STREAM or WGRAD_GROUPS != 0:           # grouped launches also read dz long after the layer's turn
+        if True:                                             # grouped launches read dz long after the layer's turn
             t = torch.empty(n, dtype=self.dt, device=self.device)
             self.keep.append(t)
             return t
@@ -264,21 +274,6 @@ class TrainPlan:
             fl = sum(2.0 * j["desc"].B * j["desc"].Ho * j["desc"].Wo * j["desc"].Cout * j["desc"].kh * j["desc"].kw * j["desc"].Cin for j in js)
             return float(by), fl, len({j["off"] for j in js})       # layers (a two-segment conv is two jobs over one weight)
 
-        if WGRAD_GROUPS == 0:
-            # one launch per layer (A/B against the grouped launches): the same kernels, a shared split-K workspace
-            need = max(int(lib.ayolo_conv_wgrad_workspace(j["desc"])) for j in jobs)
-            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
-            self.keep.append(ws)
-            for j in jobs:
-                assert j["xf"] is None and not j["dw_ld"], "transform on load needs the grouped weight-gradient launches"
-                o = _op(OP_CONV_WGRAD | side, f=(1.0,), l=(ws.numel(),), p=(j["x"], j["dy"], ga.view(j["off"], j["n"]), ws), conv=j["desc"])
-                self.bwd[j["idx"]] = o
-                self.grad_done.append((j["idx"], j["off"], j["n"]))
-                if j["slot"] >= 0:
-                    self.wgroup_slots.append((j["idx"], j["slot"]))
-            self.wgroup_single = True
-            return
-        self.wgroup_single = False
         # ---- cut the jobs (backward order) into groups of similar work; the tail is cut finer
         costs = [cost(j) for j in jobs]
         total = float(sum(costs))
@@ -405,13 +400,15 @@ class TrainPlan:
         npix = self.B * geo.Ho * geo.Wo
         op_conv = _op(OP_CONV_FWD, i=(EPI_NONE, R, 0), p=(xk, wc, z.t, None, None, None), conv=geo.desc(dt, ldx, Ct))
         self.fwd.append(op_conv)
-        if not image:
+        if image:
+            self._reads_at.add(len(self.fwd))                 # the stem reads the packed image, not an activation
+        else:
             pointwise = (kh, kw) == (1, 1) and _pair(convs[0].stride) == (1, 1) and _pair(convs[0].padding) == (0, 0) and geo.Cin_k == Cin
             if pointwise:
                 cx["xs_off"] = self.small.request(2 * Cin)           # scale | shift over the conv's input channels (transform on load)
-            self._reads.append((id(x.root), x.c0, x.c0 + x.C, "conv", dict(op=op_conv, cx=cx, pointwise=pointwise, cin=Cin, cout=Ct, x=x)))
+            self._read(x, "conv", dict(op=op_conv, cx=cx, pointwise=pointwise, cin=Cin, cout=Ct, x=x))
             if residual is not None:
-                self._reads.append((id(residual.root), residual.c0, residual.c0 + residual.C, "residual", None))
+                self._read(residual, "residual")
         self.late.append(lambda: op_conv.p.__setitem__(5, self.stats.view(st_off, R * 2 * Ct).data_ptr()))
         self.fwd_sync.append((op_conv, st_off, R * 2 * Ct))            # sync_bn: all-reduce of the batch statistics
         K = geo.kdims[0] * geo.kdims[1] * geo.Cin_k
@@ -548,8 +545,13 @@ class TrainPlan:
         shortcut keep the materialised pass.  Measured per layer: profiles/r04_xf_forward_sweep.txt (the pair of launches costs
         1.2-2.5x the fused one; it loses only where the channel table and the per-channel-tile repetition of the transform
         weigh in: Cin x channel tiles > 1024)."""
-        if not XF_ON_LOAD or self.dt != torch.float16 or WGRAD_GROUPS == 0:
+        if not XF_ON_LOAD or self.dt != torch.float16:
             return
+        # the invariant this pass stands on: every forward op that reads an activation registered the read (_read) right behind
+        # its append -- a new reader kind added without it must fail here, not compute on an unmaterialised activation
+        for i, o in enumerate(self.fwd):
+            if (o.kind & 0xff) in (OP_CONV_FWD, OP_MAXPOOL_FWD, OP_UPSAMPLE_FWD) and (i + 1) not in self._reads_at:
+                raise AssertionError(f"forward op {i} (kind {o.kind & 0xff}) reads an activation without a _read registration")
         for rd in self._reads:
             root, rlo, rhi, kind, c = rd
             if kind != "conv" or not c["pointwise"] or c["cx"]["segs"] is not None:
@@ -703,7 +705,7 @@ class TrainPlan:
         code = ops.dtype_code(self.dt)
         lds, ldd = ops.nhwc_info(src.t)[4], ops.nhwc_info(dst.t)[4]
         self.fwd.append(_op(OP_MAXPOOL_FWD, i=(code, lds, ldd, B, H, W, C, k), p=(src.t, dst.t, arg)))
-        self._reads.append((id(src.root), src.c0, src.c0 + src.C, "pool", None))
+        self._read(src, "pool")
 
         def emit():
             dy, dx = dst.grad(), src.grad()
@@ -729,7 +731,7 @@ class TrainPlan:
         out = dst if dst is not None else self._new_act(C, 2 * H, 2 * W)
         code = ops.dtype_code(self.dt)
         self.fwd.append(_op(OP_UPSAMPLE_FWD, i=(code, ops.nhwc_info(x.t)[4], ops.nhwc_info(out.t)[4], B, H, W, C), p=(x.t, out.t)))
-        self._reads.append((id(x.root), x.c0, x.c0 + x.C, "upsample", None))
+        self._read(x, "upsample")
 
         def emit():
             dy, dx = out.grad(), x.grad()
@@ -753,6 +755,11 @@ class TrainPlan:
             cp = F_._round_up(Cout, 8)
             B, _, H, W = x.t.shape
             geo = F_._Geometry(tuple(x.t.shape), conv.weight.shape, (1, 1), (0, 0), dt)
+            # a grouped weight-gradient job whose dy arrives through an override slot cannot be cut into batch halves
+            # (csrc/conv.hip wgrad_halves): a level over the 2 GiB descriptor range goes to the per-module path
+            es_ = 2 if dt == torch.float16 else 4
+            if B * H * W * max(ops.nhwc_info(x.t)[4], cp) * es_ >= (1 << 31) - 4096:
+                raise PlanUnsupported("head level over the 2 GiB buffer-descriptor range")
             wc = torch.empty((cp, 1, 1, Cin), dtype=dt, device=dev)
             wt = torch.empty((Cin, 1, 1, cp), dtype=dt, device=dev)
             buf = torch.empty((B, H, W, cp), dtype=torch.float32, device=dev)
@@ -762,7 +769,7 @@ class TrainPlan:
             op_head = _op(OP_CONV_FWD, i=(EPI_HEAD, 1, head.no), p=(x.t, wc, buf, None, conv.bias, None), conv=geo.desc(dt, ldx, cp))
             self.fwd.append(op_head)
             cx = dict(x=x.t, ldx=ldx, xf=None, segs=None, xs_off=self.small.request(2 * Cin))
-            self._reads.append((id(x.root), x.c0, x.c0 + x.C, "conv", dict(op=op_head, cx=cx, pointwise=True, cin=Cin, cout=cp, x=x)))
+            self._read(x, "conv", dict(op=op_head, cx=cx, pointwise=True, cin=Cin, cout=cp, x=x))
             gw_off = self._register_param(conv.weight, cp * Cin, lambda b, Cout=Cout, Cin=Cin: b.view(-1, Cin)[:Cout].view(Cout, Cin, 1, 1))
             gb_off = self._register_param(conv.bias, Cout, lambda b: b) if conv.bias is not None else None
             self.raw_specs.append((buf, (B, head.na, H, W, head.no), (H * W * cp, head.no, W * cp, cp, 1), gb_off, Cout))
@@ -1144,10 +1151,7 @@ class TrainPlan:
         """this step's dz of head level `lvl` -> the weight-gradient launch that carries that level"""
         for k, slot in self.wgroup_slots:
             if slot == lvl:
-                if self.wgroup_single:
-                    self.bwd_arr[k].p[1] = ptr
-                else:
-                    self.bwd_arr[k].p[3 + lvl] = ptr
+                self.bwd_arr[k].p[3 + lvl] = ptr
 
     def run_backward(self, draws: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
         from .losses import take_packed_head_grad

@@ -40,9 +40,12 @@ def _level_rows(n_rows: int, nl: int) -> List[int]:
 
 def _kept(n_rows: int, nl: int, first: bool, last: bool) -> Tuple[int, int]:
     """[lo, hi) of the rows an augmentation contributes: the first one loses its coarsest level (its tail), the last one its
-    finest level (its head)."""
+    finest level (its head).  A single augmentation is both: the reference cuts the tail first and then takes the head cut
+    from the SHORTENED row count (tta_utils.py:54-58: `y[-1].shape[1] // g` after `y[0] = y[0][:, :-i]`), golden G9 `y_single`."""
     lv = _level_rows(n_rows, nl)
-    return (lv[0] if last else 0), (n_rows - lv[-1] if first else n_rows)
+    hi = n_rows - lv[-1] if first else n_rows
+    lo = _level_rows(hi, nl)[0] if last else 0
+    return lo, hi
 
 
 def _undo(dst: torch.Tensor, src: torch.Tensor, flip: Optional[int], scale: float, img_size: Sequence[int]) -> None:
@@ -104,7 +107,10 @@ def inference_with_tta(model: nn.Module, x: torch.Tensor, s: Sequence[float], f:
             plan.run_augmented(xi, merged, base - lo, (base, base + hi - lo), s[k], fi, extent)
             base += hi - lo
         return merged, None
-    preds = [model(xi)[0] for xi in xs]
+    # (a model that returns views of plan-owned static storage -- YOLOModel.static_outputs -- would hand the SAME buffer back for
+    # two augmentations of one input shape: keep a copy of each prediction then)
+    static = bool(getattr(model, "static_outputs", False))
+    preds = [model(xi)[0].clone() if static else model(xi)[0] for xi in xs]
     keep = [_kept(p.shape[1], nl, k == 0, k == n_aug - 1) for k, p in enumerate(preds)]
     total = sum(hi - lo for lo, hi in keep)
     merged = preds[0].new_empty((preds[0].shape[0], total, preds[0].shape[2]))

@@ -104,18 +104,20 @@ def pmc_traffic(families):
     return (round(tot, 3) if tot else None), src
 
 
-def pmc_traffic_live(families, steps=3, warm=2, timeout=150):
+def pmc_traffic_live(families, workload=(), steps=3, warm=2, timeout=150):
     """HBM bytes per step of a kernel family measured IN THIS RUN: two child runs of this file (train step only) under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no other trace domain), summed per kernel,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if rocprofv3 is not on the box, a pass fails or
-    AYOLO_BENCH_PMC=0 -- the caller then reports the newest committed summary instead."""
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  `workload`: the parent's --model / --batch / --size flags,
+    so that the bytes belong to the configuration being timed.  Opt-in since round 5 (AYOLO_BENCH_PMC=1: +35 s per run): by
+    default -- and when rocprofv3 is not on the box or a pass fails -- the caller reports the newest committed summary
+    (profiles/r*_pmc_hbm_traffic.json, made by tools/profile_round.sh from the same two passes) with its file and commit."""
     import csv
     import glob
     import shutil
     import signal
     import subprocess
     import tempfile
-    if os.environ.get("AYOLO_BENCH_PMC", "1") != "1" or shutil.which("rocprofv3") is None:
+    if os.environ.get("AYOLO_BENCH_PMC", "0") != "1" or shutil.which("rocprofv3") is None:
         return None
     tot, launches = 0.0, 0
     try:
@@ -126,7 +128,7 @@ def pmc_traffic_live(families, steps=3, warm=2, timeout=150):
                    and not k.startswith("TORCHELASTIC_")}
             env.update(TMPDIR="/tmp", AYOLO_BENCH_PMC="0")
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-                   os.path.abspath(__file__), "--no-extras", "--steps", str(steps), "--warmup", str(warm)]
+                   os.path.abspath(__file__), "--no-extras", "--steps", str(steps), "--warmup", str(warm)] + list(workload)
             # own process group: a pass that outlives its limit is ended together with the python it started (by that exact pgid)
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
@@ -153,7 +155,7 @@ def pmc_traffic_live(families, steps=3, warm=2, timeout=150):
             "how": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over {nsteps} train steps of a child run of this file, FETCH_SIZE x2 (gfx950)"}
 
 
-def in_situ_roofline(model, one_step, ms_per_step, batch):
+def in_situ_roofline(model, one_step, ms_per_step, batch, workload=()):
     """Roofline of the dominant kernel family measured INSIDE the real train step: the plan executor re-runs a few steps in
     its measurement mode (ayolo_run_ops_timed: a HIP event before and after every op on the stream the op runs on, so cold
     caches and the concurrent side-stream weight gradients are in the number) and the per-op times are grouped by family.
@@ -183,7 +185,7 @@ def in_situ_roofline(model, one_step, ms_per_step, batch):
         tf = sum(fam[n][2] for n in names if n in fam) / 1e12
         return ms, gb, tf
     ms, gb, tf = view(("conv_fwd", "conv_dgrad"))
-    live = pmc_traffic_live(("k_gconv", "k_dgrad_s2"))
+    live = pmc_traffic_live(("k_gconv", "k_dgrad_s2"), workload)
     traffic, src = pmc_traffic(("k_gconv", "k_dgrad_s2"))
     if live is not None:
         traffic, src = live["gb_per_step"], "measured in this run: " + live["how"]
@@ -647,7 +649,8 @@ def main():
         ms = el / args.steps * 1e3
         value = world * args.batch * args.steps / el
         out = {
-            "metric": "img/s fwd+bwd YOLOv5s 640x640 bs=64 train step", "value": round(value, 2), "unit": "img/s",
+            "metric": f"img/s fwd+bwd {args.model.replace('yolov5', 'YOLOv5')} {args.size}x{args.size} bs={args.batch} train step",
+            "value": round(value, 2), "unit": "img/s",
             "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.size}x{args.size} per-GPU batch {args.batch}: forward + ComputeLoss "
@@ -657,7 +660,8 @@ def main():
             "step_frac_of_mfma_peak": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / world / MFMA_PEAK_TFLOPS, 4),
         }
         if not args.no_extras and world == 1:
-            out["roofline"] = in_situ_roofline(model, step, ms, args.batch)
+            out["roofline"] = in_situ_roofline(model, step, ms, args.batch,
+                                               ("--model", args.model, "--batch", str(args.batch), "--size", str(args.size)))
             out["extra"] = nms_extra(device)
             try:
                 out["extra"].update(config_extras(device))

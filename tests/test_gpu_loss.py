@@ -222,45 +222,3 @@ def test_prepare_staging_is_not_overwritten_by_the_next_step():
         got.append(cl(preds, td, prepared=prep)[0])
     torch.cuda.synchronize()
     np.testing.assert_allclose([float(g) for g in got], want, rtol=1e-6)
-
-
-def test_loss_gradient_row_writer_equals_fill_and_scatter_route(monkeypatch):
-    """The packed YOLOHead gradient written as whole rows in one pass (k_loss_grad_packed<T, 3>: zeros + the objectness groups)
-    against the three-stage route it replaces (zero fill, then the objectness groups as scattered 16-byte writes;
-    AYOLO_LOSS_ROWS=0): the same dz bits, hence -- the grouped weight gradients being bit-reproducible -- bit-identical parameter gradients,
-    with duplicate-cell rows in the batch and a map whose pixel count is not a multiple of the writer's 64-pixel pass."""
-    import copy
-    from ayolov2_amd import YOLOModel
-    from ayolov2_amd.losses import ComputeLoss
-    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ayolov2_amd", "configs", "yolov5n.yaml")
-    torch.manual_seed(9)
-    m = YOLOModel(cfg).cuda().train()
-    m.hyp, m.gr, m.nc = _mini_hyp(), 1.0, 80
-    m2 = copy.deepcopy(m)
-    x = torch.rand(3, 3, 96, 160).cuda()                      # levels of 12 x 20, 6 x 10, 3 x 5 pixels per image
-    nt = 30
-    targets = torch.cat((torch.randint(0, 3, (nt, 1)).float(), torch.randint(0, 80, (nt, 1)).float(),
-                         torch.rand(nt, 2) * 0.9 + 0.05, torch.rand(nt, 2) * 0.3 + 0.02), 1)
-    targets = torch.cat((targets, targets[:6]), 0)
-    grads = []
-    for mod, rows in ((m, "1"), (m2, "0")):
-        monkeypatch.setenv("AYOLO_LOSS_ROWS", rows)
-        cl = ComputeLoss(mod)
-        cl.packed_head_grad = True
-        with torch.autocast("cuda", dtype=torch.float16):
-            preds = mod(x)
-        prepared = cl.prepare(targets, [tuple(p.shape) for p in preds], device=x.device)
-        loss, _ = cl(preds, targets.cuda(), prepared=prepared)
-        (loss * 64.0).backward()
-        torch.cuda.synchronize()
-        grads.append({n: p.grad.detach().clone() for n, p in mod.named_parameters()})
-    # Two kinds of parameter are summed with fp32 atomics whose order is not fixed: the stem's weight (one set of atomics per
-    # workgroup of k_stem_wgrad) and the YOLOHead biases (the loss kernels add their per-workgroup partials, and the two routes
-    # cut the pixels into workgroups differently).  Everything that READS dz -- every conv weight incl. the head's -- is bit-equal.
-    differ = [n for n, g1 in grads[0].items() if not torch.equal(g1, grads[1][n])]
-    loose = {"model.0.conv.weight"} | {n for n in grads[0] if n.startswith("model.24.conv.") and n.endswith(".bias")}
-    assert set(differ) <= loose, differ
-    assert all(not torch.equal(g, torch.zeros_like(g)) for n, g in grads[0].items() if n.startswith("model.24.conv."))
-    for n in differ:
-        g1, g2 = grads[0][n].float(), grads[1][n].float()
-        assert float((g1 - g2).abs().max()) <= 1e-5 * float(g2.abs().max()), n

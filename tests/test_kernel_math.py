@@ -118,8 +118,9 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
     lane = np.arange(64)
     uch = RPS * steps_per_item
     uranges = -(-NU // uch)
-    slots = np.zeros((strips * uranges, N, K))
-    written = np.zeros((strips * uranges, N, K), dtype=np.int32)
+    slots = np.zeros((uranges, N, K))
+    written = np.zeros((uranges, N, K), dtype=np.int32)
+    xrowb, yrowb = XW * ldx * 2, OW * ldy * 2
 
     def dma(lds, dst, buf, nbytes, off):
         """one LDS-DMA piece: lane l moves 16 bytes from byte offset off[l] (zeros beyond the descriptor) to LDS dst + 16 l"""
@@ -139,112 +140,144 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
             F[px[:, None], ch[:, None] + np.arange(4)] = lds[(a // 2)[:, None] + np.arange(4)]
         return F
 
+    q16 = lane & 15
+    rowl = q16 >> 2
+    chanb = ((q16 & 3) * 4 + ((lane >> 4) & 1) * 16) * 2
+
+    def xoff(pp):
+        pp = np.minimum(pp, PX - 1)
+        return (pp // TC) * (s * rowpitch) + (pp % TC) * 64 + chanb
+
     for tile in range(tn * tc):
-        for zz in range(strips * uranges):
+        for zz in range(uranges):
             tni, tci = tile // tc, tile % tc
             nb0, cb0 = tni * NB, tci * CB
-            strip, ur = zz % strips, zz // strips
-            c0 = strip * TC
-            u0 = ur * uch
+            u0 = zz * uch
             u1 = min(u0 + uch, NU)
             nsteps = -(-(u1 - u0) // RPS)
             lds = np.full(max(g["lds"], 2 * stage) // 2, np.nan, dtype=np.float16)
             acc = np.zeros((4, 9, 32, 32))
-            # per-wave constants
             wc = []
             for wave in range(4):
                 pair = wave & (NP - 1)
                 slice_ = wave if NP == 1 else (wave >> 1 if NP == 2 else 0)
                 nb, cb = (pair >> 1, pair & 1) if CB == 2 else (pair, 0)
-                cbsz = (plo + ple) >> 4
-                XC = []
-                for k in range(3):
-                    j = wave + 4 * k
-                    ci = j * 64 + lane
-                    cbi = (ci >= cbsz).astype(int)
-                    rem = ci - cbi * cbsz
-                    even = rem >= (plo >> 4)
-                    rem2 = np.where(even, rem - (plo >> 4), rem)
-                    q, ch = rem2 >> 2, rem2 & 3
-                    ic = c0 - 1 + q if s == 1 else np.where(even, 2 * (c0 + q), 2 * (c0 + q) - 1)
-                    chan = (cb0 + cbi) * 32 + ch * 8
-                    ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < C)
-                    XC.append(np.where(ok, (ic * ldx + chan) * 2, XOOB))
-                DC = []
-                for k in range(6):
-                    e = wave + 4 * k
-                    nbk, sub = 0, e
-                    while sub >= nsub:
-                        sub -= nsub
-                        nbk += 1
-                    pp = sub * 16 + (lane >> 2)
-                    row, col = pp // TC, pp % TC
-                    chan = (nb0 + nbk) * 32 + (lane & 3) * 8
-                    ok = (e < NB * nsub) & (pp < PX) & (c0 + col < OW) & (chan < N)
-                    DC.append(np.where(ok, ((col * ldy + chan) * 2) | row, XOOB))
-                q16 = lane & 15
-                rowl = q16 >> 2
-                chanb = ((q16 & 3) * 4 + ((lane >> 4) & 1) * 16) * 2
-                XO = {}
-                for i in range(6):
-                    for h in range(2):
-                        sub = slice_ + SL * i
-                        pp = np.minimum(4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl, PX - 1)
-                        XO[i, h] = (pp // TC) * (s * rowpitch) + (pp % TC) * 64 + chanb
-                DYL = ((lane >> 5) * 8 + rowl) * 64 + chanb + nb * nsub * 1024
                 tapo = []
                 for t in range(9):
                     dh, dw = t // 3, t % 3
                     colo = dw * 64 if s == 1 else (plo if dw == 1 else (64 if dw == 2 else 0))
                     tapo.append(dh * rowpitch + cb * (plo + ple) + colo)
-                wc.append(dict(pair=pair, slice=slice_, nb=nb, cb=cb, XC=XC, DC=DC, XO=XO, DYL=DYL, tapo=tapo))
+                DYL = ((lane >> 5) * 8 + rowl) * 64 + chanb + nb * nsub * 1024
+                wc.append(dict(pair=pair, slice=slice_, nb=nb, cb=cb, DYL=DYL, tapo=tapo))
 
-            def issue(st, sb):
-                us = u0 + st * RPS
-                V0 = s * us
-                n0, vi0 = V0 // XP, V0 % XP
+            def setup_strip(c0):
+                cbsz = (plo + ple) >> 4
+                for wave in range(4):
+                    XC = []
+                    for k in range(3):
+                        j = wave + 4 * k
+                        ci = j * 64 + lane
+                        cbi = (ci >= cbsz).astype(int)
+                        rem = ci - cbi * cbsz
+                        even = rem >= (plo >> 4)
+                        rem2 = np.where(even, rem - (plo >> 4), rem)
+                        q, ch = rem2 >> 2, rem2 & 3
+                        ic = c0 - 1 + q if s == 1 else np.where(even, 2 * (c0 + q), 2 * (c0 + q) - 1)
+                        chan = (cb0 + cbi) * 32 + ch * 8
+                        ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < C)
+                        XC.append(np.where(ok, (ic * ldx + chan) * 2, XOOB))
+                    wc[wave]["XC"] = XC
+
+            cur = {}
+
+            def cursor_reset():
+                V0 = s * u0
+                cur.update(xn=V0 // XP, xvi=V0 % XP, yn=u0 // UP, yoh=u0 % UP, yu=u0)
+
+            def cursor_step():
+                cur["xvi"] += s * RPS
+                if cur["xvi"] >= XP:
+                    cur["xvi"] -= XP
+                    cur["xn"] += 1
+                cur["yoh"] += RPS
+                cur["yu"] += RPS
+                if cur["yoh"] >= UP:
+                    cur["yoh"] -= UP
+                    cur["yn"] += 1
+
+            def row_base(vi, n):
+                ih = (vi - 1) & M32
+                return (n * XH + ih) * xrowb if (ih < XH and n < B) else G_OOB
+
+            def issue(sb, c0):
                 for wave in range(4):
                     w = wc[wave]
+                    vi, n = cur["xvi"], cur["xn"]
+                    la = sb + wave * 1024
                     for r in range(nrows):
-                        vi, n = vi0 + r, n0
-                        if vi >= XP:
-                            vi -= XP
-                            n += 1
-                        ih = (vi - 1) & M32
-                        ok = ih < XH and n < B
-                        rb = ((n * XH + ih) * XW) * ldx * 2 if ok else G_OOB
+                        rb = row_base(vi, n)
                         for k in range(3):
                             if wave + 4 * k < ppr:
-                                dma(lds, sb + r * rowpitch + wave * 1024 + k * 4096, xf, g["x_bytes"], rb + w["XC"][k])
+                                dma(lds, la + 4096 * k, xf, g["x_bytes"], rb + w["XC"][k])
+                        la += rowpitch
+                        vi += 1
+                        if vi >= XP:
+                            vi, n = 0, n + 1
+                    oh, n2, u = cur["yoh"], cur["yn"], cur["yu"]
                     dyb = []
                     for r in range(4):
-                        u = us + r
-                        n, oh = u // UP, u % UP
                         ok = r < RPS and oh < OH and u < u1
-                        dyb.append(((n * OH + oh) * OW + c0) * ldy * 2 if ok else G_OOB)
-                    for k in range(6):
-                        if wave + 4 * k < NB * nsub:
-                            row = w["DC"][k] & 3
-                            b = np.choose(row, dyb)
-                            dma(lds, sb + xstage + wave * 1024 + k * 4096, yf, g["y_bytes"], b + (w["DC"][k] & ~3))
+                        dyb.append((n2 * OH + oh) * yrowb if ok else G_OOB)
+                        u += 1
+                        oh += 1
+                        if oh >= UP:
+                            oh, n2 = 0, n2 + 1
+                    ly = sb + xstage + wave * 1024
+                    nbk, sub = 0, wave
+                    for e in range(wave, NB * nsub, 4):
+                        while sub >= nsub:
+                            sub -= nsub
+                            nbk += 1
+                        pp = sub * 16 + (lane >> 2)
+                        row, col = pp // TC, pp % TC
+                        chan = (nb0 + nbk) * 32 + (lane & 3) * 8
+                        ok = (pp < PX) & (c0 + col < OW) & (chan < N)
+                        dc = np.where(ok, ((c0 + col) * ldy + chan) * 2, XOOB)
+                        bb = np.choose(np.minimum(row, 3), dyb)
+                        dma(lds, ly, yf, g["y_bytes"], bb + dc)
+                        ly += 4096
+                        sub += 4
 
             def compute(sb):
+                pp_lane = 8 * (lane >> 5) + rowl
                 for wave in range(4):
                     w = wc[wave]
-                    for i in range(6):
-                        sub = w["slice"] + SL * i
-                        if sub < nsub:
-                            ya = sb + xstage + w["DYL"] + sub * 1024
-                            A = frag(lds, ya, ya + 256)
-                            for t in range(9):
-                                Bf = frag(lds, sb + w["XO"][i, 0] + w["tapo"][t], sb + w["XO"][i, 1] + w["tapo"][t])
-                                acc[wave, t] += A.T @ Bf
+                    sub = w["slice"]
+                    while sub < nsub:
+                        ppc = pp_lane + 16 * sub
+                        xo0, xo1 = xoff(ppc), xoff(ppc + 4)
+                        ya = sb + xstage + w["DYL"] + sub * 1024
+                        A = frag(lds, ya, ya + 256)
+                        for t in range(9):
+                            acc[wave, t] += A.T @ frag(lds, sb + xo0 + w["tapo"][t], sb + xo1 + w["tapo"][t])
+                        sub += SL
 
+            G = strips * nsteps
+            strip_ld, st_ld = 0, 0
+            setup_strip(0)
+            cursor_reset()
             issue(0, 0)
-            for st in range(nsteps):
-                sb = stage if st & 1 else 0
-                if st + 1 < nsteps:
-                    issue(st + 1, stage - sb)
+            for gi in range(G):
+                sb = stage if gi & 1 else 0
+                if gi + 1 < G:
+                    st_ld += 1
+                    if st_ld == nsteps:
+                        st_ld, strip_ld = 0, strip_ld + 1
+                        setup_strip(strip_ld * TC)
+                        cursor_reset()
+                    else:
+                        cursor_step()
+                    issue(stage - sb, strip_ld * TC)
                 compute(sb)
             # slices of a block summed in slice order by slice 0, which stores the block
             for wave in range(4):
@@ -264,7 +297,7 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
                                 slots[zz, row, t * C + cc] = tot[t, m, c]
                                 written[zz, row, t * C + cc] += 1
     assert (written == 1).all(), "every element of every workspace slot is stored exactly once"
-    return slots.sum(0), strips * uranges
+    return slots.sum(0), uranges
 
 
 @pytest.mark.parametrize("case", [

@@ -223,7 +223,10 @@ def g9_tta():
     x = torch.rand(1, 3, 96, 128, generator=torch.Generator().manual_seed(9))
     s_, f_ = [1, 0.83, 0.67], [None, 3, None]
     y, _ = rt.inference_with_tta(m, x, s_, f_)
-    g9 = dict(x=x.numpy(), scales=np.array(s_), flips=np.array([0, 3, 0]), y=y.numpy(),
+    # ONE augmentation: clip_augmented cuts the tail of y[0], then computes the head cut of y[-1] -- the same, already shortened,
+    # entry -- from its NEW row count (tta_utils.py:54-58)
+    y1, _ = rt.inference_with_tta(m, x, [0.83], [3])
+    g9 = dict(x=x.numpy(), scales=np.array(s_), flips=np.array([0, 3, 0]), y=y.numpy(), y_single=y1.numpy(),
               scaled_083=rtu.scale_img(x, 0.83, gs=32).numpy(), scaled_same=rtu.scale_img(x, 0.5, same_shape=True, gs=32).numpy())
     np.savez_compressed(os.path.join(OUT, "g9_tta.npz"), **g9)
 
