@@ -3572,11 +3572,8 @@ struct WGroupPlan {
     int dtype = AYOLO_F16;
 };
 
-// modelled cycles of one k_wgrad3 step of job p (a wavefront's MFMAs + the workgroup's DMA pieces): the unit item lengths are
-// balanced in (w3_fill picks the step geometry by the same model)
-static double w3_step_cost(const W3P& p) {
-    return 600.0 + 405.0 * ((p.nsub + p.SL - 1) / p.SL) + 100.0 * ((p.nrows * p.ppr + p.NB * p.nsub + 3) / 4);
-}
+// modelled cycles of one k_wgrad3 step of job p (w3_fill's model): the unit item lengths are balanced in
+static double w3_step_cost(const W3P& p) { return p.step_cost; }
 // Steps per item of a k_wgrad3 job.  `q`: the launch's common item length (in steps of THIS job).  Every row range is one more
 // N x K slot to store and to add: a deep layer on a small map (256 -> 256 at 20 x 20: 2.4 MB per slot for 6.5 MB of operands)
 // is cut no finer than what keeps that traffic under about a third of the layer's own compute / operand time.
@@ -3860,7 +3857,11 @@ extern "C" int ayolo_wgrad_group_run(const void* table_host, const void* table_d
     }
     if (h.n_items[3]) {
         const W3P none3{};
-        int rc = w3_launch(none3, (const W3P*)(td + h.off_jobs3), (const WItem*)(td + h.off_items[3]), h.n_items[3], h.lds3, (float*)ws, (hipStream_t)s);
+        // the row-pitch instantiation all k_wgrad3 jobs of the group share (YOLOv5's stride-1 3x3 layers do), else the generic one
+        const W3P* hj3 = (const W3P*)((const unsigned char*)table_host + h.off_jobs3);
+        int rp = w3_rp_class(hj3[0]);
+        for (unsigned j = 1; j < h.njobs3; ++j) rp = w3_rp_class(hj3[j]) == rp ? rp : 0;
+        int rc = w3_launch(none3, (const W3P*)(td + h.off_jobs3), (const WItem*)(td + h.off_items[3]), h.n_items[3], h.lds3, (float*)ws, rp, (hipStream_t)s);
         if (rc) return rc;
     }
     if (h.n_red) {
@@ -3949,7 +3950,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
         S = w3_splits(p3);
         const long long blocks = (long long)w3_tiles(p3) * ((S + 7) / 8 * 8);
         AY_CHECK_ARG(blocks < (1ll << 31), "conv_wgrad: grid of %lld workgroups", blocks);
-        rc = w3_launch(p3, nullptr, nullptr, (unsigned)blocks, w3_lds_bytes(p3), (float*)ws, (hipStream_t)s);
+        rc = w3_launch(p3, nullptr, nullptr, (unsigned)blocks, w3_lds_bytes(p3), (float*)ws, w3_rp_class(p3), (hipStream_t)s);
         if (rc) return rc;
     }
     for (const WGradP& j : jobs) {

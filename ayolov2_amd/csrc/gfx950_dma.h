@@ -51,6 +51,21 @@ __device__ __forceinline__ void glds16(v4i32 srd, unsigned lds_addr, unsigned vo
                  : "memory");
 }
 
+// Predicated form: the load is issued with EXEC = all ones or zero (`on`, uniform) and EXEC is restored to all ones -- a VMEM
+// instruction with EXEC = 0 is skipped by the hardware, so a loader can be straight-line code without a branch per piece (a
+// taken branch is an instruction-buffer refill: the branchy piece cursor of k_wgrad3's first versions cost 300-400 cycles per
+// piece, profiles/r05_w3_probe_v3_experiments.txt).  Only for kernels whose wavefronts are always fully active outside this
+// statement.
+__device__ __forceinline__ void w3_glds_if(v4i32 srd, unsigned lds_addr, unsigned voff, unsigned on) {
+    unsigned keep;
+    const unsigned on_s = (unsigned)__builtin_amdgcn_readfirstlane((int)on);     // (hipcc sometimes keeps a uniform bool in a VGPR)
+    asm volatile("s_mov_b32 %0, m0\n\ts_cmp_lg_u32 %4, 0\n\ts_cselect_b64 exec, -1, 0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\t"
+                 "buffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd), "s"(on_s)
+                 : "memory", "scc");
+}
+
 // The same statement with a different text.  Two glds16 calls in the arms of an if / else are otherwise MERGED by hipcc into one
 // statement behind the join, its descriptor / LDS address operands selected per arm -- through VGPRs, which the "s" constraints
 // then reject ("invalid operand for instruction").  Use this one in the second arm.

@@ -33,10 +33,12 @@ struct W3P {
     unsigned long long ws_off;     // split-K workspace of this layer, in floats
     unsigned zz0;                  // first partial slot of this job
     FastDiv dXP, dUP, dTC;
+    double step_cost;              // modelled cycles of one step (host side: item balancing)
 };
 
-/* 0 = `d` is a conv k_wgrad3 runs (fills the geometry of `p`, not its split); != 0: use the generic kernel */
-int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p);
+/* 0 = `d` is a conv k_wgrad3 runs (fills the geometry of `p`, not its split); != 0: use the generic kernel.  any_route: the
+ * geometry whatever the routing switches say (introspection) */
+int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, bool any_route = false);
 /* cut the job into items of about `steps` steps each (all strips of a row range together; at least one item); p.uch / p.uranges */
 void w3_split(W3P& p, double steps);
 static inline unsigned w3_splits(const W3P& p) { return p.uranges; }
@@ -47,4 +49,8 @@ static inline unsigned long long w3_item_steps(const W3P& p, unsigned ur) {
 }
 size_t w3_lds_bytes(const W3P& p);
 /* grouped launch (jobs / items in device memory, pv ignored) or single job by value (items == nullptr: blocks = tiles * splits) */
-int w3_launch(const W3P& pv, const W3P* jobs, const WItem* items, unsigned blocks, size_t lds, float* ws, hipStream_t s);
+int w3_launch(const W3P& pv, const W3P* jobs, const WItem* items, unsigned blocks, size_t lds, float* ws, int rp, hipStream_t s);
+/* the row-pitch instantiation a job can run on: its window row pitch when the stride is 1 and an instantiation exists, else 0 */
+static inline int w3_rp_class(const W3P& p) {
+    return (p.s == 1 && (p.rowpitch == 2048 || p.rowpitch == 3072 || p.rowpitch == 4096 || p.rowpitch == 6144)) ? p.rowpitch : 0;
+}

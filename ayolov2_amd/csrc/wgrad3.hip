@@ -28,7 +28,8 @@ typedef const __attribute__((address_space(4))) W3P* w3job_cptr_t;
 #define W3_MAXK 3               // x pieces of one window row per wavefront (ppr <= 12)
 #define W3_MAXD 6               // dy pieces per wavefront (NB * nsub <= 24)
 #define W3_MAXI 6               // sub-steps per wavefront (nsub <= 6)
-#define W3_STAGE_MAX 81920      // two stages of ONE workgroup fill the CU's 160 KiB exactly (<= 40 KiB: two workgroups per CU)
+#define W3_STAGE_MAX 64512      // a stage: < 64 KiB (16-bit fragment offsets); <= 40 KiB: two workgroups of two stages per CU
+#define W3_TAB_BYTES 9216       // [9][256] per-lane loader constants of the current strip, behind the two stages
 #define W3_RED_BYTES 36864      // cross-wavefront reduction: up to 3 wavefronts x 3 blocks x 16 registers x 64 lanes x 4 bytes
 
 // 16 pixels x this lane's channel out of a [pixel][32 channel] plane: lane supplies the row address of pixel (q >> 2) (+ 4 for the
@@ -62,6 +63,10 @@ extern "C" int ayolo_probe3_read(void* dst, unsigned long long bytes) {
 #define W3_MARK() do { } while (0)
 #endif
 
+// RP > 0: the window's row pitch in bytes is this compile-time constant AND the stride is 1 -- the nine tap offsets then are
+// immediates of the fragment reads (3 instructions per MFMA instead of 5: the MFMA phase of a wavefront alone on its SIMD is
+// issue-bound); RP == 0: any geometry, tap offsets from registers.
+template <int RP>
 __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, const WItem* items, float* ws) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -132,13 +137,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
     // piece j fetches the 16-byte chunk ci = j * 64 + l of the row image [c-block][odd / all columns | even columns][pixel][4 chunks].
     // dy: pieces e = wave, wave + 4, .. of the NB * nsub pieces [n-block][sub-step]; lane l fetches chunk (l & 3) of pixel
     // sub * 16 + (l >> 2) of the step = (row pp / TC, column pp % TC); the row index rides in the low bits of the offset
-    // (separate scalars, not an array: the piece cursor picks one by a uniform index, and an array indexed at run time goes to
-    // scratch memory -- a scratch load per DMA piece whose s_waitcnt vmcnt would also wait for every DMA in flight)
-    unsigned XC0 = 0, XC1 = 0, XC2 = 0;
-    int c0_ld = 0;                                            // first output column of the loader's strip
+    // dy: pieces e = (3 - wave), (3 - wave) + 4, .. of the NB * nsub pieces [n-block][sub-step] (dealt from the other end: the low
+    // wavefronts carry more x pieces); the row index of the lane's pixel rides in the low bits of its offset.
+    // The nine per-lane loader constants of a strip live in LDS behind the two stages ([9][256 lanes], W3_TAB_BYTES): each is used
+    // once per step, and nine more live registers next to 144 accumulators and 40 fragment registers end in scratch -- whose
+    // reloads wait with s_waitcnt vmcnt(0), i.e. for every DMA in flight.
+    unsigned* ltab = reinterpret_cast<unsigned*>(smem_raw + 2 * (unsigned)p.stage) + tid;
+    const int wrev = 3 - wave;
     auto setup_strip = [&](int c0) __attribute__((always_inline)) {
         const int cbsz = (plo + ple) >> 4;               // chunks per c-block
-        unsigned XC[W3_MAXK];
 #pragma unroll
         for (int k = 0; k < W3_MAXK; ++k) {
             const int j = wave + 4 * k;
@@ -151,31 +158,50 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
             const int ic = s == 1 ? c0 - 1 + q : (even ? 2 * (c0 + q) : 2 * (c0 + q) - 1);
             const int chan = (cb0 + cbi) * 32 + ch * 8;
             const bool ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < Cc);
-            XC[k] = ok ? (unsigned)((ic * ldx + chan) * 2) : W3_XOOB;
+            ltab[k * 256] = ok ? (unsigned)((ic * ldx + chan) * 2) : W3_XOOB;
         }
-        XC0 = XC[0]; XC1 = XC[1]; XC2 = XC[2];
-        c0_ld = c0;
+#pragma unroll
+        for (int k = 0; k < W3_MAXD; ++k) {
+            const int e = wrev + 4 * k;
+            int nbk = 0, sub = e;
+            while (sub >= nsub) { sub -= nsub; ++nbk; }
+            const unsigned pp = (unsigned)(sub * 16 + (lane >> 2));
+            const unsigned row = fdiv(pp, fTC);
+            const int col = (int)(pp - row * (unsigned)TC);
+            const int chan = (nb0 + nbk) * 32 + (lane & 3) * 8;
+            const bool ok = (e < NB * nsub) & (pp < (unsigned)PX) & (c0 + col < OW) & (chan < Nn);
+            ltab[(W3_MAXK + k) * 256] = ok ? ((unsigned)(((c0 + col) * ldy + chan) * 2) | row) : W3_XOOB;
+        }
     };
     // ---- fragment geometry.  Sub-step `sub`, half h of its 16 pixels: this lane's pixel is 4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl
     // (TC % 4 == 0: the four pixels of a read lie in one output row); pixels beyond the step are clamped (their dy is zero, the
-    // x they meet only has to be finite).  xoff(pp): byte offset of step pixel pp in the window (tap (0, 0), c-block 0).
+    // x they meet only has to be finite).  XO[i][h]: byte offset of that pixel in the window for the wavefront's i-th sub-step,
+    // tap (0, 0), this wavefront's c-block.
     const int q16 = lane & 15, rowl = q16 >> 2;
     const unsigned chanb = (unsigned)(((q16 & 3) * 4 + ((lane >> 4) & 1) * 16) * 2);
-    const unsigned srp = (unsigned)(s * rowpitch);
-    auto xoff = [&](unsigned pp) __attribute__((always_inline)) -> unsigned {
-        pp = pp < (unsigned)PX ? pp : (unsigned)(PX - 1);
-        const unsigned row = fdiv(pp, fTC);
-        return row * srp + (pp - row * (unsigned)TC) * 64u + chanb;
-    };
-    const unsigned pp_lane = (unsigned)(8 * (lane >> 5) + rowl);      // + 16 * sub + 4 * h
+    // (the two halves of a sub-step packed into one register: a stage is < 64 KiB)
+    unsigned XO[W3_MAXI];
+#pragma unroll
+    for (int i = 0; i < W3_MAXI; ++i) {
+        unsigned o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sub = slice + SL * i;
+            unsigned pp = (unsigned)(4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl);
+            pp = pp < (unsigned)PX ? pp : (unsigned)(PX - 1);
+            const unsigned row = fdiv(pp, fTC);
+            o[h] = row * (unsigned)(s * rowpitch) + (pp - row * (unsigned)TC) * 64u + chanb + (unsigned)(cb * (plo + ple));
+        }
+        XO[i] = o[0] | (o[1] << 16);
+    }
     const unsigned DYL = (unsigned)(((lane >> 5) * 8 + rowl) * 64) + chanb + (unsigned)(nb * nsub * 1024);
-    // tap (dh, dw) -> byte offset inside the window, for this wavefront's c-block
+    // tap (dh, dw) -> byte offset inside the window: immediates when RP > 0
     unsigned tapo[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int dh = t / 3, dw = t % 3;
         const int colo = s == 1 ? dw * 64 : (dw == 1 ? plo : (dw == 2 ? 64 : 0));
-        tapo[t] = (unsigned)(dh * rowpitch + cb * (plo + ple) + colo);
+        tapo[t] = RP > 0 ? (unsigned)(dh * RP + dw * 64) : (unsigned)(dh * rowpitch + colo);
     }
 
     float16v acc[9];
@@ -207,53 +233,59 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
         yoh += (unsigned)RPS; yu += (unsigned)RPS;                           \
         if (yoh >= UP) { yoh -= UP; ++yn; }                                  \
     }
-    // ---- DMA of the cursor's step into the stage at byte offset sb_: the window's padded input rows (row base uniform per row:
-    // out of range for padding rows), then the dy rows of the step's RPS virtual output rows: piece e = wave + 4 k of the NB * nsub
-    // pieces [n-block][sub-step]; lane l fetches chunk (l & 3) of pixel sub * 16 + (l >> 2) of the step = (row pp / TC, column
-    // pp % TC).  The row index is per lane, the four row bases are uniform: masks, not selects -- hipcc turns a chain of per-lane
-    // selects between SGPR values into divergent branches and then duplicates the DMA statement into them (its SGPR operands
-    // become VGPR phis: "invalid operand for instruction").
-    // Issued as one burst behind the barrier, in front of the step's MFMAs.  One piece behind every MFMA (k_gconv's schedule)
-    // was built and dropped: the piece cursor's branches between the MFMAs cost hipcc's register allocator the accumulators
-    // (16-byte spills around every MFMA, 540 bytes of scratch per lane).
-    // vi == 0: the top padding row -> vi - 1 wraps to out of range
-#define W3_ROW_BASE(vi_, n_) (((((vi_) - 1u) < XH) & ((n_) < Bn)) ? ((n_) * XH + ((vi_) - 1u)) * xrowb : G_OOB)
-#define W3_ISSUE(sb_)                                                                                \
+    // ---- DMA of the cursor's step.  What the probes of the first three versions showed (profiles/r05_w3_probe_v*.txt,
+    // r05_ldsdma_microbench.txt): an LDS-DMA piece costs its wavefront ~45 cycles to issue while fewer than ~40 pieces are in
+    // flight on the CU -- but the piece CURSOR cost 300-400 cycles per piece, with or without the DMA instruction in it
+    // (r05_w3_probe_v3_experiments.txt): a dozen taken branches per piece, each an instruction-buffer refill.  So the loader is
+    // STRAIGHT-LINE code: row r of the window and its up to three pieces are one unrolled block whose DMA instructions are
+    // predicated through EXEC (w3_glds_if: a load with EXEC = 0 is skipped by the hardware), the row base is scalar arithmetic
+    // with selects, and the blocks of step g + 1 are spread between the sub-steps of step g (W3_CHUNK) so that the queue is fed
+    // while the matrix pipe works.  (One piece behind every MFMA -- k_gconv's schedule -- was built first and dropped: the
+    // cursor's branches between the MFMAs of a sub-step cost hipcc's register allocator the accumulators: 540 bytes of scratch.)
+    // The dy pieces' row index is per lane, the four row bases are uniform: masks, not selects -- hipcc turns a chain of per-lane
+    // selects between SGPR values into divergent branches and then duplicates the DMA statement into them.
+    unsigned p_la = 0, p_ly = 0, p_vi = 0, p_n = 0, dyb0 = 0, dyb1 = 0, dyb2 = 0, dyb3 = 0;
+#define W3_ISSUE_BEGIN(sb_)                                                                          \
     {                                                                                                \
-        unsigned vi_ = xvi, n_ = xn;                                                                 \
-        unsigned la_ = lds_tiles + (sb_) + (unsigned)(wave * 1024);                                  \
-        for (int r_ = 0; r_ < nrows; ++r_) {                                                         \
-            const unsigned rb_ = W3_ROW_BASE(vi_, n_);                                               \
-            if (wave < ppr) glds16(rsX, la_, rb_ + XC0);                                             \
-            if (wave + 4 < ppr) glds16(rsX, la_ + 4096u, rb_ + XC1);                                 \
-            if (wave + 8 < ppr) glds16(rsX, la_ + 8192u, rb_ + XC2);                                 \
-            la_ += (unsigned)rowpitch;                                                               \
-            if (++vi_ >= XP) { vi_ = 0; ++n_; }                                                      \
-        }                                                                                            \
+        p_la = lds_tiles + (sb_) + (unsigned)(wave * 1024);                                          \
+        p_ly = lds_tiles + (sb_) + (unsigned)(xstage + wrev * 1024);                                 \
+        p_vi = xvi; p_n = xn;                                                                        \
         unsigned oh_ = yoh, n2_ = yn, u_ = yu;                                                       \
-        const unsigned dyb0 = ((oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;           \
-        ++u_; if (++oh_ >= UP) { oh_ = 0; ++n2_; }                                                   \
-        const unsigned dyb1 = ((1 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;   \
-        ++u_; if (++oh_ >= UP) { oh_ = 0; ++n2_; }                                                   \
-        const unsigned dyb2 = ((2 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;   \
-        ++u_; if (++oh_ >= UP) { oh_ = 0; ++n2_; }                                                   \
-        const unsigned dyb3 = ((3 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;   \
-        unsigned ly_ = lds_tiles + (sb_) + (unsigned)(xstage + wave * 1024);                         \
-        int nbk_ = 0, sub_ = wave;                                                                   \
-        for (int e_ = wave; e_ < ndy; e_ += 4) {                                                     \
-            while (sub_ >= nsub) { sub_ -= nsub; ++nbk_; }                                           \
-            const unsigned pp_ = (unsigned)(sub_ * 16 + (lane >> 2));                                \
-            unsigned row_ = fdiv(pp_, fTC);                                                          \
-            const int col_ = (int)(pp_ - row_ * (unsigned)TC);                                       \
-            const int chan_ = (nb0 + nbk_) * 32 + (lane & 3) * 8;                                    \
-            const bool okd_ = (pp_ < (unsigned)PX) & (c0_ld + col_ < OW) & (chan_ < Nn);             \
-            const unsigned dc_ = okd_ ? (unsigned)(((c0_ld + col_) * ldy + chan_) * 2) : W3_XOOB;    \
-            asm volatile("" : "+v"(row_));                                                           \
-            const unsigned bb_ = (dyb0 & (0u - (unsigned)(row_ == 0))) | (dyb1 & (0u - (unsigned)(row_ == 1))) |   \
-                                 (dyb2 & (0u - (unsigned)(row_ == 2))) | (dyb3 & (0u - (unsigned)(row_ == 3)));    \
-            glds16_b(rsY, ly_, bb_ + dc_);                                                           \
-            ly_ += 4096u; sub_ += 4;                                                                 \
-        }                                                                                            \
+        dyb0 = ((oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;                          \
+        ++u_; ++oh_; n2_ = oh_ >= UP ? n2_ + 1u : n2_; oh_ = oh_ >= UP ? 0u : oh_;                   \
+        dyb1 = ((1 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;              \
+        ++u_; ++oh_; n2_ = oh_ >= UP ? n2_ + 1u : n2_; oh_ = oh_ >= UP ? 0u : oh_;                   \
+        dyb2 = ((2 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;              \
+        ++u_; ++oh_; n2_ = oh_ >= UP ? n2_ + 1u : n2_; oh_ = oh_ >= UP ? 0u : oh_;                   \
+        dyb3 = ((3 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;              \
+    }
+    // window row r_ (compile time): vi - 1 wraps to out of range for the top padding row
+#define W3_ROW(r_)                                                                                   \
+    {                                                                                                \
+        const unsigned ih_ = p_vi - 1u;                                                              \
+        const unsigned rb_ = ((ih_ < XH) & (p_n < Bn)) ? (p_n * XH + ih_) * xrowb : G_OOB;           \
+        const int lim_ = (r_) < nrows ? ppr : 0;              /* pieces of this row (none beyond the window) */  \
+        w3_glds_if(rsX, p_la, rb_ + ltab[0], (unsigned)(wave < lim_));                               \
+        w3_glds_if(rsX, p_la + 4096u, rb_ + ltab[256], (unsigned)(wave + 4 < lim_));                 \
+        w3_glds_if(rsX, p_la + 8192u, rb_ + ltab[512], (unsigned)(wave + 8 < lim_));                 \
+        p_la += (unsigned)rowpitch;                                                                  \
+        ++p_vi; p_n = p_vi >= XP ? p_n + 1u : p_n; p_vi = p_vi >= XP ? 0u : p_vi;                    \
+    }
+#define W3_DY(k_)                                                                                    \
+    {                                                                                                \
+        const unsigned dck_ = ltab[(W3_MAXK + (k_)) * 256];                                          \
+        unsigned row_ = dck_ & 3u;                                                                   \
+        asm volatile("" : "+v"(row_));                                                               \
+        const unsigned bb_ = (dyb0 & (0u - (unsigned)(row_ == 0))) | (dyb1 & (0u - (unsigned)(row_ == 1))) |   \
+                             (dyb2 & (0u - (unsigned)(row_ == 2))) | (dyb3 & (0u - (unsigned)(row_ == 3)));    \
+        w3_glds_if(rsY, p_ly + (unsigned)((k_) * 4096), bb_ + (dck_ & ~3u), (unsigned)(wrev + 4 * (k_) < ndy));   \
+    }
+    // chunk c_ of a step's loader: two window rows each for c_ = 0 .. 3, the ninth row and half of the dy pieces, the other half
+#define W3_CHUNK(c_)                                                                                 \
+    {                                                                                                \
+        if ((c_) < 4) { W3_ROW(2 * (c_)) W3_ROW(2 * (c_) + 1) }                                      \
+        else if ((c_) == 4) { W3_ROW(8) W3_DY(0) W3_DY(1) W3_DY(2) }                                 \
+        else { W3_DY(3) W3_DY(4) W3_DY(5) }                                                          \
     }
 
     W3_MARK();                                   // 1: prologue done
@@ -261,7 +293,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
     int strip_ld = 0, st_ld = 0;
     setup_strip(0);
     W3_CURSOR_RESET()
-    W3_ISSUE(0u)
+    W3_ISSUE_BEGIN(0u)
+    W3_CHUNK(0) W3_CHUNK(1) W3_CHUNK(2) W3_CHUNK(3) W3_CHUNK(4) W3_CHUNK(5)
     W3_MARK();                                   // 2: first issue done
     const unsigned char* sy0 = smem_raw + xstage + DYL;
     for (int g = 0; g < G; ++g) {
@@ -270,57 +303,56 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
         W3_MARK();                               // 3 + 4 g: DMA waited for
         __builtin_amdgcn_s_barrier();            // ... everyone's pieces landed, everyone finished reading step g - 1
         W3_MARK();                               // 4 + 4 g: barrier passed
-        if (g + 1 < G) {
+        const bool more = g + 1 < G;
+        if (more) {
             if (++st_ld == nsteps) {
                 st_ld = 0; ++strip_ld;
                 setup_strip(strip_ld * TC);
                 W3_CURSOR_RESET()
             } else W3_CURSOR_STEP()
-            W3_ISSUE(stage - sb)
+            W3_ISSUE_BEGIN(stage - sb)
         }
-        W3_MARK();                               // 5 + 4 g: next step issued
+        W3_MARK();                               // 5 + 4 g: next step's loader set up
         // The wavefront's sub-steps of the stage at `sb`: one dy fragment and nine shifted x fragments feed nine MFMAs.  Software
         // pipeline: the fragments of the NEXT sub-step are fetched behind the MFMAs of this one that read the registers they
-        // replace (x fragment t right after MFMA t, the dy fragment into a second register set), so the LDS latency and the
-        // address adds run in the matrix pipe's shadow -- a wavefront alone on its SIMD otherwise alternates ~400 cycles of
-        // fetch with 288 of MFMA (first probe: 60 cycles per MFMA).
+        // replace (x fragment t right after MFMA t, the dy fragment into a second register set), so the LDS latency runs in the
+        // matrix pipe's shadow; chunk i of the next step's loader follows sub-step i.
+        const unsigned char* sx = smem_raw + sb;
+        const unsigned char* sy = sy0 + sb;
+        half8 a, b[9];
         if (slice < nsub) {
-            const unsigned char* sx = smem_raw + sb;
-            const unsigned char* sy = sy0 + sb;
-            int sub = slice;
-            unsigned ppc = pp_lane + (unsigned)(16 * sub);
-            unsigned xo0 = xoff(ppc), xo1 = xoff(ppc + 4u);
-            half8 a = w3_frag(sy + sub * 1024, sy + sub * 1024 + 256);
-            half8 b[9];
+            a = w3_frag(sy + slice * 1024, sy + slice * 1024 + 256);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) b[t] = w3_frag(sx + (xo0 + tapo[t]), sx + (xo1 + tapo[t]));
-            __builtin_amdgcn_sched_barrier(0);
-            while (true) {
-                const int subn = sub + SL;
-                if (subn >= nsub) break;
-                ppc += (unsigned)(16 * SL);
-                xo0 = xoff(ppc); xo1 = xoff(ppc + 4u);
-                const half8 an = w3_frag(sy + subn * 1024, sy + subn * 1024 + 256);
+            for (int t = 0; t < 9; ++t) b[t] = w3_frag(sx + (XO[0] & 0xffffu) + tapo[t], sx + (XO[0] >> 16) + tapo[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < W3_MAXI; ++i) {
+            const int sub = slice + SL * i;
+            if (sub < nsub) {
+                const int in = i + 1 < W3_MAXI ? i + 1 : i;
+                const int subn = sub + SL < nsub ? sub + SL : sub;                    // (past the last one: a harmless re-read)
+                const unsigned char* x0 = sx + (XO[in] & 0xffffu);
+                const unsigned char* x1 = sx + (XO[in] >> 16);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
-                    b[t] = w3_frag(sx + (xo0 + tapo[t]), sx + (xo1 + tapo[t]));
+                    b[t] = w3_frag(x0 + tapo[t], x1 + tapo[t]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                a = an;
-                sub = subn;
+                a = w3_frag(sy + subn * 1024, sy + subn * 1024 + 256);       // (its latency: behind the loader chunk below)
             }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (more) W3_CHUNK(i)
         }
-        W3_MARK();                               // 6 + 4 g: MFMAs issued
+        W3_MARK();                               // 6 + 4 g: MFMAs and pieces issued
     }
 #undef W3_CURSOR_RESET
 #undef W3_CURSOR_STEP
-#undef W3_ROW_BASE
-#undef W3_ISSUE
+#undef W3_ISSUE_BEGIN
+#undef W3_ROW
+#undef W3_DY
+#undef W3_CHUNK
     // the accumulators are read below: MFMA result hazard (see AY_MFMA_PAD in conv.hip)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 11" ::: "memory");
@@ -391,16 +423,21 @@ static int w3_env(const char* name, int dflt) {
 }
 
 size_t w3_lds_bytes(const W3P& p) {
-    const size_t a = 2 * (size_t)p.stage;
+    const size_t a = 2 * (size_t)p.stage + W3_TAB_BYTES;
     return p.SL > 1 && a < W3_RED_BYTES ? (size_t)W3_RED_BYTES : a;
 }
 
-int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
+int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, bool any_route) {
     static const int on = w3_env("AYOLO_WGRAD3", 1);
-    if (!on) return 1;
+    if (!on && !any_route) return 1;
     if (d->dtype != AYOLO_F16 || d->kh != 3 || d->kw != 3 || d->ph != 1 || d->pw != 1 || d->sh != d->sw || (d->sh != 1 && d->sh != 2)) return 1;
     if (d->Cin % 8 || d->Cout % 8 || d->ldx % 8 || d->ldy % 8 || d->Cin < 16 || d->Cout < 16) return 1;
     const int s = d->sh;
+    // stride 2: the window is four input pixels per output pixel -- twice the DMA bytes per MFMA of the generic kernel's best
+    // tiles on the wide layers; measured slower on every stride-2 layer of YOLOv5s (profiles/r05_sweep_w3*.txt): generic kernel
+    // unless AYOLO_WGRAD3_S2=1
+    static const int s2on = w3_env("AYOLO_WGRAD3_S2", 0);
+    if (s == 2 && !s2on && !any_route) return 1;
     if (d->Ho != (d->H + 2 - 3) / s + 1 || d->Wo != (d->W + 2 - 3) / s + 1) return 1;
     const long long xb = (long long)d->B * d->H * d->W * d->ldx * 2, yb = (long long)d->B * d->Ho * d->Wo * d->ldy * 2;
     if (xb >= (1ll << 30) || yb >= (1ll << 30)) return 1;
@@ -419,10 +456,11 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
     else { p.NB = 1; p.CB = 2; }
     p.NP = p.NB * p.CB; p.SL = 4 / p.NP;
     p.tn = (NBt + p.NB - 1) / p.NB; p.tc = (CBt + p.CB - 1) / p.CB;
-    // step geometry: the (TC, RPS) with the least modelled time per output pixel.  A step costs ~600 cycles of barrier / waits /
-    // cursor work, ~100 cycles per DMA piece of a wavefront (interleaved with the MFMAs) and ~45 per MFMA with the fragment fetch
-    // pipelined behind it -- a 16-pixel sub-step costs its 9 MFMAs whether its pixels are live or not; a stage over 40 KiB means
-    // one workgroup per CU instead of two (tools/w3_probe.py prints the marks these numbers come from)
+    // step geometry: the (TC, RPS) with the least modelled time per output pixel (tools/w3_probe.py prints the marks these numbers
+    // come from).  A step costs ~600 cycles of barrier / waits / cursor work plus the larger of (a) its MFMAs -- ~330 cycles per
+    // 16-pixel sub-step of a wavefront with the fragment fetch pipelined behind them, live pixels or not -- and (b) the DMA pieces
+    // of its busiest wavefront at ~400 cycles each (a wavefront keeps only a handful of 1-KiB pieces in flight against 1-2 us of
+    // latency).  With a stage of <= 40 KiB two workgroups share a CU: their DMA queues run in parallel, their MFMAs do not.
     double best = 1e30;
     for (int TC = 4; TC <= 96; TC += 4)
         for (int RPS = 1; RPS <= 4; ++RPS) {
@@ -437,15 +475,22 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p) {
             if (stage > W3_STAGE_MAX) continue;
             const int strips = (p.OW + TC - 1) / TC;
             const int wsub = (nsub + p.SL - 1) / p.SL;
-            const double pieces = (double)((nrows * ppr + p.NB * nsub + 3) / 4);
-            double t = (double)strips * (600.0 + 405.0 * wsub + 100.0 * pieces) / ((double)RPS * p.OW);
-            if (stage > W3_STAGE_MAX / 2) t *= 1.15;
+            int maxp = 0;
+            for (int w = 0; w < 4; ++w) {
+                const int kc = ppr > w ? (ppr - w + 3) / 4 : 0, ndy = p.NB * nsub, wr = 3 - w;
+                const int np = nrows * kc + (ndy > wr ? (ndy - wr + 3) / 4 : 0);
+                maxp = np > maxp ? np : maxp;
+            }
+            const bool two = 2 * stage + W3_TAB_BYTES <= 81920;
+            const double mf = 330.0 * wsub * (two ? 2.0 : 1.0), dm = 400.0 * maxp;
+            const double t = (two ? 0.5 : 1.0) * (600.0 + (mf > dm ? mf : dm)) * strips / ((double)RPS * p.OW);
             if (t < best - 1e-9) {
                 best = t;
                 p.TC = TC; p.RPS = RPS; p.PX = PX; p.nsub = nsub; p.strips = strips;
                 p.nrows = nrows; p.ppr = ppr; p.rowpitch = ppr * 1024;
                 p.plo = (s == 1 ? TC + 2 : TC + 1) * 64; p.ple = s == 1 ? 0 : TC * 64;
                 p.xstage = nrows * ppr * 1024; p.stage = stage;
+                p.step_cost = (two ? 0.5 : 1.0) * (600.0 + (mf > dm ? mf : dm));
             }
         }
     if (best > 1e29) return 1;
@@ -464,17 +509,33 @@ void w3_split(W3P& p, double steps) {
     p.uranges = (p.NU + p.uch - 1) / p.uch;
 }
 
-int w3_launch(const W3P& pv, const W3P* jobs, const WItem* items, unsigned blocks, size_t lds, float* ws, hipStream_t s) {
+template <int RP>
+static int w3_launch_rp(const W3P& pv, const W3P* jobs, const WItem* items, unsigned blocks, size_t lds, float* ws, hipStream_t s) {
     static bool attr_set[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W3_STAGE_MAX);
+#ifdef AYOLO_PROBE
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<RP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W3_STAGE_MAX + W3_TAB_BYTES);
+#else
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<RP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W3_STAGE_MAX + W3_TAB_BYTES);
+#endif
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_wgrad3, dim3(blocks), dim3(256), lds, s, pv, jobs, items, ws);
+    hipLaunchKernelGGL(k_wgrad3<RP>, dim3(blocks), dim3(256), lds, s, pv, jobs, items, ws);
     AY_CHECK_LAUNCH("k_wgrad3");
     return AYOLO_OK;
+}
+
+/* rp: the launch's compile-time row pitch (w3_rp_class of every job of the launch), 0 = the generic instantiation */
+int w3_launch(const W3P& pv, const W3P* jobs, const WItem* items, unsigned blocks, size_t lds, float* ws, int rp, hipStream_t s) {
+    switch (rp) {
+        case 2048: return w3_launch_rp<2048>(pv, jobs, items, blocks, lds, ws, s);
+        case 3072: return w3_launch_rp<3072>(pv, jobs, items, blocks, lds, ws, s);
+        case 4096: return w3_launch_rp<4096>(pv, jobs, items, blocks, lds, ws, s);
+        case 6144: return w3_launch_rp<6144>(pv, jobs, items, blocks, lds, ws, s);
+        default: return w3_launch_rp<0>(pv, jobs, items, blocks, lds, ws, s);
+    }
 }
 
 /* introspection (tests/test_kernel_math.py restates the kernel's index algebra on the CPU from these numbers): the step
@@ -482,7 +543,7 @@ int w3_launch(const W3P& pv, const W3P* jobs, const WItem* items, unsigned block
 extern "C" int ayolo_wgrad3_geometry(const ayolo_conv_desc* d, long long* out, int nout) {
     AY_CHECK_ARG(d && out && nout >= 24, "wgrad3_geometry: out[24]");
     W3P p;
-    AY_CHECK_ARG(w3_fill(d, d, d, p) == 0, "wgrad3_geometry: not a fp16 3x3 / pad 1 / stride 1 or 2 layer of k_wgrad3");
+    AY_CHECK_ARG(w3_fill(d, d, d, p, true) == 0, "wgrad3_geometry: not a fp16 3x3 / pad 1 / stride 1 or 2 layer of k_wgrad3");
     const long long v[24] = {p.TC, p.RPS, p.PX, p.nsub, p.strips, p.NB, p.CB, p.NP, p.SL, p.tn, p.tc, p.nrows, p.ppr, p.rowpitch,
                              p.plo, p.ple, p.xstage, p.stage, p.UP, p.XP, (long long)p.NU, (long long)p.x_bytes, (long long)p.y_bytes,
                              (long long)w3_lds_bytes(p)};

@@ -567,3 +567,78 @@ def test_decomposed_model_train_step_fp32():
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         assert float((p.grad.cpu() - gr[k].grad).abs().max()) <= 3e-3 * float(gr[k].grad.abs().max()) + 1e-7, k
+
+
+def test_full_size_c3_block_vs_cpu_oracle():
+    """the bench's FULL-SIZE geometry meets the oracle.  The first three backbone rows of YOLOv5s (6x6 stem,
+    3x3 / stride-2 Conv, C3 with its merged cv1 | cv2, Bottleneck and cv3 -- res/configs/model/yolov5s.yaml:21-23) plus a
+    one-level YOLOHead at batch 64, 640 x 640 -- the 64 x 160 x 160 maps of the train step, where the training plan runs the
+    transform-on-load reader with store-back, BatchNorm statistics over 1.6 M pixels, the grouped weight gradients incl. the
+    patch-staged 3x3 kernel and the fused stem backward -- in the exact-fp32 mode against the CPU oracle (plain torch fp32 on the
+    box's host cores): logits to 1e-4, every parameter gradient to 2e-3 of its largest element; then the fp16 autocast mode on
+    operands pre-rounded to fp16 against the fp32 mode of the same kernels."""
+    from ayolov2_amd import YOLOModel
+    from oracle.model_ref import RefYOLO
+    anchors = [[10, 13, 16, 30, 33, 23]]
+    cfg = dict(input_size=[640, 640], input_channel=3, depth_multiple=0.33, width_multiple=0.5, n_classes=3, activation="SiLU",
+               anchors=anchors,
+               backbone=[[-1, 1, "Conv", [64, 6, 2, 2], {"activation": "SiLU"}], [-1, 1, "Conv", [128, 3, 2], {"activation": "SiLU"}],
+                         [-1, 3, "C3", [128], {"activation": "SiLU"}]],
+               head=[[[2], 1, "YOLOHead", [3, anchors]]])
+    torch.manual_seed(61)
+    m = YOLOModel(copy.deepcopy(cfg))
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.6, 1.4)
+                mod.bias.uniform_(-0.3, 0.3)
+        for p in m.parameters():                    # operands exactly representable in fp16: the fp16 leg below reads the same numbers
+            p.copy_(p.half().float())
+    r = RefYOLO(copy.deepcopy(cfg))
+    r.load_state_dict(m.state_dict())
+    m, r = m.cuda().train(), r.train()
+    B = 64
+    x = torch.rand(B, 3, 640, 640, generator=torch.Generator().manual_seed(62)).half().float()
+    wv = torch.linspace(-1.0, 1.0, 8)
+
+    def loss_of(raws):
+        o = raws[0].float()
+        return 0.5 * (o * o).mean() + (o * wv.to(o.device)).mean()
+
+    def run(mod, xin, amp):
+        mod.zero_grad(set_to_none=True)
+        scale = 1024.0 if amp else 1.0
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            raws = mod(xin)
+            loss = loss_of(raws if isinstance(raws, (list, tuple)) else [raws])
+        (loss * scale).backward()
+        rr = raws if isinstance(raws, (list, tuple)) else [raws]
+        return float(loss.detach()), rr[0].detach().float().cpu(), {k: p.grad.detach().float().cpu() / scale for k, p in mod.named_parameters()}
+
+    assert r(x[:1])[0].shape[1:] == (3, 160, 160, 8)
+    l_ref, o_ref, g_ref = run(r, x, False)
+    l32, o32, g32 = run(m, x.cuda(), False)
+    assert getattr(m, "_plans", None), "the training plan must have taken this model"
+    assert abs(l32 - l_ref) <= 1e-5 * abs(l_ref) + 1e-7, (l32, l_ref)
+    err = (o32 - o_ref).abs()
+    assert bool((err <= 1e-4 + 1e-4 * o_ref.abs()).all()), float(err.max())
+    worst = 0.0
+    for k, g in g_ref.items():
+        e = float((g32[k] - g).abs().max()) / (float(g.abs().max()) + 1e-30)
+        worst = max(worst, e)
+        assert e <= 2e-3, (k, e)
+    print("full-size C3 block, fp32 mode vs CPU oracle: logits max err %.3g, worst gradient error %.3g of its max" % (float(err.max()), worst))
+    # ---- the bench's dtype on the same (fp16-exact) operands against the fp32 mode of the same kernels
+    l16, o16, g16 = run(m, x.cuda(), True)
+    rng = float(o32.abs().max())
+    e16 = float((o16 - o32).abs().max())
+
+    def cos(a, b):
+        a, b = a.flatten().double(), b.flatten().double()
+        return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+    glob = cos(torch.cat([g16[k].flatten() for k in g32]), torch.cat([g32[k].flatten() for k in g32]))
+    wconv = min(cos(g16[k], g32[k]) for k in g32 if g32[k].dim() == 4 and float(g32[k].norm()) > 1e-12)
+    print("full-size C3 block, fp16 vs fp32 mode: loss %.6f / %.6f, logits max err %.3g of range %.3g, gradient cosine %.6f, worst conv weight %.5f"
+          % (l16, l32, e16, rng, glob, wconv))
+    assert abs(l16 - l32) <= 2e-3 * abs(l32) and e16 <= 2e-2 * rng and glob >= 0.995 and wconv >= 0.99

@@ -232,9 +232,10 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
                         oh += 1
                         if oh >= UP:
                             oh, n2 = 0, n2 + 1
-                    ly = sb + xstage + wave * 1024
-                    nbk, sub = 0, wave
-                    for e in range(wave, NB * nsub, 4):
+                    wrev = 3 - wave                  # dy pieces are dealt from the other end: the low wavefronts carry more x pieces
+                    ly = sb + xstage + wrev * 1024
+                    nbk, sub = 0, wrev
+                    for e in range(wrev, NB * nsub, 4):
                         while sub >= nsub:
                             sub -= nsub
                             nbk += 1
