@@ -2513,7 +2513,19 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 // sl adds partials sl, sl + tpc, ..; the slices are then added in slice order through LDS: still a fixed order).  A layer with a
 // tiny dw and a huge map (64 x 64 weights, 1.6 M pixels: S = 2 133 partials of 16 KB) otherwise has two blocks whose threads
 // each walk all 2 133 partials one memory round trip after the other: 250 us for 35 MB.  A block covers wred_chunk(tpc) elements.
-struct WRed { unsigned long long ws_off, stride; float* dst; unsigned n, S; float alpha; int overwrite; unsigned cols, ldd; unsigned long long e0; unsigned tpc, pad; };
+// pC > 0: the partials are k_wgrad3's TILE-MAJOR slots -- element (row n, column t * pC + c) of the dense matrix sits at
+// w3_slot_offset(n, t, c) of its slot (every workgroup stores one contiguous block; dense slots made a 256 -> 256 layer's
+// workgroups scatter 256-byte runs at a 1 KiB pitch: 0.9 TB/s of stores, profiles/r05_w3_probe_v5.txt); ws_off is then the
+// LAYER's base, whatever e0
+struct WRed { unsigned long long ws_off, stride; float* dst; unsigned n, S; float alpha; int overwrite; unsigned cols, ldd; unsigned long long e0; unsigned tpc, pC, pNB, pCB, ptc, pad; };
+// element e (multiple of 4) of a dense N x (9 * C) matrix -> offset in a tile-major slot: tiles of (NB * 32 rows) x (CB * 32
+// channels), inside a tile [n-block][c-block][tap][32 rows][32 channels]
+__host__ __device__ static inline unsigned long long w3_perm(unsigned long long e, unsigned cols, unsigned C, unsigned NB, unsigned CB, unsigned tc) {
+    const unsigned n = (unsigned)(e / cols), col = (unsigned)(e - (unsigned long long)n * cols);
+    const unsigned t = col / C, c = col - t * C;
+    const unsigned tni = n / (NB * 32u), nbl = (n >> 5) % NB, tci = c / (CB * 32u), cbl = (c >> 5) % CB;
+    return ((unsigned long long)((tni * tc + tci) * NB * CB + nbl * CB + cbl) * 9u + t) * 1024u + (n & 31u) * 32u + (c & 31u);
+}
 static inline unsigned wred_tpc(unsigned S) {
     unsigned t = 1;
     while (t < 64 && S > 32 * t) t *= 2;                       // <= 32 partials per thread (16 .. 48 measured alike, 8 / 96 worse)
@@ -2874,7 +2886,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WRed rv, const WRed* red, 
         const unsigned long long o = (unsigned long long)blockIdx.x * chunk;
         const unsigned long long left = (unsigned long long)rv.n > o ? (unsigned long long)rv.n - o : 0ull;     // rv.n: all elements
         r.n = (unsigned)(left < chunk ? left : chunk);
-        r.ws_off += o;
+        if (!rv.pC) r.ws_off += o;
         r.e0 = o;
     }
     const bool dense = r.ldd == r.cols;
@@ -2885,7 +2897,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WRed rv, const WRed* red, 
         const unsigned i = col * 4;
         float4v a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
         if (i < r.n) {
-            const float* src = ws + r.ws_off + i;
+            const float* src = ws + r.ws_off + (r.pC ? w3_perm(r.e0 + i, r.cols, r.pC, r.pNB, r.pCB, r.ptc) : (unsigned long long)i);
             unsigned q = sl;
             for (; q + 3 * r.tpc < r.S; q += 4 * r.tpc) {
                 a0 += *reinterpret_cast<const float4v*>(src + (unsigned long long)(q) * r.stride);
@@ -2909,7 +2921,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WRed rv, const WRed* red, 
         return;
     }
     for (unsigned i = threadIdx.x * 4; i < r.n; i += 1024) {
-        const float* src = ws + r.ws_off + i;
+        const float* src = ws + r.ws_off + (r.pC ? w3_perm(r.e0 + i, r.cols, r.pC, r.pNB, r.pCB, r.ptc) : (unsigned long long)i);
         float4v a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
         unsigned s = 0;
         for (; s + 4 <= r.S; s += 4) {
@@ -3656,25 +3668,29 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
     unsigned long long off = 0;
     for (const Layer& L : layers) {
         unsigned S = 0;
-        unsigned long long nk;
+        unsigned long long nk, slotf;
         unsigned cols;
+        WRed proto{};
         if (L.w3) {
             W3P& p = g.jobs3[L.j0];
             nk = (unsigned long long)p.N * (unsigned long long)p.K; cols = (unsigned)p.K;
+            slotf = w3_slot_floats(p);
             p.ws_off = off; p.zz0 = 0; S = w3_splits(p);
+            proto.pC = (unsigned)p.C; proto.pNB = (unsigned)p.NB; proto.pCB = (unsigned)p.CB; proto.ptc = (unsigned)p.tc;
         } else {
             nk = (unsigned long long)g.jobs[L.j0].N * (unsigned long long)g.jobs[L.j0].K; cols = (unsigned)g.jobs[L.j0].K;
+            slotf = nk;
             for (size_t j = L.j0; j < L.j1; ++j) { g.jobs[j].ws_off = off; g.jobs[j].zz0 = S; S += g.jobs[j].splits; }
         }
         const unsigned tpc = wred_tpc(S), chunk = wred_chunk(tpc);
         for (unsigned long long e = 0; e < nk; e += chunk) {
-            WRed r{};
+            WRed r = proto;
             r.tpc = tpc;
-            r.ws_off = off + e; r.stride = nk; r.dst = L.dw; r.e0 = e; r.n = (unsigned)(nk - e < chunk ? nk - e : chunk); r.S = S;
+            r.ws_off = proto.pC ? off : off + e; r.stride = slotf; r.dst = L.dw; r.e0 = e; r.n = (unsigned)(nk - e < chunk ? nk - e : chunk); r.S = S;
             r.alpha = L.alpha; r.overwrite = L.overwrite; r.cols = cols; r.ldd = L.ldd;
             g.red.push_back(r);
         }
-        off += (unsigned long long)S * nk;
+        off += (unsigned long long)S * slotf;
         off = (off + 63) / 64 * 64;
     }
     g.ws_floats = off;
@@ -3907,7 +3923,7 @@ extern "C" size_t ayolo_conv_wgrad_workspace(const ayolo_conv_desc* d) {
     if (!d || check_desc(d, "conv_wgrad_workspace") != AYOLO_OK || is_packed_stem(d)) return 0;
     {
         W3P p3;
-        if (w3_single_plan(d, d, d, p3)) return (size_t)w3_splits(p3) * (size_t)p3.N * (size_t)p3.K * sizeof(float);
+        if (w3_single_plan(d, d, d, p3)) return (size_t)w3_splits(p3) * (size_t)w3_slot_floats(p3) * sizeof(float);
     }
     std::vector<WGradP> jobs;
     unsigned long long wf = 0;
@@ -3935,7 +3951,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
     unsigned long long wf = 0;
     W3P p3;
     const bool use3 = w3_single_plan(d, x, dy, p3);
-    if (use3) wf = (unsigned long long)w3_splits(p3) * (unsigned long long)p3.N * (unsigned long long)p3.K;
+    if (use3) wf = (unsigned long long)w3_splits(p3) * w3_slot_floats(p3);
     else {
         rc = wgrad_single_plan(d, x, dy, jobs, &wf);
         if (rc) return rc;
@@ -3962,6 +3978,7 @@ extern "C" int ayolo_conv_wgrad(const ayolo_conv_desc* d, const void* x, const v
     }
     WRed r{};
     r.ws_off = 0; r.stride = nk; r.dst = dw; r.S = S; r.alpha = alpha; r.overwrite = 0; r.cols = r.ldd = (unsigned)(d->kh * d->kw * d->Cin); r.e0 = 0;
+    if (use3) { r.stride = w3_slot_floats(p3); r.pC = (unsigned)p3.C; r.pNB = (unsigned)p3.NB; r.pCB = (unsigned)p3.CB; r.ptc = (unsigned)p3.tc; }
     AY_CHECK_ARG(nk < (1ull << 32), "conv_wgrad: dw of %llu elements", nk);
     r.n = (unsigned)nk;
     r.tpc = wred_tpc(S);

@@ -18,8 +18,8 @@ struct W3P {
     unsigned NU;                   // B * UP
     // step geometry: a step = RPS output rows x TC columns of a column strip (PX = RPS * TC pixels in nsub 16-pixel sub-steps)
     int TC, RPS, PX, nsub, strips;
-    // workgroup tile of dw: NB x CB blocks of (32 output channels) x (32 input channels x 9 taps); NP = NB * CB of the four
-    // wavefronts own one block each, SL = 4 / NP wavefronts share a block and split the sub-steps (summed through LDS at the end)
+    // workgroup tile of dw: NB x CB blocks of (32 output channels) x (32 input channels x 9 taps); SL = 8 / (NB * CB) of the
+    // EIGHT wavefronts share a block and split its sub-steps (summed through LDS at the end)
     int NB, CB, NP, SL;
     int tn, tc;                    // tiles along N / along C
     // x window of a step: nrows padded input rows, each ppr DMA pieces (1 KiB) = [c-block][column planes][pixel][32 channels]
@@ -32,7 +32,7 @@ struct W3P {
     unsigned uch, uranges;         // virtual rows per item (a multiple of RPS; an item walks them once per column strip), items per tile
     unsigned long long ws_off;     // split-K workspace of this layer, in floats
     unsigned zz0;                  // first partial slot of this job
-    FastDiv dXP, dUP, dTC;
+    FastDiv dXP, dUP, dTC, dPPR;
     double step_cost;              // modelled cycles of one step (host side: item balancing)
 };
 
@@ -43,6 +43,8 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, boo
 void w3_split(W3P& p, double steps);
 static inline unsigned w3_splits(const W3P& p) { return p.uranges; }
 static inline unsigned w3_tiles(const W3P& p) { return (unsigned)(p.tn * p.tc); }
+/* floats of one partial slot: tile-major, [tile][n-block][c-block][tap][32 rows][32 channels] (every block whole: edge tiles padded) */
+static inline unsigned long long w3_slot_floats(const W3P& p) { return (unsigned long long)p.tn * p.tc * p.NB * p.CB * 9ull * 1024ull; }
 static inline unsigned long long w3_item_steps(const W3P& p, unsigned ur) {
     const unsigned u0 = ur * p.uch, u1 = u0 + p.uch < p.NU ? u0 + p.uch : p.NU;
     return (unsigned long long)p.strips * ((u1 - u0 + (unsigned)p.RPS - 1) / (unsigned)p.RPS);

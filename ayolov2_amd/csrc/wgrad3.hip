@@ -25,12 +25,10 @@ typedef __fp16 w3_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef const __attribute__((address_space(4))) W3P* w3job_cptr_t;
 
 #define W3_XOOB 0x40000000u     // a lane offset that is out of range on its own AND on top of any row base (tensors < 1 GiB)
-#define W3_MAXK 3               // x pieces of one window row per wavefront (ppr <= 12)
-#define W3_MAXD 6               // dy pieces per wavefront (NB * nsub <= 24)
 #define W3_MAXI 6               // sub-steps per wavefront (nsub <= 6)
 #define W3_STAGE_MAX 64512      // a stage: < 64 KiB (16-bit fragment offsets); <= 40 KiB: two workgroups of two stages per CU
-#define W3_TAB_BYTES 9216       // [9][256] per-lane loader constants of the current strip, behind the two stages
-#define W3_RED_BYTES 36864      // cross-wavefront reduction: up to 3 wavefronts x 3 blocks x 16 registers x 64 lanes x 4 bytes
+#define W3_TAB_BYTES 9216       // loader tables of the current strip ([ppr + NB * nsub <= 36][64 lanes]), behind the two stages
+#define W3_RED_BYTES 28672      // cross-wavefront reduction: up to 7 wavefronts x 16 registers x 64 lanes x 4 bytes per round
 
 // 16 pixels x this lane's channel out of a [pixel][32 channel] plane: lane supplies the row address of pixel (q >> 2) (+ 4 for the
 // second read), channels (q & 3) * 4 .. of its 16-channel half, and receives channel q of the 4 + 4 rows (see tr_frag_sw in conv.hip)
@@ -67,7 +65,7 @@ extern "C" int ayolo_probe3_read(void* dst, unsigned long long bytes) {
 // immediates of the fragment reads (3 instructions per MFMA instead of 5: the MFMA phase of a wavefront alone on its SIMD is
 // issue-bound); RP == 0: any geometry, tap offsets from registers.
 template <int RP>
-__global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, const WItem* items, float* ws) {
+__global__ __launch_bounds__(512, 2) void k_wgrad3(W3P pv, const W3P* jobs, const WItem* items, float* ws) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,11 +108,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
     unsigned XP = (unsigned)p.XP, UP = (unsigned)p.UP, XH = (unsigned)p.XH, OH = (unsigned)p.OH, Bn = (unsigned)p.B;
     unsigned xrowb = (unsigned)p.XW * (unsigned)p.ldx * 2u, yrowb = (unsigned)p.OW * (unsigned)p.ldy * 2u, ypixb = (unsigned)p.ldy * 2u;
     unsigned stage = (unsigned)p.stage;
-    int nstrips = p.strips, ndy = NB * nsub;
+    int nstrips = p.strips;
     const FastDiv fXP = W3FD(dXP), fUP = W3FD(dUP);
     unsigned fxm = fXP.m, fxs1 = fXP.s1, fxs2 = fXP.s2, fum = fUP.m, fus1 = fUP.s1, fus2 = fUP.s2;
     asm volatile("" : "+s"(s), "+s"(RPS), "+s"(nsub), "+s"(nrows), "+s"(ppr), "+s"(rowpitch), "+s"(xstage), "+s"(stage));
-    asm volatile("" : "+s"(XP), "+s"(UP), "+s"(XH), "+s"(OH), "+s"(Bn), "+s"(xrowb), "+s"(yrowb), "+s"(ypixb), "+s"(ndy), "+s"(nstrips));
+    asm volatile("" : "+s"(XP), "+s"(UP), "+s"(XH), "+s"(OH), "+s"(Bn), "+s"(xrowb), "+s"(yrowb), "+s"(ypixb), "+s"(nstrips));
     asm volatile("" : "+s"(fxm), "+s"(fxs1), "+s"(fxs2), "+s"(fum), "+s"(fus1), "+s"(fus2));
     const int tni = (int)(tile / (unsigned)p.tc), tci = (int)(tile - (unsigned)tni * (unsigned)p.tc);
     const int nb0 = tni * NB, cb0 = tci * CB;
@@ -123,9 +121,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
     unsigned u1 = u0 + p.uch < p.NU ? u0 + p.uch : p.NU;
     const int nsteps = (int)((u1 - u0 + (unsigned)RPS - 1) / (unsigned)RPS);
     asm volatile("" : "+s"(u0), "+s"(u1));
-    // this wavefront: block `pair` of the tile, slice `slice` of the sub-steps
+    // this wavefront: block `pair` of the tile, slice `slice` of the sub-steps (EIGHT wavefronts: SL = 8 / NP of them share a block)
     const int pair = wave & (NP - 1);
-    const int slice = NP == 1 ? wave : (NP == 2 ? wave >> 1 : 0);
+    const int slice = NP == 1 ? wave : (NP == 2 ? wave >> 1 : wave >> 2);
     const int nb = CB == 2 ? pair >> 1 : pair, cb = CB == 2 ? pair & 1 : 0;
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsY = make_srd(p.dy, p.y_bytes);
@@ -133,53 +131,49 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
     const int XW = p.XW, OW = p.OW, Cc = p.C, Nn = p.N, ldx = p.ldx, ldy = p.ldy;
     const FastDiv fTC = W3FD(dTC);
 
-    // ---- loader lanes of column strip c0.  x: this wavefront issues pieces j = wave, wave + 4, .. of every window row; lane l of
-    // piece j fetches the 16-byte chunk ci = j * 64 + l of the row image [c-block][odd / all columns | even columns][pixel][4 chunks].
-    // dy: pieces e = wave, wave + 4, .. of the NB * nsub pieces [n-block][sub-step]; lane l fetches chunk (l & 3) of pixel
-    // sub * 16 + (l >> 2) of the step = (row pp / TC, column pp % TC); the row index rides in the low bits of the offset
-    // dy: pieces e = (3 - wave), (3 - wave) + 4, .. of the NB * nsub pieces [n-block][sub-step] (dealt from the other end: the low
-    // wavefronts carry more x pieces); the row index of the lane's pixel rides in the low bits of its offset.
-    // The nine per-lane loader constants of a strip live in LDS behind the two stages ([9][256 lanes], W3_TAB_BYTES): each is used
-    // once per step, and nine more live registers next to 144 accumulators and 40 fragment registers end in scratch -- whose
-    // reloads wait with s_waitcnt vmcnt(0), i.e. for every DMA in flight.
-    unsigned* ltab = reinterpret_cast<unsigned*>(smem_raw + 2 * (unsigned)p.stage) + tid;
-    const int wrev = 3 - wave;
+    // ---- loader tables of column strip c0, shared by the eight wavefronts, in LDS behind the two stages.
+    // XT[j][l] (j < ppr): byte offset (inside an input row) of the 16-byte chunk ci = j * 64 + l of the window row image
+    // [c-block][odd / all columns | even columns][pixel][4 chunks] -- what lane l of piece j of ANY row fetches;
+    // DT[e][l] (e < NB * nsub): offset of chunk (l & 3) of pixel sub * 16 + (l >> 2) of the step inside its dy row, the pixel's row
+    // (pp / TC) in the low bits -- what lane l of dy piece e = [n-block][sub-step] fetches.
+    unsigned* ltab = reinterpret_cast<unsigned*>(smem_raw + 2 * (unsigned)p.stage);
+    const int ndy = NB * nsub;
     auto setup_strip = [&](int c0) __attribute__((always_inline)) {
         const int cbsz = (plo + ple) >> 4;               // chunks per c-block
-#pragma unroll
-        for (int k = 0; k < W3_MAXK; ++k) {
-            const int j = wave + 4 * k;
-            const int ci = j * 64 + lane;
-            const int cbi = ci >= cbsz ? 1 : 0;
-            const int rem = ci - cbi * cbsz;
-            const bool even = rem >= (plo >> 4);             // stride 2 only (ple == 0 otherwise: rem < plo / 16 for every live chunk)
-            const int rem2 = even ? rem - (plo >> 4) : rem;
-            const int q = rem2 >> 2, ch = rem2 & 3;
-            const int ic = s == 1 ? c0 - 1 + q : (even ? 2 * (c0 + q) : 2 * (c0 + q) - 1);
-            const int chan = (cb0 + cbi) * 32 + ch * 8;
-            const bool ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < Cc);
-            ltab[k * 256] = ok ? (unsigned)((ic * ldx + chan) * 2) : W3_XOOB;
-        }
-#pragma unroll
-        for (int k = 0; k < W3_MAXD; ++k) {
-            const int e = wrev + 4 * k;
-            int nbk = 0, sub = e;
-            while (sub >= nsub) { sub -= nsub; ++nbk; }
-            const unsigned pp = (unsigned)(sub * 16 + (lane >> 2));
-            const unsigned row = fdiv(pp, fTC);
-            const int col = (int)(pp - row * (unsigned)TC);
-            const int chan = (nb0 + nbk) * 32 + (lane & 3) * 8;
-            const bool ok = (e < NB * nsub) & (pp < (unsigned)PX) & (c0 + col < OW) & (chan < Nn);
-            ltab[(W3_MAXK + k) * 256] = ok ? ((unsigned)(((c0 + col) * ldy + chan) * 2) | row) : W3_XOOB;
+        for (int idx = tid; idx < (ppr + ndy) * 64; idx += 512) {
+            const int e = idx >> 6, l = idx & 63;
+            unsigned v;
+            if (e < ppr) {
+                const int ci = e * 64 + l;
+                const int cbi = ci >= cbsz ? 1 : 0;
+                const int rem = ci - cbi * cbsz;
+                const bool even = rem >= (plo >> 4);             // stride 2 only (ple == 0 otherwise: rem < plo / 16 for every live chunk)
+                const int rem2 = even ? rem - (plo >> 4) : rem;
+                const int q = rem2 >> 2, ch = rem2 & 3;
+                const int ic = s == 1 ? c0 - 1 + q : (even ? 2 * (c0 + q) : 2 * (c0 + q) - 1);
+                const int chan = (cb0 + cbi) * 32 + ch * 8;
+                const bool ok = (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < Cc);
+                v = ok ? (unsigned)((ic * ldx + chan) * 2) : W3_XOOB;
+            } else {
+                const int ed = e - ppr;
+                int nbk = 0, sub = ed;
+                while (sub >= nsub) { sub -= nsub; ++nbk; }
+                const unsigned pp = (unsigned)(sub * 16 + (l >> 2));
+                const unsigned row = fdiv(pp, fTC);
+                const int col = (int)(pp - row * (unsigned)TC);
+                const int chan = (nb0 + nbk) * 32 + (l & 3) * 8;
+                const bool ok = (pp < (unsigned)PX) & (c0 + col < OW) & (chan < Nn);
+                v = ok ? ((unsigned)(((c0 + col) * ldy + chan) * 2) | row) : W3_XOOB;
+            }
+            ltab[idx] = v;
         }
     };
     // ---- fragment geometry.  Sub-step `sub`, half h of its 16 pixels: this lane's pixel is 4 * (sub * 4 + (lane >> 5) * 2 + h) + rowl
     // (TC % 4 == 0: the four pixels of a read lie in one output row); pixels beyond the step are clamped (their dy is zero, the
-    // x they meet only has to be finite).  XO[i][h]: byte offset of that pixel in the window for the wavefront's i-th sub-step,
-    // tap (0, 0), this wavefront's c-block.
+    // x they meet only has to be finite).  XO[i]: byte offsets of the two halves' pixels in the window for the wavefront's i-th
+    // sub-step, tap (0, 0), this wavefront's c-block (packed: a stage is < 64 KiB).
     const int q16 = lane & 15, rowl = q16 >> 2;
     const unsigned chanb = (unsigned)(((q16 & 3) * 4 + ((lane >> 4) & 1) * 16) * 2);
-    // (the two halves of a sub-step packed into one register: a stage is < 64 KiB)
     unsigned XO[W3_MAXI];
 #pragma unroll
     for (int i = 0; i < W3_MAXI; ++i) {
@@ -233,68 +227,66 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
         yoh += (unsigned)RPS; yu += (unsigned)RPS;                           \
         if (yoh >= UP) { yoh -= UP; ++yn; }                                  \
     }
-    // ---- DMA of the cursor's step.  What the probes of the first three versions showed (profiles/r05_w3_probe_v*.txt,
-    // r05_ldsdma_microbench.txt): an LDS-DMA piece costs its wavefront ~45 cycles to issue while fewer than ~40 pieces are in
-    // flight on the CU -- but the piece CURSOR cost 300-400 cycles per piece, with or without the DMA instruction in it
-    // (r05_w3_probe_v3_experiments.txt): a dozen taken branches per piece, each an instruction-buffer refill.  So the loader is
-    // STRAIGHT-LINE code: row r of the window and its up to three pieces are one unrolled block whose DMA instructions are
-    // predicated through EXEC (w3_glds_if: a load with EXEC = 0 is skipped by the hardware), the row base is scalar arithmetic
-    // with selects, and the blocks of step g + 1 are spread between the sub-steps of step g (W3_CHUNK) so that the queue is fed
-    // while the matrix pipe works.  (One piece behind every MFMA -- k_gconv's schedule -- was built first and dropped: the
-    // cursor's branches between the MFMAs of a sub-step cost hipcc's register allocator the accumulators: 540 bytes of scratch.)
-    // The dy pieces' row index is per lane, the four row bases are uniform: masks, not selects -- hipcc turns a chain of per-lane
-    // selects between SGPR values into divergent branches and then duplicates the DMA statement into them.
-    unsigned p_la = 0, p_ly = 0, p_vi = 0, p_n = 0, dyb0 = 0, dyb1 = 0, dyb2 = 0, dyb3 = 0;
+    // ---- DMA of the cursor's step.  What the probes of the first four versions showed (profiles/r05_w3_probe_v*.txt,
+    // r05_ldsdma_microbench.txt): an LDS-DMA piece costs ~45 cycles to issue while fewer than ~40 are in flight on the CU; what
+    // cost 300-400 cycles per piece was the CODE AROUND IT -- with or without the DMA instruction (v3 experiments), branchy or
+    // straight-line and predicated (v4: 33 slots of ~25 instructions = 8 000 cycles) -- because a wavefront alone on its SIMD
+    // issues an instruction only every ~8-10 cycles.  So (1) eight wavefronts, two per SIMD: the two slices of a block split its
+    // sub-steps AND every wavefront issues an eighth of the pieces, one wavefront's loader code runs under the other's MFMAs;
+    // (2) as few instructions per piece as the hardware allows: the per-lane offsets come from the shared LDS tables, the row
+    // bases of the whole window are computed ONCE per step, one row per lane (rbv: lane r = window row r; dyv: lane r = dy row r),
+    // and a piece picks its own with v_readlane / ds_bpermute.
+    // x pieces q = wave, wave + 8, .. of the nrows * ppr pieces [row][j]; dy pieces e = 7 - wave, 15 - wave, .. (dealt from the
+    // other end).
+    const int nxq = nrows * ppr;
+    const int wrev = 7 - wave;
+    const FastDiv fPPR = W3FD(dPPR);
+    unsigned rbv = 0, dyv = 0, p_x = 0, p_y = 0;
 #define W3_ISSUE_BEGIN(sb_)                                                                          \
     {                                                                                                \
-        p_la = lds_tiles + (sb_) + (unsigned)(wave * 1024);                                          \
-        p_ly = lds_tiles + (sb_) + (unsigned)(xstage + wrev * 1024);                                 \
-        p_vi = xvi; p_n = xn;                                                                        \
-        unsigned oh_ = yoh, n2_ = yn, u_ = yu;                                                       \
-        dyb0 = ((oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;                          \
-        ++u_; ++oh_; n2_ = oh_ >= UP ? n2_ + 1u : n2_; oh_ = oh_ >= UP ? 0u : oh_;                   \
-        dyb1 = ((1 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;              \
-        ++u_; ++oh_; n2_ = oh_ >= UP ? n2_ + 1u : n2_; oh_ = oh_ >= UP ? 0u : oh_;                   \
-        dyb2 = ((2 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;              \
-        ++u_; ++oh_; n2_ = oh_ >= UP ? n2_ + 1u : n2_; oh_ = oh_ >= UP ? 0u : oh_;                   \
-        dyb3 = ((3 < RPS) & (oh_ < OH) & (u_ < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;              \
+        p_x = lds_tiles + (sb_);                                                                     \
+        p_y = lds_tiles + (sb_) + (unsigned)xstage;                                                  \
+        unsigned vi_ = xvi + (unsigned)lane, n_ = xn;                                                \
+        n_ = vi_ >= XP ? n_ + 1u : n_; vi_ = vi_ >= XP ? vi_ - XP : vi_;                             \
+        const unsigned ih_ = vi_ - 1u;              /* vi == 0: the top padding row wraps to out of range */   \
+        rbv = ((ih_ < XH) & (n_ < Bn) & (lane < nrows)) ? (n_ * XH + ih_) * xrowb : G_OOB;           \
+        unsigned oh_ = yoh + (unsigned)lane, n2_ = yn;                                               \
+        n2_ = oh_ >= UP ? n2_ + 1u : n2_; oh_ = oh_ >= UP ? oh_ - UP : oh_;                          \
+        dyv = ((lane < RPS) & (oh_ < OH) & (yu + (unsigned)lane < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;   \
     }
-    // window row r_ (compile time): vi - 1 wraps to out of range for the top padding row
-#define W3_ROW(r_)                                                                                   \
+    // all of this wavefront's pieces of the cursor's step: at most four x pieces and three dy pieces (w3_fill keeps nrows * ppr <= 32
+    // and NB * nsub <= 24); their table entries are fetched first, together -- one LDS latency per step, not one per piece
+#define W3_ISSUE_ALL()                                                                               \
     {                                                                                                \
-        const unsigned ih_ = p_vi - 1u;                                                              \
-        const unsigned rb_ = ((ih_ < XH) & (p_n < Bn)) ? (p_n * XH + ih_) * xrowb : G_OOB;           \
-        const int lim_ = (r_) < nrows ? ppr : 0;              /* pieces of this row (none beyond the window) */  \
-        w3_glds_if(rsX, p_la, rb_ + ltab[0], (unsigned)(wave < lim_));                               \
-        w3_glds_if(rsX, p_la + 4096u, rb_ + ltab[256], (unsigned)(wave + 4 < lim_));                 \
-        w3_glds_if(rsX, p_la + 8192u, rb_ + ltab[512], (unsigned)(wave + 8 < lim_));                 \
-        p_la += (unsigned)rowpitch;                                                                  \
-        ++p_vi; p_n = p_vi >= XP ? p_n + 1u : p_n; p_vi = p_vi >= XP ? 0u : p_vi;                    \
-    }
-#define W3_DY(k_)                                                                                    \
-    {                                                                                                \
-        const unsigned dck_ = ltab[(W3_MAXK + (k_)) * 256];                                          \
-        unsigned row_ = dck_ & 3u;                                                                   \
-        asm volatile("" : "+v"(row_));                                                               \
-        const unsigned bb_ = (dyb0 & (0u - (unsigned)(row_ == 0))) | (dyb1 & (0u - (unsigned)(row_ == 1))) |   \
-                             (dyb2 & (0u - (unsigned)(row_ == 2))) | (dyb3 & (0u - (unsigned)(row_ == 3)));    \
-        w3_glds_if(rsY, p_ly + (unsigned)((k_) * 4096), bb_ + (dck_ & ~3u), (unsigned)(wrev + 4 * (k_) < ndy));   \
-    }
-    // chunk c_ of a step's loader: two window rows each for c_ = 0 .. 3, the ninth row and half of the dy pieces, the other half
-#define W3_CHUNK(c_)                                                                                 \
-    {                                                                                                \
-        if ((c_) < 4) { W3_ROW(2 * (c_)) W3_ROW(2 * (c_) + 1) }                                      \
-        else if ((c_) == 4) { W3_ROW(8) W3_DY(0) W3_DY(1) W3_DY(2) }                                 \
-        else { W3_DY(3) W3_DY(4) W3_DY(5) }                                                          \
+        unsigned r_[4], j_[4], t_[4], d_[3];                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                           \
+            const unsigned q_ = (unsigned)(wave + 8 * k_) < (unsigned)nxq ? (unsigned)(wave + 8 * k_) : 0u;   \
+            r_[k_] = fdiv(q_, fPPR);                                                                 \
+            j_[k_] = q_ - r_[k_] * (unsigned)ppr;                                                    \
+            t_[k_] = ltab[j_[k_] * 64u + (unsigned)lane];                                            \
+        }                                                                                            \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                             \
+            d_[k_] = ltab[(unsigned)(ppr + (wrev + 8 * k_ < ndy ? wrev + 8 * k_ : 0)) * 64u + (unsigned)lane];   \
+        _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                             \
+            if (wave + 8 * k_ < nxq) {                                                               \
+                const unsigned rb_ = (unsigned)__builtin_amdgcn_readlane((int)rbv, (int)r_[k_]);     \
+                glds16(rsX, p_x + r_[k_] * (unsigned)rowpitch + j_[k_] * 1024u, rb_ + t_[k_]);       \
+            }                                                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                             \
+            if (wrev + 8 * k_ < ndy) {                                                               \
+                const unsigned bb_ = (unsigned)__builtin_amdgcn_ds_bpermute((int)((d_[k_] & 3u) << 2), (int)dyv);   \
+                glds16_b(rsY, p_y + (unsigned)(wrev + 8 * k_) * 1024u, bb_ + (d_[k_] & ~3u));        \
+            }                                                                                        \
     }
 
     W3_MARK();                                   // 1: prologue done
     const int G = nstrips * nsteps;              // steps of the item, strip after strip
     int strip_ld = 0, st_ld = 0;
     setup_strip(0);
+    __syncthreads();                             // tables visible
     W3_CURSOR_RESET()
     W3_ISSUE_BEGIN(0u)
-    W3_CHUNK(0) W3_CHUNK(1) W3_CHUNK(2) W3_CHUNK(3) W3_CHUNK(4) W3_CHUNK(5)
+    W3_ISSUE_ALL()
     W3_MARK();                                   // 2: first issue done
     const unsigned char* sy0 = smem_raw + xstage + DYL;
     for (int g = 0; g < G; ++g) {
@@ -305,101 +297,90 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
         W3_MARK();                               // 4 + 4 g: barrier passed
         const bool more = g + 1 < G;
         if (more) {
-            if (++st_ld == nsteps) {
+            if (++st_ld == nsteps) {             // next strip: every wavefront has issued its last pieces of this one (barrier above)
                 st_ld = 0; ++strip_ld;
                 setup_strip(strip_ld * TC);
+                __syncthreads();
                 W3_CURSOR_RESET()
             } else W3_CURSOR_STEP()
             W3_ISSUE_BEGIN(stage - sb)
+            W3_ISSUE_ALL()
         }
-        W3_MARK();                               // 5 + 4 g: next step's loader set up
+        W3_MARK();                               // 5 + 4 g: next step issued
         // The wavefront's sub-steps of the stage at `sb`: one dy fragment and nine shifted x fragments feed nine MFMAs.  Software
         // pipeline: the fragments of the NEXT sub-step are fetched behind the MFMAs of this one that read the registers they
-        // replace (x fragment t right after MFMA t, the dy fragment into a second register set), so the LDS latency runs in the
-        // matrix pipe's shadow; chunk i of the next step's loader follows sub-step i.
-        const unsigned char* sx = smem_raw + sb;
-        const unsigned char* sy = sy0 + sb;
-        half8 a, b[9];
+        // replace (x fragment t right after MFMA t), so the LDS latency runs in the matrix pipe's shadow.
         if (slice < nsub) {
-            a = w3_frag(sy + slice * 1024, sy + slice * 1024 + 256);
+            const unsigned char* sx = smem_raw + sb;
+            const unsigned char* sy = sy0 + sb;
+            half8 a = w3_frag(sy + slice * 1024, sy + slice * 1024 + 256);
+            half8 b[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) b[t] = w3_frag(sx + (XO[0] & 0xffffu) + tapo[t], sx + (XO[0] >> 16) + tapo[t]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < W3_MAXI; ++i) {
-            const int sub = slice + SL * i;
-            if (sub < nsub) {
-                const int in = i + 1 < W3_MAXI ? i + 1 : i;
-                const int subn = sub + SL < nsub ? sub + SL : sub;                    // (past the last one: a harmless re-read)
-                const unsigned char* x0 = sx + (XO[in] & 0xffffu);
-                const unsigned char* x1 = sx + (XO[in] >> 16);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
-                    b[t] = w3_frag(x0 + tapo[t], x1 + tapo[t]);
+            for (int i = 0; i < W3_MAXI; ++i) {
+                const int sub = slice + SL * i;
+                if (sub < nsub) {
+                    const int in = i + 1 < W3_MAXI ? i + 1 : i;
+                    const int subn = sub + SL < nsub ? sub + SL : sub;                    // (past the last one: a harmless re-read)
+                    const unsigned char* x0 = sx + (XO[in] & 0xffffu);
+                    const unsigned char* x1 = sx + (XO[in] >> 16);
                     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[t], acc[t], 0, 0, 0);
+                        b[t] = w3_frag(x0 + tapo[t], x1 + tapo[t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    a = w3_frag(sy + subn * 1024, sy + subn * 1024 + 256);
                 }
-                a = w3_frag(sy + subn * 1024, sy + subn * 1024 + 256);       // (its latency: behind the loader chunk below)
             }
-            if (more) W3_CHUNK(i)
         }
-        W3_MARK();                               // 6 + 4 g: MFMAs and pieces issued
+        W3_MARK();                               // 6 + 4 g: MFMAs issued
     }
 #undef W3_CURSOR_RESET
 #undef W3_CURSOR_STEP
 #undef W3_ISSUE_BEGIN
-#undef W3_ROW
-#undef W3_DY
-#undef W3_CHUNK
+#undef W3_ISSUE_ALL
     // the accumulators are read below: MFMA result hazard (see AY_MFMA_PAD in conv.hip)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 11" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                             // the stages are free
-    // ---- wavefronts that share a block: slices 1 .. SL - 1 hand their sums to slice 0 through LDS, three taps per round, added in
+    // ---- wavefronts that share a block: slices 1 .. SL - 1 hand their sums to slice 0 through LDS, one tap per round, added in
     // slice order (a fixed order: the partial is bit-reproducible)
     if (SL > 1) {
         float* red = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
+        for (int t = 0; t < 9; ++t) {
             if (slice > 0) {
-                float* dst = red + (size_t)((slice - 1) * NP + pair) * (48 * 64) + lane;
+                float* dst = red + (size_t)((slice - 1) * NP + pair) * (16 * 64) + lane;
 #pragma unroll
-                for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[(tt * 16 + r) * 64] = acc[3 * g + tt][r];
+                for (int r = 0; r < 16; ++r) dst[r * 64] = acc[t][r];
             }
             __syncthreads();
             if (slice == 0) {
                 for (int sl = 1; sl < SL; ++sl) {
-                    const float* src = red + (size_t)((sl - 1) * NP + pair) * (48 * 64) + lane;
+                    const float* src = red + (size_t)((sl - 1) * NP + pair) * (16 * 64) + lane;
 #pragma unroll
-                    for (int tt = 0; tt < 3; ++tt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[3 * g + tt][r] += src[(tt * 16 + r) * 64];
+                    for (int r = 0; r < 16; ++r) acc[t][r] += src[r * 64];
                 }
             }
             __syncthreads();
         }
     }
-    // ---- acc[t][r]: output channel (nb0 + nb) * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), column t * C + (cb0 + cb) * 32 + (lane & 31)
-    // -> this split's slot of the workspace: lanes 0 .. 31 of a store cover 128 contiguous bytes of one dw row
+    // ---- acc[t][r]: output channel 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), input channel lane & 31 of block (nb, cb), tap t
+    // -> this split's TILE-MAJOR slot of the workspace ([tile][n-block][c-block][tap][32 rows][32 channels], w3_perm in
+    // conv.hip): the workgroup's 9 * NB * CB blocks are one contiguous run, a store covers two 128-byte rows
     if (slice == 0) {
-        float* slotp = ws + p.ws_off + (unsigned long long)(p.zz0 + zz) * ((unsigned long long)p.N * (unsigned long long)p.K);
-        const int K = p.K, N = p.N, C = p.C;
-        const int cc = (cb0 + cb) * 32 + (lane & 31);
-        const int rbase = (nb0 + nb) * 32 + 4 * (lane >> 5);
-        if (cc < C) {
+        float* slotp = ws + p.ws_off + (unsigned long long)(p.zz0 + zz) * ((unsigned long long)p.tn * p.tc * NB * CB * 9ull * 1024ull)
+                       + ((unsigned long long)(tile * (unsigned)(NB * CB) + (unsigned)(nb * CB + cb)) * 9ull) * 1024ull
+                       + (unsigned)((4 * (lane >> 5)) * 32 + (lane & 31));
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + 8 * (r >> 2) + (r & 3);
-                    if (row < N) slotp[(long long)row * K + t * C + cc] = acc[t][r];
-                }
-        }
+            for (int r = 0; r < 16; ++r) slotp[t * 1024 + (8 * (r >> 2) + (r & 3)) * 32] = acc[t][r];
     }
 #undef p
 #undef W3FD
@@ -424,11 +405,16 @@ static int w3_env(const char* name, int dflt) {
 
 size_t w3_lds_bytes(const W3P& p) {
     const size_t a = 2 * (size_t)p.stage + W3_TAB_BYTES;
-    return p.SL > 1 && a < W3_RED_BYTES ? (size_t)W3_RED_BYTES : a;
+    return a < W3_RED_BYTES ? (size_t)W3_RED_BYTES : a;
 }
 
 int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, bool any_route) {
-    static const int on = w3_env("AYOLO_WGRAD3", 1);
+    // Opt-in (AYOLO_WGRAD3=1; read at every planning call so that a test can switch it): alone on the chip the kernel beats the
+    // generic k_wgrad on the stride-1 3x3 layers of YOLOv5s (121 vs 154, 62 vs 82, 67 vs 73 us; 82 vs 73 on 256 -> 256 at 20 x 20:
+    // profiles/r05_wgrad3_layer_sweep.txt), but inside the train step -- one more launch and tail per weight-gradient group, one
+    // 8-wavefront workgroup owning a CU while the main stream's kernels look for slots -- the step was 0.05-0.25 ms SLOWER in
+    // every same-box A/B of every version (profiles/r05_ab_wgrad3_*.txt).
+    const int on = w3_env("AYOLO_WGRAD3", 0);
     if (!on && !any_route) return 1;
     if (d->dtype != AYOLO_F16 || d->kh != 3 || d->kw != 3 || d->ph != 1 || d->pw != 1 || d->sh != d->sw || (d->sh != 1 && d->sh != 2)) return 1;
     if (d->Cin % 8 || d->Cout % 8 || d->ldx % 8 || d->ldy % 8 || d->Cin < 16 || d->Cout < 16) return 1;
@@ -436,7 +422,7 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, boo
     // stride 2: the window is four input pixels per output pixel -- twice the DMA bytes per MFMA of the generic kernel's best
     // tiles on the wide layers; measured slower on every stride-2 layer of YOLOv5s (profiles/r05_sweep_w3*.txt): generic kernel
     // unless AYOLO_WGRAD3_S2=1
-    static const int s2on = w3_env("AYOLO_WGRAD3_S2", 0);
+    const int s2on = w3_env("AYOLO_WGRAD3_S2", 0);
     if (s == 2 && !s2on && !any_route) return 1;
     if (d->Ho != (d->H + 2 - 3) / s + 1 || d->Wo != (d->W + 2 - 3) / s + 1) return 1;
     const long long xb = (long long)d->B * d->H * d->W * d->ldx * 2, yb = (long long)d->B * d->Ho * d->Wo * d->ldy * 2;
@@ -454,13 +440,12 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, boo
     if (CBt >= 2 && NBt >= 2) { p.NB = 2; p.CB = 2; }
     else if (CBt == 1) { p.CB = 1; p.NB = NBt >= 3 ? 4 : NBt; }
     else { p.NB = 1; p.CB = 2; }
-    p.NP = p.NB * p.CB; p.SL = 4 / p.NP;
+    p.NP = p.NB * p.CB; p.SL = 8 / p.NP;
     p.tn = (NBt + p.NB - 1) / p.NB; p.tc = (CBt + p.CB - 1) / p.CB;
     // step geometry: the (TC, RPS) with the least modelled time per output pixel (tools/w3_probe.py prints the marks these numbers
-    // come from).  A step costs ~600 cycles of barrier / waits / cursor work plus the larger of (a) its MFMAs -- ~330 cycles per
-    // 16-pixel sub-step of a wavefront with the fragment fetch pipelined behind them, live pixels or not -- and (b) the DMA pieces
-    // of its busiest wavefront at ~400 cycles each (a wavefront keeps only a handful of 1-KiB pieces in flight against 1-2 us of
-    // latency).  With a stage of <= 40 KiB two workgroups share a CU: their DMA queues run in parallel, their MFMAs do not.
+    // come from).  A wavefront's instruction stream per step: ~300 cycles of waits / barrier / row bases, ~150 per DMA piece it
+    // issues (an eighth of the step's), ~330 per 16-pixel sub-step of its own (9 MFMAs with the fragment fetch pipelined behind
+    // them, live pixels or not); two wavefronts share a SIMD, so the matrix pipe needs 2 x 288 cycles per sub-step of a slice.
     double best = 1e30;
     for (int TC = 4; TC <= 96; TC += 4)
         for (int RPS = 1; RPS <= 4; ++RPS) {
@@ -470,31 +455,27 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, boo
             const int pw = s == 1 ? TC + 2 : 2 * TC + 1;
             const int ppr = (p.CB * pw * 4 + 63) / 64;
             const int nrows = s * (RPS - 1) + 3;
-            if (ppr > 4 * W3_MAXK || nrows > p.XP || p.NB * nsub > 4 * W3_MAXD) continue;
+            if (nrows > p.XP || nrows * ppr > 32 || p.NB * nsub > 24 || (ppr + p.NB * nsub) * 256 > W3_TAB_BYTES) continue;
             const int stage = nrows * ppr * 1024 + p.NB * nsub * 1024;
             if (stage > W3_STAGE_MAX) continue;
             const int strips = (p.OW + TC - 1) / TC;
             const int wsub = (nsub + p.SL - 1) / p.SL;
-            int maxp = 0;
-            for (int w = 0; w < 4; ++w) {
-                const int kc = ppr > w ? (ppr - w + 3) / 4 : 0, ndy = p.NB * nsub, wr = 3 - w;
-                const int np = nrows * kc + (ndy > wr ? (ndy - wr + 3) / 4 : 0);
-                maxp = np > maxp ? np : maxp;
-            }
-            const bool two = 2 * stage + W3_TAB_BYTES <= 81920;
-            const double mf = 330.0 * wsub * (two ? 2.0 : 1.0), dm = 400.0 * maxp;
-            const double t = (two ? 0.5 : 1.0) * (600.0 + (mf > dm ? mf : dm)) * strips / ((double)RPS * p.OW);
+            const int npw = (nrows * ppr + 7) / 8 + (p.NB * nsub + 7) / 8;
+            const double issue = 300.0 + 150.0 * npw + 330.0 * wsub, pipe = 200.0 + 576.0 * wsub;
+            const double tstep = issue > pipe ? issue : pipe;
+            const double t = tstep * strips / ((double)RPS * p.OW);
             if (t < best - 1e-9) {
                 best = t;
                 p.TC = TC; p.RPS = RPS; p.PX = PX; p.nsub = nsub; p.strips = strips;
                 p.nrows = nrows; p.ppr = ppr; p.rowpitch = ppr * 1024;
                 p.plo = (s == 1 ? TC + 2 : TC + 1) * 64; p.ple = s == 1 ? 0 : TC * 64;
                 p.xstage = nrows * ppr * 1024; p.stage = stage;
-                p.step_cost = (two ? 0.5 : 1.0) * (600.0 + (mf > dm ? mf : dm));
+                p.step_cost = tstep;
             }
         }
     if (best > 1e29) return 1;
     p.dXP = make_fastdiv((unsigned)p.XP); p.dUP = make_fastdiv((unsigned)p.UP); p.dTC = make_fastdiv((unsigned)p.TC);
+    p.dPPR = make_fastdiv((unsigned)p.ppr);
     p.uch = (unsigned)p.RPS; p.uranges = (p.NU + p.uch - 1) / p.uch;
     return 0;
 }
@@ -522,7 +503,7 @@ static int w3_launch_rp(const W3P& pv, const W3P* jobs, const WItem* items, unsi
 #endif
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(k_wgrad3<RP>, dim3(blocks), dim3(256), lds, s, pv, jobs, items, ws);
+    hipLaunchKernelGGL(k_wgrad3<RP>, dim3(blocks), dim3(512), lds, s, pv, jobs, items, ws);
     AY_CHECK_LAUNCH("k_wgrad3");
     return AYOLO_OK;
 }

@@ -811,3 +811,57 @@ def test_batched_weight_cast_equals_per_layer_cast():
         assert torch.equal(wt, rt), case
         if case[5]:
             assert bool((wide[:, :, :64] == 7.0).all()) and bool((wide[:, :, 64 + case[3]:] == 7.0).all()), case
+
+
+W3_SHAPES = [  # (B, Cin, Cout, stride, H, W)
+    (2, 32, 32, 1, 24, 40),      # one block: eight wavefronts split the sub-steps
+    (3, 64, 64, 1, 20, 20),      # 2 x 2 blocks, four-row steps that straddle images
+    (2, 64, 64, 1, 80, 80),      # the 80 x 80 Bottleneck layer of YOLOv5s: column strips
+    (2, 128, 128, 1, 40, 40),    # 2 x 2 tiles of 2 x 2 blocks
+    (2, 40, 72, 1, 12, 16),      # ragged channel blocks
+    (4, 256, 256, 1, 20, 20),
+    (2, 32, 64, 2, 64, 96),      # stride 2: odd / even column planes
+    (2, 64, 128, 2, 40, 40),
+    (2, 128, 32, 2, 9, 13),      # odd map: bottom padding row, strip wider than the map
+]
+
+
+@pytest.mark.parametrize("shape", W3_SHAPES)
+def test_wgrad3_patch_kernel_vs_torch_and_generic(shape, monkeypatch):
+    """k_wgrad3 (csrc/wgrad3.hip: the 3x3 weight gradient on a once-staged input patch, opt-in through AYOLO_WGRAD3=1) through
+    the C ABI's ayolo_conv_wgrad: against plain PyTorch fp32 on the CPU (same fp16-rounded operands, fp32 accumulation on both
+    sides), against the generic k_wgrad on the same device buffers, bit-reproducible from run to run, and accumulating into dw
+    (alpha) like the generic entry."""
+    import ctypes
+    from ayolov2_amd import _lib, ops, functional as F_
+    B, Cin, Cout, s, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g).half().float()
+    dt = torch.float16
+    geo = F_._Geometry((B, Cin, H, W), (Cout, Cin, 3, 3), (s, s), (1, 1), dt)
+    dy = torch.randn(B, Cout, geo.Ho, geo.Wo, generator=g).half().float()
+    wr = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x, wr, None, s, 1).backward(dy)
+    ref = wr.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)                       # [n][(dh, dw)][c]
+    xg = x.cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    dyg = dy.cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    d = geo.desc(dt, Cin, Cout)
+    out = {}
+    for name, env in (("patch", "1"), ("generic", "0")):
+        monkeypatch.setenv("AYOLO_WGRAD3", env)
+        monkeypatch.setenv("AYOLO_WGRAD3_S2", env)
+        if name == "patch":
+            gq = (ctypes.c_int64 * 24)()
+            _lib.check(_lib.lib().ayolo_wgrad3_geometry(d, gq, 24), "ayolo_wgrad3_geometry")
+        dw = torch.zeros((Cout, 9 * Cin), dtype=torch.float32, device="cuda")
+        ops.conv_wgrad(d, xg, dyg, dw)
+        dw2 = torch.zeros_like(dw)
+        ops.conv_wgrad(d, xg, dyg, dw2)
+        assert torch.equal(dw, dw2), name + ": not bit-reproducible"
+        ops.conv_wgrad(d, xg, dyg, dw2, alpha=0.5)                               # accumulates
+        torch.cuda.synchronize()
+        out[name] = dw.cpu()
+        assert _rel_err(dw2.cpu(), 1.5 * out[name]) < 1e-6, name
+    assert _rel_err(out["patch"], ref) < 2e-4, _rel_err(out["patch"], ref)
+    assert _rel_err(out["generic"], ref) < 2e-4
+    assert _rel_err(out["patch"], out["generic"]) < 2e-5

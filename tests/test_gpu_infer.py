@@ -333,7 +333,7 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
-def test_fp16_train_step_is_reproducible_and_routes_agree():
+def test_fp16_train_step_is_reproducible_and_routes_agree(monkeypatch):
     """BatchNorm statistics are accumulated in fp64 from the workgroup level on, so the only order-dependent roundings of a
     step sit at 1e-16 -- below one fp32 ulp of every mean / variance -- and the fp16 rounding of every activation repeats:
     two identical fp16 steps give the same loss and the same gradients (conv weight gradients bit for bit since round 4).  That makes every ROUTE comparison discriminating in the bench's own dtype: the plan executor vs the
@@ -359,6 +359,7 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
         P.BN_REDUCE_IN_DGRAD = kw.get("bnr", True)
         P.XF_ON_LOAD = kw.get("xf", True)
         P.XF_WGRAD_ON_LOAD = kw.get("xf_wgrad", False)
+        monkeypatch.setenv("AYOLO_WGRAD3", "1" if kw.get("wgrad3") else "0")      # read when the plan's group tables are built
         try:
             loss, _, g = _train_step(m, x, t, amp=True)
             if kw.get("use_plan", True):
@@ -395,6 +396,12 @@ def test_fp16_train_step_is_reproducible_and_routes_agree():
     assert l5 == l0, (l5, l0)
     assert _cos(g0, g5) >= 1.0 - 1e-9
     bad = [k for k in conv_w if float((last[0][k] - last[-1][k]).abs().max()) > 1e-6 * float(last[0][k].abs().max())]
+    assert not bad, bad
+    # the 3x3 weight gradients on the patch-staged k_wgrad3 (opt-in): same fp16 operands, fp32 partial sums in another order
+    l6, g6 = run(wgrad3=True)
+    assert l6 == l0, (l6, l0)
+    assert _cos(g0, g6) >= 1.0 - 1e-9
+    bad = [k for k in conv_w if float((last[0][k] - last[-1][k]).abs().max()) > 1e-5 * float(last[0][k].abs().max())]
     assert not bad, bad
     l2, g2 = run(bnr=False)
     l3, g3 = run(use_plan=False)

@@ -368,7 +368,7 @@ def test_plan_gradient_buckets_cover_the_arena():
     assert pl.bn_in_dgrad == 54 and kinds[0] >= 54 and kinds[7] == 3
 
 
-def test_wgrad_group_tables_cover_every_tile_once():
+def test_wgrad_group_tables_cover_every_tile_once(monkeypatch):
     """The planner of the grouped weight-gradient launch (ayolo_wgrad_group_size / _build; needs no GPU): every (layer,
     dw tile, pixel split) is exactly one item of its tile class, the gx * gy tiles of one split sit on ONE XCD queue (block
     index % 8) back to back, queues are padded to equal length, the splits of a layer own disjoint workspace slots and a
@@ -378,6 +378,7 @@ def test_wgrad_group_tables_cover_every_tile_once():
     from ayolov2_amd._lib import WgradJob
     lib = _lib.lib()
     F16 = 0
+    monkeypatch.setenv("AYOLO_WGRAD3", "1")      # the patch-staged 3x3 kernel is opt-in; its planner is part of what is checked here
     shapes = [  # (B, H, W, Cin, Cout, k, s)
         (8, 40, 40, 128, 128, 3, 1), (8, 40, 40, 256, 64, 1, 1), (8, 80, 80, 64, 32, 3, 2), (8, 20, 20, 512, 255 + 1, 1, 1),
         (192, 320, 320, 64, 64, 1, 1)]           # the last: x = dy = 2.5 GB -> two batch halves of 1.26 GB

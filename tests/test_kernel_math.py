@@ -118,8 +118,9 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
     lane = np.arange(64)
     uch = RPS * steps_per_item
     uranges = -(-NU // uch)
-    slots = np.zeros((uranges, N, K))
-    written = np.zeros((uranges, N, K), dtype=np.int32)
+    slotf = tn * tc * NB * CB * 9 * 1024       # floats of a TILE-MAJOR slot: [tile][n-block][c-block][tap][32 rows][32 channels]
+    slots = np.zeros((uranges, slotf))
+    written = np.zeros((uranges, slotf), dtype=np.int32)
     xrowb, yrowb = XW * ldx * 2, OW * ldy * 2
 
     def dma(lds, dst, buf, nbytes, off):
@@ -148,6 +149,7 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
         pp = np.minimum(pp, PX - 1)
         return (pp // TC) * (s * rowpitch) + (pp % TC) * 64 + chanb
 
+    NW = 8                                  # wavefronts per workgroup; SL = NW / NP of them share a block
     for tile in range(tn * tc):
         for zz in range(uranges):
             tni, tci = tile // tc, tile % tc
@@ -156,11 +158,11 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
             u1 = min(u0 + uch, NU)
             nsteps = -(-(u1 - u0) // RPS)
             lds = np.full(max(g["lds"], 2 * stage) // 2, np.nan, dtype=np.float16)
-            acc = np.zeros((4, 9, 32, 32))
+            acc = np.zeros((NW, 9, 32, 32))
             wc = []
-            for wave in range(4):
+            for wave in range(NW):
                 pair = wave & (NP - 1)
-                slice_ = wave if NP == 1 else (wave >> 1 if NP == 2 else 0)
+                slice_ = wave if NP == 1 else (wave >> 1 if NP == 2 else wave >> 2)
                 nb, cb = (pair >> 1, pair & 1) if CB == 2 else (pair, 0)
                 tapo = []
                 for t in range(9):
@@ -169,24 +171,32 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
                     tapo.append(dh * rowpitch + cb * (plo + ple) + colo)
                 DYL = ((lane >> 5) * 8 + rowl) * 64 + chanb + nb * nsub * 1024
                 wc.append(dict(pair=pair, slice=slice_, nb=nb, cb=cb, DYL=DYL, tapo=tapo))
+            ndy = NB * nsub
+            tabs = {}
 
             def setup_strip(c0):
+                """the loader tables of a strip, shared by the wavefronts: XT[j][lane], DT[e][lane]"""
                 cbsz = (plo + ple) >> 4
-                for wave in range(4):
-                    XC = []
-                    for k in range(3):
-                        j = wave + 4 * k
-                        ci = j * 64 + lane
-                        cbi = (ci >= cbsz).astype(int)
-                        rem = ci - cbi * cbsz
-                        even = rem >= (plo >> 4)
-                        rem2 = np.where(even, rem - (plo >> 4), rem)
-                        q, ch = rem2 >> 2, rem2 & 3
-                        ic = c0 - 1 + q if s == 1 else np.where(even, 2 * (c0 + q), 2 * (c0 + q) - 1)
-                        chan = (cb0 + cbi) * 32 + ch * 8
-                        ok = (j < ppr) & (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < C)
-                        XC.append(np.where(ok, (ic * ldx + chan) * 2, XOOB))
-                    wc[wave]["XC"] = XC
+                XT, DT = [], []
+                for j in range(ppr):
+                    ci = j * 64 + lane
+                    cbi = (ci >= cbsz).astype(int)
+                    rem = ci - cbi * cbsz
+                    even = rem >= (plo >> 4)
+                    rem2 = np.where(even, rem - (plo >> 4), rem)
+                    q, ch = rem2 >> 2, rem2 & 3
+                    ic = c0 - 1 + q if s == 1 else np.where(even, 2 * (c0 + q), 2 * (c0 + q) - 1)
+                    chan = (cb0 + cbi) * 32 + ch * 8
+                    ok = (ci < CB * cbsz) & (ic >= 0) & (ic < XW) & (chan < C)
+                    XT.append(np.where(ok, (ic * ldx + chan) * 2, XOOB))
+                for e in range(ndy):
+                    nbk, sub = e // nsub, e % nsub
+                    pp = sub * 16 + (lane >> 2)
+                    row, col = pp // TC, pp % TC
+                    chan = (nb0 + nbk) * 32 + (lane & 3) * 8
+                    ok = (pp < PX) & (c0 + col < OW) & (chan < N)
+                    DT.append(np.where(ok, (((c0 + col) * ldy + chan) * 2) | row, XOOB))
+                tabs["XT"], tabs["DT"] = XT, DT
 
             cur = {}
 
@@ -205,53 +215,28 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
                     cur["yoh"] -= UP
                     cur["yn"] += 1
 
-            def row_base(vi, n):
+            def issue(sb):
+                # row bases of the whole window / of the step's dy rows, one row per lane
+                vi, n = cur["xvi"] + lane, np.full(64, cur["xn"])
+                n = np.where(vi >= XP, n + 1, n)
+                vi = np.where(vi >= XP, vi - XP, vi)
                 ih = (vi - 1) & M32
-                return (n * XH + ih) * xrowb if (ih < XH and n < B) else G_OOB
-
-            def issue(sb, c0):
-                for wave in range(4):
-                    w = wc[wave]
-                    vi, n = cur["xvi"], cur["xn"]
-                    la = sb + wave * 1024
-                    for r in range(nrows):
-                        rb = row_base(vi, n)
-                        for k in range(3):
-                            if wave + 4 * k < ppr:
-                                dma(lds, la + 4096 * k, xf, g["x_bytes"], rb + w["XC"][k])
-                        la += rowpitch
-                        vi += 1
-                        if vi >= XP:
-                            vi, n = 0, n + 1
-                    oh, n2, u = cur["yoh"], cur["yn"], cur["yu"]
-                    dyb = []
-                    for r in range(4):
-                        ok = r < RPS and oh < OH and u < u1
-                        dyb.append((n2 * OH + oh) * yrowb if ok else G_OOB)
-                        u += 1
-                        oh += 1
-                        if oh >= UP:
-                            oh, n2 = 0, n2 + 1
-                    wrev = 3 - wave                  # dy pieces are dealt from the other end: the low wavefronts carry more x pieces
-                    ly = sb + xstage + wrev * 1024
-                    nbk, sub = 0, wrev
-                    for e in range(wrev, NB * nsub, 4):
-                        while sub >= nsub:
-                            sub -= nsub
-                            nbk += 1
-                        pp = sub * 16 + (lane >> 2)
-                        row, col = pp // TC, pp % TC
-                        chan = (nb0 + nbk) * 32 + (lane & 3) * 8
-                        ok = (pp < PX) & (c0 + col < OW) & (chan < N)
-                        dc = np.where(ok, ((c0 + col) * ldy + chan) * 2, XOOB)
-                        bb = np.choose(np.minimum(row, 3), dyb)
-                        dma(lds, ly, yf, g["y_bytes"], bb + dc)
-                        ly += 4096
-                        sub += 4
+                rbv = np.where((ih < XH) & (n < B) & (lane < nrows), (n * XH + ih) * xrowb, G_OOB)
+                oh, n2 = cur["yoh"] + lane, np.full(64, cur["yn"])
+                n2 = np.where(oh >= UP, n2 + 1, n2)
+                oh = np.where(oh >= UP, oh - UP, oh)
+                dyv = np.where((lane < RPS) & (oh < OH) & (cur["yu"] + lane < u1), (n2 * OH + oh) * yrowb, G_OOB)
+                for wave in range(NW):
+                    for q in range(wave, nrows * ppr, 8):
+                        r, j = q // ppr, q % ppr
+                        dma(lds, sb + r * rowpitch + j * 1024, xf, g["x_bytes"], int(rbv[r]) + tabs["XT"][j])
+                    for e in range(7 - wave, ndy, 8):
+                        dc = tabs["DT"][e]
+                        dma(lds, sb + xstage + e * 1024, yf, g["y_bytes"], dyv[dc & 3] + (dc & ~3))
 
             def compute(sb):
                 pp_lane = 8 * (lane >> 5) + rowl
-                for wave in range(4):
+                for wave in range(NW):
                     w = wc[wave]
                     sub = w["slice"]
                     while sub < nsub:
@@ -263,11 +248,12 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
                             acc[wave, t] += A.T @ frag(lds, sb + xo0 + w["tapo"][t], sb + xo1 + w["tapo"][t])
                         sub += SL
 
+            assert SL * NP == NW
             G = strips * nsteps
             strip_ld, st_ld = 0, 0
             setup_strip(0)
             cursor_reset()
-            issue(0, 0)
+            issue(0)
             for gi in range(G):
                 sb = stage if gi & 1 else 0
                 if gi + 1 < G:
@@ -278,27 +264,28 @@ def _w3_emulate(x, dy, g, s, steps_per_item):
                         cursor_reset()
                     else:
                         cursor_step()
-                    issue(stage - sb, strip_ld * TC)
+                    issue(stage - sb)
                 compute(sb)
             # slices of a block summed in slice order by slice 0, which stores the block
-            for wave in range(4):
+            for wave in range(NW):
                 w = wc[wave]
                 if w["slice"] != 0:
                     continue
                 tot = acc[wave].copy()
                 for sl in range(1, SL):
-                    other = next(v for v in range(4) if wc[v]["pair"] == w["pair"] and wc[v]["slice"] == sl)
+                    other = next(v for v in range(NW) if wc[v]["pair"] == w["pair"] and wc[v]["slice"] == sl)
                     tot += acc[other]
+                base = (tile * NB * CB + w["nb"] * CB + w["cb"]) * 9 * 1024      # the kernel's store: whole blocks, edge tiles padded
                 for t in range(9):
-                    for m in range(32):
-                        row = (nb0 + w["nb"]) * 32 + m
-                        for c in range(32):
-                            cc = (cb0 + w["cb"]) * 32 + c
-                            if cc < C and row < N:
-                                slots[zz, row, t * C + cc] = tot[t, m, c]
-                                written[zz, row, t * C + cc] += 1
+                    blk = slots[zz, base + t * 1024:base + (t + 1) * 1024].reshape(32, 32)
+                    blk[:] = tot[t]
+                    written[zz, base + t * 1024:base + (t + 1) * 1024] += 1
     assert (written == 1).all(), "every element of every workspace slot is stored exactly once"
-    return slots.sum(0), uranges
+    # k_wgrad_reduce's view of a slot (w3_perm in csrc/conv.hip): dense element (n, t * C + c) -> tile-major offset
+    n, col = np.divmod(np.arange(N * K), K)
+    t, c = np.divmod(col, C)
+    off = (((n // (NB * 32) * tc + c // (CB * 32)) * NB * CB + ((n >> 5) % NB) * CB + ((c >> 5) % CB)) * 9 + t) * 1024 + (n & 31) * 32 + (c & 31)
+    return slots.sum(0)[off].reshape(N, K), uranges
 
 
 @pytest.mark.parametrize("case", [
