@@ -35,6 +35,9 @@ struct GConvP {
     int epi; const float* scale; const float* shift; double* stats;
     int head_no; int accumulate; int stat_reps;
     int x_linear, y_linear, ntn, nslots;
+    // 1x1 / stride 1 / no padding with whole 32-channel chunks (C % 32 == 0) and the weight tap at column 0: the step loop's
+    // address work is ONE add per DMA piece (row offset + k offset) -- no tap decode, no tap-table read, no halo test
+    int lin;
     long long Mtotal;
     signed char dh[MAX_TAPS], dw[MAX_TAPS], wt[MAX_TAPS];
     unsigned x_bytes, w_bytes, y_bytes;      // extents for the buffer descriptors (k_gconv)
@@ -755,7 +758,7 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, in
     g_stats_to_global<TM, BNR>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
 }
 
-template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false>
+template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false, bool LIN = false>
 __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, TPX>::lds(EM, BNR) > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
     static_assert(TM == 32 || TM == 64 || TM == 128, "output-channel tiles of 32 / 64 / 128");
     static_assert(!XF || (sizeof(T) == 2 && !BNR && (EM == 0 || EM == 3)), "transform on load: fp16 forward of a 1x1 conv");
@@ -978,8 +981,27 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
         }
         return s1;
     };
+    // lin (see GConvP::lin): a row's byte offset, out of range for rows beyond the tensor, + the k offset of the step -- an
+    // out-of-range base plus a small k offset is still out of range, so the step needs no select at all.  The generic path spent
+    // ~45 VALU instructions and a tap-table read per step on tap decode and halo tests a 1x1 conv does not have; a wavefront issues
+    // an instruction every ~8 cycles (profiles/r05_w3_probe_*.txt), so that was a third of the step's time.
+    static_assert(!LIN || (!XF && sizeof(T) == 2), "the 1x1 loader: fp16, not transform-on-load");
+    constexpr bool lin = LIN;
+    auto lin_rows = [&]() __attribute__((always_inline)) {
+        if (lin) {
+#pragma unroll
+            for (int r = 0; r < G::XR; ++r) xoff[r] = xh0[r] < 0 ? (int)G_OOB : xoff[r];
+        }
+    };
+    auto lin_prep = [&](int kt, unsigned (&offs)[G::LPS]) __attribute__((always_inline)) {
+        const unsigned k0b = (unsigned)(kt * BK + kc * G::CE) * G::ES;
+#pragma unroll
+        for (int r = 0; r < G::XR; ++r) offs[r] = (unsigned)xoff[r] + k0b;
+#pragma unroll
+        for (int r = 0; r < G::WR; ++r) offs[G::XR + r] = woff[r] + k0b;
+    };
     if constexpr (XF) xf_setup_rows(ld_tile, true);
-    else g_setup_rows<T, TM, TPX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0);
+    else { g_setup_rows<T, TM, TPX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0); lin_rows(); }
     AY_PROBE(AY_PROBE_N - 5);
     __syncthreads();                          // tap table visible
     AY_PROBE(AY_PROBE_N - 6);
@@ -1000,7 +1022,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
                 ld_tile += lstride;                                                           \
                 ld_valid = ld_valid && ld_tile < ntiles;                                      \
                 if constexpr (XF) xf_setup_rows(ld_tile, ld_valid);                           \
-                else g_setup_rows<T, TM, TPX>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0);   \
+                else { g_setup_rows<T, TM, TPX>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0); lin_rows(); }   \
             }                                                                                 \
             ld_nk = G_NK(ld_cls);                                                             \
             ld_tap0 = p.ctap0[ld_cls]; ld_ntap = p.cnt[ld_cls];                               \
@@ -1091,6 +1113,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
             unsigned offs[G::LPS];
             v4i32 rsXs = rsX;
             if constexpr (XF) { if (xf_prep(ld_kt, offs)) rsXs = rsX2; }
+            else if (lin) lin_prep(ld_kt, offs);
             else g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
             __builtin_amdgcn_sched_barrier(0);
             g_mma_k_issue<T, TM, TPX>(f0, acc, offs, lds_tiles, so2, rsXs, rsW, wave);   // -> the stage step s-1 used
@@ -1106,6 +1129,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
             unsigned offs[G::LPS];
             v4i32 rsXs = rsX;
             if constexpr (XF) { if (xf_prep(ld_kt, offs)) rsXs = rsX2; }
+            else if (lin) lin_prep(ld_kt, offs);
             else g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
             __builtin_amdgcn_sched_barrier(0);
             g_mma_frags_issue<T, TM, TPX>(fr, acc, offs, lds_tiles, so2, rsXs, rsW, wave);   // step s+2 -> the stage step s-1 used
@@ -2026,7 +2050,7 @@ static GGrid gconv_grid(long long Mtotal, int tp, int ntn, int bpc) {
     return {slots, (tpx + spx - 1) / spx};
 }
 
-template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false>
+template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false, bool LIN = false>
 static int launch_gconv_tp(GConvP p, hipStream_t s) {
     using G = GT<T, TM, TPX>;
     const size_t lds = G::lds(EM, BNR) + (XF ? 2 * (size_t)((p.C + BK - 1) / BK * BK) * sizeof(float) : 0);
@@ -2077,11 +2101,11 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
     dim3 grid((unsigned)(slots * p.ntn));
     static size_t attr_set[16] = {0};        // per device (function attributes belong to the device's context): largest size set
     if (dev < 0 || dev >= 16 || attr_set[dev] < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX, BNR, XF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX, BNR, XF, LIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(XF ? 160 * 1024 : lds));
         if (dev >= 0 && dev < 16) attr_set[dev] = XF ? 160 * 1024 : lds;
     }
-    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR, XF>), grid, dim3(G::NT), lds, s, p);
+    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR, XF, LIN>), grid, dim3(G::NT), lds, s, p);
     AY_CHECK_LAUNCH("k_gconv");
     return AYOLO_OK;
 }
@@ -2109,6 +2133,11 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
         else wide = TM == 64 ? true : (TM == 128 ? K >= 256 : K >= 128);
     }
     if (p.s2f && TM == 128) wide = false;          // k_gconv_s2f: the 128 x 256 tile would spill (all four fragment sets live)
+    // the 1x1 loader (GConvP::lin): the Conv / dgrad / inference epilogues of the 64- and 128-channel tiles (YOLOHead keeps the
+    // generic loader: three launches per step)
+    if constexpr (sizeof(T) == 2 && !XF && EM != 3 && TM >= 64) {
+        if (p.lin) return wide ? launch_gconv_tp<T, TM, EM, 256, BNR, false, true>(p, s) : launch_gconv_tp<T, TM, EM, 128, BNR, false, true>(p, s);
+    }
     if (wide) return launch_gconv_tp<T, TM, EM, 256, BNR, XF>(p, s);
     return launch_gconv_tp<T, TM, EM, 128, BNR, XF>(p, s);
 }
@@ -2226,6 +2255,9 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     p.y_bytes = (unsigned)(y_img * p.B);
     p.w_bytes = (unsigned)w_bytes;
     p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)(p.C > 0 ? p.C : 1));
+    static const int lin_on = getenv("AYOLO_GCONV_LIN") ? atoi(getenv("AYOLO_GCONV_LIN")) : 1;
+    p.lin = (lin_on && dtype == AYOLO_F16 && p.x_linear && p.ncls <= 1 && p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.wt[0] == 0 &&
+             p.C % BK == 0 && p.XH == p.OH && p.XW == p.OW && p.ish == 1 && p.isw == 1 && !p.xf) ? 1 : 0;
     if (p.ncls <= 0) {                       // ordinary launch: one class = all taps
         p.ncls = 1; p.ctap0[0] = 0; p.cnt[0] = p.ntaps; p.coah[0] = p.oah; p.coaw[0] = p.oaw;
     }

@@ -422,6 +422,8 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, boo
     // stride 2: the window is four input pixels per output pixel -- twice the DMA bytes per MFMA of the generic kernel's best
     // tiles on the wide layers; measured slower on every stride-2 layer of YOLOv5s (profiles/r05_sweep_w3*.txt): generic kernel
     // unless AYOLO_WGRAD3_S2=1
+    const int minhw = w3_env("AYOLO_WGRAD3_MINHW", 0);         // only maps at least this high (A/B: the large maps alone)
+    if (d->Ho < minhw && !any_route) return 1;
     const int s2on = w3_env("AYOLO_WGRAD3_S2", 0);
     if (s == 2 && !s2on && !any_route) return 1;
     if (d->Ho != (d->H + 2 - 3) / s + 1 || d->Wo != (d->W + 2 - 3) / s + 1) return 1;
