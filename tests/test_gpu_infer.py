@@ -360,6 +360,7 @@ def test_fp16_train_step_is_reproducible_and_routes_agree(monkeypatch):
         P.XF_ON_LOAD = kw.get("xf", True)
         P.XF_WGRAD_ON_LOAD = kw.get("xf_wgrad", False)
         monkeypatch.setenv("AYOLO_WGRAD3", "1" if kw.get("wgrad3") else "0")      # read when the plan's group tables are built
+        monkeypatch.setenv("AYOLO_WGRAD3_MINHW", "0")                             # (every stride-1 3x3 layer, not only the large maps)
         try:
             loss, _, g = _train_step(m, x, t, amp=True)
             if kw.get("use_plan", True):
@@ -397,7 +398,8 @@ def test_fp16_train_step_is_reproducible_and_routes_agree(monkeypatch):
     assert _cos(g0, g5) >= 1.0 - 1e-9
     bad = [k for k in conv_w if float((last[0][k] - last[-1][k]).abs().max()) > 1e-6 * float(last[0][k].abs().max())]
     assert not bad, bad
-    # the 3x3 weight gradients on the patch-staged k_wgrad3 (opt-in): same fp16 operands, fp32 partial sums in another order
+    # the stride-1 3x3 weight gradients on the patch-staged k_wgrad3 (all of them here): same fp16 operands, fp32 partial sums in
+    # another order
     l6, g6 = run(wgrad3=True)
     assert l6 == l0, (l6, l0)
     assert _cos(g0, g6) >= 1.0 - 1e-9

@@ -378,7 +378,8 @@ def test_wgrad_group_tables_cover_every_tile_once(monkeypatch):
     from ayolov2_amd._lib import WgradJob
     lib = _lib.lib()
     F16 = 0
-    monkeypatch.setenv("AYOLO_WGRAD3", "1")      # the patch-staged 3x3 kernel is opt-in; its planner is part of what is checked here
+    monkeypatch.setenv("AYOLO_WGRAD3", "1")      # the patch-staged 3x3 kernel for every stride-1 3x3 layer (default: maps of >= 80 rows):
+    monkeypatch.setenv("AYOLO_WGRAD3_MINHW", "0")    # its planner is part of what is checked here
     shapes = [  # (B, H, W, Cin, Cout, k, s)
         (8, 40, 40, 128, 128, 3, 1), (8, 40, 40, 256, 64, 1, 1), (8, 80, 80, 64, 32, 3, 2), (8, 20, 20, 512, 255 + 1, 1, 1),
         (192, 320, 320, 64, 64, 1, 1)]           # the last: x = dy = 2.5 GB -> two batch halves of 1.26 GB
