@@ -1196,6 +1196,8 @@ class TrainPlan:
         if active and getattr(sync, "overlap", True):
             cuts += [(ready, 1, (lo, hi)) for ready, lo, hi in self.buckets]
         cuts.sort(key=lambda c: (c[0], c[1]))
+        if active and getattr(sync, "measure", False):
+            sync.mark_backward_start()
         a = 0
         for k, kind, payload in cuts:
             # AYOLO_RUN_NO_JOIN: the compute stream does not wait for the side-stream weight gradients here; the

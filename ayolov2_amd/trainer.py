@@ -201,6 +201,14 @@ class _FlatSync:
         if self.measure:
             self._marks.append(("bucket", ev, view.numel() * view.element_size()))
 
+    def mark_backward_start(self) -> None:
+        """Measurement mode: the compute stream's time at the start of the backward list (exposed_ms reports every bucket's
+        completion and the join against it: the backward window the exchange has to hide in)."""
+        if self.measure and torch.cuda.is_available():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self._marks.append(("start", ev, 0))
+
     def wait_all(self) -> None:
         cur = torch.cuda.current_stream() if self._works and torch.cuda.is_available() else None
         if self.measure and cur is not None:
@@ -225,23 +233,35 @@ class _FlatSync:
                 steps.append(cur)
                 cur = []
         self._marks = []
-        per_bucket, sizes = None, None
+        per_bucket, sizes, done, window, nwin = None, None, None, 0.0, 0
         for st in steps:
             join = st[-1][1]
+            start = next((ev for kind, ev, _ in st if kind == "start"), None)
+            bk = [m for m in st[:-1] if m[0] == "bucket"]
             edge, row = 0.0, []
-            for kind, ev, nbytes in st[:-1]:
+            for kind, ev, nbytes in bk:
                 t = max(join.elapsed_time(ev), 0.0)          # ms the bucket finished after the join point (<= 0: hidden)
                 row.append(max(t - edge, 0.0))
                 edge = max(edge, t)
             if per_bucket is None:
-                per_bucket, sizes = [0.0] * len(row), [b for _, _, b in st[:-1]]
+                per_bucket, sizes, done = [0.0] * len(row), [b for _, _, b in bk], [0.0] * len(row)
             if len(row) == len(per_bucket):
                 per_bucket = [a + b for a, b in zip(per_bucket, row)]
+                if start is not None:
+                    done = [a + start.elapsed_time(ev) for a, (_, ev, _) in zip(done, bk)]
+                    window += start.elapsed_time(join)
+                    nwin += 1
         n = max(len(steps), 1)
         per_bucket = [round(v / n, 4) for v in (per_bucket or [])]
-        return {"buckets": len(per_bucket), "bucket_mb": [round(b / 1e6, 2) for b in (sizes or [])],
-                "exposed_ms_per_bucket": per_bucket, "exposed_ms_per_step": round(sum(per_bucket), 4),
-                "overlap": self.overlap, "compress": self.compress, "measured_steps": len(steps)}
+        out = {"buckets": len(per_bucket), "bucket_mb": [round(b / 1e6, 2) for b in (sizes or [])],
+               "exposed_ms_per_bucket": per_bucket, "exposed_ms_per_step": round(sum(per_bucket), 4),
+               "overlap": self.overlap, "compress": self.compress, "measured_steps": len(steps)}
+        if nwin:
+            # the backward window (start of the backward list -> the compute stream reaches wait_all) and when, inside it, each
+            # bucket's averaged all-reduce was complete
+            out["backward_window_ms"] = round(window / nwin, 3)
+            out["bucket_done_ms_after_backward_start"] = [round(v / nwin, 3) for v in done]
+        return out
 
     def average_now(self, t: torch.Tensor) -> None:
         """sync_bn: in-stream average of one layer's BatchNorm accumulators (sum, sum of squares / backward sums) over

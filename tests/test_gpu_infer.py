@@ -295,11 +295,12 @@ def test_yolov5s_train_step_fp32_and_fp16_vs_oracle():
     for a, b in zip(raws16, raws_r):
         assert float((a.cpu() - b.detach()).abs().max()) <= 0.02 * float(b.max() - b.min())
     assert abs(l16 - float(loss_r.detach())) <= 5e-3 * abs(float(loss_r.detach()))
-    # fp16 gradients at random initialisation: every element is a sum of 10^4..10^6 signed terms that largely cancel, so a
-    # parameter's worst element is a noisy quantity: measured on MI355X, largest error / largest element has median 3-15 %,
-    # 90th percentile 8-21 %, maximum 12-38 % from run to run (the first layers, at the END of the fp16 backward chain, and
-    # BatchNorm vectors lead), while the direction of the whole gradient is stable at cosine 0.992 -- the same value the
-    # full-size fp16 step shows against its own fp32 mode.  Checked as a distribution plus directions.
+    # fp16 gradients at random initialisation: every element is a sum of 10^4..10^6 signed terms that largely cancel while fp16
+    # storage rounds every activation and activation gradient to 1e-3, so a parameter's worst element is a noisy quantity (the
+    # first layers, at the END of the fp16 backward chain, and BatchNorm vectors lead) while the direction of the whole gradient
+    # holds.  The step is bit-reproducible since rounds 3 / 4 (fp64 statistics, no atomics in the weight gradients), so these are
+    # fixed numbers of this seed, not a distribution: measured on MI355X in round 5 (profiles/r05_gpu_tests.txt) largest error /
+    # largest element median 0.146, 90th percentile 0.205, maximum 0.337; whole-gradient cosine 0.9880.
     errs, flat16, flat32 = {}, [], []
     for k, g in g16.items():
         errs[k] = float((g.cpu() - gr[k]).abs().max()) / (float(gr[k].abs().max()) + 1e-12)
@@ -314,15 +315,10 @@ def test_yolov5s_train_step_fp32_and_fp16_vs_oracle():
     glob = float((a_ @ b_) / (a_.norm() * b_.norm()))
     print("yolov5s fp16 vs oracle: gradient error / max element: median %.4f, p90 %.4f, max %.4f %s; whole-gradient cosine %.5f"
           % (np.median(e), e[int(0.9 * len(e))], e[-1], [(k, round(v, 3)) for k, v in top], glob))
-    # the per-parameter worst-element statistic is an extreme value of noise (3-4 sigma of a parameter's elements) and moves a
-    # lot between runs; it is bounded loosely, the gradient's direction is what is held tight
-    assert np.median(e) <= 0.35 and e[int(0.9 * len(e))] <= 0.6, (np.median(e), e[int(0.9 * len(e))], e[-1], top)
-    # measured 0.968 .. 0.994 over repeated runs.  The spread is NOT the kernels (tools/race_screen.py: forward and dgrad
-    # are bit-reproducible) and not only conditioning: two IDENTICAL fp16 steps agree to cosine 0.993-0.998 with each other
-    # (tools/cond_explore.py; two fp32-mode steps: 1.000000) -- the BatchNorm statistics are accumulated with fp32 atomics in
-    # launch order, their last bits move the fp16 rounding of a few % of the activations, and that is the run-to-run floor of
-    # any whole-gradient comparison in fp16.  A wrong tile / channel chunk moves the cosine below 0.9.
-    assert glob >= 0.95, glob
+    # thresholds = the measured values plus room for a different summation order after a kernel change (a wrong tile / channel
+    # chunk moves the cosine below 0.9; the discriminating fp16 comparison is test_fp16_train_step_well_conditioned_vs_oracle)
+    assert np.median(e) <= 0.25 and e[int(0.9 * len(e))] <= 0.35, (np.median(e), e[int(0.9 * len(e))], e[-1], top)
+    assert glob >= 0.975, glob
 
 
 def _flat(g):

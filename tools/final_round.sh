@@ -2,12 +2,14 @@
 # Round-end validation on one GPU box: full GPU tests, smoke, full bench line, rocprofv3 kernel stats + PMC HBM traffic + SQ counters of
 # the train step, kernel stats of cfg 5, the DDP code path of bench.py under torchrun (one rank, exchange forced).
 # usage (GPU box, repo root): bash tools/final_round.sh r03
-tag=${1:-r03}
+tag=${1:-r05}
 out=gpurun_out; mkdir -p $out
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $out/${tag}_gpu_tests.txt
+[ -z "$SKIP_TESTS" ] && timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $out/${tag}_gpu_tests_tail.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.txt 2>&1
-timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/${tag}_bench_n1.json
+# kernel stats + the two PMC passes first: bench.py's roofline.traffic then cites THIS tree's summary (copy it into profiles/)
 bash tools/profile_round.sh $tag > /dev/null 2>&1
+cp $out/${tag}_pmc_hbm_traffic.json profiles/ 2>/dev/null
+timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/${tag}_bench_n1.json
 bash tools/pmc_sq.sh $tag > /dev/null 2>&1
 export TMPDIR=/tmp; root=$(pwd)
 (cd /tmp && rm -rf /tmp/prof_c5 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -o c5 -- python $root/tools/cfg5_time.py > $root/$out/${tag}_cfg5_under_rocprof.txt 2>/dev/null; cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) $root/$out/${tag}_eval_cfg5_kernel_stats.csv)
@@ -16,7 +18,7 @@ python tools/config_bench.py 3 2>/dev/null | tail -1 > $out/${tag}_cfg3.json
 AYOLO_WGRAD_STREAM=0 python tools/op_table.py yolov5l 32 > $out/${tag}_op_table_isolated_yolov5l.txt 2>&1
 python tools/op_table.py > $out/${tag}_op_table_in_situ.txt 2>&1
 AYOLO_WGRAD_STREAM=0 python tools/op_table.py > $out/${tag}_op_table_isolated.txt 2>&1
-cat $out/${tag}_gpu_tests.txt $out/${tag}_smoke.txt; python - <<PY
+cat $out/${tag}_gpu_tests_tail.txt $out/${tag}_smoke.txt 2>/dev/null; python - <<PY
 import json
 for f in ("$out/${tag}_bench_n1.json", "$out/${tag}_bench_torchrun_forced_ddp.json"):
     try:
