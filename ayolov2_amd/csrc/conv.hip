@@ -3683,7 +3683,11 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
     // k_wgrad3's launch: two workgroups per CU, items of equal modelled time
     if (!g.jobs3.empty()) {
         const double slots3 = (double)num_cus() * 2.0;
-        const double waves3 = (double)wgrad_env("AYOLO_WGRAD3_WAVES", 2);
+        // (half a round of workgroups -- one per CU: every extra row range is one more slot to store and add and one more
+        // epilogue; 3 / 2 / 1 / 0.5 rounds measured +0.12 / +0.07 / 0 / -0.05 ms against one, all inside +-0.06 ms of each other on
+        // a second box: profiles/r05_ab_wgrad_groups_waves.txt, r05_ab_wgrad3_waves.txt)
+        const char* w3e = getenv("AYOLO_WGRAD3_WAVES");
+        const double waves3 = w3e ? atof(w3e) : 0.5;
         const double minq3 = (double)wgrad_env("AYOLO_WGRAD3_MINQ", 6);
         double total3 = 0.0;
         for (const W3P& p : g.jobs3) total3 += (double)w3_tiles(p) * p.strips * (double)((p.NU + p.RPS - 1) / p.RPS) * w3_step_cost(p);

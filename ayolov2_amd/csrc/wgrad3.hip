@@ -254,28 +254,41 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
         n2_ = oh_ >= UP ? n2_ + 1u : n2_; oh_ = oh_ >= UP ? oh_ - UP : oh_;                          \
         dyv = ((lane < RPS) & (oh_ < OH) & (yu + (unsigned)lane < u1)) ? (n2_ * OH + oh_) * yrowb : G_OOB;   \
     }
-    // all of this wavefront's pieces of the cursor's step: at most four x pieces and three dy pieces (w3_fill keeps nrows * ppr <= 32
-    // and NB * nsub <= 24); their table entries are fetched first, together -- one LDS latency per step, not one per piece
-#define W3_ISSUE_ALL()                                                                               \
+    // This wavefront's pieces of a step: at most four x pieces and three dy pieces (w3_fill keeps nrows * ppr <= 32 and
+    // NB * nsub <= 24).  Which window row / piece-in-row each of them is never changes (pr_ / plds_: row and LDS offset, uniform),
+    // their table entries change with the strip (pt_ / pd_: W3_PIECES_OF_STRIP) -- all of it out of the step loop: a step's loader
+    // is the row bases (one row per lane) + per piece a v_readlane, an add and the DMA (probe v5c: 1 280 cycles of issue per step
+    // with this bookkeeping inside the loop, 9-10 cycles per instruction)
+    unsigned pr_[4], plds_[4], pt_[4], pd_[3];
+#pragma unroll
+    for (int k_ = 0; k_ < 4; ++k_) {
+        const unsigned q_ = (unsigned)(wave + 8 * k_) < (unsigned)nxq ? (unsigned)(wave + 8 * k_) : 0u;
+        pr_[k_] = fdiv(q_, fPPR);
+        plds_[k_] = pr_[k_] * (unsigned)rowpitch + (q_ - pr_[k_] * (unsigned)ppr) * 1024u;
+        pt_[k_] = 0;
+    }
+#pragma unroll
+    for (int k_ = 0; k_ < 3; ++k_) pd_[k_] = 0;
+#define W3_PIECES_OF_STRIP()                                                                         \
     {                                                                                                \
-        unsigned r_[4], j_[4], t_[4], d_[3];                                                         \
         _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                           \
             const unsigned q_ = (unsigned)(wave + 8 * k_) < (unsigned)nxq ? (unsigned)(wave + 8 * k_) : 0u;   \
-            r_[k_] = fdiv(q_, fPPR);                                                                 \
-            j_[k_] = q_ - r_[k_] * (unsigned)ppr;                                                    \
-            t_[k_] = ltab[j_[k_] * 64u + (unsigned)lane];                                            \
+            pt_[k_] = ltab[(q_ - pr_[k_] * (unsigned)ppr) * 64u + (unsigned)lane];                   \
         }                                                                                            \
         _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                             \
-            d_[k_] = ltab[(unsigned)(ppr + (wrev + 8 * k_ < ndy ? wrev + 8 * k_ : 0)) * 64u + (unsigned)lane];   \
+            pd_[k_] = ltab[(unsigned)(ppr + (wrev + 8 * k_ < ndy ? wrev + 8 * k_ : 0)) * 64u + (unsigned)lane];   \
+    }
+#define W3_ISSUE_ALL()                                                                               \
+    {                                                                                                \
         _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                             \
             if (wave + 8 * k_ < nxq) {                                                               \
-                const unsigned rb_ = (unsigned)__builtin_amdgcn_readlane((int)rbv, (int)r_[k_]);     \
-                glds16(rsX, p_x + r_[k_] * (unsigned)rowpitch + j_[k_] * 1024u, rb_ + t_[k_]);       \
+                const unsigned rb_ = (unsigned)__builtin_amdgcn_readlane((int)rbv, (int)pr_[k_]);    \
+                glds16(rsX, p_x + plds_[k_], rb_ + pt_[k_]);                                         \
             }                                                                                        \
         _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_)                                             \
             if (wrev + 8 * k_ < ndy) {                                                               \
-                const unsigned bb_ = (unsigned)__builtin_amdgcn_ds_bpermute((int)((d_[k_] & 3u) << 2), (int)dyv);   \
-                glds16_b(rsY, p_y + (unsigned)(wrev + 8 * k_) * 1024u, bb_ + (d_[k_] & ~3u));        \
+                const unsigned bb_ = (unsigned)__builtin_amdgcn_ds_bpermute((int)((pd_[k_] & 3u) << 2), (int)dyv);   \
+                glds16_b(rsY, p_y + (unsigned)(wrev + 8 * k_) * 1024u, bb_ + (pd_[k_] & ~3u));       \
             }                                                                                        \
     }
 
@@ -284,6 +297,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
     int strip_ld = 0, st_ld = 0;
     setup_strip(0);
     __syncthreads();                             // tables visible
+    W3_PIECES_OF_STRIP()
     W3_CURSOR_RESET()
     W3_ISSUE_BEGIN(0u)
     W3_ISSUE_ALL()
@@ -301,6 +315,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
                 st_ld = 0; ++strip_ld;
                 setup_strip(strip_ld * TC);
                 __syncthreads();
+                W3_PIECES_OF_STRIP()
                 W3_CURSOR_RESET()
             } else W3_CURSOR_STEP()
             W3_ISSUE_BEGIN(stage - sb)
@@ -343,11 +358,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
 #undef W3_CURSOR_STEP
 #undef W3_ISSUE_BEGIN
 #undef W3_ISSUE_ALL
+#undef W3_PIECES_OF_STRIP
     // the accumulators are read below: MFMA result hazard (see AY_MFMA_PAD in conv.hip)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 11" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                             // the stages are free
+#ifdef AYOLO_PROBE
+    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) s_probe[W3_PROBE_N - 6] = t_; }
+#endif
     // ---- wavefronts that share a block: slices 1 .. SL - 1 hand their sums to slice 0 through LDS, one tap per round, added in
     // slice order (a fixed order: the partial is bit-reproducible)
     if (SL > 1) {
@@ -370,6 +389,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
             __syncthreads();
         }
     }
+#ifdef AYOLO_PROBE
+    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) s_probe[W3_PROBE_N - 5] = t_; }
+#endif
     // ---- acc[t][r]: output channel 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), input channel lane & 31 of block (nb, cb), tap t
     // -> this split's TILE-MAJOR slot of the workspace ([tile][n-block][c-block][tap][32 rows][32 channels], w3_perm in
     // conv.hip): the workgroup's 9 * NB * CB blocks are one contiguous run, a store covers two 128-byte rows
@@ -385,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad3(W3P pv, const W3P* jobs, cons
 #undef p
 #undef W3FD
 #ifdef AYOLO_PROBE
+    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) s_probe[W3_PROBE_N - 4] = t_; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();
@@ -415,7 +438,7 @@ int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, boo
     // tail per weight-gradient group, an 8-wavefront workgroup owning a CU while the main stream's kernels look for slots -- taking
     // ALL of them made the step 0.04-0.25 ms slower in every same-box A/B of every version (profiles/r05_ab_wgrad3_*.txt); taking
     // only the maps of >= 80 rows, where the layer is HBM-heavy and the gain per layer largest, is worth -0.06 ms
-    // (r05_ab_wgrad3_minhw.txt).  AYOLO_WGRAD3=0: generic kernel everywhere; AYOLO_WGRAD3_MINHW: the row threshold.
+    // (r05_ab_wgrad3_minhw.txt) and -0.11 ms with the final loader (r05_ab_wgrad3_v5d.txt: every stride-1 layer -0.05).  AYOLO_WGRAD3=0: generic kernel everywhere; AYOLO_WGRAD3_MINHW: the row threshold.
     const int on = w3_env("AYOLO_WGRAD3", 1);
     if (!on && !any_route) return 1;
     const int minhw = w3_env("AYOLO_WGRAD3_MINHW", 80);

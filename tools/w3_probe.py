@@ -61,6 +61,11 @@ def main():
     if len(allsteps):
         m = allsteps.mean(0)
         print(f"mean over {len(allsteps)} inner steps: dma wait {m[0]:.0f} | barrier {m[1]:.0f} | issue next {m[2]:.0f} | sub-steps {m[3]:.0f}   (sum {m.sum():.0f})")
+    ep = np.array([(t[b][N - 6] - t[b][3 + 4 * ((min(int(t[b][N - 2]), N - 2) - 3) // 4) - 1], t[b][N - 5] - t[b][N - 6], t[b][N - 4] - t[b][N - 5],
+                    t[b][N - 1] - t[b][N - 4]) for b in np.nonzero(live)[0] if t[b][N - 6] > 0])
+    if len(ep):
+        m = ep.mean(0)
+        print(f"epilogue parts (mean): last step -> final barrier {m[0]:.0f} | slice reduction through LDS {m[1]:.0f} | stores issued {m[2]:.0f} | stores landed {m[3]:.0f}")
     print("mean prologue %.0f, first issue %.0f, epilogue %.0f, life %.0f" % (np.mean([r[1] for r in rows]), np.mean([r[2] for r in rows]),
                                                                            np.mean([r[4] for r in rows]), np.mean([r[5] for r in rows])))
 
