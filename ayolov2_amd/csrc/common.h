@@ -36,6 +36,34 @@ void ayolo_set_error(const char* fmt, ...);
         }                                                                           \
     } while (0)
 
+// Sum of the `reps` replicas of a pair of fp64 accumulators, in replica order (bit-identical to the plain loop: the running sums
+// are never -0.0, so "+ 0.0" for a replica beyond `reps` changes nothing).  The plain loop `for r: s1 += a[r * rs]` compiles to ONE
+// MEMORY ROUND TRIP PER REPLICA (load, s_waitcnt vmcnt(0), add, branch): with eight replicas every workgroup of a BatchNorm pass
+// spent ~8 dependent L2 latencies in its prologue before it streamed its first byte -- 19 us for a 39 MB pass that needs 9
+// (round 5, profiles/r05_bn_prologue.txt).  Here the loads of eight replicas are in flight together.
+__device__ __forceinline__ void rep_sum2(const double* a, size_t rs, size_t off2, int reps, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
+    for (int r0 = 0; r0 < reps; r0 += 8) {
+        double u[8], v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + k < reps ? r0 + k : reps - 1;      // clamped: every load unconditional
+            u[k] = a[(size_t)r * rs];
+            v[k] = a[(size_t)r * rs + off2];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s1 += r0 + k < reps ? u[k] : 0.0;
+            s2 += r0 + k < reps ? v[k] : 0.0;
+        }
+    }
+}
+// an optional per-channel vector (null: `dflt`), loaded without a branch around the load
+__device__ __forceinline__ float opt_load(const float* v, const float* any, int i, float dflt) {
+    const float t = (v ? v : any)[i];
+    return v ? t : dflt;
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -858,11 +858,8 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
             for (int f = 0; f < p.nfin; ++f) {
                 const ayolo_xf_fin& q = p.fin[f];
                 for (int c = tid; c < q.C; c += (int)blockDim.x) {
-                    double s1 = 0.0, s2 = 0.0;
-                    for (int r = 0; r < q.reps; ++r) {
-                        s1 += q.stats[(size_t)r * 2 * q.sld + c];
-                        s2 += q.stats[(size_t)r * 2 * q.sld + q.sld + c];
-                    }
+                    double s1, s2;
+                    rep_sum2(q.stats + c, (size_t)2 * q.sld, (size_t)q.sld, q.reps, s1, s2);   // eight replicas in flight (common.h)
                     // the SAME expression sequence as k_bn_finalize / k_bn_train_act's prologue: bit-identical scale / shift
                     const double mean = s1 / q.count;
                     double var = s2 / q.count - mean * mean;
@@ -3039,10 +3036,10 @@ __global__ __launch_bounds__(256, (MB == 1 ? 2 : 1)) void k_stem_wgrad(StemWP p)
         for (int c = tid; c < 32 * MB; c += 256) {
             float A = 0.0f, Bc = 0.0f, P = 0.0f, R2 = 0.0f, Q2 = 0.0f;
             if (c < p.N) {
-                double d1 = 0.0, d2 = 0.0;
-                for (int r = 0; r < p.reps; ++r) { d1 += p.sums[(size_t)r * 2 * p.NS + c]; d2 += p.sums[(size_t)r * 2 * p.NS + p.NS + c]; }
+                const float mu = p.mean[c], is = p.invstd[c], ga = opt_load(p.gamma, p.mean, c, 1.0f), be = opt_load(p.beta, p.mean, c, 0.0f);
+                double d1, d2;
+                rep_sum2(p.sums + c, (size_t)2 * p.NS, (size_t)p.NS, p.reps, d1, d2);
                 const float s1 = (float)d1, s2 = (float)d2;
-                const float mu = p.mean[c], is = p.invstd[c], ga = p.gamma ? p.gamma[c] : 1.0f, be = p.beta ? p.beta[c] : 0.0f;
                 const float m1 = s1 * invn, m2 = s2 * invn;
                 A = is * ga; Bc = be - mu * A; P = ga * is;
                 const float Rr = -P * m2, Q = -P * m1, nmi = -mu * is;

@@ -82,11 +82,8 @@ __global__ void k_bn_finalize(const double* stats, int reps, int sld, int C, dou
                               float* scale, float* shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < reps; ++r) {               // [reps][2][sld] accumulators; this layer's channels start at `stats`
-        s1 += stats[(size_t)r * 2 * sld + c];
-        s2 += stats[(size_t)r * 2 * sld + sld + c];
-    }
+    double s1, s2;                                 // [reps][2][sld] accumulators; this layer's channels start at `stats`
+    rep_sum2(stats + c, (size_t)2 * sld, (size_t)sld, reps, s1, s2);
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
@@ -244,18 +241,15 @@ __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a,
     // stats: [reps][2][sld] accumulators of the producing conv; this layer's channels start at `stats` (sld > C when the
     // conv computed several layers at once -- C3's cv1 | cv2 -- and this is one channel slice of it)
     for (int c = threadIdx.x; c < C; c += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < reps; ++r) {
-            s1 += stats[(size_t)r * 2 * sld + c];
-            s2 += stats[(size_t)r * 2 * sld + sld + c];
-        }
+        const float g = opt_load(gamma, reinterpret_cast<const float*>(stats), c, 1.0f), b = opt_load(beta, reinterpret_cast<const float*>(stats), c, 0.0f);
+        double s1, s2;
+        rep_sum2(stats + c, (size_t)2 * sld, (size_t)sld, reps, s1, s2);   // all loads of the prologue in flight together
         // the SAME expression sequence as k_bn_finalize (the per-module path): with reproducible statistics the two routes
         // then derive bit-identical scale / shift vectors, and a route comparison in fp16 is about the kernels only
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;        // the cancellation-prone step stays in fp64
         if (var < 0) var = 0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
         const float sc = g * invstd;
         sc_sh[pl_idx<VE>(c, C)] = sc;
         sc_sh[C + pl_idx<VE>(c, C)] = b - (float)mean * sc;
@@ -461,10 +455,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     // cooperative prologue: replica sums once per workgroup, then every thread keeps ITS channel group in registers
     for (int i = threadIdx.x; i < C; i += 256) {
         const int q = pl_idx<VE>(i, C);
-        sh[q] = mean[i]; sh[C + q] = invstd[i];
-        sh[2 * C + q] = gamma ? gamma[i] : 1.0f; sh[3 * C + q] = beta ? beta[i] : 0.0f;
-        double d1 = 0.0, d2 = 0.0;
-        for (int r = 0; r < reps; ++r) { d1 += sums[(size_t)r * 2 * C + i]; d2 += sums[(size_t)r * 2 * C + C + i]; }
+        // every load of the prologue issued before the first use: one memory round trip, not twelve (rep_sum2, common.h)
+        const float mu_ = mean[i], is_ = invstd[i], ga_ = opt_load(gamma, mean, i, 1.0f), be_ = opt_load(beta, mean, i, 0.0f);
+        double d1, d2;
+        rep_sum2(sums + i, (size_t)2 * C, (size_t)C, reps, d1, d2);
+        sh[q] = mu_; sh[C + q] = is_;
+        sh[2 * C + q] = ga_; sh[3 * C + q] = be_;
         const float s1 = (float)d1, s2 = (float)d2;
         sh[4 * C + q] = s1 * invn; sh[5 * C + q] = s2 * invn;
         if (blockIdx.x == 0) {
