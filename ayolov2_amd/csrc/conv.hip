@@ -427,12 +427,14 @@ __device__ __forceinline__ void g_bnr_setup(const GConvP& p, float* sBn, int n0,
         const int sg = (p.bnr > 1 && c >= p.bseg[1].c0) ? 1 : 0;
         const int cl = c - p.bseg[sg].c0;
         float is = 0.0f, nmi = 0.0f, A = 0.0f, Bc = 0.0f;
-        if (c < p.Nout && cl >= 0 && cl < p.bseg[sg].C) {
-            const float mu = p.bseg[sg].mean_invstd[cl];
-            is = p.bseg[sg].mean_invstd[p.bseg[sg].C + cl];
-            const float ga = p.bseg[sg].gamma ? p.bseg[sg].gamma[cl] : 1.0f, be = p.bseg[sg].beta ? p.bseg[sg].beta[cl] : 0.0f;
-            A = is * ga; Bc = be - mu * A; nmi = -mu * is;
-        }
+        // the four loads unconditional (clamped index) and together: behind a branch each was a memory round trip of its own
+        // in front of the workgroup's first DMA (see rep_sum2, common.h)
+        const bool in = c < p.Nout && cl >= 0 && cl < p.bseg[sg].C;
+        const int cq = in ? cl : 0;
+        const float* mi = p.bseg[sg].mean_invstd;
+        const float mu = mi[cq], isv = mi[p.bseg[sg].C + cq];
+        const float ga = opt_load(p.bseg[sg].gamma, mi, cq, 1.0f), be = opt_load(p.bseg[sg].beta, mi, cq, 0.0f);
+        if (in) { is = isv; A = is * ga; Bc = be - mu * A; nmi = -mu * is; }
         sBn[i] = is; sBn[TM + i] = nmi; sBn[2 * TM + i] = A; sBn[3 * TM + i] = Bc;
     }
 }
@@ -760,6 +762,7 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, in
 
 template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false, bool LIN = false>
 __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, TPX>::lds(EM, BNR) > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
+    AY_KERNARG_TOUCH(kt_, GConvP);           // every line of the parameter struct requested at once (gfx950_dma.h)
     static_assert(TM == 32 || TM == 64 || TM == 128, "output-channel tiles of 32 / 64 / 128");
     static_assert(!XF || (sizeof(T) == 2 && !BNR && (EM == 0 || EM == 3)), "transform on load: fp16 forward of a 1x1 conv");
     using G = GT<T, TM, TPX>;
@@ -798,6 +801,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
     const unsigned lslot = idx / (unsigned)p.ntn;
     const unsigned lstride = (unsigned)p.nslots / 8u;
     unsigned cur_tile = band_lo + lslot;
+    kt_.done();
     if (cur_tile >= ntiles) return;
 
     // ---- tap table -> LDS: {x byte delta, dh, dw, w column byte offset}; entries >= ntaps never hit (K padding)
@@ -841,8 +845,15 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
         // affine epilogue constants of this channel tile -> LDS [scale | shift] (identity beyond Nout / for null pointers)
         for (int i = tid; i < TM; i += (int)blockDim.x) {
             const bool in = n0 + i < p.Nout;
-            sStat[i] = (in && p.scale) ? p.scale[n0 + i] : 1.0f;
-            sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
+            const float* any = p.scale ? p.scale : p.shift;       // both loads together (one memory round trip in the prologue)
+            float sc_ = 1.0f, sh_ = 0.0f;
+            if (any) {
+                const float a_ = (p.scale ? p.scale : any)[in ? n0 + i : 0], b_ = (p.shift ? p.shift : any)[in ? n0 + i : 0];
+                sc_ = (in && p.scale) ? a_ : 1.0f;
+                sh_ = (in && p.shift) ? b_ : 0.0f;
+            }
+            sStat[i] = sc_;
+            sStat[TM + i] = sh_;
         }
     }
     // XF: per-input-channel scale | shift behind the epilogue's tail, [2][C rounded up to 32] floats (zeros beyond C: the
@@ -1234,6 +1245,7 @@ struct GT3 {
 
 template <typename T, int TM, int EM, int TPX, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
+    AY_KERNARG_TOUCH(kt_, GConvP);           // every line of the parameter struct requested at once (gfx950_dma.h)
     using G = GT<T, TM, TPX>;
     using G3 = GT3<T, TM, TPX>;
     constexpr int NSTK = G::NACC * 2;
@@ -1261,13 +1273,21 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
     const unsigned lslot = idx / (unsigned)p.ntn;
     const unsigned lstride = (unsigned)p.nslots / 8u;
     unsigned cur_tile = band_lo + lslot;
+    kt_.done();
     if (cur_tile >= ntiles) return;
 
     if constexpr (EM == 2 || EM == 4) {
         for (int i = tid; i < TM; i += 256) {
             const bool in = n0 + i < p.Nout;
-            sStat[i] = (in && p.scale) ? p.scale[n0 + i] : 1.0f;
-            sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
+            const float* any = p.scale ? p.scale : p.shift;       // both loads together (one memory round trip in the prologue)
+            float sc_ = 1.0f, sh_ = 0.0f;
+            if (any) {
+                const float a_ = (p.scale ? p.scale : any)[in ? n0 + i : 0], b_ = (p.shift ? p.shift : any)[in ? n0 + i : 0];
+                sc_ = (in && p.scale) ? a_ : 1.0f;
+                sh_ = (in && p.shift) ? b_ : 0.0f;
+            }
+            sStat[i] = sc_;
+            sStat[TM + i] = sh_;
         }
     }
     if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 4 * TM, n0, tid);
@@ -1519,6 +1539,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int TM, int EM, int TPX, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
+    AY_KERNARG_TOUCH(kt_, GConvP);           // every line of the parameter struct requested at once (gfx950_dma.h)
     using G = GT<T, TM, TPX>;
     static_assert(sizeof(T) == 2 && G::MI == 1 && G::NI == 2 && (TM == 32 || TM == 64), "fp16, 32- or 64-channel tiles");
     constexpr int XR = G::XR;
@@ -1552,6 +1573,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
     const unsigned lslot = idx / (unsigned)p.ntn;
     const unsigned lstride = (unsigned)p.nslots / 8u;
     unsigned cur_tile = band_lo + lslot;
+    kt_.done();
     if (cur_tile >= ntiles) return;
 
     const v4i32 rsX = make_srd(p.x, p.x_bytes), rsW = make_srd(p.w, p.w_bytes);
@@ -1773,6 +1795,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int TM, int EM, int TPX>
 __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
+    AY_KERNARG_TOUCH(kt_, GConvP);           // every line of the parameter struct requested at once (gfx950_dma.h)
     using G = GT<T, TM, TPX>;
     static_assert(sizeof(T) == 2, "fp16");
     constexpr int XR = G::XR;
@@ -1803,13 +1826,21 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
     const unsigned lslot = idx / (unsigned)p.ntn;
     const unsigned lstride = (unsigned)p.nslots / 8u;
     unsigned cur_tile = band_lo + lslot;
+    kt_.done();
     if (cur_tile >= ntiles) return;
 
     if constexpr (EM == 2 || EM == 4) {
         for (int i = tid; i < TM; i += 256) {
             const bool in = n0 + i < p.Nout;
-            sStat[i] = (in && p.scale) ? p.scale[n0 + i] : 1.0f;
-            sStat[TM + i] = (in && p.shift) ? p.shift[n0 + i] : 0.0f;
+            const float* any = p.scale ? p.scale : p.shift;       // both loads together (one memory round trip in the prologue)
+            float sc_ = 1.0f, sh_ = 0.0f;
+            if (any) {
+                const float a_ = (p.scale ? p.scale : any)[in ? n0 + i : 0], b_ = (p.shift ? p.shift : any)[in ? n0 + i : 0];
+                sc_ = (in && p.scale) ? a_ : 1.0f;
+                sh_ = (in && p.shift) ? b_ : 0.0f;
+            }
+            sStat[i] = sc_;
+            sStat[TM + i] = sh_;
         }
     }
     const bool want_stats = (EM == 0) && (p.stats != nullptr);
@@ -2662,12 +2693,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 3 : 1)) void k_wgrad(WGradP 
     }
 #define p (*pj)
 #define WFD(f_) FastDiv{pj->f_.m, pj->f_.s1, pj->f_.s2}     /* member-wise: an address-space-4 struct has no copy constructor */
+    ScalarTouch<(int)sizeof(WGradP)> jt_;             // every line of the job requested at once (gfx950_dma.h)
+    jt_.issue((unsigned long long)pj);
     const int j0 = (int)(tile % p.gx) * TNW;          // dw column tile (tap*C + c)
     const int n0 = (int)(tile / p.gx) * TM;           // output-channel tile
     const unsigned P = (unsigned)p.P;
     const unsigned pbeg = zz * (unsigned)p.chunk;
     const unsigned pend = pbeg + (unsigned)p.chunk < P ? pbeg + (unsigned)p.chunk : P;
     // (the host never creates an empty split: every slot of the workspace is written)
+    jt_.done();
 
     const int slot = p.dy_slot;
     const void* dyp = slot < 0 ? p.dy : (slot == 0 ? ovr.q[0] : (slot == 1 ? ovr.q[1] : (slot == 2 ? ovr.q[2] : ovr.q[3])));
