@@ -18,6 +18,18 @@ __device__ __forceinline__ void load_vec(const T* p, float (&v)[VecT<T>::VE]) {
 #pragma unroll
     for (int i = 0; i < VecT<T>::VE; ++i) v[i] = (float)e[i];
 }
+// the same in two halves, for the software-pipelined streaming loops: the raw 16 bytes of the NEXT iteration are requested before
+// the current one is computed.  Left to its own devices hipcc sinks every load of an unrolled 4-pixel body to just in front of
+// its first use (to save registers): the body then waits for one memory round trip per pixel with two loads in flight, and at
+// three wavefronts per SIMD a CU has 24 KB in flight -- ~3 TB/s by Little's law, which is what k_bn_bwd_apply measured
+// (profiles/r05_bn_stream_mlp.txt).
+template <typename T> __device__ __forceinline__ uint4 load_raw(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+template <typename T>
+__device__ __forceinline__ void unpack_raw(const uint4& raw, float (&v)[VecT<T>::VE]) {
+    const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < VecT<T>::VE; ++i) v[i] = (float)e[i];
+}
 template <typename T>
 __device__ __forceinline__ void store_vec(T* p, const float (&v)[VecT<T>::VE]) {
     uint4 raw;
@@ -150,27 +162,52 @@ __device__ __forceinline__ void affine_act_rows(const T* z, int ldz, T* a, int l
                                                 const float (&sc)[VecT<T>::VE], const float (&sh)[VecT<T>::VE],
                                                 const T* res, int ldr, long long pix, long long stride) {
     constexpr int VE = VecT<T>::VE;
-    // four pixels per iteration: all loads issued before the first use
-    for (; pix + 3 * stride < npix; pix += 4 * stride) {
-        float v[4][VE], r[4][VE];
+    // four pixels per iteration, software-pipelined with two register sets (see k_bn_bwd_apply and load_raw): the raw vectors
+    // of the next four pixels are in flight while the current four are computed and stored
+    constexpr int NPX = 2;                           // pixels per register set
+    int opaque_true = 1;
+    asm volatile("" : "+s"(opaque_true));
+    auto request = [&](uint4 (&zq)[NPX], uint4 (&rq)[RES ? NPX : 1], long long at) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, v[j]);
+        for (int j = 0; j < NPX; ++j) zq[j] = load_raw<T>(z + (at + j * stride) * ldz + cg * VE);
         if constexpr (RES) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) load_vec<T>(res + (pix + j * stride) * ldr + cg * VE, r[j]);
+            for (int j = 0; j < NPX; ++j) rq[j] = load_raw<T>(res + (at + j * stride) * ldr + cg * VE);
         }
+    };
+    auto compute = [&](const uint4 (&zq)[NPX], const uint4 (&rq)[RES ? NPX : 1], long long at) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NPX; ++j) {
+            float v[VE], r[VE];
+            unpack_raw<T>(zq[j], v);
+            if constexpr (RES) unpack_raw<T>(rq[j], r);
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
                 float u;
-                if constexpr (sizeof(T) == 2) u = __builtin_fmaf(v[j][i], sc[i], sh[i]);
-                else u = v[j][i] * sc[i] + sh[i];
+                if constexpr (sizeof(T) == 2) u = __builtin_fmaf(v[i], sc[i], sh[i]);
+                else u = v[i] * sc[i] + sh[i];
                 if constexpr (ACT) u = silu_t<T>(u);
-                if constexpr (RES) u += r[j][i];
-                v[j][i] = u;
+                if constexpr (RES) u += r[i];
+                v[i] = u;
             }
-            store_vec<T>(a + (pix + j * stride) * lda + cg * VE, v[j]);
+            store_vec<T>(a + (at + j * stride) * lda + cg * VE, v);
+        }
+    };
+    if (pix + (NPX - 1) * stride < npix) {
+        uint4 zA[NPX], rA[RES ? NPX : 1], zB[NPX], rB[RES ? NPX : 1];
+        long long pa = pix;
+        request(zA, rA, pa);
+        while (true) {
+            const long long pb = pa + NPX * stride;
+            const bool hb = pb + (NPX - 1) * stride < npix;
+            if (opaque_true) request(zB, rB, hb ? pb : 0);              // (no next group: the tensor's first rows, cache hits for everyone)
+            compute(zA, rA, pa);
+            if (!hb) { pix = pb; break; }
+            pa = pb + NPX * stride;
+            const bool ha = pa + (NPX - 1) * stride < npix;
+            if (opaque_true) request(zA, rA, ha ? pa : 0);
+            compute(zB, rB, pb);
+            if (!ha) { pix = pa; break; }
         }
     }
     for (; pix < npix; pix += stride) {
@@ -486,36 +523,65 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
         }
         const long long stride = (long long)gridDim.x * RPB;
         long long pix = (long long)blockIdx.x * RPB + prow;
-        for (; pix + 3 * stride < npix; pix += 4 * stride) {
-            float zz[4][VE], dd[4][VE];
+        // four pixels per iteration, software-pipelined (see load_raw): the z / da (/ dres) vectors of the next four pixels are
+        // requested before the current four are computed.  Two register sets take turns (A, B: no copies on the back edge --
+        // with one "current" and one "next" set the copies land right behind the loads, with a wait for them), and each request
+        // group sits in a basic block of its own behind an always-true branch the compiler cannot see through, so that there
+        // is nothing in the block to sink the loads behind.
+        constexpr int NPX = 2;                       // pixels per register set
+        int opaque_true = 1;
+        asm volatile("" : "+s"(opaque_true));
+        auto request = [&](uint4 (&zq)[NPX], uint4 (&dq)[NPX], uint4 (&rq)[RESOUT ? NPX : 1], long long at) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                load_vec<T>(z + (pix + j * stride) * ldz + cg * VE, zz[j]);
-                load_vec<T>(da + (pix + j * stride) * ldda + cg * VE, dd[j]);
+            for (int j = 0; j < NPX; ++j) {
+                zq[j] = load_raw<T>(z + (at + j * stride) * ldz + cg * VE);
+                dq[j] = load_raw<T>(da + (at + j * stride) * ldda + cg * VE);
             }
             if constexpr (RESOUT) {
-                float rr[4][VE];
                 if (res_acc) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) load_vec<T>(dres + (pix + j * stride) * lddres + cg * VE, rr[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int i = 0; i < VE; ++i) rr[j][i] = res_acc ? rr[j][i] + dd[j][i] : dd[j][i];
-                    store_vec<T>(dres + (pix + j * stride) * lddres + cg * VE, rr[j]);
+                    for (int j = 0; j < NPX; ++j) rq[j] = load_raw<T>(dres + (at + j * stride) * lddres + cg * VE);
                 }
             }
+        };
+        auto compute = [&](const uint4 (&zq)[NPX], const uint4 (&dq)[NPX], const uint4 (&rq)[RESOUT ? NPX : 1], long long at) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NPX; ++j) {
+                float zz[VE], dd[VE];
+                unpack_raw<T>(zq[j], zz);
+                unpack_raw<T>(dq[j], dd);
+                if constexpr (RESOUT) {
+                    float rv[VE];
+                    if (res_acc) unpack_raw<T>(rq[j], rv);
+#pragma unroll
+                    for (int i = 0; i < VE; ++i) rv[i] = res_acc ? rv[i] + dd[i] : dd[i];
+                    store_vec<T>(dres + (at + j * stride) * lddres + cg * VE, rv);
+                }
 #pragma unroll
                 for (int i = 0; i < VE; ++i) {
                     float xh, du;
-                    bn_bwd_elem<T, ACT>(zz[j][i], dd[j][i], mu[i], is[i], ga[i], be[i], A[i], Bc[i], nmi[i], xh, du);
-                    if constexpr (sizeof(T) == 2) dd[j][i] = __builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
-                    else dd[j][i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
+                    bn_bwd_elem<T, ACT>(zz[i], dd[i], mu[i], is[i], ga[i], be[i], A[i], Bc[i], nmi[i], xh, du);
+                    if constexpr (sizeof(T) == 2) dd[i] = __builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
+                    else dd[i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
                 }
-                store_vec<T>(dz + (pix + j * stride) * lddz + cg * VE, dd[j]);
+                store_vec<T>(dz + (at + j * stride) * lddz + cg * VE, dd);
+            }
+        };
+        if (pix + (NPX - 1) * stride < npix) {
+            uint4 zA[NPX], dA[NPX], rA[RESOUT ? NPX : 1], zB[NPX], dB[NPX], rB[RESOUT ? NPX : 1];
+            long long pa = pix;
+            request(zA, dA, rA, pa);
+            while (true) {
+                const long long pb = pa + NPX * stride;
+                const bool hb = pb + (NPX - 1) * stride < npix;
+                if (opaque_true) request(zB, dB, rB, hb ? pb : 0);      // (no next group: the tensor's first rows, cache hits for everyone)
+                compute(zA, dA, rA, pa);
+                if (!hb) { pix = pb; break; }
+                pa = pb + NPX * stride;
+                const bool ha = pa + (NPX - 1) * stride < npix;
+                if (opaque_true) request(zA, dA, rA, ha ? pa : 0);
+                compute(zB, dB, rB, pb);
+                if (!ha) { pix = pa; break; }
             }
         }
         for (; pix < npix; pix += stride) {
