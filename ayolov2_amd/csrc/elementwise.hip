@@ -691,7 +691,9 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const T* x, int ldx, T* y, 
 // each of the PSW + 4 input columns of a window row ONCE (the per-pixel kernel above loads every input 25 times: 20 M 16-byte
 // loads for the 13 MB tensor of YOLOv5s at batch 64, 40 us at 0.8 TB/s) and scans the taps of every output in the same row-major
 // order, so the recorded first maximum is the same.  The PSW x VE window positions leave as ONE 8- (4-) byte store per pixel.
-#define PSW 4
+// PSW = 2: 108 / 112 registers per lane (four wavefronts per SIMD); with four pixels per thread the kernels held 179 / 156 and ran
+// two per SIMD, five serial window rows each: forward 41.8 -> 32.2 us, backward 32.7 -> 31.0 us (profiles/r05_pool_strip_width.txt)
+#define PSW 2
 template <typename T>
 __global__ __launch_bounds__(256) void k_maxpool5_fwd(const T* x, int ldx, T* y, int ldy, unsigned char* idx, int B, int H, int W, int C) {
     constexpr int VE = VecT<T>::VE, K = 5, PAD = 2, NC = PSW + K - 1;
