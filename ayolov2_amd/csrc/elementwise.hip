@@ -6,7 +6,9 @@
 // Conv, SPPF, UpSample, Concat and YOLOHead modules.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
+typedef unsigned int v4u32_t __attribute__((ext_vector_type(4)));
 template <typename T> struct VecT;
 template <> struct VecT<half_t> { static constexpr int VE = 8; };
 template <> struct VecT<float> { static constexpr int VE = 4; };
@@ -480,7 +482,10 @@ extern "C" int ayolo_bn_act_bwd_reduce(int dtype, const void* z, int ldz, const 
 
 // RESOUT: the block's output also fed a shortcut add (Bottleneck: out = x + act(bn(z))), so d(x) (+)= da.  The pass reads da
 // anyway: it forwards it to the shortcut's gradient buffer `dres` instead of a separate strided copy re-reading it.
-template <typename T, int ACT, bool RESOUT = false>
+// B32: every tensor of the pass is < 2 GiB (host check), so the streaming loads / stores go through buffer descriptors with one
+// 32-bit byte offset per access instead of a 64-bit pointer each: a dozen address registers and their 64-bit arithmetic less --
+// 136 -> 1xx registers per lane for the fp16 SiLU instantiation, i.e. four wavefronts per SIMD instead of three.
+template <typename T, int ACT, bool RESOUT = false, bool B32 = false>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const T* da, int ldda, T* dz, int lddz,
                                                       long long npix, int C, const float* mean, const float* invstd,
                                                       const float* gamma, const float* beta, const double* sums,
@@ -511,6 +516,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
     const int RPB = 256 / CGT;
     const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
     if (prow >= RPB) return;
+    const unsigned ldzb = (unsigned)ldz * sizeof(T), lddab = (unsigned)ldda * sizeof(T), lddzb = (unsigned)lddz * sizeof(T),
+                   lddresb = (unsigned)lddres * sizeof(T);
+    const unsigned npu = (unsigned)npix;
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(z), 0, B32 ? (int)(npu * ldzb) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsDa = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(da), 0, B32 ? (int)(npu * lddab) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsDz = __builtin_amdgcn_make_buffer_rsrc(dz, 0, B32 ? (int)(npu * lddzb) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsRes = __builtin_amdgcn_make_buffer_rsrc(dres, 0, (B32 && RESOUT) ? (int)(npu * lddresb) : 0, 0x00020000);
     for (int cg = cgl; cg < CG; cg += CGT) {
         // fp16 storage: dz = du*P + (xhat*Rr + Q) with P = gamma*invstd, Q = -P*m1, Rr = -P*m2 (two fmas)
         float mu[VE], is[VE], ga[VE], be[VE], m1[VE], m2[VE], A[VE], Bc[VE], nmi[VE], P[VE], Q[VE], Rr[VE];
@@ -521,8 +533,32 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
             A[i] = is[i] * ga[i]; Bc[i] = be[i] - mu[i] * A[i]; nmi[i] = -mu[i] * is[i];
             P[i] = ga[i] * is[i]; Q[i] = -P[i] * m1[i]; Rr[i] = -P[i] * m2[i];
         }
-        const long long stride = (long long)gridDim.x * RPB;
-        long long pix = (long long)blockIdx.x * RPB + prow;
+        typedef typename std::conditional<B32, unsigned, long long>::type pix_t;
+        const pix_t stride = (pix_t)gridDim.x * RPB, npx = (pix_t)npix;
+        pix_t pix = (pix_t)blockIdx.x * RPB + prow;
+        // accessors: pixel row -> this thread's 16-byte group of z / da / dres / dz
+        const unsigned cgb = (unsigned)cg * 16u;
+        auto ld_z = [&](pix_t px) __attribute__((always_inline)) -> uint4 {
+            if constexpr (B32) return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, px * ldzb + cgb, 0, 0));
+            else return load_raw<T>(z + px * ldz + cg * VE);
+        };
+        auto ld_da = [&](pix_t px) __attribute__((always_inline)) -> uint4 {
+            if constexpr (B32) return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsDa, px * lddab + cgb, 0, 0));
+            else return load_raw<T>(da + px * ldda + cg * VE);
+        };
+        auto ld_res = [&](pix_t px) __attribute__((always_inline)) -> uint4 {
+            if constexpr (B32) return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsRes, px * lddresb + cgb, 0, 0));
+            else return load_raw<T>(dres + px * lddres + cg * VE);
+        };
+        auto st16 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, T* ptr, const float (&v)[VE]) __attribute__((always_inline)) {
+            if constexpr (B32) {
+                uint4 raw;
+                T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) e[i] = (T)v[i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32_t, raw), rs, off, 0, 0);
+            } else store_vec<T>(ptr, v);
+        };
         // four pixels per iteration, software-pipelined (see load_raw): the z / da (/ dres) vectors of the next four pixels are
         // requested before the current four are computed.  Two register sets take turns (A, B: no copies on the back edge --
         // with one "current" and one "next" set the copies land right behind the loads, with a wait for them), and each request
@@ -531,20 +567,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
         constexpr int NPX = 2;                       // pixels per register set
         int opaque_true = 1;
         asm volatile("" : "+s"(opaque_true));
-        auto request = [&](uint4 (&zq)[NPX], uint4 (&dq)[NPX], uint4 (&rq)[RESOUT ? NPX : 1], long long at) __attribute__((always_inline)) {
+        auto request = [&](uint4 (&zq)[NPX], uint4 (&dq)[NPX], uint4 (&rq)[RESOUT ? NPX : 1], pix_t at) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
-                zq[j] = load_raw<T>(z + (at + j * stride) * ldz + cg * VE);
-                dq[j] = load_raw<T>(da + (at + j * stride) * ldda + cg * VE);
+                zq[j] = ld_z(at + j * stride);
+                dq[j] = ld_da(at + j * stride);
             }
             if constexpr (RESOUT) {
                 if (res_acc) {
 #pragma unroll
-                    for (int j = 0; j < NPX; ++j) rq[j] = load_raw<T>(dres + (at + j * stride) * lddres + cg * VE);
+                    for (int j = 0; j < NPX; ++j) rq[j] = ld_res(at + j * stride);
                 }
             }
         };
-        auto compute = [&](const uint4 (&zq)[NPX], const uint4 (&dq)[NPX], const uint4 (&rq)[RESOUT ? NPX : 1], long long at) __attribute__((always_inline)) {
+        auto compute = [&](const uint4 (&zq)[NPX], const uint4 (&dq)[NPX], const uint4 (&rq)[RESOUT ? NPX : 1], pix_t at) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
                 float zz[VE], dd[VE];
@@ -555,7 +591,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
                     if (res_acc) unpack_raw<T>(rq[j], rv);
 #pragma unroll
                     for (int i = 0; i < VE; ++i) rv[i] = res_acc ? rv[i] + dd[i] : dd[i];
-                    store_vec<T>(dres + (at + j * stride) * lddres + cg * VE, rv);
+                    st16(rsRes, (unsigned)(at + j * stride) * lddresb + cgb, RESOUT ? dres + (long long)(at + j * stride) * lddres + cg * VE : nullptr, rv);
                 }
 #pragma unroll
                 for (int i = 0; i < VE; ++i) {
@@ -564,36 +600,36 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
                     if constexpr (sizeof(T) == 2) dd[i] = __builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
                     else dd[i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
                 }
-                store_vec<T>(dz + (at + j * stride) * lddz + cg * VE, dd);
+                st16(rsDz, (unsigned)(at + j * stride) * lddzb + cgb, dz + (long long)(at + j * stride) * lddz + cg * VE, dd);
             }
         };
-        if (pix + (NPX - 1) * stride < npix) {
+        if (pix + (NPX - 1) * stride < npx) {
             uint4 zA[NPX], dA[NPX], rA[RESOUT ? NPX : 1], zB[NPX], dB[NPX], rB[RESOUT ? NPX : 1];
-            long long pa = pix;
+            pix_t pa = pix;
             request(zA, dA, rA, pa);
             while (true) {
-                const long long pb = pa + NPX * stride;
-                const bool hb = pb + (NPX - 1) * stride < npix;
+                const pix_t pb = pa + NPX * stride;
+                const bool hb = pb + (NPX - 1) * stride < npx;
                 if (opaque_true) request(zB, dB, rB, hb ? pb : 0);      // (no next group: the tensor's first rows, cache hits for everyone)
                 compute(zA, dA, rA, pa);
                 if (!hb) { pix = pb; break; }
                 pa = pb + NPX * stride;
-                const bool ha = pa + (NPX - 1) * stride < npix;
+                const bool ha = pa + (NPX - 1) * stride < npx;
                 if (opaque_true) request(zA, dA, rA, ha ? pa : 0);
                 compute(zB, dB, rB, pb);
                 if (!ha) { pix = pa; break; }
             }
         }
-        for (; pix < npix; pix += stride) {
+        for (; pix < npx; pix += stride) {
             float zv[VE], dv[VE];
-            load_vec<T>(z + pix * ldz + cg * VE, zv);
-            load_vec<T>(da + pix * ldda + cg * VE, dv);
+            unpack_raw<T>(ld_z(pix), zv);
+            unpack_raw<T>(ld_da(pix), dv);
             if constexpr (RESOUT) {
                 float rv[VE];
-                if (res_acc) load_vec<T>(dres + pix * lddres + cg * VE, rv);
+                if (res_acc) unpack_raw<T>(ld_res(pix), rv);
 #pragma unroll
                 for (int i = 0; i < VE; ++i) rv[i] = res_acc ? rv[i] + dv[i] : dv[i];
-                store_vec<T>(dres + pix * lddres + cg * VE, rv);
+                st16(rsRes, (unsigned)pix * lddresb + cgb, dres + (long long)pix * lddres + cg * VE, rv);
             }
 #pragma unroll
             for (int i = 0; i < VE; ++i) {
@@ -602,7 +638,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
                 if constexpr (sizeof(T) == 2) dv[i] = __builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
                 else dv[i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
             }
-            store_vec<T>(dz + pix * lddz + cg * VE, dv);
+            st16(rsDz, (unsigned)pix * lddzb + cgb, dz + (long long)pix * lddz + cg * VE, dv);
         }
     }
 }
@@ -621,18 +657,20 @@ extern "C" int ayolo_bn_act_bwd_apply_res(int dtype, const void* z, int ldz, con
     // the per-workgroup prologue stages (6 + 2*reps)*C floats in LDS: scale the elements per workgroup with C
     unsigned grid = grid_pixels(npix, C, ve, C >= 256 ? 16 : 8);
     if (grid > 2048u) grid = 2048u;
+    // every tensor below 2 GiB: 32-bit buffer offsets (B32)
+    const int64_t es = dtype == AYOLO_F16 ? 2 : 4, lim = (int64_t)1 << 31;
+    const bool b32 = npix * ldz * es < lim && npix * ldda * es < lim && npix * lddz * es < lim && (!dres || npix * lddres * es < lim);
+#define BWD_APPLY_LAUNCH(RO_, B32_, dres_, lddres_, racc_)                                                                           \
+    DISPATCH_T(dtype, DISPATCH_AR(act, false,                                                                                        \
+               (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT, RO_, B32_>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s, \
+                                  (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,                  \
+                                  save_invstd, gamma, beta, sums, sum_reps, dgamma, dbeta, grad_scale, (T*)(dres_), lddres_, racc_);))
     if (dres) {
-        DISPATCH_T(dtype, DISPATCH_AR(act, false,
-                   (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT, true>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s,
-                                      (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,
-                                      save_invstd, gamma, beta, sums, sum_reps, dgamma, dbeta, grad_scale, (T*)dres, lddres,
-                                      res_accumulate);))
+        if (b32) { BWD_APPLY_LAUNCH(true, true, dres, lddres, res_accumulate) } else { BWD_APPLY_LAUNCH(true, false, dres, lddres, res_accumulate) }
     } else {
-        DISPATCH_T(dtype, DISPATCH_AR(act, false,
-                   (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply<T, ACT, false>), dim3(grid), dim3(256), 6 * C * sizeof(float), (hipStream_t)s,
-                                      (const T*)z, ldz, (const T*)da, ldda, (T*)dz, lddz, (long long)npix, C, save_mean,
-                                      save_invstd, gamma, beta, sums, sum_reps, dgamma, dbeta, grad_scale, (T*)nullptr, 0, 0);))
+        if (b32) { BWD_APPLY_LAUNCH(false, true, nullptr, 0, 0) } else { BWD_APPLY_LAUNCH(false, false, nullptr, 0, 0) }
     }
+#undef BWD_APPLY_LAUNCH
     AY_CHECK_LAUNCH("k_bn_bwd_apply");
     return AYOLO_OK;
 }
