@@ -64,6 +64,40 @@ __device__ __forceinline__ float opt_load(const float* v, const float* any, int 
     return v ? t : dflt;
 }
 
+// Scalar-cache prefetch of a uniform parameter block (the kernel-argument segment, or a job struct in global memory).
+// hipcc loads the fields of a by-value parameter struct LAZILY, next to their first use: a 400-byte GConvP spans seven 64-byte
+// lines, each first touched in another basic block in front of its own `s_waitcnt lgkmcnt(0)` -- seven DEPENDENT scalar-cache
+// misses, ~3 000 cycles between a k_gconv workgroup's entry and its tap table (tools/gconv_probe.py), for every workgroup of a
+// launch's first round (a launch has a fresh kernarg address).  Touching one dword of every line at entry overlaps the misses;
+// the compiler's own loads then hit.  done() goes behind the kernel's first use of a parameter (the compiler waits there anyway).
+template <int NB>
+struct ScalarTouch {
+    static constexpr int NL = (NB + 63) / 64;
+    int t[NL];
+    template <int I = 0>
+    __device__ __forceinline__ void issue(unsigned long long base) {
+        if constexpr (I < NL) {
+            asm volatile("s_load_dword %0, %1, %2" : "=s"(t[I]) : "s"(base), "n"(I * 64));
+            issue<I + 1>(base);
+        }
+    }
+    template <int I = 0>
+    __device__ __forceinline__ void keep() {
+        if constexpr (I < NL) {
+            asm volatile("" ::"s"(t[I]));      // the destination registers stay allocated until the loads have written them
+            keep<I + 1>();
+        }
+    }
+    __device__ __forceinline__ void done() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        keep<0>();
+    }
+};
+#define AY_KERNARG_TOUCH_BYTES(name_, NB_)                                                                           \
+    ScalarTouch<(NB_)> name_;                                                                                        \
+    name_.issue((unsigned long long)(__attribute__((address_space(4))) const char*)__builtin_amdgcn_kernarg_segment_ptr())
+#define AY_KERNARG_TOUCH(name_, P_) AY_KERNARG_TOUCH_BYTES(name_, (int)sizeof(P_))
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

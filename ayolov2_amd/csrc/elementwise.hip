@@ -275,8 +275,12 @@ __global__ __launch_bounds__(256) void k_bn_train_act(const T* z, int ldz, T* a,
                                                       const double* stats, int reps, int sld, double count, const float* gamma,
                                                       const float* beta, float eps, float momentum, float* rmean, float* rvar,
                                                       float* smean, float* sinv, const T* res, int ldr) {
+    AY_KERNARG_TOUCH_BYTES(kt_, 192);   // the three lines of the argument block at once (common.h)
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sc_sh[];   // [2][C]
+    const int c_first_ = C;            // (first use of an argument: the compiler's wait is here anyway)
+    asm volatile("" ::"s"(c_first_));
+    kt_.done();
     // stats: [reps][2][sld] accumulators of the producing conv; this layer's channels start at `stats` (sld > C when the
     // conv computed several layers at once -- C3's cv1 | cv2 -- and this is one channel slice of it)
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -491,9 +495,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* z, int ldz, const
                                                       const float* gamma, const float* beta, const double* sums,
                                                       int reps, float* dgamma, float* dbeta, float grad_scale,
                                                       T* dres = nullptr, int lddres = 0, int res_acc = 0) {
+    AY_KERNARG_TOUCH_BYTES(kt_, 192);   // the three lines of the argument block at once (common.h)
     constexpr int VE = VecT<T>::VE;
     extern __shared__ float sh[];   // [6][C]: mean, invstd, gamma, beta, sum_du/n, sum_dux/n
     const float invn = 1.0f / (float)npix;
+    kt_.done();
     // cooperative prologue: replica sums once per workgroup, then every thread keeps ITS channel group in registers
     for (int i = threadIdx.x; i < C; i += 256) {
         const int q = pl_idx<VE>(i, C);
