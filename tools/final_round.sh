@@ -13,7 +13,7 @@ timeout 900 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/$
 bash tools/pmc_sq.sh $tag > /dev/null 2>&1
 export TMPDIR=/tmp; root=$(pwd)
 (cd /tmp && rm -rf /tmp/prof_c5 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -o c5 -- python $root/tools/cfg5_time.py > $root/$out/${tag}_cfg5_under_rocprof.txt 2>/dev/null; cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) $root/$out/${tag}_eval_cfg5_kernel_stats.csv)
-AYOLO_FORCE_DDP=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --no-extras 2>/dev/null | tail -1 > $out/${tag}_bench_torchrun_forced_ddp.json
+AYOLO_FORCE_DDP=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras 2>/dev/null | tail -1 > $out/${tag}_bench_torchrun_forced_ddp.json
 python tools/config_bench.py 3 2>/dev/null | tail -1 > $out/${tag}_cfg3.json
 AYOLO_WGRAD_STREAM=0 python tools/op_table.py yolov5l 32 > $out/${tag}_op_table_isolated_yolov5l.txt 2>&1
 python tools/op_table.py > $out/${tag}_op_table_in_situ.txt 2>&1
