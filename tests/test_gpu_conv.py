@@ -467,6 +467,43 @@ def test_bn_backward_apply_forwards_the_shortcut_gradient(dt, accumulate):
     assert torch.equal(wide[:, :C], old[:, :C])        # the other half of the wide buffer is untouched
 
 
+def test_bn_backward_apply_two_gib_tensors_take_the_pointer_path():
+    """k_bn_bwd_apply addresses tensors below 2 GiB through 32-bit buffer offsets (B32) and larger ones through 64-bit pointers:
+    the same pass over a 2 GiB activation (64 x 64 x 512 x 512 fp16 = 2^31 bytes: not below the limit) and over its two halves
+    (B32) must agree bit for bit.  With zero sums the per-channel constants do not depend on the pixel count, so the halves are
+    exactly the rows of the whole."""
+    from ayolov2_amd import ops
+    from ayolov2_amd._lib import call
+    B, C, H, W = 64, 64, 512, 512
+    dt = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    z = torch.empty(B, H, W, C, device="cuda", dtype=dt).normal_(generator=g)            # NHWC storage, rows of C
+    da = torch.empty(B, H, W, C, device="cuda", dtype=dt).normal_(generator=g)
+    assert z.numel() * 2 == 1 << 31
+    mean = torch.randn(C, device="cuda") * 0.1
+    invstd = torch.rand(C, device="cuda") + 0.5
+    gamma, beta = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    sums = torch.zeros(ops.STAT_REPS, 2 * C, dtype=torch.float64, device="cuda")
+    dgm, dbt = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    code = ops.dtype_code(dt)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(zz, dd, out, npix):
+        call("ayolo_bn_act_bwd_apply", code, zz.data_ptr(), C, dd.data_ptr(), C, out.data_ptr(), C, npix, C, mean.data_ptr(), invstd.data_ptr(),
+             gamma.data_ptr(), beta.data_ptr(), 1, sums.data_ptr(), ops.STAT_REPS, dgm.data_ptr(), dbt.data_ptr(), 1.0, st)
+
+    npix = B * H * W
+    whole = torch.empty_like(z)
+    run(z, da, whole, npix)
+    halves = torch.empty_like(z)
+    h = B // 2
+    run(z[:h], da[:h], halves[:h], npix // 2)
+    run(z[h:], da[h:], halves[h:], npix // 2)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, halves)
+    assert bool(torch.isfinite(whole.float()).all()) and float(whole.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 64, 96), (3, 16, 70, 100), (1, 48, 38, 132), (2, 64, 24, 40), (2, 80, 64, 96)])
 def test_stem_weight_gradient_kernel(shape):
     """k_stem_wgrad (the packed 6x6 / stride 2 / pad 2 stem, fp16, Cout <= 64: input patch staged once per 4 x 64 output tile,
