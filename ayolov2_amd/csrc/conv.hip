@@ -128,6 +128,52 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Reduce-scatter of the per-lane BatchNorm partials over the 32 pixel lanes of a half wavefront.  Every lane holds NV = 16 * MI
+// partial sums (value r = one channel of its half); wanted: for every r the total over the half's 32 lanes.  The epilogues used
+// to reduce EVERY value over each 16-lane row (4 DPP adds per value) and send it to LDS with an fp64 atomic from 4 (2) active lanes:
+// 2 * NV atomic instructions per wavefront and tile, ~50 cycles each with the four wavefronts of a workgroup arriving together
+// -- 4 400 cycles per tile epilogue for the 128-channel tiles against 1 100 for the DPP sums alone
+// (tools/experiments/lds_atomic_bench.hip, profiles/r05_lds_atomic_bench.txt).  A butterfly that HALVES the number of values at
+// every level (the two lanes of a pair keep one value each) needs fewer adds than that, leaves value rs_index(lane) in each lane
+// and the whole reduction leaves through ONE atomic instruction with all lanes active.  Level 16: v_permlane16_swap (odd rows of
+// the first operand <-> even rows of the second, new on gfx950); levels 8 / 4 / 2 / 1: DPP row_ror:8, row_half_mirror, quad_perm.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float rs_step(float s0, float s1, bool hi) {
+    const float keep = hi ? s1 : s0, oth = hi ? s0 : s1;
+    return keep + dpp_f<CTRL>(oth);
+}
+template <int NV>
+__device__ __forceinline__ float half_reduce_scatter(float (&v)[NV], int lq) {
+    static_assert(NV == 16 || NV == 32, "16 values per 32-channel block of the wave tile");
+#pragma unroll
+    for (int j = 0; j < NV / 2; ++j) {
+        const v2u32 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[2 * j]), __float_as_uint(v[2 * j + 1]), false, false);
+        v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);          // even rows: value 2j, odd rows: value 2j + 1
+    }
+    const bool b3 = (lq & 8) != 0, b2 = (lq & 4) != 0, b1 = (lq & 2) != 0, b0 = (lq & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < NV / 4; ++j) v[j] = rs_step<0x128>(v[2 * j], v[2 * j + 1], b3);       // row_ror:8      lane ^ 8
+#pragma unroll
+    for (int j = 0; j < NV / 8; ++j) v[j] = rs_step<0x141>(v[2 * j], v[2 * j + 1], b2);       // row_half_mirror: lane ^ 7 (flips bit 2)
+#pragma unroll
+    for (int j = 0; j < NV / 16; ++j) v[j] = rs_step<0x4E>(v[2 * j], v[2 * j + 1], b1);       // quad_perm [2,3,0,1]: lane ^ 2
+    if constexpr (NV == 32) v[0] = rs_step<0xB1>(v[0], v[1], b0);                              // quad_perm [1,0,3,2]: lane ^ 1
+    else v[0] += dpp_f<0xB1>(v[0]);                                    // 16 values: the lanes of a pair end with the same total
+    return v[0];
+}
+// which value a lane holds afterwards (NV = 16: both lanes of a pair hold it -- the even one reports)
+template <int NV>
+__device__ __forceinline__ int rs_index(int lq) {
+    int r = ((lq >> 4) & 1) + 2 * ((lq >> 3) & 1) + 4 * ((lq >> 2) & 1) + 8 * ((lq >> 1) & 1);
+    if constexpr (NV == 32) r += 16 * (lq & 1);
+    return r;
+}
+template <int NV> __device__ __forceinline__ bool rs_reports(int lq) { return NV == 32 || (lq & 1) == 0; }
+
 #define GNS 3                      // LDS stages
 
 // Timeline probe (tools/gconv_probe.py; built only with -DAYOLO_PROBE into ab/libayolo_probe.so, never into the product
@@ -744,14 +790,14 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, in
                                               const float (&ssum)[16 * MI], const float (&ssq)[16 * MI]) {
     for (int i = tid; i < 2 * TM; i += (int)blockDim.x) sStat[i] = 0.0;
     __syncthreads();
+    {
+        // 32 pixel lanes per half-wave: reduce-scatter (half_reduce_scatter), one atomic instruction per sum with every lane active
+        float sa[16 * MI], sb[16 * MI];
 #pragma unroll
-    for (int r = 0; r < 16 * MI; ++r) {
-        // 32 pixel lanes per half-wave: DPP sums over each 16-lane row (no LDS traffic), then ONE exchange between the rows
-        float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
-        a += __shfl_xor(a, 16);
-        b += __shfl_xor(b, 16);
-        if ((lane & 31) == 0) {
-            const int cl = wm * 32 * MI + g_stat_chan<BNR>(r, lane >> 5);
+        for (int r = 0; r < 16 * MI; ++r) { sa[r] = ssum[r]; sb[r] = ssq[r]; }
+        const float a = half_reduce_scatter<16 * MI>(sa, lane), b = half_reduce_scatter<16 * MI>(sb, lane);
+        if (rs_reports<16 * MI>(lane)) {
+            const int cl = wm * 32 * MI + g_stat_chan<BNR>(rs_index<16 * MI>(lane), lane >> 5);
             atomicAdd(&sStat[cl], (double)a);
             atomicAdd(&sStat[TM + cl], (double)b);
         }
@@ -1175,15 +1221,13 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
                 int lq = lane;
                 asm volatile("" : "+v"(lq));
                 double* sl = reinterpret_cast<double*>(sStat) + wm * 32 * G::MI;
+                const float a = half_reduce_scatter<16 * G::MI>(ssum, lq), b = half_reduce_scatter<16 * G::MI>(ssq, lq);
 #pragma unroll
-                for (int r = 0; r < 16 * G::MI; ++r) {
-                    const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
-                    ssum[r] = 0.0f; ssq[r] = 0.0f;
-                    if ((lq & 15) == 0) {
-                        const int cl = g_stat_chan<true>(r, lq >> 5);
-                        atomicAdd(&sl[cl], (double)a);
-                        atomicAdd(&sl[TM + cl], (double)b);
-                    }
+                for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
+                if (rs_reports<16 * G::MI>(lq)) {
+                    const int cl = g_stat_chan<true>(rs_index<16 * G::MI>(lq), lq >> 5);
+                    atomicAdd(&sl[cl], (double)a);
+                    atomicAdd(&sl[TM + cl], (double)b);
                 }
             }
             after_epi = true;
@@ -1488,15 +1532,12 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
                 int lq = lane;                              // opaque: keeps the LDS addresses below from being hoisted out of the
                 asm volatile("" : "+v"(lq));                // tile loop (and spilled: every reload would drain the DMA queue)
                 double* sl = reinterpret_cast<double*>(sStat) + wm * 32 * G::MI;
-#pragma unroll
-                for (int r = 0; r < 16 * G::MI; ++r) {
-                    const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
-                    if ((lq & 15) == 0) {
-                        const int cl = g_stat_chan<BNR>(r, lq >> 5);
-                        atomicAdd(&sl[cl], (double)a);
-                        atomicAdd(&sl[TM + cl], (double)b);
-                    }
-                }
+                // (one array after the other, each with its atomic: the 128 x 256 tile has no register to spare for a second result)
+                const int cl = g_stat_chan<BNR>(rs_index<16 * G::MI>(lq), lq >> 5);
+                const float a = half_reduce_scatter<16 * G::MI>(ssum, lq);
+                if (rs_reports<16 * G::MI>(lq)) atomicAdd(&sl[cl], (double)a);
+                const float b = half_reduce_scatter<16 * G::MI>(ssq, lq);
+                if (rs_reports<16 * G::MI>(lq)) atomicAdd(&sl[TM + cl], (double)b);
             }
             after_epi = true;
             cur_tile += lstride;
@@ -1753,14 +1794,11 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_s2(GConvP p) {
                 int lq = lane;
                 asm volatile("" : "+v"(lq));
                 double* sl = reinterpret_cast<double*>(sStat) + wm * 32;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
-                    if ((lq & 15) == 0) {
-                        const int cl = g_stat_chan<true>(r, lq >> 5);
-                        atomicAdd(&sl[cl], (double)a);
-                        atomicAdd(&sl[TM + cl], (double)b);
-                    }
+                const float a = half_reduce_scatter<16>(ssum, lq), b = half_reduce_scatter<16>(ssq, lq);
+                if (rs_reports<16>(lq)) {
+                    const int cl = g_stat_chan<true>(rs_index<16>(lq), lq >> 5);
+                    atomicAdd(&sl[cl], (double)a);
+                    atomicAdd(&sl[TM + cl], (double)b);
                 }
             }
             after_epi = true;
@@ -2014,14 +2052,12 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
                 int lq = lane;
                 asm volatile("" : "+v"(lq));
                 double* sl = reinterpret_cast<double*>(sStat) + wm * 32 * G::MI + 4 * (lq >> 5);
-#pragma unroll
-                for (int r = 0; r < 16 * G::MI; ++r) {
-                    const float a = row16_sum(ssum[r]), b = row16_sum(ssq[r]);
-                    if ((lq & 15) == 0) {
-                        const int cl = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + (r & 3);
-                        atomicAdd(&sl[cl], (double)a);
-                        atomicAdd(&sl[TM + cl], (double)b);
-                    }
+                const float a = half_reduce_scatter<16 * G::MI>(ssum, lq), b = half_reduce_scatter<16 * G::MI>(ssq, lq);
+                if (rs_reports<16 * G::MI>(lq)) {
+                    const int r = rs_index<16 * G::MI>(lq);
+                    const int cl = (r >> 4) * 32 + 8 * ((r & 15) >> 2) + (r & 3);
+                    atomicAdd(&sl[cl], (double)a);
+                    atomicAdd(&sl[TM + cl], (double)b);
                 }
             }
             after_epi = true;
