@@ -410,8 +410,11 @@ def test_fp16_train_step_is_reproducible_and_routes_agree(monkeypatch):
     assert abs(l2 - l0) <= 1e-6 * abs(l0) and _cos(g0, g2) >= 1.0 - 1e-5
     # the per-module path is different ARITHMETIC at the fp16 level, not only a different order: the Bottleneck shortcut is a
     # separate fp16 add there (the sum is rounded twice; the plan adds inside the BatchNorm + SiLU pass and rounds once), so it
-    # is held to what one fp16 rounding per residual block costs on this well-conditioned net
-    assert abs(l3 - l0) <= 1e-4 * abs(l0) and _cos(g0, g3) >= 0.999, (l3, l0, _cos(g0, g3))
+    # is held to what one fp16 rounding per residual block costs on this well-conditioned net.  That cost is a BAND, not a number:
+    # over six seeds 0.9985 ... 0.9992 with the round-4 summation order of the BatchNorm sums and 0.9973 ... 0.9993 with round 5's
+    # (tools/route_noise.py, profiles/r05_route_noise.txt; this seed: 0.99910 / 0.99868) -- which fp16 roundings flip depends on the
+    # last fp32 bit of every statistic.  The threshold sits at the band's lower edge, the same 0.997 the oracle comparison holds.
+    assert abs(l3 - l0) <= 1e-4 * abs(l0) and _cos(g0, g3) >= 0.997, (l3, l0, _cos(g0, g3))
 
 
 @pytest.mark.parametrize("name,size,thr", [("s", 320, (0.997, 0.99)), ("l", 256, (0.997, 0.99))])
