@@ -315,3 +315,70 @@ def test_wgrad3_patch_index_math(case):
     ref = w.grad.permute(0, 2, 3, 1).reshape(N, 9 * C).numpy()      # [n][(dh, dw)][c]
     assert nslots >= 1
     np.testing.assert_allclose(dw, ref, rtol=1e-9, atol=1e-9)
+
+
+def _dpp(v, ctrl):
+    """What a lane reads under a DPP control (all lanes active, bound_ctrl): the source lane's value, per 16-lane row."""
+    out = np.empty_like(v)
+    for lane in range(64):
+        row, i = lane & ~15, lane & 15
+        if ctrl == 0x128:                      # row_ror:8
+            src = (i + 8) % 16
+        elif ctrl == 0x141:                    # row_half_mirror: i <-> 7 - i inside each half row
+            src = (i & 8) | (7 - (i & 7))
+        elif ctrl == 0x4E:                     # quad_perm [2,3,0,1]
+            src = (i & ~3) | [2, 3, 0, 1][i & 3]
+        elif ctrl == 0xB1:                     # quad_perm [1,0,3,2]
+            src = (i & ~3) | [1, 0, 3, 2][i & 3]
+        else:
+            raise AssertionError(ctrl)
+        out[lane] = v[row + src]
+    return out
+
+
+def _permlane16_swap(a, b):
+    """v_permlane16_swap: the odd rows of the first operand <-> the even rows of the second (rows of 16 lanes)."""
+    a2, b2 = a.copy(), b.copy()
+    for row in (0, 2):
+        a2[(row + 1) * 16:(row + 2) * 16] = b[row * 16:(row + 1) * 16]
+        b2[row * 16:(row + 1) * 16] = a[(row + 1) * 16:(row + 2) * 16]
+    return a2, b2
+
+
+@pytest.mark.parametrize("nv", [16, 32])
+def test_half_wavefront_reduce_scatter_lane_map(nv):
+    """csrc/conv.hip half_reduce_scatter / rs_index / rs_reports, lane by lane: every lane holds nv partial sums (value r = one
+    channel of its 32-lane half); after the butterfly lane l must hold the total of value rs_index(l) over the 32 lanes of ITS half
+    (nv = 16: both lanes of a pair hold it, the even one reports), every value of a half reported exactly once -- the contract the
+    conv epilogues' single fp64 LDS atomic per sum relies on.  Integers, so the check is exact."""
+    rng = np.random.default_rng(nv)
+    v = [rng.integers(-1000, 1000, size=64).astype(np.int64) for _ in range(nv)]          # v[r][lane]
+    want = np.stack([[x[:32].sum(), x[32:].sum()] for x in v])                             # [r][half]
+    lanes = np.arange(64)
+    cur = [x.copy() for x in v]
+    nxt = []
+    for j in range(nv // 2):                                                               # level 16
+        a2, b2 = _permlane16_swap(cur[2 * j], cur[2 * j + 1])
+        nxt.append(a2 + b2)
+    cur = nxt
+    for ctrl, bit in ((0x128, 8), (0x141, 4), (0x4E, 2)):
+        hi = (lanes & bit) != 0
+        nxt = []
+        for j in range(len(cur) // 2):
+            s0, s1 = cur[2 * j], cur[2 * j + 1]
+            keep, oth = np.where(hi, s1, s0), np.where(hi, s0, s1)
+            nxt.append(keep + _dpp(oth, ctrl))
+        cur = nxt
+    if nv == 32:
+        hi = (lanes & 1) != 0
+        res = np.where(hi, cur[1], cur[0]) + _dpp(np.where(hi, cur[0], cur[1]), 0xB1)
+    else:
+        assert len(cur) == 1
+        res = cur[0] + _dpp(cur[0], 0xB1)
+    rs_index = ((lanes >> 4) & 1) + 2 * ((lanes >> 3) & 1) + 4 * ((lanes >> 2) & 1) + 8 * ((lanes >> 1) & 1) + (16 * (lanes & 1) if nv == 32 else 0)
+    reports = np.ones(64, bool) if nv == 32 else (lanes & 1) == 0
+    for lane in range(64):
+        assert res[lane] == want[rs_index[lane], lane >> 5], (lane, rs_index[lane])
+    for half in (0, 1):
+        got = sorted(rs_index[(lanes >> 5 == half) & reports])
+        assert got == list(range(nv)), got
