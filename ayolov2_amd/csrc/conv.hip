@@ -194,7 +194,7 @@ extern "C" int ayolo_probe_read(void* dst, unsigned long long bytes) {
 #else
 #define AY_PROBE(k_) do { } while (0)
 #endif
-template <typename T, int TM, int TPX = 128>
+template <typename T, int TM, int TPX = 128, int NWX = 4>
 struct GT {
     static constexpr int ES = sizeof(T);
     static constexpr int CE = 16 / ES;              // elements per 16-byte chunk
@@ -205,7 +205,7 @@ struct GT {
     // pixels per block tile: 128, or 256 for the narrow channel tiles on multi-step reductions (K >= 128) so that a
     // wave still has 4-8 MFMAs per barrier
     static constexpr int TP = TPX;
-    static constexpr int NW = 4;                    // wavefronts per workgroup
+    static constexpr int NW = NWX;                  // wavefronts per workgroup: 4, or 8 (k_gconv on the small maps, round 6)
     static constexpr int NT = NW * 64;
     static constexpr int PIECE = NW * 1024;         // bytes one DMA instruction of every wave covers
     static constexpr int XSTAGE = TP * ROWB;        // 8-16 KiB / 16-32 KiB
@@ -245,10 +245,10 @@ struct GT {
 
 // pixel decode of the loader's rows for pixel tile `tile` (invalid tile / rows beyond Mtotal -> never in range).
 // Branch-free on purpose (selects only): see the header comment.
-template <typename T, int TM, int TPX>
+template <typename T, int TM, int TPX, int NWX = 4>
 __device__ __forceinline__ void g_setup_rows(const GConvP& p, unsigned tile, bool valid, int wave, int rowin, int kc,
-                                             int (&xoff)[GT<T, TM, TPX>::XR], int (&xh0)[GT<T, TM, TPX>::XR], int (&xw0)[GT<T, TM, TPX>::XR]) {
-    using G = GT<T, TM, TPX>;
+                                             int (&xoff)[GT<T, TM, TPX, NWX>::XR], int (&xh0)[GT<T, TM, TPX, NWX>::XR], int (&xw0)[GT<T, TM, TPX, NWX>::XR]) {
+    using G = GT<T, TM, TPX, NWX>;
 #pragma unroll
     for (int r = 0; r < G::XR; ++r) {
         const int row = (r * G::NW + wave) * G::RW + rowin;
@@ -267,12 +267,12 @@ __device__ __forceinline__ void g_setup_rows(const GConvP& p, unsigned tile, boo
 }
 
 // issue the DMA of one step (k slice `kt` of the loader's current tile) into the LDS stage at byte offset `so`
-template <typename T, int TM, int TPX>
-__device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T, TM, TPX>::XR], const int (&xh0)[GT<T, TM, TPX>::XR],
-                                        const int (&xw0)[GT<T, TM, TPX>::XR], const unsigned (&woff)[GT<T, TM, TPX>::WR], int kt,
+template <typename T, int TM, int TPX, int NWX = 4>
+__device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T, TM, TPX, NWX>::XR], const int (&xh0)[GT<T, TM, TPX, NWX>::XR],
+                                        const int (&xw0)[GT<T, TM, TPX, NWX>::XR], const unsigned (&woff)[GT<T, TM, TPX, NWX>::WR], int kt,
                                         int tap0, int ntap, const int4* sTap, unsigned lds_tiles, unsigned so, v4i32 rsX,
                                         v4i32 rsW, int wave, int kc) {
-    using G = GT<T, TM, TPX>;
+    using G = GT<T, TM, TPX, NWX>;
     const unsigned k0 = (unsigned)(kt * BK + kc * G::CE);
     unsigned tap = fdiv(k0, p.dC);
     const int cb = (int)(k0 - tap * (unsigned)p.C) * G::ES;
@@ -297,13 +297,13 @@ __device__ __forceinline__ void g_issue(const GConvP& p, const int (&xoff)[GT<T,
 // per step): the wave then pays the LDS latency per MFMA instead of once per step.  The step loop issues the fetch right
 // after the barrier and puts the address arithmetic + DMA issue of step s+2 between the fetch and the MFMAs, so the LDS
 // latency is covered by that scalar / VALU work instead of being waited for.
-template <typename T, int TM, int TPX>
-struct GFrags { half8 a[BK / 16][GT<T, TM, TPX>::MI], b[BK / 16][GT<T, TM, TPX>::NI]; };
+template <typename T, int TM, int TPX, int NWX = 4>
+struct GFrags { half8 a[BK / 16][GT<T, TM, TPX, NWX>::MI], b[BK / 16][GT<T, TM, TPX, NWX>::NI]; };
 
-template <typename T, int TM, int TPX>
+template <typename T, int TM, int TPX, int NWX = 4>
 __device__ __forceinline__ void g_fetch_frags(const unsigned char* stage, int arow, int xrow, int swz, int lane,
-                                              GFrags<T, TM, TPX>& f) {
-    using G = GT<T, TM, TPX>;
+                                              GFrags<T, TM, TPX, NWX>& f) {
+    using G = GT<T, TM, TPX, NWX>;
     const unsigned char* bx = stage + xrow;
     const unsigned char* bw = stage + G::XSTAGE + arow;
 #pragma unroll
@@ -319,13 +319,13 @@ __device__ __forceinline__ void g_fetch_frags(const unsigned char* stage, int ar
 // one 16-deep half of a step (the 256-pixel x 128-channel tile fetches and consumes a step in two halves: all of its
 // 18 fragments at once would not fit the 256-register budget of 2 waves per SIMD next to the 128 accumulators; the
 // eight MFMAs of the first half (512 cycles in the matrix pipe) cover the LDS latency of the second half's fetch)
-template <typename T, int TM, int TPX>
-struct GFragK { half8 a[GT<T, TM, TPX>::MI], b[GT<T, TM, TPX>::NI]; };
+template <typename T, int TM, int TPX, int NWX = 4>
+struct GFragK { half8 a[GT<T, TM, TPX, NWX>::MI], b[GT<T, TM, TPX, NWX>::NI]; };
 
-template <typename T, int TM, int TPX>
+template <typename T, int TM, int TPX, int NWX = 4>
 __device__ __forceinline__ void g_fetch_k(const unsigned char* stage, int arow, int xrow, int swz, int lane, int kk,
-                                          GFragK<T, TM, TPX>& f) {
-    using G = GT<T, TM, TPX>;
+                                          GFragK<T, TM, TPX, NWX>& f) {
+    using G = GT<T, TM, TPX, NWX>;
     const unsigned char* bx = stage + xrow;
     const unsigned char* bw = stage + G::XSTAGE + arow;
     const int slot = ((kk * 2 + (lane >> 5)) ^ swz) * 16;
@@ -335,9 +335,9 @@ __device__ __forceinline__ void g_fetch_k(const unsigned char* stage, int arow, 
     for (int ni = 0; ni < G::NI; ++ni) f.b[ni] = *reinterpret_cast<const half8*>(bx + ni * 32 * G::ROWB + slot);
 }
 
-template <typename T, int TM, int TPX>
-__device__ __forceinline__ void g_mma_k(const GFragK<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC]) {
-    using G = GT<T, TM, TPX>;
+template <typename T, int TM, int TPX, int NWX = 4>
+__device__ __forceinline__ void g_mma_k(const GFragK<T, TM, TPX, NWX>& f, float16v (&acc)[GT<T, TM, TPX, NWX>::NACC]) {
+    using G = GT<T, TM, TPX, NWX>;
 #pragma unroll
     for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
@@ -349,11 +349,11 @@ __device__ __forceinline__ void g_mma_k(const GFragK<T, TM, TPX>& f, float16v (&
 // among bare MFMAs but 100-185 in a block of its own next to fragment reads (MI355X_MICROARCH.md), and a wave has ~5 free
 // issue slots behind every 32 x 32 x 16 MFMA: issued one per MFMA, the six pieces of a step ride in the matrix pipe's shadow
 // instead of standing in front of it (probe, 512 -> 512 1x1 on 20 x 20 x 64: step body 1 300 cycles for 512 of MFMA).
-template <typename T, int TM, int TPX>
-__device__ __forceinline__ void g_issue_prep(const GConvP& p, const int (&xoff)[GT<T, TM, TPX>::XR], const int (&xh0)[GT<T, TM, TPX>::XR],
-                                             const int (&xw0)[GT<T, TM, TPX>::XR], const unsigned (&woff)[GT<T, TM, TPX>::WR], int kt,
-                                             int tap0, int ntap, const int4* sTap, int kc, unsigned (&offs)[GT<T, TM, TPX>::LPS]) {
-    using G = GT<T, TM, TPX>;
+template <typename T, int TM, int TPX, int NWX = 4>
+__device__ __forceinline__ void g_issue_prep(const GConvP& p, const int (&xoff)[GT<T, TM, TPX, NWX>::XR], const int (&xh0)[GT<T, TM, TPX, NWX>::XR],
+                                             const int (&xw0)[GT<T, TM, TPX, NWX>::XR], const unsigned (&woff)[GT<T, TM, TPX, NWX>::WR], int kt,
+                                             int tap0, int ntap, const int4* sTap, int kc, unsigned (&offs)[GT<T, TM, TPX, NWX>::LPS]) {
+    using G = GT<T, TM, TPX, NWX>;
     const unsigned k0 = (unsigned)(kt * BK + kc * G::CE);
     unsigned tap = fdiv(k0, p.dC);
     const int cb = (int)(k0 - tap * (unsigned)p.C) * G::ES;
@@ -368,31 +368,31 @@ __device__ __forceinline__ void g_issue_prep(const GConvP& p, const int (&xoff)[
 #pragma unroll
     for (int r = 0; r < G::WR; ++r) offs[G::XR + r] = woff[r] + (unsigned)te.w + (unsigned)cb;
 }
-template <typename T, int TM, int TPX, int I>
-__device__ __forceinline__ void g_issue_piece(const unsigned (&offs)[GT<T, TM, TPX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
+template <typename T, int TM, int TPX, int I, int NWX = 4>
+__device__ __forceinline__ void g_issue_piece(const unsigned (&offs)[GT<T, TM, TPX, NWX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
                                               v4i32 rsW, int wave) {
-    using G = GT<T, TM, TPX>;
+    using G = GT<T, TM, TPX, NWX>;
     if constexpr (I < G::XR) glds16(rsX, lds_tiles + so + (I * G::NW + wave) * 1024, offs[I]);
     else if constexpr (I < G::LPS) glds16(rsW, lds_tiles + so + G::XSTAGE + ((I - G::XR) * G::NW + wave) * 1024, offs[I]);
 }
 // first 16-deep half of a step with the step's DMA pieces interleaved: MFMA q, then piece q (q < LPS <= 8)
-template <typename T, int TM, int TPX, int Q = 0>
-__device__ __forceinline__ void g_mma_k_issue(const GFragK<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC],
-                                              const unsigned (&offs)[GT<T, TM, TPX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
+template <typename T, int TM, int TPX, int NWX = 4, int Q = 0>
+__device__ __forceinline__ void g_mma_k_issue(const GFragK<T, TM, TPX, NWX>& f, float16v (&acc)[GT<T, TM, TPX, NWX>::NACC],
+                                              const unsigned (&offs)[GT<T, TM, TPX, NWX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
                                               v4i32 rsW, int wave) {
-    using G = GT<T, TM, TPX>;
+    using G = GT<T, TM, TPX, NWX>;
     static_assert(G::LPS <= G::NACC, "one DMA piece per MFMA of the first half");
     if constexpr (Q < G::NACC) {
         mma_step(f.a[Q / G::NI], f.b[Q % G::NI], acc[Q]);
-        g_issue_piece<T, TM, TPX, Q>(offs, lds_tiles, so, rsX, rsW, wave);
+        g_issue_piece<T, TM, TPX, Q, NWX>(offs, lds_tiles, so, rsX, rsW, wave);
         __builtin_amdgcn_sched_barrier(0);
-        g_mma_k_issue<T, TM, TPX, Q + 1>(f, acc, offs, lds_tiles, so, rsX, rsW, wave);
+        g_mma_k_issue<T, TM, TPX, NWX, Q + 1>(f, acc, offs, lds_tiles, so, rsX, rsW, wave);
     }
 }
 
-template <typename T, int TM, int TPX>
-__device__ __forceinline__ void g_mma_frags(const GFrags<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC]) {
-    using G = GT<T, TM, TPX>;
+template <typename T, int TM, int TPX, int NWX = 4>
+__device__ __forceinline__ void g_mma_frags(const GFrags<T, TM, TPX, NWX>& f, float16v (&acc)[GT<T, TM, TPX, NWX>::NACC]) {
+    using G = GT<T, TM, TPX, NWX>;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
@@ -403,28 +403,28 @@ __device__ __forceinline__ void g_mma_frags(const GFrags<T, TM, TPX>& f, float16
 
 // whole-step variant of g_mma_k_issue (tiles with fewer than 8 accumulator blocks per wave): MFMA q of the step, then DMA
 // piece q; pieces beyond the step's MFMA count (32-channel tiles) follow the last MFMA
-template <typename T, int TM, int TPX, int Q = 0>
-__device__ __forceinline__ void g_mma_frags_issue(const GFrags<T, TM, TPX>& f, float16v (&acc)[GT<T, TM, TPX>::NACC],
-                                                  const unsigned (&offs)[GT<T, TM, TPX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
+template <typename T, int TM, int TPX, int NWX = 4, int Q = 0>
+__device__ __forceinline__ void g_mma_frags_issue(const GFrags<T, TM, TPX, NWX>& f, float16v (&acc)[GT<T, TM, TPX, NWX>::NACC],
+                                                  const unsigned (&offs)[GT<T, TM, TPX, NWX>::LPS], unsigned lds_tiles, unsigned so, v4i32 rsX,
                                                   v4i32 rsW, int wave) {
-    using G = GT<T, TM, TPX>;
+    using G = GT<T, TM, TPX, NWX>;
     constexpr int NMMA = (BK / 16) * G::NACC;
     if constexpr (Q < (NMMA > G::LPS ? NMMA : G::LPS)) {
         if constexpr (Q < NMMA) {
             constexpr int kk = Q / G::NACC, blk = Q % G::NACC;
             mma_step(f.a[kk][blk / G::NI], f.b[kk][blk % G::NI], acc[blk]);
         }
-        g_issue_piece<T, TM, TPX, Q>(offs, lds_tiles, so, rsX, rsW, wave);
+        g_issue_piece<T, TM, TPX, Q, NWX>(offs, lds_tiles, so, rsX, rsW, wave);
         __builtin_amdgcn_sched_barrier(0);
-        g_mma_frags_issue<T, TM, TPX, Q + 1>(f, acc, offs, lds_tiles, so, rsX, rsW, wave);
+        g_mma_frags_issue<T, TM, TPX, NWX, Q + 1>(f, acc, offs, lds_tiles, so, rsX, rsW, wave);
     }
 }
 
 // fp32 (exact-parity mode): fragments are fetched and consumed pair by pair
-template <typename T, int TM, int TPX>
+template <typename T, int TM, int TPX, int NWX = 4>
 __device__ __forceinline__ void g_mma(const unsigned char* stage, int arow, int xrow, int swz, int lane,
-                                      float16v (&acc)[GT<T, TM, TPX>::NACC]) {
-    using G = GT<T, TM, TPX>;
+                                      float16v (&acc)[GT<T, TM, TPX, NWX>::NACC]) {
+    using G = GT<T, TM, TPX, NWX>;
     static_assert(G::MI == 1, "fp32 mode keeps the 1 x NI wave tile");
     const unsigned char* bx = stage + xrow;
     const unsigned char* bw = stage + G::XSTAGE + arow;
@@ -502,12 +502,12 @@ __device__ __forceinline__ BnrCtx<MI> g_bnr_ctx(const GConvP& p, const float* sB
     return b;
 }
 
-template <typename T, int TM, int EM, int TPX, bool BNR = false>
+template <typename T, int TM, int EM, int TPX, bool BNR = false, int NWX = 4>
 __device__ __forceinline__ void g_epilogue(const GConvP& p, unsigned tile, int oah, int oaw, int wp, int lane, int cbase,
-                                           bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM, TPX>::NACC],
-                                           float (&ssum)[16 * GT<T, TM, TPX>::MI], float (&ssq)[16 * GT<T, TM, TPX>::MI], const float* sAff, int cl0,
-                                           const BnrCtx<GT<T, TM, TPX>::MI> bc = BnrCtx<GT<T, TM, TPX>::MI>{}) {
-    using G = GT<T, TM, TPX>;
+                                           bool want_stats, __amdgpu_buffer_rsrc_t rsY, float16v (&acc)[GT<T, TM, TPX, NWX>::NACC],
+                                           float (&ssum)[16 * GT<T, TM, TPX, NWX>::MI], float (&ssq)[16 * GT<T, TM, TPX, NWX>::MI], const float* sAff, int cl0,
+                                           const BnrCtx<GT<T, TM, TPX, NWX>::MI> bc = BnrCtx<GT<T, TM, TPX, NWX>::MI>{}) {
+    using G = GT<T, TM, TPX, NWX>;
     constexpr int YES = (EM == 3) ? 4 : G::ES;       // bytes per output element
     static_assert(!BNR || (sizeof(T) == 2 && (EM == 0 || EM == 1)), "BN-backward statistics: fp16 dgrad epilogues only");
     const unsigned m0 = tile * G::TP;
@@ -806,12 +806,13 @@ __device__ __forceinline__ void g_stats_flush(const GConvP& p, double* sStat, in
     g_stats_to_global<TM, BNR>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
 }
 
-template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false, bool LIN = false>
-__global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, TPX>::lds(EM, BNR) > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4)) : 1)) void k_gconv(GConvP p) {
+template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false, bool LIN = false, int NWX = 4>
+__global__ __launch_bounds__((GT<T, TM, TPX, NWX>::NT), (NWX == 8 ? 4 : (sizeof(T) == 2 ? (GT<T, TM, TPX, NWX>::lds(EM, BNR) > 56 * 1024 ? 2 : ((TM == 128 || (TM == 64 && (EM == 0 || BNR))) ? 3 : 4)) : 1))) void k_gconv(GConvP p) {
+    static_assert(NWX == 4 || (NWX == 8 && sizeof(T) == 2 && TPX == 128 && TM >= 64), "eight wavefronts: fp16, 128-pixel tiles (two workgroups = four wavefronts per SIMD per CU)");
     AY_KERNARG_TOUCH(kt_, GConvP);           // every line of the parameter struct requested at once (gfx950_dma.h)
     static_assert(TM == 32 || TM == 64 || TM == 128, "output-channel tiles of 32 / 64 / 128");
     static_assert(!XF || (sizeof(T) == 2 && !BNR && (EM == 0 || EM == 3)), "transform on load: fp16 forward of a 1x1 conv");
-    using G = GT<T, TM, TPX>;
+    using G = GT<T, TM, TPX, NWX>;
     // stores per thread and epilogue (the step loop's vmcnt arithmetic): fp16 tiles leave in 16-byte stores
     constexpr int NSTK = (sizeof(T) == 2 && EM != 3) ? G::NACC * 2 : G::NST;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
@@ -947,7 +948,8 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
             }
         }
     }
-    constexpr bool TILE_RED = BNR && TM >= 128;
+    // (eight wavefronts: the forward statistics too -- 32 sum registers across the step loop do not fit the 128-register budget)
+    constexpr bool TILE_RED = (BNR && TM >= 128) || (NWX == 8 && EM == 0);
     if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 4 * TM, n0, tid);
     if constexpr (TILE_RED) {
         for (int i = tid; i < 2 * TM; i += (int)blockDim.x) reinterpret_cast<double*>(sStat)[i] = 0.0;
@@ -1055,7 +1057,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
         for (int r = 0; r < G::WR; ++r) offs[G::XR + r] = woff[r] + k0b;
     };
     if constexpr (XF) xf_setup_rows(ld_tile, true);
-    else { g_setup_rows<T, TM, TPX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0); lin_rows(); }
+    else { g_setup_rows<T, TM, TPX, NWX>(p, ld_tile, true, wave, rowin, kc, xoff, xh0, xw0); lin_rows(); }
     AY_PROBE(AY_PROBE_N - 5);
     __syncthreads();                          // tap table visible
     AY_PROBE(AY_PROBE_N - 6);
@@ -1066,7 +1068,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
         const v4i32 rs_ = s1_ ? rsX2 : rsX;                                                                                          \
         _Pragma("unroll") for (int r = 0; r < G::XR; ++r) glds16(rs_, lds_tiles + (so) + (r * G::NW + wave) * 1024, offs_[r]);       \
         _Pragma("unroll") for (int r = 0; r < G::WR; ++r) glds16(rsW, lds_tiles + (so) + G::XSTAGE + (r * G::NW + wave) * 1024, offs_[G::XR + r]); \
-    } else g_issue<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, lds_tiles, so, rsX, rsW, wave, kc);
+    } else g_issue<T, TM, TPX, NWX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, lds_tiles, so, rsX, rsW, wave, kc);
 #define G_ADVANCE()                                                                           \
     {                                                                                         \
         if (++ld_kt == ld_nk) {                                                               \
@@ -1076,7 +1078,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
                 ld_tile += lstride;                                                           \
                 ld_valid = ld_valid && ld_tile < ntiles;                                      \
                 if constexpr (XF) xf_setup_rows(ld_tile, ld_valid);                           \
-                else { g_setup_rows<T, TM, TPX>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0); lin_rows(); }   \
+                else { g_setup_rows<T, TM, TPX, NWX>(p, ld_tile, ld_valid, wave, rowin, kc, xoff, xh0, xw0); lin_rows(); }   \
             }                                                                                 \
             ld_nk = G_NK(ld_cls);                                                             \
             ld_tap0 = p.ctap0[ld_cls]; ld_ntap = p.cnt[ld_cls];                               \
@@ -1160,38 +1162,38 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
 #endif
         if constexpr (sizeof(T) == 2 && G::NACC >= 8) {
             static_assert(BK == 32, "two 16-deep halves per step");
-            GFragK<T, TM, TPX> f0, f1;
-            g_fetch_k<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, 0, f0);
+            GFragK<T, TM, TPX, NWX> f0, f1;
+            g_fetch_k<T, TM, TPX, NWX>(sTiles + so0, arow, xrow, swz, lane, 0, f0);
             __builtin_amdgcn_sched_barrier(0);
             // address work of step s+2 (covers the LDS latency of the fetch), its DMA pieces one per MFMA of the first half
             unsigned offs[G::LPS];
             v4i32 rsXs = rsX;
             if constexpr (XF) { if (xf_prep(ld_kt, offs)) rsXs = rsX2; }
             else if (lin) lin_prep(ld_kt, offs);
-            else g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
+            else g_issue_prep<T, TM, TPX, NWX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
             __builtin_amdgcn_sched_barrier(0);
-            g_mma_k_issue<T, TM, TPX>(f0, acc, offs, lds_tiles, so2, rsXs, rsW, wave);   // -> the stage step s-1 used
-            g_fetch_k<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, 1, f1);
+            g_mma_k_issue<T, TM, TPX, NWX>(f0, acc, offs, lds_tiles, so2, rsXs, rsW, wave);   // -> the stage step s-1 used
+            g_fetch_k<T, TM, TPX, NWX>(sTiles + so0, arow, xrow, swz, lane, 1, f1);
             __builtin_amdgcn_sched_barrier(0);
             G_ADVANCE()
             __builtin_amdgcn_sched_barrier(0);
-            g_mma_k<T, TM, TPX>(f1, acc);
+            g_mma_k<T, TM, TPX, NWX>(f1, acc);
         } else if constexpr (sizeof(T) == 2) {
-            GFrags<T, TM, TPX> fr;
-            g_fetch_frags<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, fr);
+            GFrags<T, TM, TPX, NWX> fr;
+            g_fetch_frags<T, TM, TPX, NWX>(sTiles + so0, arow, xrow, swz, lane, fr);
             __builtin_amdgcn_sched_barrier(0);
             unsigned offs[G::LPS];
             v4i32 rsXs = rsX;
             if constexpr (XF) { if (xf_prep(ld_kt, offs)) rsXs = rsX2; }
             else if (lin) lin_prep(ld_kt, offs);
-            else g_issue_prep<T, TM, TPX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
+            else g_issue_prep<T, TM, TPX, NWX>(p, xoff, xh0, xw0, woff, ld_kt, ld_tap0, ld_ntap, sTap, kc, offs);
             __builtin_amdgcn_sched_barrier(0);
-            g_mma_frags_issue<T, TM, TPX>(fr, acc, offs, lds_tiles, so2, rsXs, rsW, wave);   // step s+2 -> the stage step s-1 used
+            g_mma_frags_issue<T, TM, TPX, NWX>(fr, acc, offs, lds_tiles, so2, rsXs, rsW, wave);   // step s+2 -> the stage step s-1 used
             G_ADVANCE()
         } else {
             G_ISSUE(so2)
             G_ADVANCE()
-            g_mma<T, TM, TPX>(sTiles + so0, arow, xrow, swz, lane, acc);
+            g_mma<T, TM, TPX, NWX>(sTiles + so0, arow, xrow, swz, lane, acc);
         }
         // The last MFMA's result must not be read for passes+2 wait states.  hipcc (ROCm 7.2) covers that hazard inside a
         // basic block but was seen to miss it across the loop back edge (fp32 head variant: the next iteration opened
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
 #endif
         if (cur_kt == cur_nk - 1) {
             if constexpr (sizeof(T) == 2) AY_MFMA_PAD("s_nop 11");   // fp16: accumulators are only read here
-            g_epilogue<T, TM, EM, TPX, BNR>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq,
+            g_epilogue<T, TM, EM, TPX, BNR, NWX>(p, cur_tile, p.coah[cur_cls], p.coaw[cur_cls], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq,
                                             sStat, cbase - n0, bctx);
             if constexpr (TILE_RED) {
                 // 128-channel tiles: the BNR sums are reduced per tile (DPP row sums + LDS atomics, as k_gconv3) instead of
@@ -1224,8 +1226,8 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
                 const float a = half_reduce_scatter<16 * G::MI>(ssum, lq), b = half_reduce_scatter<16 * G::MI>(ssq, lq);
 #pragma unroll
                 for (int r = 0; r < 16 * G::MI; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }
-                if (rs_reports<16 * G::MI>(lq)) {
-                    const int cl = g_stat_chan<true>(rs_index<16 * G::MI>(lq), lq >> 5);
+                if ((BNR || want_stats) && rs_reports<16 * G::MI>(lq)) {
+                    const int cl = g_stat_chan<BNR>(rs_index<16 * G::MI>(lq), lq >> 5);
                     atomicAdd(&sl[cl], (double)a);
                     atomicAdd(&sl[TM + cl], (double)b);
                 }
@@ -1255,7 +1257,7 @@ __global__ __launch_bounds__((GT<T, TM, TPX>::NT), (sizeof(T) == 2 ? (GT<T, TM, 
 #endif
     if constexpr (TILE_RED) {
         __syncthreads();
-        g_stats_to_global<TM, true>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
+        if (BNR || want_stats) g_stats_to_global<TM, BNR>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
     } else if constexpr (BNR) g_stats_flush<T, TM, G::MI, true>(p, reinterpret_cast<double*>(sStat), tid, lane, wm, n0, slot, ssum, ssq);
     else if (want_stats) g_stats_flush<T, TM, G::MI>(p, reinterpret_cast<double*>(sStat), tid, lane, wm, n0, slot, ssum, ssq);
 }
@@ -2077,6 +2079,349 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_pw (round 6): the 1x1 / stride-1 conv -- forward AND dgrad -- of the layers with K = 128 / 256 reduction
+// channels as a STREAMING kernel.
+//
+// Why: on the <= 40 x 40 maps k_gconv runs one 256-pixel tile per workgroup at 1-1.5 workgroups per CU.  A life of 18 k cycles
+// (128 -> 128 on 40 x 40, tools/gconv_probe.py, profiles/r06_probe_small_maps.txt) is 4.5 k of prologue, 4 k-steps of ~1.35 k (one
+// barrier + counted wait + fragment fetch + DMA issue per 32-deep step, 512 cycles of them matrix pipe) and 5.3 k of epilogue, all
+// at the issue rate of one or two wavefronts per SIMD.  Eight wavefronts on the same step structure bought nothing (v1 of this
+// round, profiles/r06_probe_nw8_v1.txt: a step costs ~800 cycles however few MFMAs it holds -- it is the barrier / wait / fetch
+// chain, not the work).  So the step structure goes:
+//   * the WEIGHTS of a wavefront's 32 output channels live in REGISTERS for the whole kernel (K / 16 A fragments of 16 bytes per
+//     lane: 32 registers for K = 128, 64 for K = 256), loaded once per workgroup straight from global memory -- no W tile in LDS,
+//     no W DMA per step;
+//   * a pixel tile's x rows arrive WHOLE (all K channels: 256 / 512-byte rows) by LDS-DMA into a ring of three stages, two tiles
+//     ahead; ONE barrier per pixel tile, then K / 16 back-to-back MFMAs per wavefront against its resident A fragments;
+//   * eight wavefronts: 32 channels x 32 pixels each = ONE accumulator block (16 registers), so the epilogue handles 16 values
+//     per lane and the BatchNorm sums of a tile go straight into the reduce-scatter (no sum registers across tiles);
+//   * persistent: 1-2 workgroups per CU walk their XCD band's pixel tiles, so the DMA of tile t + 2 and the stores of tile t - 1
+//     run under tile t's MFMAs and epilogue, and the prologue (kernel arguments, A fragments, BatchNorm constants) is paid once.
+// LDS image of a stage: row-major [pixel][K] as the DMA writes it (lane-linear), the 16-byte chunk position XOR-swizzled by the
+// pixel row (row & 15, on the SOURCE address): the 16 lanes of a ds_read_b128 group read 16 different rows at the same logical
+// chunk = 16 different bank groups.  Epilogues are k_gconv's (g_epilogue on a one-block wave tile).
+// ---------------------------------------------------------------------------------------------------
+template <int TM, int KC>
+struct PW {
+    static constexpr int NW = 8;
+    static constexpr int WM = TM / 32, WP = NW / WM, TP = 32 * WP;     // 128 channels: 64-pixel tiles; 64 channels: 128-pixel tiles
+    static constexpr int K = KC * 16, RB = K * 2;                      // bytes per x row
+    static constexpr int CPR = RB / 16;                                // 16-byte chunks per row: 16 / 32
+    static constexpr int XT = TP * RB;                                 // bytes per stage
+    static constexpr int PPT = XT / 1024, PPW = PPT / NW;              // DMA pieces per tile / per wavefront
+    static constexpr int RPP = 1024 / RB;                              // pixel rows per piece
+    // swizzle: chunk c of pixel row r sits at position c ^ swz(r), swz(r) = (r / RPB) & SWM -- rows shorter than a 256-byte bank
+    // line (K = 32 / 64) share the line RPB at a time, so the row's index inside the line already separates them
+    static constexpr int RPB = RB >= 256 ? 1 : 256 / RB;
+    static constexpr int SWM = CPR - 1 < 15 ? CPR - 1 : 15;
+    static constexpr int R = 3;                                        // ring stages
+    using G = GT<half_t, TM, TP, 8>;
+    static_assert(G::MI == 1 && G::NI == 1 && G::WM == WM && G::WP == WP, "one accumulator block per wavefront");
+    static_assert(PPT % NW == 0 && RB <= 1024, "whole pieces per wavefront");
+    static constexpr size_t lds(int EM, bool BNR) { return (size_t)R * XT + G::tail(EM, BNR); }
+};
+
+// XFM: 0 plain x; 1 / 2 = transform on load (ayolo_conv_fwd_xf) over one / two input segments: the x tile is the producer's
+// pre-activation z, transformed IN PLACE in its stage -- by the lanes whose DMA wrote it, one tile ahead of the MFMAs -- with
+// k_bn_train_act's arithmetic (the operand bits equal the materialised activation's; see k_gconv<.., XF>).  Two segments: a piece
+// holds whole pixel rows, i.e. chunks of both buffers -- two lane-masked loads per piece (glds16_exec).
+template <int TM, int KC, int EM, bool BNR, int XFM = 0>
+__global__ __launch_bounds__(512, (KC <= 8 ? 4 : 2)) void k_pw(GConvP p) {
+    AY_KERNARG_TOUCH(kt_, GConvP);
+    using P = PW<TM, KC>;
+    using G = typename P::G;
+    using T = half_t;
+    static_assert(XFM == 0 || (!BNR && (EM == 0 || EM == 3)), "transform on load: forward of a 1x1 conv");
+    constexpr int NSTK = (EM != 3) ? G::NACC * 2 : G::NST;
+    constexpr int PPW = P::PPW;
+    constexpr int NP = PPW * (XFM == 2 ? 2 : 1);                                  // DMA instructions per thread and tile
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    unsigned char* sX = smem_raw;                                                 // [R][TP][K]
+    float* sStat = reinterpret_cast<float*>(smem_raw + P::R * P::XT);             // GT::tail: statistics / BNR constants / affine
+    float* sXf = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sStat) + G::tail(EM, BNR));   // XFM: [scale | shift][K]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % P::WM, wp = wave / P::WM;
+
+    // block -> (channel tile, XCD band, slot): as k_gconv
+    const unsigned Lb = blockIdx.x;
+#ifdef AYOLO_PROBE
+    __shared__ unsigned long long s_probe[AY_PROBE_N];
+    const bool probe_on = blockIdx.x < 512;
+    int probe_k = 2;
+    if (threadIdx.x < AY_PROBE_N) s_probe[threadIdx.x] = 0;
+    __syncthreads();
+    AY_PROBE(0);
+    if (threadIdx.x == 0) s_probe[AY_PROBE_N - 3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const unsigned xcd = Lb & 7u, idx = Lb >> 3;
+    const unsigned nt = idx % (unsigned)p.ntn;
+    const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
+    const int n0 = (int)nt * TM;
+    const unsigned ntiles_all = (unsigned)((p.Mtotal + P::TP - 1) / P::TP);
+    const unsigned tpx = (ntiles_all + 7) / 8;
+    const unsigned band_lo = xcd * tpx;
+    const unsigned ntiles = band_lo + tpx < ntiles_all ? band_lo + tpx : ntiles_all;
+    const unsigned lslot = idx / (unsigned)p.ntn;
+    const unsigned lstride = (unsigned)p.nslots / 8u;
+    unsigned cur_tile = band_lo + lslot;
+    kt_.done();
+    if (cur_tile >= ntiles) return;
+
+    const v4i32 rsX = make_srd(p.x, p.x_bytes);
+    const unsigned lds_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)sX);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    // ---- loader lane geometry: piece q = j * 8 + wave covers stage bytes [q * 1024, +1024) = RPP whole pixel rows; this lane
+    // writes chunk position cp of row rowj[j] and must FETCH chunk cp ^ (row & 15) of that pixel
+    const unsigned ldxb = (unsigned)p.ldx * 2u;
+    const int rowin = lane / P::CPR, cp = lane % P::CPR;
+    unsigned coff[PPW];
+    int rowj[PPW];
+    // two segments: channels [xs_split, K) come from x2 (channel stride ldx2); a lane's chunk belongs to one of them for good
+    const v4i32 rsX2 = XFM == 2 ? make_srd(p.x2, p.x2_bytes) : rsX;
+    const unsigned ldxb2 = XFM == 2 ? (unsigned)p.ldx2 * 2u : 0u;
+    unsigned coff2[XFM == 2 ? PPW : 1];
+    unsigned long long m2[XFM == 2 ? PPW : 1];                                    // lanes of piece j that load from segment 1
+    int ch0[XFM ? PPW : 1];                                                       // first channel of this lane's chunk of piece j
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        rowj[j] = (j * P::NW + wave) * P::RPP + rowin;
+        const int c = cp ^ ((rowj[j] / P::RPB) & P::SWM);
+        coff[j] = (unsigned)rowj[j] * ldxb + (unsigned)(c * 16);
+        if constexpr (XFM) ch0[j] = c * 8;
+        if constexpr (XFM == 2) {
+            const bool s1 = c * 8 >= p.xs_split;
+            coff2[j] = (unsigned)rowj[j] * ldxb2 + (unsigned)(c * 8 - p.xs_split) * 2u;
+            m2[j] = __builtin_amdgcn_ballot_w64(s1);
+        }
+    }
+    // all pieces of tile `tile` (beyond the band / the tensor: out-of-range offset, zero fill) -> stage `st`
+    auto issue_tile = [&](unsigned tile, int st) __attribute__((always_inline)) {
+        const bool tv = tile < ntiles;
+        const unsigned base = tile * (unsigned)P::TP;                             // first pixel of the tile (< 2^31, host check)
+        const int rem = tv ? (int)((unsigned)p.Mtotal - base) : 0;               // pixels left from there
+        const unsigned bb = base * ldxb;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const unsigned off = rowj[j] < rem ? bb + coff[j] : G_OOB;
+            const unsigned la = lds_x + (unsigned)(st * P::XT + (j * P::NW + wave) * 1024);
+            if constexpr (XFM == 2) {
+                const unsigned off2 = rowj[j] < rem ? base * ldxb2 + coff2[j] : G_OOB;
+                glds16_exec(rsX, la, off, ~m2[j]);
+                glds16_exec(rsX2, la, off2, m2[j]);
+            } else glds16(rsX, la, off);
+        }
+    };
+    issue_tile(cur_tile, 0);
+    issue_tile(cur_tile + lstride, 1);
+
+    // ---- the wavefront's weights: A fragments of its 32 output channels for the whole reduction, in registers
+    half8 afrag[KC];
+    {
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+        const int n = n0 + wm * 32 + (lane & 31);
+        const unsigned wo = n < p.Nout ? (unsigned)n * (unsigned)p.ldw * 2u + (unsigned)(lane >> 5) * 16u : G_OOB;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk)
+            afrag[kk] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsW, wo + (unsigned)(kk * 32), 0, 0));
+    }
+
+    if constexpr (EM == 2 || EM == 4) {
+        for (int i = tid; i < TM; i += (int)blockDim.x) {
+            const bool in = n0 + i < p.Nout;
+            const float* any = p.scale ? p.scale : p.shift;
+            float sc_ = 1.0f, sh_ = 0.0f;
+            if (any) {
+                const float a_ = (p.scale ? p.scale : any)[in ? n0 + i : 0], b_ = (p.shift ? p.shift : any)[in ? n0 + i : 0];
+                sc_ = (in && p.scale) ? a_ : 1.0f;
+                sh_ = (in && p.shift) ? b_ : 0.0f;
+            }
+            sStat[i] = sc_;
+            sStat[TM + i] = sh_;
+        }
+    }
+    if constexpr (BNR) g_bnr_setup<TM>(p, sStat + 4 * TM, n0, tid);
+    const bool want_stats = (EM == 0) && !BNR && (p.stats != nullptr);
+    const bool any_stats = BNR || want_stats;
+    if constexpr (EM == 0 || BNR) {
+        for (int i = tid; i < 2 * TM; i += (int)blockDim.x) reinterpret_cast<double*>(sStat)[i] = 0.0;
+    }
+    const BnrCtx<1> bctx = BNR ? g_bnr_ctx<1>(p, sStat + 4 * TM, n0 + wm * 32) : BnrCtx<1>{};
+
+    // ---- transform on load: per-input-channel scale | shift -> LDS (from the producer's batch statistics when the finalize rides
+    // in this launch: k_bn_finalize's expression sequence, workgroup 0 also writes the saved / running statistics), then the
+    // in-place transform of a landed tile by the lanes that own its bytes
+    if constexpr (XFM != 0) {
+        if (p.nfin > 0) {
+            for (int i = tid; i < 2 * P::K; i += (int)blockDim.x) sXf[i] = 0.0f;
+            __syncthreads();
+            float* gsc = const_cast<float*>(p.xf_scale);
+            float* gsh = const_cast<float*>(p.xf_shift);
+            for (int f = 0; f < p.nfin; ++f) {
+                const ayolo_xf_fin& q = p.fin[f];
+                for (int c = tid; c < q.C; c += (int)blockDim.x) {
+                    double s1, s2;
+                    rep_sum2(q.stats + c, (size_t)2 * q.sld, (size_t)q.sld, q.reps, s1, s2);
+                    const double mean = s1 / q.count;
+                    double var = s2 / q.count - mean * mean;
+                    if (var < 0) var = 0;
+                    const float invstd = (float)(1.0 / sqrt(var + (double)q.eps));
+                    const float g = q.gamma ? q.gamma[c] : 1.0f, b = q.beta ? q.beta[c] : 0.0f;
+                    const float sc = g * invstd;
+                    const float sh = b - (float)mean * sc;
+                    sXf[q.c0 + c] = sc;
+                    sXf[P::K + q.c0 + c] = sh;
+                    if (Lb == 0) {
+                        gsc[q.c0 + c] = sc;
+                        gsh[q.c0 + c] = sh;
+                        if (q.save_mean) q.save_mean[c] = (float)mean;
+                        if (q.save_invstd) q.save_invstd[c] = invstd;
+                        if (q.running_mean) q.running_mean[c] = (1.0f - q.momentum) * q.running_mean[c] + q.momentum * (float)mean;
+                        if (q.running_var) {
+                            const double unb = q.count > 1.0 ? var * q.count / (q.count - 1.0) : var;
+                            q.running_var[c] = (1.0f - q.momentum) * q.running_var[c] + q.momentum * (float)unb;
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int i = tid; i < P::K; i += (int)blockDim.x) {
+                sXf[i] = p.xf_scale[i];
+                sXf[P::K + i] = p.xf_shift[i];
+            }
+        }
+    }
+    const bool xst = XFM != 0 && p.xa != nullptr && nt == 0;           // this workgroup also stores the activation it forms
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(XFM ? p.xa : nullptr, 0, XFM ? p.xa_bytes : 0, 0x00020000);
+    // exactly PPW stores per transformed tile when this workgroup stores back (plain segments / rows beyond the tensor: dropped by
+    // the out-of-range offset), so that the counted waits stay exact
+    auto xf_transform = [&](int st, unsigned tile) __attribute__((always_inline)) {
+        if constexpr (XFM != 0) {
+            const bool tv = tile < ntiles;
+            const unsigned base = tile * (unsigned)P::TP;
+            const int rem = tv ? (int)((unsigned)p.Mtotal - base) : 0;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const int sg = (XFM == 2 && ch0[j] >= p.xs_split) ? 1 : 0;
+                const bool virt = ((p.xf_virt >> sg) & 1) != 0, act = ((p.xf_act >> sg) & 1) != 0;
+                half8* q = reinterpret_cast<half8*>(sX + st * P::XT + (j * P::NW + wave) * 1024 + lane * 16);
+                half8 h = *q;
+                const float4v a0_ = *reinterpret_cast<const float4v*>(sXf + ch0[j]), a1_ = *reinterpret_cast<const float4v*>(sXf + ch0[j] + 4);
+                const float4v b0_ = *reinterpret_cast<const float4v*>(sXf + P::K + ch0[j]), b1_ = *reinterpret_cast<const float4v*>(sXf + P::K + ch0[j] + 4);
+                if (virt) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float u = __builtin_fmaf((float)h[e], e < 4 ? a0_[e & 3] : a1_[e & 3], e < 4 ? b0_[e & 3] : b1_[e & 3]);
+                        if (act) u = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f));
+                        h[e] = (half_t)u;
+                    }
+                    *q = h;
+                }
+                if (xst) {
+                    const bool ok = virt & (rowj[j] < rem);
+                    const unsigned off = ok ? (base + (unsigned)rowj[j]) * ((unsigned)p.ldxa * 2u) + (unsigned)ch0[j] * 2u : G_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, h), rsA, off, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // written before this wave reaches the next barrier
+        }
+    };
+
+    // ---- B fragment geometry: this lane's pixel row of the stage and its swizzled chunk base; fragment kk = chunk 2 kk + hi
+    const int prow = wp * 32 + (lane & 31);
+    const unsigned a0 = (unsigned)prow * P::RB + (unsigned)(((lane >> 5) ^ ((prow / P::RPB) & P::SWM)) << 4);
+    const int cbase = n0 + wm * 32 + 4 * (lane >> 5);
+
+    float16v acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+    __syncthreads();                          // constants / zeroed statistics visible
+    if constexpr (XFM != 0) {
+        wait_vm<NP>();                        // tile 0's pieces (the older half of the two issues)
+        xf_transform(0, cur_tile);
+    }
+    AY_PROBE(1);
+
+    unsigned ld_tile = cur_tile + 2 * lstride;
+    bool after_epi = false;
+    bool done = false;
+#define PW_TILE(S_)                                                                                        \
+    if (!done) {                                                                                           \
+        /* tile t's pieces of THIS wave landed (behind them: tile t + 1's pieces and the last epilogue's stores), then everyone's, \
+           and everyone is through with the stage tile t + 2 goes to */                                   \
+        AY_PROBE_STEP();                                                                                   \
+        if constexpr (XFM == 0) { if (after_epi) wait_vm<NP + NSTK>(); else wait_vm<NP>(); }               \
+        AY_PROBE_STEP();                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        AY_PROBE_STEP();                                                                                   \
+        issue_tile(ld_tile, ((S_) + 2) % 3);                                                               \
+        ld_tile += lstride;                                                                                \
+        {                                                                                                  \
+            const unsigned char* st = sX + (S_) * P::XT;                                                   \
+            half8 bf[KC];                                                                                  \
+            _Pragma("unroll") for (int kk = 0; kk < KC; ++kk) bf[kk] = *reinterpret_cast<const half8*>(st + (a0 ^ (unsigned)(kk << 5))); \
+            _Pragma("unroll") for (int kk = 0; kk < KC; ++kk) mma_step(afrag[kk], bf[kk], acc[0]);         \
+        }                                                                                                  \
+        AY_MFMA_PAD("s_nop 11");                                                                           \
+        AY_PROBE_STEP();                                                                                   \
+        {                                                                                                  \
+            float ssum[16], ssq[16];                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) { ssum[r] = 0.0f; ssq[r] = 0.0f; }              \
+            g_epilogue<T, TM, EM, P::TP, BNR, 8>(p, cur_tile, p.coah[0], p.coaw[0], wp, lane, cbase, want_stats, rsY, acc, ssum, ssq, sStat, \
+                                                 cbase - n0, bctx);                                        \
+            if constexpr (EM == 0 || BNR) {                                                                \
+                if (any_stats) {                                                                           \
+                    int lq = lane;                                                                         \
+                    asm volatile("" : "+v"(lq));                                                           \
+                    double* sl = reinterpret_cast<double*>(sStat) + wm * 32;                               \
+                    const int cl = g_stat_chan<BNR>(rs_index<16>(lq), lq >> 5);                            \
+                    const float a = half_reduce_scatter<16>(ssum, lq);                                     \
+                    const float b = half_reduce_scatter<16>(ssq, lq);                                      \
+                    if (rs_reports<16>(lq)) { atomicAdd(&sl[cl], (double)a); atomicAdd(&sl[TM + cl], (double)b); } \
+                }                                                                                          \
+            }                                                                                              \
+        }                                                                                                  \
+        after_epi = true;                                                                                  \
+        if constexpr (XFM != 0) {                                                                          \
+            /* tile t + 1's pieces (behind them: the last transform's stores, tile t + 2's pieces, this epilogue's stores): \
+               transformed now, published by the next barrier */                                          \
+            if (xst) wait_vm<NP + NSTK + PPW>(); else wait_vm<NP + NSTK>();                                \
+            xf_transform(((S_) + 1) % 3, cur_tile + lstride);                                              \
+        }                                                                                                  \
+        cur_tile += lstride;                                                                               \
+        done = cur_tile >= ntiles;                                                                         \
+    }
+#ifdef AYOLO_PROBE
+#define AY_PROBE_STEP() do { AY_PROBE(probe_k); ++probe_k; } while (0)
+#else
+#define AY_PROBE_STEP() do { } while (0)
+#endif
+    while (!done) {
+        PW_TILE(0)
+        PW_TILE(1)
+        PW_TILE(2)
+    }
+#undef PW_TILE
+#undef AY_PROBE_STEP
+    wait_vm<0>();                             // trailing zero-fill DMAs must land before this LDS is released
+#ifdef AYOLO_PROBE
+    AY_PROBE(AY_PROBE_N - 1);
+    if (threadIdx.x == 0) s_probe[AY_PROBE_N - 2] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (probe_on && threadIdx.x < AY_PROBE_N) g_probe[blockIdx.x * AY_PROBE_N + threadIdx.x] = s_probe[threadIdx.x];
+#endif
+    if constexpr (EM == 0 || BNR) {
+        if (any_stats) {
+            __syncthreads();
+            g_stats_to_global<TM, BNR>(p, reinterpret_cast<const double*>(sStat), tid, n0, slot);
+        }
+    }
+}
+
 // compute units of the CURRENT device (cached per device ordinal: one process may drive several GPUs)
 static int num_cus() {
     static int cache[16] = {0};
@@ -2092,9 +2437,10 @@ static int num_cus() {
 }
 
 // workgroups per CU of one k_gconv instantiation (LDS-bound; the launch bounds give the register budget to match)
-template <typename T, int TM, int TPX, int EM, bool BNR>
+template <typename T, int TM, int TPX, int EM, bool BNR, int NWX = 4>
 static constexpr int gconv_bpc() {
-    using G = GT<T, TM, TPX>;
+    if constexpr (NWX == 8) return 2;          // register budget: 128 per lane = four wavefronts per SIMD = two 512-thread workgroups
+    using G = GT<T, TM, TPX, NWX>;
     constexpr size_t lds_alloc = (G::lds(EM, BNR) + 1279) / 1280 * 1280;          // LDS allocation granule of gfx950
     int bpc = (int)(160 * 1024 / lds_alloc);
     const int bpc_max = sizeof(T) == 2 ? (G::lds(EM, BNR) > 56 * 1024 ? 2 : (TM == 128 ? 3 : 4)) : 1;
@@ -2114,9 +2460,9 @@ static GGrid gconv_grid(long long Mtotal, int tp, int ntn, int bpc) {
     return {slots, (tpx + spx - 1) / spx};
 }
 
-template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false, bool LIN = false>
+template <typename T, int TM, int EM, int TPX, bool BNR = false, bool XF = false, bool LIN = false, int NWX = 4>
 static int launch_gconv_tp(GConvP p, hipStream_t s) {
-    using G = GT<T, TM, TPX>;
+    using G = GT<T, TM, TPX, NWX>;
     const size_t lds = G::lds(EM, BNR) + (XF ? 2 * (size_t)((p.C + BK - 1) / BK * BK) * sizeof(float) : 0);
     p.ntn = (p.Nout + TM - 1) / TM;
     constexpr int bpc_env = 0;
@@ -2155,27 +2501,95 @@ static int launch_gconv_tp(GConvP p, hipStream_t s) {
             return AYOLO_OK;
         }
     }
-    int bpc = bpc_env > 0 ? bpc_env : gconv_bpc<T, TM, TPX, EM, BNR>();
+    int bpc = bpc_env > 0 ? bpc_env : gconv_bpc<T, TM, TPX, EM, BNR, NWX>();
     if constexpr (XF) {                      // the constants table counts against the LDS budget
         const int fit = (int)(160 * 1024 / ((lds + 1279) / 1280 * 1280));
         bpc = fit < bpc ? (fit < 1 ? 1 : fit) : bpc;
     }
-    const long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc).slots;
+    long long slots = gconv_grid(p.Mtotal, G::TP, p.ntn, bpc).slots;
+    if constexpr (NWX == 8) {
+        // balanced persistent grid: every workgroup walks the same number of tiles (800 tiles on 512 slots = 288 workgroups with two
+        // tiles + 224 with one; 400 workgroups with two tiles each end together)
+        const long long ntiles = (p.Mtotal + G::TP - 1) / G::TP, tpx = (ntiles + 7) / 8, spx = slots / 8;
+        const long long waves = (tpx + spx - 1) / spx;
+        slots = ((tpx + waves - 1) / waves) * 8;
+    }
     p.nslots = (int)slots;
     dim3 grid((unsigned)(slots * p.ntn));
     static size_t attr_set[16] = {0};        // per device (function attributes belong to the device's context): largest size set
     if (dev < 0 || dev >= 16 || attr_set[dev] < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX, BNR, XF, LIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gconv<T, TM, EM, TPX, BNR, XF, LIN, NWX>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(XF ? 160 * 1024 : lds));
         if (dev >= 0 && dev < 16) attr_set[dev] = XF ? 160 * 1024 : lds;
     }
-    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR, XF, LIN>), grid, dim3(G::NT), lds, s, p);
+    hipLaunchKernelGGL((k_gconv<T, TM, EM, TPX, BNR, XF, LIN, NWX>), grid, dim3(G::NT), lds, s, p);
     AY_CHECK_LAUNCH("k_gconv");
+    return AYOLO_OK;
+}
+
+// k_pw: grid = 1-2 persistent workgroups per CU (and channel tile), every workgroup the same number of pixel tiles
+template <int TM, int KC, int EM, bool BNR, int XFM = 0>
+static int launch_pw(GConvP p, hipStream_t s) {
+    using P = PW<TM, KC>;
+    const size_t lds = P::lds(EM, BNR) + (XFM ? 2 * (size_t)P::K * sizeof(float) : 0);
+    p.ntn = (p.Nout + TM - 1) / TM;
+    const int fit = (int)(160 * 1024 / ((lds + 1279) / 1280 * 1280));
+    const int bpc = KC <= 8 ? (fit < 2 ? fit : 2) : 1;                 // register budget: 128 (two workgroups per CU) / 256 per lane
+    long long slots = gconv_grid(p.Mtotal, P::TP, p.ntn, bpc).slots;
+    {
+        const long long ntiles = (p.Mtotal + P::TP - 1) / P::TP, tpx = (ntiles + 7) / 8, spx = slots / 8;
+        const long long waves = (tpx + spx - 1) / spx;
+        slots = ((tpx + waves - 1) / waves) * 8;
+    }
+    p.nslots = (int)slots;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw<TM, KC, EM, BNR, XFM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((k_pw<TM, KC, EM, BNR, XFM>), dim3((unsigned)(slots * p.ntn)), dim3(512), lds, s, p);
+    AY_CHECK_LAUNCH("k_pw");
     return AYOLO_OK;
 }
 
 template <typename T, int TM, int EM, bool BNR = false, bool XF = false>
 static int launch_gconv_em(const GConvP& p, hipStream_t s) {
+    // the streaming 1x1 kernel (k_pw): whole reductions of 32 .. 256 channels whose three stages fit the LDS
+    if constexpr (sizeof(T) == 2 && XF && EM == 0) {
+        static const int pw_on = getenv("AYOLO_PW") ? atoi(getenv("AYOLO_PW")) : 0;
+        // transform on load: the same tilings as the plain conv of the same shape (a layer's two routes share one kernel family, so
+        // that they stay bit-identical: test_conv_transform_on_load_equals_materialised_route)
+        if ((pw_on & 8) && p.xf && p.C % BK == 0 && p.xs_split % 8 == 0) {
+            const bool two = p.x2 != nullptr;
+            if constexpr (TM == 128) {
+                if (p.C == 64 && (pw_on & 2)) return two ? launch_pw<TM, 4, EM, false, 2>(p, s) : launch_pw<TM, 4, EM, false, 1>(p, s);
+                if (p.C == 128) return two ? launch_pw<TM, 8, EM, false, 2>(p, s) : launch_pw<TM, 8, EM, false, 1>(p, s);
+                if (p.C == 256) return two ? launch_pw<TM, 16, EM, false, 2>(p, s) : launch_pw<TM, 16, EM, false, 1>(p, s);
+            } else if constexpr (TM == 64) {
+                if (p.C == 64 && (pw_on & 2)) return two ? launch_pw<TM, 4, EM, false, 2>(p, s) : launch_pw<TM, 4, EM, false, 1>(p, s);
+                if (p.C == 128 && (pw_on & 2)) return two ? launch_pw<TM, 8, EM, false, 2>(p, s) : launch_pw<TM, 8, EM, false, 1>(p, s);
+            }
+        }
+    }
+    if constexpr (sizeof(T) == 2 && !XF && EM != 3) {
+        static const int pw_on = getenv("AYOLO_PW") ? atoi(getenv("AYOLO_PW")) : 0;
+        static const long long pw_maxm = getenv("AYOLO_PW_MAXM") ? atoll(getenv("AYOLO_PW_MAXM")) : (1ll << 40);
+        if (pw_on && p.lin && p.Mtotal <= pw_maxm) {
+            if constexpr (TM == 128) {
+                if (p.C == 64 && (pw_on & 2)) return launch_pw<TM, 4, EM, BNR>(p, s);
+                if (p.C == 128) return launch_pw<TM, 8, EM, BNR>(p, s);
+                if (p.C == 256) return launch_pw<TM, 16, EM, BNR>(p, s);
+            } else if constexpr (TM == 64) {
+                if (p.C == 64 && (pw_on & 2)) return launch_pw<TM, 4, EM, BNR>(p, s);
+                if (p.C == 128 && (pw_on & 2)) return launch_pw<TM, 8, EM, BNR>(p, s);
+            } else {
+                if (p.C == 32 && (pw_on & 4)) return launch_pw<TM, 2, EM, BNR>(p, s);
+                if (p.C == 64 && (pw_on & 4)) return launch_pw<TM, 4, EM, BNR>(p, s);
+            }
+        }
+    }
     // Pixel-tile size, 128 or 256 (measured per layer on the YOLOv5s shapes at batch 64, profiles/r02_conv_tile_sweep.txt):
     //  * one wave of 128-pixel tiles fits the chip: keep 128 (most workgroups in flight; the 20^2 maps);
     //  * few waves (<= 3) and 256-pixel tiles need fewer: take 256.  A workgroup's step is latency-bound there, so the
@@ -2197,6 +2611,21 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
         else wide = TM == 64 ? true : (TM == 128 ? K >= 256 : K >= 128);
     }
     if (p.s2f && TM == 128) wide = false;          // k_gconv_s2f: the 128 x 256 tile would spill (all four fragment sets live)
+    // Round 6: the 1x1 layers of the small maps on EIGHT wavefronts per 128 x 128 tile.  One 256-pixel tile per
+    // workgroup at 1-1.5 workgroups per CU leaves one or two wavefronts on a SIMD, and a lone wavefront issues an instruction every
+    // 8-10 cycles: prologue and epilogue (4.5 k + 5.3 k cycles of an 18 k-cycle life on 128 -> 128 at 40 x 40, tools/gconv_probe.py) run at
+    // that rate.  Here every wavefront owns 32 channels x 64 pixels (32 accumulator registers), two workgroups per CU put four
+    // wavefronts on every SIMD, and a workgroup walks two or more tiles so that the next tile's DMA runs under the epilogue.
+    if constexpr (sizeof(T) == 2 && TM == 128 && (EM != 3 || XF)) {
+        static const int nw8 = getenv("AYOLO_GCONV_NW8") ? atoi(getenv("AYOLO_GCONV_NW8")) : 0;
+        static const long long nw8_maxm = getenv("AYOLO_GCONV_NW8_MAXM") ? atoll(getenv("AYOLO_GCONV_NW8_MAXM")) : 102400;
+        // (transform on load: only with whole 32-channel chunks, the 1x1 loader's condition, so that a layer's two routes -- reader
+        // over z / conv over the materialised activation -- always share one tiling and stay bit-identical)
+        if (nw8 && (p.lin || (XF && p.C % BK == 0)) && !p.row3 && !p.s2f && p.Mtotal <= nw8_maxm) {
+            if constexpr (XF) return launch_gconv_tp<T, TM, EM, 128, BNR, true, false, 8>(p, s);
+            else if constexpr (EM != 3) { if (p.lin) return launch_gconv_tp<T, TM, EM, 128, BNR, false, true, 8>(p, s); }
+        }
+    }
     // the 1x1 loader (GConvP::lin): the Conv / dgrad / inference epilogues of the 64- and 128-channel tiles (YOLOHead keeps the
     // generic loader: three launches per step)
     if constexpr (sizeof(T) == 2 && !XF && EM != 3 && TM >= 64) {
@@ -3920,13 +4349,18 @@ template <typename T, int TM, bool XFW>
 static int launch_wgrad_k(const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned blocks, float* ws, const WOvr& ovr, hipStream_t s) {
     using W = WT<T, TM>;
     static bool attr_set[16] = {false};
+    // experiment (round 6, fork placement): grouped launches may ask for more LDS than they use, so that fewer of their workgroups
+    // fit a CU and the main stream's kernels always find a free slot
+    static const int lds_pad = getenv("AYOLO_WGRAD_LDS") ? atoi(getenv("AYOLO_WGRAD_LDS")) : 0;
+    const size_t lds = (items != nullptr && lds_pad > (int)W::LDS) ? (size_t)lds_pad : W::LDS;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM, XFW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM, XFW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(lds_pad > (int)W::LDS ? lds_pad : W::LDS));
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_wgrad<T, TM, XFW>), dim3(blocks), dim3(256), W::LDS, s, pv, jobs, items, ws, ovr);
+    hipLaunchKernelGGL((k_wgrad<T, TM, XFW>), dim3(blocks), dim3(256), lds, s, pv, jobs, items, ws, ovr);
     AY_CHECK_LAUNCH("k_wgrad");
     return AYOLO_OK;
 }

@@ -80,6 +80,18 @@ __device__ __forceinline__ void glds16_b(v4i32 srd, unsigned lds_addr, unsigned 
                  : "memory");
 }
 
+// Lane-masked form: only the lanes of `mask` load and write their 16 bytes of the piece (LDS position = lane * 16 whatever the
+// mask), EXEC is all ones before and after.  k_pw's two-segment loader: a piece holds whole pixel rows, i.e. chunks of both input
+// segments -- two loads with complementary masks and the segments' own descriptors fill it.
+__device__ __forceinline__ void glds16_exec(v4i32 srd, unsigned lds_addr, unsigned voff, unsigned long long mask) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                 "s_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd), "s"(mask)
+                 : "memory");
+}
+
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
     const unsigned t = __umulhi(f.m, n);
     return (t + ((n - t) >> f.s1)) >> f.s2;

@@ -93,6 +93,11 @@ XF_WGRAD_ON_LOAD = False
 WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "-1"))
 WGRAD_GROUP_WORK = 0.36e6
 WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
+# Fork placement: group g may launch LATER than the slot where its last layer's dz is complete -- at the slot
+# of the weight-gradient job `k_g` jobs further down the backward list ("k0,k1,..."; every layer keeps its dz buffer until the end
+# of backward, so any later slot is valid).  Lets the small-map (issue-bound, cache-resident) groups run under the large-map
+# (HBM-bound) part of the main chain instead of under the small-map dgrads they stall.
+WGRAD_DEFER = [int(v) for v in _os.environ.get("AYOLO_WGRAD_DEFER", "").split(",") if v.strip()]
 # (A cap on a group's resident workgroups per CU -- so that the kernels of backward's dependent chain forked behind it find free
 # slots at once -- was measured and lost: 13.58 ms uncapped, 14.45 with two workgroups per CU, 16.3 with one; the weight
 # gradients are latency-bound per workgroup and need every slot they can get, profiles/r04_ab_wgrad_cap.txt; code removed.)
@@ -317,8 +322,19 @@ class TrainPlan:
         ws = torch.empty(ws_need, dtype=torch.uint8, device=self.device)
         self.keep.append(ws)
         self.wgroup_ws_bytes = ws_need
-        for js, host, dev in built:
-            idx = js[-1]["idx"]                           # the group launches where its LAST layer's dz is complete
+        job_pos = {id(j): k for k, j in enumerate(jobs)}
+        taken = set()
+        for g, (js, host, dev) in enumerate(built):
+            # the group launches where its LAST layer's dz is complete, or (WGRAD_DEFER) at a later layer's slot
+            k = job_pos[id(js[-1])] + (WGRAD_DEFER[g] if g < len(WGRAD_DEFER) else 0)
+            k = max(job_pos[id(js[-1])], min(k, len(jobs) - 1))
+            while jobs[k]["idx"] in taken and k + 1 < len(jobs):
+                k += 1
+            while jobs[k]["idx"] in taken:
+                k -= 1
+            assert k >= job_pos[id(js[-1])], "no free slot behind the group's last layer"
+            idx = jobs[k]["idx"]
+            taken.add(idx)
             slots = sorted({j["slot"] for j in js if j["slot"] >= 0})
             nov = (max(slots) + 1) if slots else 0
             o = _op(OP_WGRAD_GROUP | side, i=(nov,), l=(ws.numel(),), p=(ctypes.addressof(host), dev, ws))

@@ -35,6 +35,13 @@ SHAPES = [
     (1, 32, 32, 3, 1, 1, 257, 1),      # 257 pixels in one column: the halo row of tile 0 is the first pixel of tile 1
     (1, 80, 160, 3, 1, 1, 20, 24),     # yolov5x: 80 channels = 2.5 chunks of 32, the last one half beyond C (zero-filled x and W)
     (2, 72, 40, 3, 1, 1, 9, 9),
+    # k_pw (round 6: streaming 1x1 kernel, weights in registers): K = 128 / 256 with >= 128 output channels, ragged last pixel tile,
+    # one / two / three channel tiles, fewer tiles than workgroup slots and more
+    (2, 128, 128, 1, 1, 0, 7, 9),
+    (3, 256, 256, 1, 1, 0, 13, 11),
+    (2, 256, 128, 1, 1, 0, 16, 16),
+    (2, 128, 384, 1, 1, 0, 5, 5),
+    (5, 128, 136, 1, 1, 0, 64, 65),
 ]
 
 
@@ -54,6 +61,9 @@ FULL_SIZE = [
     (64, 32, 64, 3, 2, 1, 320, 320),
     (64, 128, 128, 3, 1, 1, 40, 40),
     (64, 512, 256, 1, 1, 0, 20, 20),
+    (64, 128, 128, 1, 1, 0, 40, 40),
+    (64, 256, 256, 1, 1, 0, 40, 40),
+    (64, 128, 128, 1, 1, 0, 80, 80),
 ]
 
 
@@ -385,6 +395,9 @@ BNR_CASES = [
     ((1, 128, 256, 3, 2, 1, 16, 16), [(0, 128)]),              # k_gconv walking the four residue classes
     ((2, 64, 64, 3, 2, 1, 13, 17), [(0, 64)]),                 # odd map: one launch per residue class
     ((2, 96, 48, 1, 1, 0, 12, 12), [(8, 80)]),                 # a segment that is a strict sub-range of dx's channels
+    ((2, 128, 128, 1, 1, 0, 13, 17), [(0, 128)]),              # k_pw (K = Cout = 128), ragged last tile
+    ((3, 256, 256, 1, 1, 0, 9, 11), [(0, 128), (128, 128)]),   # k_pw (K = 256), two channel tiles, a segment each
+    ((2, 256, 128, 1, 1, 0, 40, 40), [(0, 96), (96, 160)]),    # k_pw, segment boundary inside a channel tile (32-channel blocks)
 ]
 
 
