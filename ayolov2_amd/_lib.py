@@ -28,6 +28,12 @@ class BnSeg(ctypes.Structure):
                 ("ldz", c_int), ("c0", c_int), ("C", c_int), ("reserved", c_int)]
 
 
+class BnApplySeg(ctypes.Structure):
+    """ayolo_bn_apply_seg (include/ayolo.h): one of the two blocks of an ayolo_bn_act_bwd_apply2 launch."""
+    _fields_ = [("da", c_void_p), ("save_mean", c_void_p), ("save_invstd", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("sums", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("ldda", c_int), ("C", c_int)]
+
+
 class WgradJob(ctypes.Structure):
     """ayolo_wgrad_job (include/ayolo.h): one layer's weight gradient inside a grouped launch."""
     _fields_ = [("conv", ConvDesc), ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("alpha", c_float),
@@ -89,6 +95,7 @@ _SIGNATURES = {
                                _P, _P, c_float, _P],
     "ayolo_bn_act_bwd_apply_res": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, c_int,
                                    _P, _P, c_float, _P, c_int, c_int, _P],
+    "ayolo_bn_act_bwd_apply2": [c_int, _P, c_int, _P, c_int, c_int64, POINTER(BnApplySeg), POINTER(BnApplySeg), c_int, c_int, c_float, _P],
     "ayolo_maxpool_fwd": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "ayolo_maxpool_bwd": [c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ayolo_upsample2x_fwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],

@@ -690,6 +690,176 @@ extern "C" int ayolo_bn_act_bwd_apply(int dtype, const void* z, int ldz, const v
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_bn_bwd_apply2 (round 6): the apply pass of TWO Conv-BN-act blocks whose pre-activations lie side by side
+// in one buffer -- C3's cv1 | cv2 run as one conv (res/configs/model/yolov5s.yaml:23-52), so z and dz of the two blocks are the
+// channel slices [0, C0) and [C0, C0 + C1) of shared rows -- in ONE launch over whole rows.  As two launches each pass read and
+// wrote HALF rows of a double-pitch buffer (YOLOv5s at 160 x 160: 64-byte runs of a 128-byte pitch, 2.3-3.6 TB/s against 5 for the
+// contiguous sibling) and every pair paid two prologues.  Each block keeps its own output gradient buffer (da: the Bottleneck
+// chain's gradient for cv1, a slice of the concat gradient for cv2), saved statistics, affine parameters and sums; the arithmetic
+// per element is k_bn_bwd_apply's, so dz / dgamma / dbeta equal the two-launch route bit for bit.
+// ---------------------------------------------------------------------------------------------------
+struct BnApply2P {
+    ayolo_bn_apply_seg g[2];
+};
+
+template <typename T, int ACT, bool B32>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply2(const T* z, int ldz, T* dz, int lddz, long long npix, BnApply2P q, int reps,
+                                                       float grad_scale) {
+    AY_KERNARG_TOUCH_BYTES(kt_, 192);
+    constexpr int VE = VecT<T>::VE;
+    extern __shared__ float sh[];   // [6][Ct]: mean, invstd, gamma, beta, sum_du/n, sum_dux/n
+    const float invn = 1.0f / (float)npix;
+    kt_.done();
+    const int C0 = q.g[0].C, Ct = q.g[0].C + q.g[1].C;
+    for (int i = threadIdx.x; i < Ct; i += 256) {
+        const int sg = i >= C0 ? 1 : 0;
+        const ayolo_bn_apply_seg& g = q.g[sg];
+        const int il = i - (sg ? C0 : 0), Cs = g.C;
+        const int qi = pl_idx<VE>(i, Ct);
+        const float mu_ = g.save_mean[il], is_ = g.save_invstd[il], ga_ = opt_load(g.gamma, g.save_mean, il, 1.0f),
+                    be_ = opt_load(g.beta, g.save_mean, il, 0.0f);
+        double d1, d2;
+        rep_sum2(g.sums + il, (size_t)2 * Cs, (size_t)Cs, reps, d1, d2);
+        sh[qi] = mu_; sh[Ct + qi] = is_;
+        sh[2 * Ct + qi] = ga_; sh[3 * Ct + qi] = be_;
+        const float s1 = (float)d1, s2 = (float)d2;
+        sh[4 * Ct + qi] = s1 * invn; sh[5 * Ct + qi] = s2 * invn;
+        if (blockIdx.x == 0) {
+            if (g.dbeta) g.dbeta[il] = s1 * grad_scale;
+            if (g.dgamma) g.dgamma[il] = s2 * grad_scale;
+        }
+    }
+    __syncthreads();
+    const int CG = Ct / VE;
+    const int CGT = CG < 256 ? CG : 256;
+    const int RPB = 256 / CGT;
+    const int cgl = threadIdx.x % CGT, prow = threadIdx.x / CGT;
+    if (prow >= RPB) return;
+    const unsigned ldzb = (unsigned)ldz * sizeof(T), lddzb = (unsigned)lddz * sizeof(T);
+    const unsigned npu = (unsigned)npix;
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(z), 0, B32 ? (int)(npu * ldzb) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsDz = __builtin_amdgcn_make_buffer_rsrc(dz, 0, B32 ? (int)(npu * lddzb) : 0, 0x00020000);
+    for (int cg = cgl; cg < CG; cg += CGT) {
+        float mu[VE], is[VE], ga[VE], be[VE], m1[VE], m2[VE], A[VE], Bc[VE], nmi[VE], P[VE], Q[VE], Rr[VE];
+        pl_load<VE>(sh, cg, Ct, mu); pl_load<VE>(sh + Ct, cg, Ct, is); pl_load<VE>(sh + 2 * Ct, cg, Ct, ga);
+        pl_load<VE>(sh + 3 * Ct, cg, Ct, be); pl_load<VE>(sh + 4 * Ct, cg, Ct, m1); pl_load<VE>(sh + 5 * Ct, cg, Ct, m2);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+            A[i] = is[i] * ga[i]; Bc[i] = be[i] - mu[i] * A[i]; nmi[i] = -mu[i] * is[i];
+            P[i] = ga[i] * is[i]; Q[i] = -P[i] * m1[i]; Rr[i] = -P[i] * m2[i];
+        }
+        // this thread's 16-byte group of da: its block's own buffer (per-lane base pointer and row stride)
+        const int sg = cg * VE >= C0 ? 1 : 0;
+        const T* dab = static_cast<const T*>(q.g[sg].da) + (cg * VE - (sg ? C0 : 0));
+        const long long ldd = q.g[sg].ldda;
+        typedef typename std::conditional<B32, unsigned, long long>::type pix_t;
+        const pix_t stride = (pix_t)gridDim.x * RPB, npx = (pix_t)npix;
+        pix_t pix = (pix_t)blockIdx.x * RPB + prow;
+        const unsigned cgb = (unsigned)cg * 16u;
+        auto ld_z = [&](pix_t px) __attribute__((always_inline)) -> uint4 {
+            if constexpr (B32) return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, px * ldzb + cgb, 0, 0));
+            else return load_raw<T>(z + px * ldz + cg * VE);
+        };
+        auto ld_da = [&](pix_t px) __attribute__((always_inline)) -> uint4 { return load_raw<T>(dab + (long long)px * ldd); };
+        auto st_dz = [&](pix_t px, const float (&v)[VE]) __attribute__((always_inline)) {
+            if constexpr (B32) {
+                uint4 raw;
+                T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) e[i] = (T)v[i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32_t, raw), rsDz, (unsigned)px * lddzb + cgb, 0, 0);
+            } else store_vec<T>(dz + (long long)px * lddz + cg * VE, v);
+        };
+        constexpr int NPX = 2;
+        int opaque_true = 1;
+        asm volatile("" : "+s"(opaque_true));
+        auto request = [&](uint4 (&zq)[NPX], uint4 (&dq)[NPX], pix_t at) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) {
+                zq[j] = ld_z(at + j * stride);
+                dq[j] = ld_da(at + j * stride);
+            }
+        };
+        auto compute = [&](const uint4 (&zq)[NPX], const uint4 (&dq)[NPX], pix_t at) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) {
+                float zz[VE], dd[VE];
+                unpack_raw<T>(zq[j], zz);
+                unpack_raw<T>(dq[j], dd);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    float xh, du;
+                    bn_bwd_elem<T, ACT>(zz[i], dd[i], mu[i], is[i], ga[i], be[i], A[i], Bc[i], nmi[i], xh, du);
+                    if constexpr (sizeof(T) == 2) dd[i] = __builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
+                    else dd[i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
+                }
+                st_dz(at + j * stride, dd);
+            }
+        };
+        if (pix + (NPX - 1) * stride < npx) {
+            uint4 zA[NPX], dA[NPX], zB[NPX], dB[NPX];
+            pix_t pa = pix;
+            request(zA, dA, pa);
+            while (true) {
+                const pix_t pb = pa + NPX * stride;
+                const bool hb = pb + (NPX - 1) * stride < npx;
+                if (opaque_true) request(zB, dB, hb ? pb : 0);
+                compute(zA, dA, pa);
+                if (!hb) { pix = pb; break; }
+                pa = pb + NPX * stride;
+                const bool ha = pa + (NPX - 1) * stride < npx;
+                if (opaque_true) request(zA, dA, ha ? pa : 0);
+                compute(zB, dB, pb);
+                if (!ha) { pix = pa; break; }
+            }
+        }
+        for (; pix < npx; pix += stride) {
+            float zv[VE], dv[VE];
+            unpack_raw<T>(ld_z(pix), zv);
+            unpack_raw<T>(ld_da(pix), dv);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                float xh, du;
+                bn_bwd_elem<T, ACT>(zv[i], dv[i], mu[i], is[i], ga[i], be[i], A[i], Bc[i], nmi[i], xh, du);
+                if constexpr (sizeof(T) == 2) dv[i] = __builtin_fmaf(du, P[i], __builtin_fmaf(xh, Rr[i], Q[i]));
+                else dv[i] = ga[i] * is[i] * (du - m1[i] - xh * m2[i]);
+            }
+            st_dz(pix, dv);
+        }
+    }
+}
+
+extern "C" int ayolo_bn_act_bwd_apply2(int dtype, const void* z, int ldz, void* dz, int lddz, int64_t npix, const ayolo_bn_apply_seg* seg0,
+                                       const ayolo_bn_apply_seg* seg1, int act, int sum_reps, float grad_scale, ayolo_stream s) {
+    const int ve = dtype == AYOLO_F16 ? 8 : 4;
+    if (sum_reps < 1) sum_reps = 1;
+    AY_CHECK_ARG(z && dz && seg0 && seg1, "bn_bwd_apply2: null pointer");
+    BnApply2P q;
+    q.g[0] = *seg0; q.g[1] = *seg1;
+    int Ct = 0;
+    for (int k = 0; k < 2; ++k) {
+        const ayolo_bn_apply_seg& g = q.g[k];
+        AY_CHECK_ARG(g.da && g.save_mean && g.save_invstd && g.sums, "bn_bwd_apply2: null pointer in segment %d", k);
+        AY_CHECK_ARG(g.C > 0 && g.C % ve == 0 && g.ldda % ve == 0 && g.ldda >= g.C, "bn_bwd_apply2: segment %d: C=%d ldda=%d", k, g.C, g.ldda);
+        Ct += g.C;
+    }
+    AY_CHECK_ARG(ldz % ve == 0 && lddz % ve == 0 && ldz >= Ct && lddz >= Ct && Ct <= 2048, "bn_bwd_apply2: ldz=%d lddz=%d for %d channels", ldz, lddz, Ct);
+    if (npix == 0) return AYOLO_OK;
+    unsigned grid = grid_pixels(npix, Ct, ve, Ct >= 256 ? 16 : 8);
+    if (grid > 2048u) grid = 2048u;
+    const int64_t es = dtype == AYOLO_F16 ? 2 : 4, lim = (int64_t)1 << 31;
+    const bool b32 = npix * ldz * es < lim && npix * lddz * es < lim;
+#define BWD_APPLY2_LAUNCH(B32_)                                                                                                      \
+    DISPATCH_T(dtype, DISPATCH_AR(act, false,                                                                                        \
+               (void)RES; hipLaunchKernelGGL((k_bn_bwd_apply2<T, ACT, B32_>), dim3(grid), dim3(256), 6 * Ct * sizeof(float), (hipStream_t)s, \
+                                  (const T*)z, ldz, (T*)dz, lddz, (long long)npix, q, sum_reps, grad_scale);))
+    if (b32) { BWD_APPLY2_LAUNCH(true) } else { BWD_APPLY2_LAUNCH(false) }
+#undef BWD_APPLY2_LAUNCH
+    AY_CHECK_LAUNCH("k_bn_bwd_apply2");
+    return AYOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // max-pool k x k, stride 1, pad k/2 (SPPF).  Forward records the window position of the first maximum
 // (row-major scan, `val > max || isnan(val)` as torch) so backward is a 25-tap gather without atomics.
 // ---------------------------------------------------------------------------------------------------

@@ -218,6 +218,21 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
                                             o.i[5], (const double*)o.p[7], o.i[6], (float*)o.p[8], (float*)o.p[9], o.f[0],
                                             o.p[10], o.i[7], o.i[8], cs);
             break;
+        case AYOLO_OP_BN_BWD_APPLY2: {
+            ayolo_bn_apply_seg g[2];
+            for (int k = 0; k < 2; ++k) {
+                void* const* q = o.p + 2 + 7 * k;
+                g[k].da = q[0];
+                g[k].save_mean = (const float*)q[1];
+                g[k].save_invstd = (const float*)q[1] + o.i[5 + k];
+                g[k].gamma = (const float*)q[2]; g[k].beta = (const float*)q[3];
+                g[k].sums = (const double*)q[4];
+                g[k].dgamma = (float*)q[5]; g[k].dbeta = (float*)q[6];
+                g[k].C = o.i[5 + k]; g[k].ldda = o.i[7 + k];
+            }
+            rc = ayolo_bn_act_bwd_apply2(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], &g[0], &g[1], o.i[3], o.i[4], o.f[0], cs);
+            break;
+        }
         case AYOLO_OP_MAXPOOL_FWD:
             rc = ayolo_maxpool_fwd(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], (unsigned char*)o.p[2], o.i[3], o.i[4], o.i[5], o.i[6],
                                    o.i[7], cs);

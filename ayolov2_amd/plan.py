@@ -35,11 +35,12 @@ from .modules import C3, SPPF, Bottleneck, Concat, Conv, UpSample, YOLOHead, _ac
 OP_JOIN_SIDE = 21
 OP_STEM_BN_WGRAD = 22
 OP_WGRAD_GROUP = 23
+OP_BN_BWD_APPLY2 = 24
 
 
 class Op(ctypes.Structure):
     _fields_ = [("kind", c_int), ("i", c_int * 12), ("f", c_float * 2), ("d", c_double * 1), ("l", c_int64 * 1),
-                ("p", c_void_p * 12), ("conv", ConvDesc)]
+                ("p", c_void_p * 16), ("conv", ConvDesc)]
 
 
 def _op(kind, i=(), f=(), d=(), l=(), p=(), conv: Optional[ConvDesc] = None) -> Op:
@@ -68,6 +69,9 @@ FUSE_STEM_BACKWARD = True     # stem block: BatchNorm-backward apply inside its 
 FOLD_SHORTCUT_GRAD = True     # Bottleneck shortcut gradients written by the BatchNorm-backward apply pass (ayolo_bn_act_bwd_apply_res)
 MAX_PLANS = int(_os.environ.get("AYOLO_MAX_PLANS", "4"))                 # cached plans per model (multi-scale training)
 MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: cv1 | cv2 as one conv
+# the BatchNorm-backward apply passes of a merged cv1 | cv2 pair as ONE launch over whole rows of the shared z / dz buffers
+# (ayolo_bn_act_bwd_apply2) instead of two over half rows
+BN_APPLY_PAIR = _os.environ.get("AYOLO_BN_APPLY2", "1") == "1"
 # BatchNorm-backward sums (the first of the two backward passes of a Conv-BN-act block) computed in the epilogue of the
 # dgrad that produces the block's output gradient, instead of a pass of its own over da and z (ayolo_conv_dgrad_bn)
 BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
@@ -176,7 +180,7 @@ class TrainPlan:
         self.gradarena = _FloatArena()              # every parameter gradient (zeroed at the start of backward)
         self.param_grad_view: Dict[int, Callable[[], torch.Tensor]] = {}
         self.params: List[nn.Parameter] = []
-        self.dz_elems = 0
+        self.dz_list: List[torch.Tensor] = []
         self.late: List[Callable[[], None]] = []    # closures run after the arenas exist (pointer binding)
         self.bn_counters: List[torch.Tensor] = []
         self.bn_buffers: List[torch.Tensor] = []            # running statistics the forward kernels update in place
@@ -231,13 +235,12 @@ class TrainPlan:
         self._gwrites.append((len(self.bwd) - 1, id(act.root), act.c0, act.c0 + act.C, is_dgrad))
 
     def _dz(self, n: int) -> torch.Tensor:
-        """Backward operand dz of one layer: a slice of the shared scratch buffer, or -- when weight gradients run on the
-        side stream and therefore outlive the layer's turn -- a buffer of its own."""
-        if True:                                             # grouped launches read dz long after the layer's turn
-            t = torch.empty(n, dtype=self.dt, device=self.device)
-            self.keep.append(t)
-            return t
-        return self.dz_buf[:n]
+        """Backward operand dz of one layer: a buffer of its own -- the grouped weight-gradient launches on the side stream read it
+        long after the layer's turn on the main stream."""
+        t = torch.empty(n, dtype=self.dt, device=self.device)
+        self.keep.append(t)
+        self.dz_list.append(t)                               # tools/grad_dump.py: layer-by-layer comparison of two routes
+        return t
 
     def _wgrad_jobs_of(self, cx: dict, desc: ConvDesc, dy: torch.Tensor, off: int, n: int, dy_slot: int = -1) -> None:
         """The weight-gradient job(s) of a conv whose x the transform-on-load pass may have redirected: one job over the plain
@@ -428,7 +431,6 @@ class TrainPlan:
         self.late.append(lambda: op_conv.p.__setitem__(5, self.stats.view(st_off, R * 2 * Ct).data_ptr()))
         self.fwd_sync.append((op_conv, st_off, R * 2 * Ct))            # sync_bn: all-reduce of the batch statistics
         K = geo.kdims[0] * geo.kdims[1] * geo.Cin_k
-        self.dz_elems = max(self.dz_elems, npix * Ct)
         outs: List[Act] = []
         per = []          # per block: (bn, act, a, zj, c0, co, sm_off, su_off, gg_off, gb_off)
         gw_off0 = None
@@ -496,6 +498,9 @@ class TrainPlan:
             ga = self.gradarena
             dz = self._dz(npix * Ct) if not stem_fused else None
             dzv = dz.view(self.B, geo.Ho, geo.Wo, Ct).permute(0, 3, 1, 2) if dz is not None else None
+            pair = (BN_APPLY_PAIR and len(per) == 2 and residual is None and not stem_fused and per[0][1] == per[1][1]
+                    and Ct <= 2048 and all(e[5] % (8 if dt == torch.float16 else 4) == 0 for e in per))
+            pair_p, pair_i = [], []
             for bn, act, a, zj, c0, co, sm_off, su_off, gg_off, gb_off in per:
                 da = a.grad()
                 if not a.is_init():
@@ -518,6 +523,9 @@ class TrainPlan:
                                         p=(xk, zj, da, sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, ga.view(gw_off0, Ct * K), dgam, dbet),
                                         conv=geo.desc(dt, ldx, ldda)))
                     self._wrote(gw_off0, Ct * K)
+                elif pair:
+                    pair_p += [da, sm[0:2 * co], bn.weight, bn.bias, su, dgam, dbet]
+                    pair_i += [co, ldda]
                 else:
                     self.bwd.append(_op(OP_BN_BWD_APPLY, i=(code, Ct, ldda, Ct, co, act, R) + ((ops.nhwc_info(dr)[4], int(residual.is_init())) if fold_res else (0, 0)),
                                         l=(npix,), f=(1.0,),
@@ -525,8 +533,9 @@ class TrainPlan:
                                            dr if fold_res else None)))
                 self._wrote(gg_off, co)
                 self._wrote(gb_off, co)
-                self.bwd_sync.append((len(self.bwd) - 2, su))  # sync_bn: all-reduce of the sums between reduce and apply
-                self._bn_layers.append(dict(reduce=len(self.bwd) - 2, a=a, z=zj, ldz=Ct, sm=sm[0:2 * co], gamma=bn.weight,
+                ridx = len(self.bwd) - (1 if pair else 2)       # this block's reduce op
+                self.bwd_sync.append((ridx, su))               # sync_bn: all-reduce of the sums between reduce and apply
+                self._bn_layers.append(dict(reduce=ridx, a=a, z=zj, ldz=Ct, sm=sm[0:2 * co], gamma=bn.weight,
                                             beta=bn.bias, sums=su, C=co, act=act, R=R))
                 if residual is not None:      # shortcut: d(residual) += d(a)
                     if not fold_res:
@@ -534,6 +543,10 @@ class TrainPlan:
                                             p=(da, dr)))
                     self._gw(residual, False)
                     residual.mark_init()
+            if pair:
+                # both blocks' sums are complete (two reduce ops / dgrad epilogues above): one apply pass over whole rows
+                self.bwd.append(_op(OP_BN_BWD_APPLY2, i=(code, Ct, Ct, per[0][1], R, pair_i[0], pair_i[2], pair_i[1], pair_i[3]),
+                                    l=(npix,), f=(1.0,), p=[z.t, dzv] + pair_p))
             if stem_fused:
                 return
             # the weight gradient only needs dz: its slot comes BEFORE the layer's dgrad, so that a (grouped) launch forked
@@ -790,7 +803,6 @@ class TrainPlan:
             gb_off = self._register_param(conv.bias, Cout, lambda b: b) if conv.bias is not None else None
             self.raw_specs.append((buf, (B, head.na, H, W, head.no), (H * W * cp, head.no, W * cp, cp, 1), gb_off, Cout))
             npix = B * H * W
-            self.dz_elems = max(self.dz_elems, npix * cp)
             code = ops.dtype_code(dt)
 
             def emit(x=x, geo=geo, wt=wt, cp=cp, Cin=Cin, Cout=Cout, B=B, H=H, W=W, gw_off=gw_off, gb_off=gb_off, ldx=ldx, npix=npix, lvl=lvl, cx=cx):
@@ -891,7 +903,6 @@ class TrainPlan:
         dev = self.device
         for ar in (self.stats, self.sums, self.small, self.gradarena):
             ar.allocate(dev)
-        self.dz_buf = torch.empty(max(self.dz_elems, 8), dtype=self.dt, device=dev)
         for fn in self.late:
             fn()
         self._fold_bn_act_into_consumers()
@@ -1115,6 +1126,8 @@ class TrainPlan:
             elif kind == OP_BN_BWD_APPLY:
                 # + the shortcut gradient written (and, accumulating, read) by the same pass
                 out.append(("bn_bwd_apply", es * o.l[0] * o.i[4] * (3 + ((2 if o.i[8] else 1) if o.p[10] else 0)), 0.0))
+            elif kind == OP_BN_BWD_APPLY2:
+                out.append(("bn_bwd_apply", es * o.l[0] * (o.i[5] + o.i[6]) * 3, 0.0))
             elif kind in (OP_MAXPOOL_FWD, OP_UPSAMPLE_FWD):
                 n = o.i[3] * o.i[4] * o.i[5] * o.i[6] * (4 if kind == OP_UPSAMPLE_FWD else 1)
                 out.append(("pool_upsample", es * n * (1.25 if kind == OP_UPSAMPLE_FWD else 2) + (n if kind == OP_MAXPOOL_FWD else 0), 0.0))

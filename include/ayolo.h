@@ -269,6 +269,22 @@ int ayolo_bn_act_bwd_apply_res(int dtype, const void* z, int ldz, const void* da
                                int64_t npix, int C, const float* save_mean, const float* save_invstd, const float* gamma,
                                const float* beta, int act, const double* sums, int sum_reps, float* dgamma, float* dbeta,
                                float grad_scale, void* dres, int lddres, int res_accumulate, ayolo_stream s);
+/* the same pass for TWO blocks whose pre-activations lie side by side in one buffer (kindle C3: cv1 and cv2 read the same input,
+ * res/configs/model/yolov5s.yaml:23-52; this repo runs them as ONE conv, so z / dz of the two blocks are the channel slices
+ * [0, C0) and [C0, C0 + C1) of shared rows starting at `z` / `dz`): one launch over whole rows instead of two over half rows.
+ * Every block keeps its own output-gradient buffer, saved statistics, affine parameters, sums and dgamma / dbeta.  Results equal
+ * two ayolo_bn_act_bwd_apply calls bit for bit. */
+typedef struct ayolo_bn_apply_seg {
+    const void* da;           /* output gradient of the block, NHWC, channel stride ldda                 */
+    const float* save_mean; const float* save_invstd;     /* float[C] each                               */
+    const float* gamma;       /* float[C] or NULL (= 1)                                                  */
+    const float* beta;        /* float[C] or NULL (= 0)                                                  */
+    const double* sums;       /* double[sum_reps][2*C] (ayolo_bn_act_bwd_reduce / ayolo_conv_dgrad_bn)   */
+    float* dgamma; float* dbeta;                          /* float[C] each or NULL                        */
+    int ldda, C;
+} ayolo_bn_apply_seg;
+int ayolo_bn_act_bwd_apply2(int dtype, const void* z, int ldz, void* dz, int lddz, int64_t npix, const ayolo_bn_apply_seg* seg0,
+                            const ayolo_bn_apply_seg* seg1, int act, int sum_reps, float grad_scale, ayolo_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * Small NHWC ops: kindle SPPF's MaxPool2d(5,1,2), UpSample(None,2) nearest, input packing, bias grad.
@@ -506,8 +522,11 @@ enum {
     AYOLO_OP_MEMSET, AYOLO_OP_BN_EVAL_AFFINE, AYOLO_OP_BN_TRAIN_ACT, AYOLO_OP_CAST_WEIGHTS, AYOLO_OP_HEAD_DECODE,
     AYOLO_OP_JOIN_SIDE,         /* the caller's stream waits for everything enqueued so far on the side stream */
     AYOLO_OP_STEM_BN_WGRAD,     /* ayolo_stem_bn_wgrad */
-    AYOLO_OP_WGRAD_GROUP        /* ayolo_wgrad_group_run: p[0] table (host), p[1] table (device), p[2] workspace, l[0] its bytes,
+    AYOLO_OP_WGRAD_GROUP,       /* ayolo_wgrad_group_run: p[0] table (host), p[1] table (device), p[2] workspace, l[0] its bytes,
                                  * p[3..6] dy overrides, i[0] their count */
+    AYOLO_OP_BN_BWD_APPLY2      /* ayolo_bn_act_bwd_apply2: i[0] dtype, i[1] ldz, i[2] lddz, i[3] act, i[4] sum_reps, i[5 + k] / i[7 + k] =
+                                 * C / ldda of block k; l[0] npix; f[0] grad_scale; p[0] z, p[1] dz, p[2 + 7 k ..] = da, save_mean (invstd
+                                 * follows at + C), gamma, beta, sums, dgamma, dbeta of block k */
 };
 typedef struct ayolo_op {
     int kind;
@@ -515,7 +534,7 @@ typedef struct ayolo_op {
     float f[2];
     double d[1];
     int64_t l[1];
-    void* p[12];
+    void* p[16];
     ayolo_conv_desc conv;
 } ayolo_op;
 int ayolo_run_ops(const ayolo_op* ops, int n, ayolo_stream s);

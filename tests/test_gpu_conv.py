@@ -480,6 +480,57 @@ def test_bn_backward_apply_forwards_the_shortcut_gradient(dt, accumulate):
     assert torch.equal(wide[:, :C], old[:, :C])        # the other half of the wide buffer is untouched
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(3, 32, 32, 9, 11, 1), (2, 64, 64, 16, 16, 1), (1, 128, 128, 5, 7, 0), (2, 32, 96, 12, 12, 1), (1, 256, 256, 4, 4, 1)])
+def test_bn_backward_apply_of_a_merged_pair_equals_two_passes(dt, shape):
+    """ayolo_bn_act_bwd_apply2: the apply passes of the two blocks of a merged cv1 | cv2 conv (kindle C3,
+    res/configs/model/yolov5s.yaml:23-52) as ONE launch over whole rows of the shared z / dz buffers must equal two
+    ayolo_bn_act_bwd_apply launches over the half rows bit for bit: dz, dgamma and dbeta of both blocks.  Each block has its own
+    output-gradient buffer (one contiguous, one a channel slice of a wider buffer, as in the plan), statistics and sums."""
+    from ayolov2_amd import ops
+    from ayolov2_amd._lib import BnApplySeg, call
+    torch.manual_seed(31)
+    B, C0, C1, H, W, act = shape
+    Ct, npix = C0 + C1, B * H * W
+    z = torch.randn(B, Ct, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    da0 = torch.randn(B, C0, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    wide = torch.randn(B, C1 + 32, H, W, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    da1 = wide[:, 32:]                                                              # row stride C1 + 32
+    das, c0s, Cs = (da0, da1), (0, C0), (C0, C1)
+    code, st = ops.dtype_code(dt), torch.cuda.current_stream().cuda_stream
+    mean = z.float().mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(z.float().var((0, 2, 3), unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(Ct, device="cuda") + 0.5, torch.randn(Ct, device="cuda")
+    sums, want_dz = [], torch.zeros_like(z)
+    want_g, want_b = torch.empty(Ct, device="cuda"), torch.empty(Ct, device="cuda")
+    for k in range(2):
+        c0, C = c0s[k], Cs[k]
+        zk, sl = z[:, c0:c0 + C], slice(c0, c0 + C)
+        su = torch.zeros(ops.STAT_REPS, 2 * C, dtype=torch.float64, device="cuda")
+        call("ayolo_bn_act_bwd_reduce", code, zk.data_ptr(), Ct, das[k].data_ptr(), ops.nhwc_info(das[k])[4], npix, C, mean[sl].data_ptr(),
+             invstd[sl].data_ptr(), gamma[sl].data_ptr(), beta[sl].data_ptr(), act, su.data_ptr(), ops.STAT_REPS, st)
+        sums.append(su)
+        call("ayolo_bn_act_bwd_apply", code, zk.data_ptr(), Ct, das[k].data_ptr(), ops.nhwc_info(das[k])[4], want_dz[:, sl].data_ptr(), Ct, npix, C,
+             mean[sl].data_ptr(), invstd[sl].data_ptr(), gamma[sl].data_ptr(), beta[sl].data_ptr(), act, su.data_ptr(), ops.STAT_REPS,
+             want_g[sl].data_ptr(), want_b[sl].data_ptr(), 1.0, st)
+    dz = torch.zeros_like(z)
+    got_g, got_b = torch.empty(Ct, device="cuda"), torch.empty(Ct, device="cuda")
+    segs = []
+    for k in range(2):
+        sl = slice(c0s[k], c0s[k] + Cs[k])
+        g = BnApplySeg()
+        g.da, g.save_mean, g.save_invstd = das[k].data_ptr(), mean[sl].data_ptr(), invstd[sl].data_ptr()
+        g.gamma, g.beta, g.sums = gamma[sl].data_ptr(), beta[sl].data_ptr(), sums[k].data_ptr()
+        g.dgamma, g.dbeta, g.ldda, g.C = got_g[sl].data_ptr(), got_b[sl].data_ptr(), ops.nhwc_info(das[k])[4], Cs[k]
+        segs.append(g)
+    import ctypes
+    call("ayolo_bn_act_bwd_apply2", code, z.data_ptr(), Ct, dz.data_ptr(), Ct, npix, ctypes.byref(segs[0]), ctypes.byref(segs[1]), act,
+         ops.STAT_REPS, 1.0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dz, want_dz)
+    assert torch.equal(got_g, want_g) and torch.equal(got_b, want_b)
+
+
 def test_bn_backward_apply_two_gib_tensors_take_the_pointer_path():
     """k_bn_bwd_apply addresses tensors below 2 GiB through 32-bit buffer offsets (B32) and larger ones through 64-bit pointers:
     the same pass over a 2 GiB activation (64 x 64 x 512 x 512 fp16 = 2^31 bytes: not below the limit) and over its two halves

@@ -64,6 +64,8 @@ def main():
                 shape = f"C={o.i[3]:4d} npix={o.l[0]}"
             elif kind == P.OP_BN_BWD_APPLY:
                 shape = f"C={o.i[4]:4d} npix={o.l[0]}"
+            elif kind == P.OP_BN_BWD_APPLY2:
+                shape = f"C={o.i[5]:3d}|{o.i[6]:3d} npix={o.l[0]}"
             gbs = byts / ms / 1e6 if ms > 0 else 0.0
             tfs = flop / ms / 1e9 if ms > 0 else 0.0
             print(f"{k:4d} {side} {str(NAMES.get(kind, kind)):18s} {shape:34s} {ms * 1e3:8.1f} us {byts / 1e6:8.1f} MB {gbs:7.0f} GB/s {tfs:6.0f} TF/s")
