@@ -96,6 +96,9 @@ _SIGNATURES = {
     "ayolo_bn_act_bwd_apply_res": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int64, c_int, _P, _P, _P, _P, c_int, _P, c_int,
                                    _P, _P, c_float, _P, c_int, c_int, _P],
     "ayolo_bn_act_bwd_apply2": [c_int, _P, c_int, _P, c_int, c_int64, POINTER(BnApplySeg), POINTER(BnApplySeg), c_int, c_int, c_float, _P],
+    "ayolo_sppf_pool_fwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P],
+    "ayolo_sppf_pool_bwd": [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "ayolo_sppf_pool_supported": [c_int, c_int, c_int, c_int],
     "ayolo_maxpool_fwd": [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "ayolo_maxpool_bwd": [c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ayolo_upsample2x_fwd": [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],

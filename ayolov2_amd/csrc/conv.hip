@@ -2558,7 +2558,7 @@ template <typename T, int TM, int EM, bool BNR = false, bool XF = false>
 static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     // the streaming 1x1 kernel (k_pw): whole reductions of 32 .. 256 channels whose three stages fit the LDS
     if constexpr (sizeof(T) == 2 && XF && EM == 0) {
-        static const int pw_on = getenv("AYOLO_PW") ? atoi(getenv("AYOLO_PW")) : 0;
+        static const int pw_on = getenv("AYOLO_PW") ? atoi(getenv("AYOLO_PW")) : 11;
         // transform on load: the same tilings as the plain conv of the same shape (a layer's two routes share one kernel family, so
         // that they stay bit-identical: test_conv_transform_on_load_equals_materialised_route)
         if ((pw_on & 8) && p.xf && p.C % BK == 0 && p.xs_split % 8 == 0) {
@@ -2574,7 +2574,7 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
         }
     }
     if constexpr (sizeof(T) == 2 && !XF && EM != 3) {
-        static const int pw_on = getenv("AYOLO_PW") ? atoi(getenv("AYOLO_PW")) : 0;
+        static const int pw_on = getenv("AYOLO_PW") ? atoi(getenv("AYOLO_PW")) : 11;
         static const long long pw_maxm = getenv("AYOLO_PW_MAXM") ? atoll(getenv("AYOLO_PW_MAXM")) : (1ll << 40);
         if (pw_on && p.lin && p.Mtotal <= pw_maxm) {
             if constexpr (TM == 128) {
@@ -2617,7 +2617,7 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     // that rate.  Here every wavefront owns 32 channels x 64 pixels (32 accumulator registers), two workgroups per CU put four
     // wavefronts on every SIMD, and a workgroup walks two or more tiles so that the next tile's DMA runs under the epilogue.
     if constexpr (sizeof(T) == 2 && TM == 128 && (EM != 3 || XF)) {
-        static const int nw8 = getenv("AYOLO_GCONV_NW8") ? atoi(getenv("AYOLO_GCONV_NW8")) : 0;
+        static const int nw8 = getenv("AYOLO_GCONV_NW8") ? atoi(getenv("AYOLO_GCONV_NW8")) : 1;
         static const long long nw8_maxm = getenv("AYOLO_GCONV_NW8_MAXM") ? atoll(getenv("AYOLO_GCONV_NW8_MAXM")) : 102400;
         // (transform on load: only with whole 32-channel chunks, the 1x1 loader's condition, so that a layer's two routes -- reader
         // over z / conv over the materialised activation -- always share one tiling and stay bit-identical)

@@ -1131,6 +1131,237 @@ extern "C" int ayolo_maxpool_bwd(int dtype, const unsigned char* argmax, const v
 }
 
 // ---------------------------------------------------------------------------------------------------
+// SPPF's pool cascade in ONE launch per direction (round 6; kindle SPPF = cv1 -> three chained
+// MaxPool2d(5, 1, 2) -> concat [x, y1, y2, y3] -> cv2, res/configs/model/yolov5s.yaml:33).  As three k_maxpool5_fwd + three
+// k_maxpool5_bwd launches the cascade cost 0.21 ms of the YOLOv5s step for 0.2 GB: every launch is compare-select-bound (25 taps
+// x (compare + two selects + NaN test) per output channel) and the chain is serial.  Here a workgroup owns one image and NCG
+// 16-byte channel groups of the 4 C-channel concat buffer, keeps the map in LDS and runs all three pools on it:
+//   forward: every fp16 value becomes a 32-bit KEY = [sortable 16-bit value | 8 low bits], so that "first maximum in row-major
+//     scan order" is ONE unsigned max: a tap's key is XOR-ed with (7 - dx) in the row pass and ((7 - dy) << 3) in the column
+//     pass -- among equal values the smaller dy, then the smaller dx wins, the scan's tie rule -- and the 5 x 5 window is
+//     separable (5 + 5 taps instead of 25).  torch's NaN rule (a NaN always replaces the running maximum: the LAST NaN of the
+//     scan is recorded) is the same max with the index bits complemented: a NaN's key carries 0x3f in its low bits, the XOR turns
+//     (7 - d) into d.  -0.0 is stored as +0.0 (float compare treats them as equal: the first of them wins either way; the output
+//     value then reads +0.0 where the scan would copy -0.0 -- equal under ==).  The winner's key, low bits cleared, is the next
+//     pool's input; values and window positions are written exactly as k_maxpool5_fwd would (a window with no value above -inf
+//     records its first in-image tap, torch's rule; the scan kernels record tap 0).
+//   backward: g3 = d3; g2 = d2 + scatter(g3; arg3); g1 = d1 + scatter(g2; arg2); dx = d0 + scatter(g1; arg1), every g rounded to
+//     fp16 as the three launches store it.  The scatter is an fp64 LDS atomic per (output, channel): a sum of <= 26 fp16 values is
+//     EXACT in fp64 (40 bits of exponent range + 11 of mantissa + 5 of count < 53), so the result does not depend on the order
+//     of the atomics -- deterministic -- and equals the sequential fp32 sums of k_maxpool5_bwd whenever those are exact too
+//     (always, unless a window's gradients span more than 2^13 in magnitude).  Only dx (slice 0) is written.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sppf_key(unsigned b) {            // b: fp16 bits in [15:0]
+    const unsigned mag = b & 0x7fffu;
+    b = mag == 0u ? 0u : b;                                           // -0.0 -> +0.0
+    const unsigned s = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+    return mag > 0x7c00u ? 0xffff3fu : (s << 8);
+}
+
+template <int NCG>
+__global__ __launch_bounds__(256) void k_sppf_fwd(half_t* cat, int ld, unsigned char* arg, long long plane, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sppf_lds[];
+    const int HW = H * W, NIT = HW * NCG;
+    uint4* cur = reinterpret_cast<uint4*>(sppf_lds);                   // [2][NIT]: the two 4-channel halves of an item in two planes
+    uint4* rowk = cur + 2 * NIT;
+    const int nblk = C / (8 * NCG);
+    const int n = blockIdx.x / nblk, cg0 = (blockIdx.x % nblk) * NCG;
+    const long long pix0 = (long long)n * HW;
+    for (int it = threadIdx.x; it < NIT; it += 256) {
+        const int pix = it / NCG, g = it % NCG;
+        const uint4 raw = *reinterpret_cast<const uint4*>(cat + (pix0 + pix) * ld + (cg0 + g) * 8);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+        unsigned k[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { k[2 * q] = sppf_key(w[q] & 0xffffu); k[2 * q + 1] = sppf_key(w[q] >> 16); }
+        cur[it] = make_uint4(k[0], k[1], k[2], k[3]);
+        cur[NIT + it] = make_uint4(k[4], k[5], k[6], k[7]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 1; j <= 3; ++j) {
+        for (int it = threadIdx.x; it < NIT; it += 256) {              // row pass: max over dx of cur[h][w + dx - 2] ^ (7 - dx)
+            const int pix = it / NCG, w0 = pix % W;
+            unsigned m[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m[c] = 0u;
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                const int ww = w0 + dx - 2;
+                const bool ok = ww >= 0 && ww < W;
+                const int at = ok ? it + (dx - 2) * NCG : it;
+                const uint4 a = cur[at], b = cur[NIT + at];
+                const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const unsigned kk = ok ? v[c] ^ (unsigned)(7 - dx) : 0u;
+                    m[c] = kk > m[c] ? kk : m[c];
+                }
+            }
+            rowk[it] = make_uint4(m[0], m[1], m[2], m[3]);
+            rowk[NIT + it] = make_uint4(m[4], m[5], m[6], m[7]);
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < NIT; it += 256) {              // column pass: max over dy of rowk[h + dy - 2][w] ^ ((7 - dy) << 3)
+            const int pix = it / NCG, g = it % NCG, h0 = pix / W;
+            unsigned m[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m[c] = 0u;
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy) {
+                const int hh = h0 + dy - 2;
+                const bool ok = hh >= 0 && hh < H;
+                const int at = ok ? it + (dy - 2) * W * NCG : it;
+                const uint4 a = rowk[at], b = rowk[NIT + at];
+                const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const unsigned kk = ok ? v[c] ^ (unsigned)((7 - dy) << 3) : 0u;
+                    m[c] = kk > m[c] ? kk : m[c];
+                }
+            }
+            unsigned val[8], pos[8], nk[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned sk = m[c] >> 8;
+                const bool nan = sk == 0xffffu;
+                const unsigned f = (m[c] & 63u) ^ (nan ? 0u : 63u);    // [5:3] = dy, [2:0] = dx
+                pos[c] = (f >> 3) * 5u + (f & 7u);
+                val[c] = nan ? 0x7e00u : ((sk & 0x8000u) ? (sk & 0x7fffu) : (~sk & 0xffffu));
+                nk[c] = nan ? (m[c] | 63u) : (m[c] & ~63u);
+            }
+            cur[it] = make_uint4(nk[0], nk[1], nk[2], nk[3]);
+            cur[NIT + it] = make_uint4(nk[4], nk[5], nk[6], nk[7]);
+            *reinterpret_cast<uint4*>(cat + (pix0 + pix) * ld + (long long)j * C + (cg0 + g) * 8) =
+                make_uint4(val[0] | (val[1] << 16), val[2] | (val[3] << 16), val[4] | (val[5] << 16), val[6] | (val[7] << 16));
+            if (arg)
+                *reinterpret_cast<uint2*>(arg + (j - 1) * plane + (pix0 + pix) * C + (cg0 + g) * 8) =
+                    make_uint2(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24), pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24));
+        }
+        __syncthreads();
+    }
+}
+
+// largest map a workgroup can hold: 64 bytes of LDS per (pixel, channel group) in either direction
+static int sppf_ncg(int H, int W, int C) {
+    const long long hw = (long long)H * W;
+    if (C % 16 == 0 && hw * 2 * 64 <= 56 * 1024) return 2;             // three workgroups per CU on the 20 x 20 map
+    if (hw * 64 <= 128 * 1024 && hw <= 2048) return 1;
+    return 0;
+}
+
+extern "C" int ayolo_sppf_pool_fwd(int dtype, void* cat, int ld, unsigned char* argmax, int B, int H, int W, int C, ayolo_stream s) {
+    AY_CHECK_ARG(dtype == AYOLO_F16, "sppf_pool_fwd: fp16 only (fp32 plans run three ayolo_maxpool_fwd launches)");
+    AY_CHECK_ARG(cat && C % 8 == 0 && ld % 8 == 0 && ld >= 4 * C && ((uintptr_t)cat % 16) == 0, "sppf_pool_fwd: bad args");
+    AY_CHECK_ARG(argmax == nullptr || ((uintptr_t)argmax % 8) == 0, "sppf_pool_fwd: argmax must be 8-byte aligned");
+    const int ncg = sppf_ncg(H, W, C);
+    AY_CHECK_ARG(ncg > 0, "sppf_pool_fwd: a %d x %d map does not fit a workgroup's LDS (use ayolo_maxpool_fwd)", H, W);
+    if (B == 0) return AYOLO_OK;
+    const size_t lds = (size_t)H * W * ncg * 64;
+    const long long plane = (long long)B * H * W * C;
+    const unsigned grid = (unsigned)(B * (C / (8 * ncg)));
+    if (ncg == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sppf_fwd<2>, dim3(grid), dim3(256), lds, (hipStream_t)s, (half_t*)cat, ld, argmax, plane, H, W, C);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sppf_fwd<1>, dim3(grid), dim3(256), lds, (hipStream_t)s, (half_t*)cat, ld, argmax, plane, H, W, C);
+    }
+    AY_CHECK_LAUNCH("k_sppf_fwd");
+    return AYOLO_OK;
+}
+
+template <int NCG>
+__global__ __launch_bounds__(256) void k_sppf_bwd(const unsigned char* arg, long long plane, half_t* dcat, int ld, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sppf_lds[];
+    constexpr int MAXI = 8;                                            // items per thread: H * W * NCG <= 2048 (host check)
+    const int HW = H * W, NIT = HW * NCG;
+    double* acc = reinterpret_cast<double*>(sppf_lds);                 // [8][NIT]: channel c of item it at acc[c * NIT + it]
+    const int nblk = C / (8 * NCG);
+    const int n = blockIdx.x / nblk, cg0 = (blockIdx.x % nblk) * NCG;
+    const long long pix0 = (long long)n * HW;
+    uint4 gq[MAXI];                                                    // this thread's items of the current stage's gradient
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int it = threadIdx.x + 256 * i;
+        if (it < NIT) {
+            const int pix = it / NCG, g = it % NCG;
+            gq[i] = *reinterpret_cast<const uint4*>(dcat + (pix0 + pix) * ld + 3ll * C + (cg0 + g) * 8);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c * NIT + it] = 0.0;
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 3; j >= 1; --j) {
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {                               // scatter g_j through arg_j
+            const int it = threadIdx.x + 256 * i;
+            if (it < NIT) {
+                const int pix = it / NCG, g = it % NCG, h0 = pix / W, w0 = pix % W;
+                const uint2 pw = *reinterpret_cast<const uint2*>(arg + (j - 1) * plane + (pix0 + pix) * C + (cg0 + g) * 8);
+                const half_t* gv = reinterpret_cast<const half_t*>(&gq[i]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const unsigned tap = ((c < 4 ? pw.x : pw.y) >> (8 * (c & 3))) & 0xffu;
+                    const int dy = (int)((tap * 13u) >> 6), dx = (int)tap - 5 * dy;        // tap / 5, tap % 5 for tap < 25
+                    const int hh = h0 + dy - 2, ww = w0 + dx - 2;
+                    if (tap < 25u && hh >= 0 && hh < H && ww >= 0 && ww < W)
+                        atomicAdd(&acc[c * NIT + (hh * W + ww) * NCG + g], (double)gv[c]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {                               // g_{j-1} = d_{j-1} + what arrived, rounded to fp16
+            const int it = threadIdx.x + 256 * i;
+            if (it < NIT) {
+                const int pix = it / NCG, g = it % NCG;
+                half_t* at = dcat + (pix0 + pix) * ld + (long long)(j - 1) * C + (cg0 + g) * 8;
+                const uint4 dq = *reinterpret_cast<const uint4*>(at);
+                const half_t* dv = reinterpret_cast<const half_t*>(&dq);
+                uint4 out;
+                half_t* ov = reinterpret_cast<half_t*>(&out);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    ov[c] = (half_t)(float)((double)dv[c] + acc[c * NIT + it]);
+                    acc[c * NIT + it] = 0.0;
+                }
+                gq[i] = out;
+                if (j == 1) *reinterpret_cast<uint4*>(at) = out;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int ayolo_sppf_pool_bwd(int dtype, const unsigned char* argmax, void* dcat, int ld, int B, int H, int W, int C, ayolo_stream s) {
+    AY_CHECK_ARG(dtype == AYOLO_F16, "sppf_pool_bwd: fp16 only (fp32 plans run three ayolo_maxpool_bwd launches)");
+    AY_CHECK_ARG(argmax && dcat && C % 8 == 0 && ld % 8 == 0 && ld >= 4 * C && ((uintptr_t)dcat % 16) == 0 && ((uintptr_t)argmax % 8) == 0,
+                 "sppf_pool_bwd: bad args");
+    const int ncg = sppf_ncg(H, W, C);
+    AY_CHECK_ARG(ncg > 0, "sppf_pool_bwd: a %d x %d map does not fit a workgroup's LDS (use ayolo_maxpool_bwd)", H, W);
+    if (B == 0) return AYOLO_OK;
+    const size_t lds = (size_t)H * W * ncg * 64;
+    const long long plane = (long long)B * H * W * C;
+    const unsigned grid = (unsigned)(B * (C / (8 * ncg)));
+    if (ncg == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_bwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sppf_bwd<2>, dim3(grid), dim3(256), lds, (hipStream_t)s, argmax, plane, (half_t*)dcat, ld, H, W, C);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_sppf_bwd<1>, dim3(grid), dim3(256), lds, (hipStream_t)s, argmax, plane, (half_t*)dcat, ld, H, W, C);
+    }
+    AY_CHECK_LAUNCH("k_sppf_bwd");
+    return AYOLO_OK;
+}
+
+/* 1 when ayolo_sppf_pool_fwd / _bwd accept this map (it fits a workgroup's LDS), else 0 */
+extern "C" int ayolo_sppf_pool_supported(int dtype, int H, int W, int C) {
+    return dtype == AYOLO_F16 && C % 8 == 0 && sppf_ncg(H, W, C) > 0 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // nearest 2x upsample
 // ---------------------------------------------------------------------------------------------------
 template <typename T>

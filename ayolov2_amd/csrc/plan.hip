@@ -233,6 +233,12 @@ static int run_ops_impl(const ayolo_op* ops, int n, ayolo_stream s, int flags, h
             rc = ayolo_bn_act_bwd_apply2(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], o.l[0], &g[0], &g[1], o.i[3], o.i[4], o.f[0], cs);
             break;
         }
+        case AYOLO_OP_SPPF_FWD:
+            rc = ayolo_sppf_pool_fwd(o.i[0], o.p[0], o.i[1], (unsigned char*)o.p[1], o.i[2], o.i[3], o.i[4], o.i[5], cs);
+            break;
+        case AYOLO_OP_SPPF_BWD:
+            rc = ayolo_sppf_pool_bwd(o.i[0], (const unsigned char*)o.p[0], o.p[1], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], cs);
+            break;
         case AYOLO_OP_MAXPOOL_FWD:
             rc = ayolo_maxpool_fwd(o.i[0], o.p[0], o.i[1], o.p[1], o.i[2], (unsigned char*)o.p[2], o.i[3], o.i[4], o.i[5], o.i[6],
                                    o.i[7], cs);

@@ -267,6 +267,24 @@ def maxpool_bwd(argmax, dy, k: int, dx=None, accumulate=False):
     return dx
 
 
+def sppf_pool_fwd(cat, C: int, want_argmax=True):
+    """kindle SPPF's three chained 5 x 5 max-pools in one launch on the concat buffer `cat` (4 C channels: x | y1 | y2 | y3;
+    slice 0 is read, slices 1..3 written).  Returns the three window-position planes uint8[3][B][H][W][C] (or None)."""
+    B, C4, H, W, ld = nhwc_info(cat)
+    assert C4 == 4 * C and cat.dtype == torch.float16
+    arg = torch.empty((3, B, H, W, C), dtype=torch.uint8, device=cat.device) if want_argmax else None
+    call("ayolo_sppf_pool_fwd", dtype_code(cat.dtype), _ptr(cat), ld, _ptr(arg), B, H, W, C, _stream())
+    return arg
+
+
+def sppf_pool_bwd(argmax, dcat, C: int):
+    """Backward of the cascade: slice 0 of `dcat` (the concat buffer's gradient) becomes d(x)."""
+    B, C4, H, W, ld = nhwc_info(dcat)
+    assert C4 == 4 * C and dcat.dtype == torch.float16
+    call("ayolo_sppf_pool_bwd", dtype_code(dcat.dtype), _ptr(argmax), _ptr(dcat), ld, B, H, W, C, _stream())
+    return dcat[:, :C]
+
+
 def upsample2x_fwd(x, y=None):
     B, C, H, W, ldx = nhwc_info(x)
     if y is None:

@@ -36,6 +36,8 @@ OP_JOIN_SIDE = 21
 OP_STEM_BN_WGRAD = 22
 OP_WGRAD_GROUP = 23
 OP_BN_BWD_APPLY2 = 24
+OP_SPPF_FWD = 25
+OP_SPPF_BWD = 26
 
 
 class Op(ctypes.Structure):
@@ -72,6 +74,8 @@ MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: c
 # the BatchNorm-backward apply passes of a merged cv1 | cv2 pair as ONE launch over whole rows of the shared z / dz buffers
 # (ayolo_bn_act_bwd_apply2) instead of two over half rows
 BN_APPLY_PAIR = _os.environ.get("AYOLO_BN_APPLY2", "1") == "1"
+# SPPF's three chained max-pools as one launch per direction on the LDS-resident map (ayolo_sppf_pool_fwd / _bwd; fp16 plans)
+SPPF_FUSED = _os.environ.get("AYOLO_SPPF_FUSED", "1") == "1"
 # BatchNorm-backward sums (the first of the two backward passes of a Conv-BN-act block) computed in the epilogue of the
 # dgrad that produces the block's output gradient, instead of a pass of its own over da and z (ayolo_conv_dgrad_bn)
 BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
@@ -579,7 +583,7 @@ class TrainPlan:
         # the invariant this pass stands on: every forward op that reads an activation registered the read (_read) right behind
         # its append -- a new reader kind added without it must fail here, not compute on an unmaterialised activation
         for i, o in enumerate(self.fwd):
-            if (o.kind & 0xff) in (OP_CONV_FWD, OP_MAXPOOL_FWD, OP_UPSAMPLE_FWD) and (i + 1) not in self._reads_at:
+            if (o.kind & 0xff) in (OP_CONV_FWD, OP_MAXPOOL_FWD, OP_UPSAMPLE_FWD, OP_SPPF_FWD) and (i + 1) not in self._reads_at:
                 raise AssertionError(f"forward op {i} (kind {o.kind & 0xff}) reads an activation without a _read registration")
         for rd in self._reads:
             root, rlo, rhi, kind, c = rd
@@ -751,8 +755,26 @@ class TrainPlan:
         cat = self._new_act(4 * h, H, W)
         self._conv_block(m.cv1, x, cat.slice(0, h))
         k = m.pool.kernel_size
-        for j in range(3):
-            self._pool(k, cat.slice(j * h, (j + 1) * h), cat.slice((j + 1) * h, (j + 2) * h))
+        code = ops.dtype_code(self.dt)
+        if SPPF_FUSED and k == 5 and self.dt == torch.float16 and _lib.lib().ayolo_sppf_pool_supported(code, H, W, h):
+            B = self.B
+            arg = torch.empty((3, B, H, W, h), dtype=torch.uint8, device=self.device)
+            self.keep.append(arg)
+            ld = ops.nhwc_info(cat.t)[4]
+            self.fwd.append(_op(OP_SPPF_FWD, i=(code, ld, B, H, W, h), p=(cat.t, arg)))
+            self._read(cat.slice(0, h), "pool")
+
+            def emit():
+                if not cat.is_init():
+                    raise RuntimeError("plan: SPPF concat gradient incomplete before the pool cascade's backward")
+                dcat = cat.grad()
+                self.bwd.append(_op(OP_SPPF_BWD, i=(code, ops.nhwc_info(dcat)[4], B, H, W, h), p=(arg, dcat)))
+                self._gw(cat.slice(0, h), False)
+
+            self.bwd_emitters.append(emit)
+        else:
+            for j in range(3):
+                self._pool(k, cat.slice(j * h, (j + 1) * h), cat.slice((j + 1) * h, (j + 2) * h))
         return self._conv_block(m.cv2, cat, dst)
 
     def _upsample(self, x: Act, dst: Optional[Act]) -> Act:
@@ -1134,6 +1156,12 @@ class TrainPlan:
             elif kind in (OP_MAXPOOL_BWD, OP_UPSAMPLE_BWD):
                 n = o.i[3] * o.i[4] * o.i[5] * o.i[6]
                 out.append(("pool_upsample", es * n * (5 if kind == OP_UPSAMPLE_BWD else 2) + (n if kind == OP_MAXPOOL_BWD else 0), 0.0))
+            elif kind == OP_SPPF_FWD:                 # x read, three outputs + three position planes written
+                n = o.i[2] * o.i[3] * o.i[4] * o.i[5]
+                out.append(("pool_upsample", es * n * 4 + 3 * n, 0.0))
+            elif kind == OP_SPPF_BWD:                 # four gradient slices + three position planes read, d(x) written
+                n = o.i[2] * o.i[3] * o.i[4] * o.i[5]
+                out.append(("pool_upsample", es * n * 5 + 3 * n, 0.0))
             elif kind == OP_COPY2D:
                 out.append(("copy", es * o.l[0] * o.i[3] * (3 if o.i[4] else 2), 0.0))
             elif kind == OP_PACK_INPUT:

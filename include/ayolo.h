@@ -296,6 +296,16 @@ int ayolo_maxpool_fwd(int dtype, const void* x, int ldx, void* y, int ldy, unsig
 /* dx (+)= gather of dy through argmax */
 int ayolo_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, int lddy, void* dx, int lddx, int B,
                       int H, int W, int C, int k, int accumulate, ayolo_stream s);
+/* kindle SPPF's three chained MaxPool2d(5, 1, 2) (res/configs/model/yolov5s.yaml:33) in one launch per direction, fp16, on the
+ * module's concat buffer `cat` = [npix][ld] with the four C-channel slices x | y1 | y2 | y3 at channel offsets 0, C, 2C, 3C:
+ * forward reads slice 0 and writes slices 1..3 plus (argmax != NULL) the three window-position planes uint8[3][B*H*W*C] in
+ * ayolo_maxpool_fwd's format (first maximum in row-major scan order, torch's NaN rule);  backward takes the gradient of the
+ * concat buffer and leaves d(x) = d0 + pool_bwd(d1 + pool_bwd(d2 + pool_bwd(d3))) in slice 0 (intermediate sums rounded to fp16
+ * as three ayolo_maxpool_bwd launches would store them; slices 1..3 are left as they were).  The map must fit a workgroup's
+ * LDS: ayolo_sppf_pool_supported() == 1, else use the per-pool entry points. */
+int ayolo_sppf_pool_fwd(int dtype, void* cat, int ld, unsigned char* argmax, int B, int H, int W, int C, ayolo_stream s);
+int ayolo_sppf_pool_bwd(int dtype, const unsigned char* argmax, void* dcat, int ld, int B, int H, int W, int C, ayolo_stream s);
+int ayolo_sppf_pool_supported(int dtype, int H, int W, int C);
 int ayolo_upsample2x_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C,
                          ayolo_stream s);
 int ayolo_upsample2x_bwd(int dtype, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C,
@@ -524,9 +534,11 @@ enum {
     AYOLO_OP_STEM_BN_WGRAD,     /* ayolo_stem_bn_wgrad */
     AYOLO_OP_WGRAD_GROUP,       /* ayolo_wgrad_group_run: p[0] table (host), p[1] table (device), p[2] workspace, l[0] its bytes,
                                  * p[3..6] dy overrides, i[0] their count */
-    AYOLO_OP_BN_BWD_APPLY2      /* ayolo_bn_act_bwd_apply2: i[0] dtype, i[1] ldz, i[2] lddz, i[3] act, i[4] sum_reps, i[5 + k] / i[7 + k] =
+    AYOLO_OP_BN_BWD_APPLY2,     /* ayolo_bn_act_bwd_apply2: i[0] dtype, i[1] ldz, i[2] lddz, i[3] act, i[4] sum_reps, i[5 + k] / i[7 + k] =
                                  * C / ldda of block k; l[0] npix; f[0] grad_scale; p[0] z, p[1] dz, p[2 + 7 k ..] = da, save_mean (invstd
                                  * follows at + C), gamma, beta, sums, dgamma, dbeta of block k */
+    AYOLO_OP_SPPF_FWD,          /* ayolo_sppf_pool_fwd: i[0] dtype, i[1] ld, i[2..5] B H W C; p[0] cat, p[1] argmax */
+    AYOLO_OP_SPPF_BWD           /* ayolo_sppf_pool_bwd: i[] as above; p[0] argmax, p[1] dcat */
 };
 typedef struct ayolo_op {
     int kind;

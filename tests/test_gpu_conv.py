@@ -366,6 +366,98 @@ def test_maxpool_ties_and_strips(shape, k):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
+SPPF_SHAPES = [(2, 16, 20, 20), (1, 8, 7, 9), (3, 256, 20, 20), (1, 32, 40, 40), (2, 24, 4, 3), (1, 16, 10, 10)]
+
+
+def _sppf_inputs(shape, mode, g):
+    B, C, H, W = shape
+    if mode == "normal":
+        x = torch.randn(B, C, H, W, generator=g)
+    elif mode == "ties":                                     # four levels: nearly every window has ties, zeros of both signs
+        x = torch.randint(-1, 3, (B, C, H, W), generator=g).float()
+        x = torch.where((x == 0) & (torch.rand(x.shape, generator=g) < 0.5), torch.full_like(x, -0.0), x)
+    else:                                                    # NaN / inf sprinkled in
+        x = torch.randn(B, C, H, W, generator=g)
+        r = torch.rand(x.shape, generator=g)
+        x = torch.where(r < 0.02, torch.full_like(x, float("nan")), x)
+        x = torch.where((r >= 0.02) & (r < 0.04), torch.full_like(x, float("inf")), x)
+        x = torch.where((r >= 0.04) & (r < 0.08), torch.full_like(x, float("-inf")), x)
+    return x.half()
+
+
+@pytest.mark.parametrize("shape", SPPF_SHAPES)
+@pytest.mark.parametrize("mode", ["normal", "ties", "special"])
+def test_sppf_pool_cascade_equals_three_pool_launches(shape, mode):
+    """ayolo_sppf_pool_fwd / _bwd (kindle SPPF's three chained MaxPool2d(5, 1, 2), res/configs/model/yolov5s.yaml:33, as one
+    launch per direction over the LDS-resident map) against three ayolo_maxpool_fwd / _bwd launches on the same concat buffer:
+    values and recorded window positions bit for bit -- on ties (first maximum in row-major order), signed zeros, infinities and
+    NaN (torch's rule: the last NaN of the scan) -- and the input gradient: the cascade's sums are exact (fp64 atomics), the
+    launches' sequential fp32 sums almost always are, so at most a stray last-place difference is tolerated.  Both NCG = 2 and
+    NCG = 1 geometries (C not a multiple of 16; 40 x 40 maps)."""
+    from ayolov2_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + len(mode))
+    x = _sppf_inputs(shape, mode, g)
+    cat_a = torch.zeros(B, 4 * C + 8, H, W, dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)[:, :4 * C]
+    cat_a[:, :C] = x.cuda()
+    cat_b = cat_a.clone(memory_format=torch.preserve_format)[:, :4 * C] if False else torch.zeros_like(cat_a)
+    cat_b[:, :C] = x.cuda()
+    args_b = []
+    for j in range(3):
+        _, a = ops.maxpool_fwd(cat_b[:, j * C:(j + 1) * C], 5, y=cat_b[:, (j + 1) * C:(j + 2) * C])
+        args_b.append(a)
+    args_a = ops.sppf_pool_fwd(cat_a, C)
+    torch.cuda.synchronize()
+    va, vb = cat_a.float(), cat_b.float()
+    assert torch.equal(torch.isnan(va), torch.isnan(vb))
+    assert torch.equal(torch.nan_to_num(va, nan=0.0), torch.nan_to_num(vb, nan=0.0))
+    if mode != "special":                                    # (an all -inf window records its first in-image tap; the scan kernels tap 0)
+        for j in range(3):
+            assert torch.equal(args_a[j], args_b[j]), j
+    else:
+        for j in range(3):
+            ok = torch.isfinite(cat_b[:, (j + 1) * C:(j + 2) * C].permute(0, 2, 3, 1)) | torch.isnan(cat_b[:, (j + 1) * C:(j + 2) * C].permute(0, 2, 3, 1)) \
+                | (cat_b[:, (j + 1) * C:(j + 2) * C].permute(0, 2, 3, 1) == float("inf"))
+            assert torch.equal(args_a[j][ok], args_b[j][ok]), j
+    if mode == "special":
+        return
+    # backward: same gradient of the concat buffer into both routes
+    d = torch.randn(B, 4 * C, H, W, generator=g).half()
+    da = torch.zeros_like(cat_a)
+    da.copy_(d.cuda())
+    db = da.clone(memory_format=torch.preserve_format)
+    for j in (2, 1, 0):
+        ops.maxpool_bwd(args_b[j], db[:, (j + 1) * C:(j + 2) * C], 5, dx=db[:, j * C:(j + 1) * C], accumulate=True)
+    dxa = ops.sppf_pool_bwd(args_a, da, C)
+    torch.cuda.synchronize()
+    assert torch.equal(da[:, C:], d.cuda()[:, C:])           # slices 1..3 untouched
+    a, b = dxa.float(), db[:, :C].float()
+    diff = (a != b)
+    assert float(diff.float().mean()) <= 1e-4, float(diff.float().mean())
+    assert float((a - b).abs().max()) <= 2.0 ** -10 * float(b.abs().max())
+
+
+def test_sppf_pool_cascade_vs_torch_autograd():
+    """The same cascade against torch's own max_pool2d chain with autograd on the CPU (the oracle's SPPF body)."""
+    from ayolov2_amd import ops
+    B, C, H, W = 2, 16, 20, 20
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 6, (B, C, H, W), generator=g).float()
+    xr = x.clone().requires_grad_(True)
+    y1 = F.max_pool2d(xr, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    cr = torch.cat((xr, y1, y2, y3), 1)
+    d = torch.randint(-3, 4, cr.shape, generator=g).float()
+    cr.backward(d)
+    cat = torch.zeros(B, 4 * C, H, W, dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    cat[:, :C] = x.cuda().half()
+    arg = ops.sppf_pool_fwd(cat, C)
+    np.testing.assert_array_equal(cat.float().cpu().numpy(), cr.detach().numpy())
+    dc = torch.zeros_like(cat)
+    dc.copy_(d.cuda().half())
+    dx = ops.sppf_pool_bwd(arg, dc, C)
+    np.testing.assert_array_equal(dx.float().cpu().numpy(), xr.grad.numpy())      # small integers: every sum exact in fp16
+
+
 def test_wide_pixel_tile_variants():
     """k_gconv's 256-pixel-tile instantiations are chosen only for large maps (>= 131072 output pixels); force them
     (AYOLO_GCONV_TP=256, read once per process) on the small shapes so that every element is checked, fp32 and fp16."""
