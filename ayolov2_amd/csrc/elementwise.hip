@@ -1136,118 +1136,169 @@ extern "C" int ayolo_maxpool_bwd(int dtype, const unsigned char* argmax, const v
 // k_maxpool5_bwd launches the cascade cost 0.21 ms of the YOLOv5s step for 0.2 GB: every launch is compare-select-bound (25 taps
 // x (compare + two selects + NaN test) per output channel) and the chain is serial.  Here a workgroup owns one image and NCG
 // 16-byte channel groups of the 4 C-channel concat buffer, keeps the map in LDS and runs all three pools on it:
-//   forward: every fp16 value becomes a 32-bit KEY = [sortable 16-bit value | 8 low bits], so that "first maximum in row-major
-//     scan order" is ONE unsigned max: a tap's key is XOR-ed with (7 - dx) in the row pass and ((7 - dy) << 3) in the column
-//     pass -- among equal values the smaller dy, then the smaller dx wins, the scan's tie rule -- and the 5 x 5 window is
-//     separable (5 + 5 taps instead of 25).  torch's NaN rule (a NaN always replaces the running maximum: the LAST NaN of the
-//     scan is recorded) is the same max with the index bits complemented: a NaN's key carries 0x3f in its low bits, the XOR turns
-//     (7 - d) into d.  -0.0 is stored as +0.0 (float compare treats them as equal: the first of them wins either way; the output
-//     value then reads +0.0 where the scan would copy -0.0 -- equal under ==).  The winner's key, low bits cleared, is the next
-//     pool's input; values and window positions are written exactly as k_maxpool5_fwd would (a window with no value above -inf
-//     records its first in-image tap, torch's rule; the scan kernels record tap 0).
+//   forward: every fp16 value becomes a 32-bit KEY = [sortable 16-bit value | 63 - h | 63 - w] with (h, w) the element's own map
+//     position, so that "first maximum in row-major scan order" is ONE unsigned max over the window -- among equal values the
+//     smaller row, then the smaller column wins, the scan's tie rule -- without any per-tap arithmetic, and the 5 x 5 window is
+//     separable (two v_max3_u32 per channel and direction instead of 25 compare-selects).  torch's NaN rule (a NaN always replaces
+//     the running maximum: the LAST NaN of the scan is recorded) is the same max with the position fields not complemented
+//     (value 0xffff | h | w).  -0.0 is stored as +0.0 (float compare treats them as equal: the first of them wins either way; the
+//     output value then reads +0.0 where the scan would copy -0.0 -- equal under ==).  The winner's key with the position of the
+//     OUTPUT element is the next pool's input; values and window positions are written exactly as k_maxpool5_fwd would (a window
+//     with no value above -inf records its first in-image tap, torch's rule; the scan kernels record tap 0).  The LDS maps carry
+//     two zero columns / rows of padding (key 0 never wins), so no tap tests a bound.
 //   backward: g3 = d3; g2 = d2 + scatter(g3; arg3); g1 = d1 + scatter(g2; arg2); dx = d0 + scatter(g1; arg1), every g rounded to
 //     fp16 as the three launches store it.  The scatter is an fp64 LDS atomic per (output, channel): a sum of <= 26 fp16 values is
 //     EXACT in fp64 (40 bits of exponent range + 11 of mantissa + 5 of count < 53), so the result does not depend on the order
 //     of the atomics -- deterministic -- and equals the sequential fp32 sums of k_maxpool5_bwd whenever those are exact too
 //     (always, unless a window's gradients span more than 2^13 in magnitude).  Only dx (slice 0) is written.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned sppf_key(unsigned b) {            // b: fp16 bits in [15:0]
+// key = [sortable value : 16 | row field : 6 | column field : 6].  Fields of a non-NaN value: 63 - h, 63 - w (the first maximum in
+// row-major order has the largest fields); of a NaN (value 0xffff): h, w (the last NaN wins).
+__device__ __forceinline__ unsigned sppf_key(unsigned b, unsigned pos_first, unsigned pos_last) {            // b: fp16 bits in [15:0]
     const unsigned mag = b & 0x7fffu;
     b = mag == 0u ? 0u : b;                                           // -0.0 -> +0.0
     const unsigned s = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
-    return mag > 0x7c00u ? 0xffff3fu : (s << 8);
+    return mag > 0x7c00u ? (0xffff000u | pos_last) : ((s << 12) | pos_first);
+}
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) {
+    const unsigned m = a > b ? a : b;
+    return m > c ? m : c;
 }
 
-template <int NCG>
-__global__ __launch_bounds__(256) void k_sppf_fwd(half_t* cat, int ld, unsigned char* arg, long long plane, int H, int W, int C) {
+// MAXI: items (pixel, channel group) per thread, H * W * NCG <= 256 * MAXI.  LDS: `cur` [2][H][W + 4][NCG] uint4 (two zero columns
+// on either side of a row) and `rowk` [2][H + 4][W][NCG] uint4 (two zero rows above and below): the window never tests a bound.
+template <int NCG, int MAXI, int NT>
+__global__ __launch_bounds__(NT) void k_sppf_fwd(half_t* cat, int ld, unsigned char* arg, long long plane, int H, int W, int C) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sppf_lds[];
-    const int HW = H * W, NIT = HW * NCG;
-    uint4* cur = reinterpret_cast<uint4*>(sppf_lds);                   // [2][NIT]: the two 4-channel halves of an item in two planes
-    uint4* rowk = cur + 2 * NIT;
+    const int HW = H * W, NIT = HW * NCG, WP = W + 4;
+    const int NCUR = H * WP * NCG, NROW = (H + 4) * W * NCG;
+    uint4* cur = reinterpret_cast<uint4*>(sppf_lds);
+    uint4* rowk = cur + 2 * NCUR;
     const int nblk = C / (8 * NCG);
     const int n = blockIdx.x / nblk, cg0 = (blockIdx.x % nblk) * NCG;
     const long long pix0 = (long long)n * HW;
-    for (int it = threadIdx.x; it < NIT; it += 256) {
-        const int pix = it / NCG, g = it % NCG;
-        const uint4 raw = *reinterpret_cast<const uint4*>(cat + (pix0 + pix) * ld + (cg0 + g) * 8);
-        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-        unsigned k[8];
+    // this thread's items: every load of the kernel is requested before anything waits (one memory round trip)
+    uint4 raw[MAXI];
+    int hh[MAXI], ww[MAXI], gg[MAXI];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { k[2 * q] = sppf_key(w[q] & 0xffffu); k[2 * q + 1] = sppf_key(w[q] >> 16); }
-        cur[it] = make_uint4(k[0], k[1], k[2], k[3]);
-        cur[NIT + it] = make_uint4(k[4], k[5], k[6], k[7]);
+    for (int i = 0; i < MAXI; ++i) {
+        const int it = threadIdx.x + NT * i, itc = it < NIT ? it : NIT - 1;
+        const int pix = itc / NCG;
+        gg[i] = itc % NCG; hh[i] = pix / W; ww[i] = pix % W;
+        raw[i] = *reinterpret_cast<const uint4*>(cat + (pix0 + pix) * ld + (cg0 + gg[i]) * 8);
+    }
+    for (int k = threadIdx.x; k < 2 * (NCUR + NROW); k += NT) cur[k] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        if (threadIdx.x + NT * i < NIT) {
+            const unsigned pf = (unsigned)(((63 - hh[i]) << 6) | (63 - ww[i])), pl = (unsigned)((hh[i] << 6) | ww[i]);
+            const unsigned w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+            unsigned k[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { k[2 * q] = sppf_key(w[q] & 0xffffu, pf, pl); k[2 * q + 1] = sppf_key(w[q] >> 16, pf, pl); }
+            const int at = (hh[i] * WP + ww[i] + 2) * NCG + gg[i];
+            cur[at] = make_uint4(k[0], k[1], k[2], k[3]);
+            cur[NCUR + at] = make_uint4(k[4], k[5], k[6], k[7]);
+        }
     }
     __syncthreads();
 #pragma unroll 1
     for (int j = 1; j <= 3; ++j) {
-        for (int it = threadIdx.x; it < NIT; it += 256) {              // row pass: max over dx of cur[h][w + dx - 2] ^ (7 - dx)
-            const int pix = it / NCG, w0 = pix % W;
-            unsigned m[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) m[c] = 0u;
+        for (int i = 0; i < MAXI; ++i) {                               // row pass: max of cur[h][w - 2 .. w + 2]
+            if (threadIdx.x + NT * i < NIT) {
+                const int at = (hh[i] * WP + ww[i] + 2) * NCG + gg[i];
+                uint4 a[5], b[5];
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx) {
-                const int ww = w0 + dx - 2;
-                const bool ok = ww >= 0 && ww < W;
-                const int at = ok ? it + (dx - 2) * NCG : it;
-                const uint4 a = cur[at], b = cur[NIT + at];
-                const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const unsigned kk = ok ? v[c] ^ (unsigned)(7 - dx) : 0u;
-                    m[c] = kk > m[c] ? kk : m[c];
-                }
+                for (int dx = 0; dx < 5; ++dx) { a[dx] = cur[at + (dx - 2) * NCG]; b[dx] = cur[NCUR + at + (dx - 2) * NCG]; }
+                uint4 lo, hi;
+                lo.x = umax3(umax3(a[0].x, a[1].x, a[2].x), a[3].x, a[4].x); lo.y = umax3(umax3(a[0].y, a[1].y, a[2].y), a[3].y, a[4].y);
+                lo.z = umax3(umax3(a[0].z, a[1].z, a[2].z), a[3].z, a[4].z); lo.w = umax3(umax3(a[0].w, a[1].w, a[2].w), a[3].w, a[4].w);
+                hi.x = umax3(umax3(b[0].x, b[1].x, b[2].x), b[3].x, b[4].x); hi.y = umax3(umax3(b[0].y, b[1].y, b[2].y), b[3].y, b[4].y);
+                hi.z = umax3(umax3(b[0].z, b[1].z, b[2].z), b[3].z, b[4].z); hi.w = umax3(umax3(b[0].w, b[1].w, b[2].w), b[3].w, b[4].w);
+                const int ro = ((hh[i] + 2) * W + ww[i]) * NCG + gg[i];
+                rowk[ro] = lo;
+                rowk[NROW + ro] = hi;
             }
-            rowk[it] = make_uint4(m[0], m[1], m[2], m[3]);
-            rowk[NIT + it] = make_uint4(m[4], m[5], m[6], m[7]);
         }
         __syncthreads();
-        for (int it = threadIdx.x; it < NIT; it += 256) {              // column pass: max over dy of rowk[h + dy - 2][w] ^ ((7 - dy) << 3)
-            const int pix = it / NCG, g = it % NCG, h0 = pix / W;
-            unsigned m[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) m[c] = 0u;
+        for (int i = 0; i < MAXI; ++i) {                               // column pass: max of rowk[h - 2 .. h + 2][w]
+            if (threadIdx.x + NT * i < NIT) {
+                const int ro = ((hh[i] + 2) * W + ww[i]) * NCG + gg[i], st = W * NCG;
+                uint4 a[5], b[5];
 #pragma unroll
-            for (int dy = 0; dy < 5; ++dy) {
-                const int hh = h0 + dy - 2;
-                const bool ok = hh >= 0 && hh < H;
-                const int at = ok ? it + (dy - 2) * W * NCG : it;
-                const uint4 a = rowk[at], b = rowk[NIT + at];
-                const unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                for (int dy = 0; dy < 5; ++dy) { a[dy] = rowk[ro + (dy - 2) * st]; b[dy] = rowk[NROW + ro + (dy - 2) * st]; }
+                unsigned m[8];
+                m[0] = umax3(umax3(a[0].x, a[1].x, a[2].x), a[3].x, a[4].x); m[1] = umax3(umax3(a[0].y, a[1].y, a[2].y), a[3].y, a[4].y);
+                m[2] = umax3(umax3(a[0].z, a[1].z, a[2].z), a[3].z, a[4].z); m[3] = umax3(umax3(a[0].w, a[1].w, a[2].w), a[3].w, a[4].w);
+                m[4] = umax3(umax3(b[0].x, b[1].x, b[2].x), b[3].x, b[4].x); m[5] = umax3(umax3(b[0].y, b[1].y, b[2].y), b[3].y, b[4].y);
+                m[6] = umax3(umax3(b[0].z, b[1].z, b[2].z), b[3].z, b[4].z); m[7] = umax3(umax3(b[0].w, b[1].w, b[2].w), b[3].w, b[4].w);
+                // winner (hw, ww') = (63 - rb, 63 - cb): tap = (hw - h + 2) * 5 + (ww' - w + 2) = c0 - (5 rb + cb)
+                const unsigned pf = (unsigned)(((63 - hh[i]) << 6) | (63 - ww[i])), pl = (unsigned)((hh[i] << 6) | ww[i]);
+                const unsigned c0 = (unsigned)(5 * (65 - hh[i]) + (65 - ww[i]));
+                unsigned val[8], pos[8], nk[8];
+                bool anynan = false;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const unsigned kk = ok ? v[c] ^ (unsigned)((7 - dy) << 3) : 0u;
-                    m[c] = kk > m[c] ? kk : m[c];
+                    const unsigned sk = m[c] >> 12, rb = (m[c] >> 6) & 63u, cb = m[c] & 63u;
+                    pos[c] = c0 - (5u * rb + cb);
+                    val[c] = sk ^ ((sk & 0x8000u) ? 0x8000u : 0xffffu);
+                    nk[c] = (m[c] & 0xffff000u) | pf;
+                    anynan |= sk == 0xffffu;
                 }
-            }
-            unsigned val[8], pos[8], nk[8];
+                if (__builtin_amdgcn_ballot_w64(anynan) != 0ull) {     // NaN: fields hold (h, w) of the last one
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const unsigned sk = m[c] >> 8;
-                const bool nan = sk == 0xffffu;
-                const unsigned f = (m[c] & 63u) ^ (nan ? 0u : 63u);    // [5:3] = dy, [2:0] = dx
-                pos[c] = (f >> 3) * 5u + (f & 7u);
-                val[c] = nan ? 0x7e00u : ((sk & 0x8000u) ? (sk & 0x7fffu) : (~sk & 0xffffu));
-                nk[c] = nan ? (m[c] | 63u) : (m[c] & ~63u);
+                    for (int c = 0; c < 8; ++c) {
+                        const unsigned sk = m[c] >> 12, rb = (m[c] >> 6) & 63u, cb = m[c] & 63u;
+                        if (sk == 0xffffu) {
+                            pos[c] = 5u * (rb + 2u - (unsigned)hh[i]) + (cb + 2u - (unsigned)ww[i]);
+                            val[c] = 0x7e00u;
+                            nk[c] = 0xffff000u | pl;
+                        }
+                    }
+                }
+                const int at = (hh[i] * WP + ww[i] + 2) * NCG + gg[i];
+                cur[at] = make_uint4(nk[0], nk[1], nk[2], nk[3]);
+                cur[NCUR + at] = make_uint4(nk[4], nk[5], nk[6], nk[7]);
+                const long long pix = pix0 + hh[i] * W + ww[i];
+                *reinterpret_cast<uint4*>(cat + pix * ld + (long long)j * C + (cg0 + gg[i]) * 8) =
+                    make_uint4(val[0] | (val[1] << 16), val[2] | (val[3] << 16), val[4] | (val[5] << 16), val[6] | (val[7] << 16));
+                if (arg)
+                    *reinterpret_cast<uint2*>(arg + (j - 1) * plane + pix * C + (cg0 + gg[i]) * 8) =
+                        make_uint2(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24), pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24));
             }
-            cur[it] = make_uint4(nk[0], nk[1], nk[2], nk[3]);
-            cur[NIT + it] = make_uint4(nk[4], nk[5], nk[6], nk[7]);
-            *reinterpret_cast<uint4*>(cat + (pix0 + pix) * ld + (long long)j * C + (cg0 + g) * 8) =
-                make_uint4(val[0] | (val[1] << 16), val[2] | (val[3] << 16), val[4] | (val[5] << 16), val[6] | (val[7] << 16));
-            if (arg)
-                *reinterpret_cast<uint2*>(arg + (j - 1) * plane + (pix0 + pix) * C + (cg0 + g) * 8) =
-                    make_uint2(pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24), pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24));
         }
         __syncthreads();
     }
 }
 
-// largest map a workgroup can hold: 64 bytes of LDS per (pixel, channel group) in either direction
+// channel groups per workgroup (0: the map does not fit): LDS = 32 bytes x NCG x (H (W + 4) + (H + 4) W) forward, 64 x NCG x H W backward.
+// FOUR groups = 64-byte runs per pixel row of the concat buffer: with two (32-byte runs, four workgroups sharing every 128-byte line)
+// the kernels ran at a third of the speed the instruction count allows (profiles/r06_sppf_geometry.txt).
+static size_t sppf_lds_fwd(int H, int W, int ncg) { return (size_t)32 * ncg * ((size_t)H * (W + 4) + (size_t)(H + 4) * W); }
 static int sppf_ncg(int H, int W, int C) {
+    if (H < 1 || W < 1 || H > 64 || W > 64) return 0;                  // 6-bit position fields
+    static const int force = getenv("AYOLO_SPPF_NCG") ? atoi(getenv("AYOLO_SPPF_NCG")) : 0;
     const long long hw = (long long)H * W;
-    if (C % 16 == 0 && hw * 2 * 64 <= 56 * 1024) return 2;             // three workgroups per CU on the 20 x 20 map
-    if (hw * 64 <= 128 * 1024 && hw <= 2048) return 1;
+    if ((force == 0 || force == 4) && C % 32 == 0 && hw * 4 <= 2048 && sppf_lds_fwd(H, W, 4) <= 150 * 1024) return 4;
+    if ((force == 0 || force == 2) && C % 16 == 0 && hw * 2 <= 1024 && sppf_lds_fwd(H, W, 2) <= 64 * 1024) return 2;
+    if (hw <= 2048 && sppf_lds_fwd(H, W, 1) <= 150 * 1024) return 1;
     return 0;
+}
+
+// (the function attribute is set once per device and instantiation, to the largest size asked for so far)
+template <int NCG, int MAXI, int NT>
+static void sppf_launch_fwd(unsigned grid, size_t lds, hipStream_t s, half_t* cat, int ld, unsigned char* argmax, long long plane, int H, int W, int C) {
+    static size_t attr_set[16] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || attr_set[dev] < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_fwd<NCG, MAXI, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 16) attr_set[dev] = lds;
+    }
+    hipLaunchKernelGGL((k_sppf_fwd<NCG, MAXI, NT>), dim3(grid), dim3(NT), lds, s, cat, ld, argmax, plane, H, W, C);
 }
 
 extern "C" int ayolo_sppf_pool_fwd(int dtype, void* cat, int ld, unsigned char* argmax, int B, int H, int W, int C, ayolo_stream s) {
@@ -1257,69 +1308,71 @@ extern "C" int ayolo_sppf_pool_fwd(int dtype, void* cat, int ld, unsigned char* 
     const int ncg = sppf_ncg(H, W, C);
     AY_CHECK_ARG(ncg > 0, "sppf_pool_fwd: a %d x %d map does not fit a workgroup's LDS (use ayolo_maxpool_fwd)", H, W);
     if (B == 0) return AYOLO_OK;
-    const size_t lds = (size_t)H * W * ncg * 64;
+    const size_t lds = sppf_lds_fwd(H, W, ncg);
     const long long plane = (long long)B * H * W * C;
     const unsigned grid = (unsigned)(B * (C / (8 * ncg)));
-    if (ncg == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_fwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sppf_fwd<2>, dim3(grid), dim3(256), lds, (hipStream_t)s, (half_t*)cat, ld, argmax, plane, H, W, C);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sppf_fwd<1>, dim3(grid), dim3(256), lds, (hipStream_t)s, (half_t*)cat, ld, argmax, plane, H, W, C);
-    }
+    const int nit = H * W * ncg;
+    if (ncg == 4) sppf_launch_fwd<4, 4, 512>(grid, lds, (hipStream_t)s, (half_t*)cat, ld, argmax, plane, H, W, C);
+    else if (ncg == 2) sppf_launch_fwd<2, 4, 256>(grid, lds, (hipStream_t)s, (half_t*)cat, ld, argmax, plane, H, W, C);
+    else if (nit <= 1024) sppf_launch_fwd<1, 4, 256>(grid, lds, (hipStream_t)s, (half_t*)cat, ld, argmax, plane, H, W, C);
+    else sppf_launch_fwd<1, 8, 256>(grid, lds, (hipStream_t)s, (half_t*)cat, ld, argmax, plane, H, W, C);
     AY_CHECK_LAUNCH("k_sppf_fwd");
     return AYOLO_OK;
 }
 
-template <int NCG>
-__global__ __launch_bounds__(256) void k_sppf_bwd(const unsigned char* arg, long long plane, half_t* dcat, int ld, int H, int W, int C) {
+// MAXI items per thread; every global load of the kernel -- the four gradient slices and the three position planes of the thread's
+// items -- is requested up front (as three dependent stages of guarded loads the kernel spent ~20 serial memory round trips)
+template <int NCG, int MAXI, int NT>
+__global__ __launch_bounds__(NT) void k_sppf_bwd(const unsigned char* arg, long long plane, half_t* dcat, int ld, int H, int W, int C) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sppf_lds[];
-    constexpr int MAXI = 8;                                            // items per thread: H * W * NCG <= 2048 (host check)
     const int HW = H * W, NIT = HW * NCG;
     double* acc = reinterpret_cast<double*>(sppf_lds);                 // [8][NIT]: channel c of item it at acc[c * NIT + it]
     const int nblk = C / (8 * NCG);
     const int n = blockIdx.x / nblk, cg0 = (blockIdx.x % nblk) * NCG;
     const long long pix0 = (long long)n * HW;
-    uint4 gq[MAXI];                                                    // this thread's items of the current stage's gradient
+    uint4 dq[MAXI][4];                                                 // gradient slices 0..3 of this thread's items
+    uint2 pq[MAXI][3];                                                 // window positions of pools 1..3
+    int hh[MAXI], ww[MAXI], gg[MAXI];
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int it = threadIdx.x + 256 * i;
-        if (it < NIT) {
-            const int pix = it / NCG, g = it % NCG;
-            gq[i] = *reinterpret_cast<const uint4*>(dcat + (pix0 + pix) * ld + 3ll * C + (cg0 + g) * 8);
+        const int it = threadIdx.x + NT * i, itc = it < NIT ? it : NIT - 1;
+        const int pix = itc / NCG;
+        gg[i] = itc % NCG; hh[i] = pix / W; ww[i] = pix % W;
+        const half_t* at = dcat + (pix0 + pix) * ld + (cg0 + gg[i]) * 8;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c * NIT + it] = 0.0;
-        }
+        for (int k = 0; k < 4; ++k) dq[i][k] = *reinterpret_cast<const uint4*>(at + (long long)k * C);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pq[i][k] = *reinterpret_cast<const uint2*>(arg + k * plane + (pix0 + pix) * C + (cg0 + gg[i]) * 8);
     }
+    for (int k = threadIdx.x; k < 8 * NIT; k += NT) acc[k] = 0.0;
     __syncthreads();
-#pragma unroll 1
+    uint4 gq[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) gq[i] = dq[i][3];
+#pragma unroll
     for (int j = 3; j >= 1; --j) {
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {                               // scatter g_j through arg_j
-            const int it = threadIdx.x + 256 * i;
+            const int it = threadIdx.x + NT * i;
             if (it < NIT) {
-                const int pix = it / NCG, g = it % NCG, h0 = pix / W, w0 = pix % W;
-                const uint2 pw = *reinterpret_cast<const uint2*>(arg + (j - 1) * plane + (pix0 + pix) * C + (cg0 + g) * 8);
+                const uint2 pw = pq[i][j - 1];
                 const half_t* gv = reinterpret_cast<const half_t*>(&gq[i]);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const unsigned tap = ((c < 4 ? pw.x : pw.y) >> (8 * (c & 3))) & 0xffu;
                     const int dy = (int)((tap * 13u) >> 6), dx = (int)tap - 5 * dy;        // tap / 5, tap % 5 for tap < 25
-                    const int hh = h0 + dy - 2, ww = w0 + dx - 2;
-                    if (tap < 25u && hh >= 0 && hh < H && ww >= 0 && ww < W)
-                        atomicAdd(&acc[c * NIT + (hh * W + ww) * NCG + g], (double)gv[c]);
+                    const int h2 = hh[i] + dy - 2, w2 = ww[i] + dx - 2;
+                    if (tap < 25u && h2 >= 0 && h2 < H && w2 >= 0 && w2 < W)
+                        atomicAdd(&acc[c * NIT + (h2 * W + w2) * NCG + gg[i]], (double)gv[c]);
                 }
             }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {                               // g_{j-1} = d_{j-1} + what arrived, rounded to fp16
-            const int it = threadIdx.x + 256 * i;
+            const int it = threadIdx.x + NT * i;
             if (it < NIT) {
-                const int pix = it / NCG, g = it % NCG;
-                half_t* at = dcat + (pix0 + pix) * ld + (long long)(j - 1) * C + (cg0 + g) * 8;
-                const uint4 dq = *reinterpret_cast<const uint4*>(at);
-                const half_t* dv = reinterpret_cast<const half_t*>(&dq);
+                const half_t* dv = reinterpret_cast<const half_t*>(&dq[i][j - 1]);
                 uint4 out;
                 half_t* ov = reinterpret_cast<half_t*>(&out);
 #pragma unroll
@@ -1328,11 +1381,23 @@ __global__ __launch_bounds__(256) void k_sppf_bwd(const unsigned char* arg, long
                     acc[c * NIT + it] = 0.0;
                 }
                 gq[i] = out;
-                if (j == 1) *reinterpret_cast<uint4*>(at) = out;
+                if (j == 1) *reinterpret_cast<uint4*>(dcat + (pix0 + hh[i] * W + ww[i]) * ld + (cg0 + gg[i]) * 8) = out;
             }
         }
-        __syncthreads();
+        if (j > 1) __syncthreads();
     }
+}
+
+template <int NCG, int MAXI, int NT>
+static void sppf_launch_bwd(unsigned grid, size_t lds, hipStream_t s, const unsigned char* argmax, long long plane, half_t* dcat, int ld, int H, int W, int C) {
+    static size_t attr_set[16] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || attr_set[dev] < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_bwd<NCG, MAXI, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 16) attr_set[dev] = lds;
+    }
+    hipLaunchKernelGGL((k_sppf_bwd<NCG, MAXI, NT>), dim3(grid), dim3(NT), lds, s, argmax, plane, dcat, ld, H, W, C);
 }
 
 extern "C" int ayolo_sppf_pool_bwd(int dtype, const unsigned char* argmax, void* dcat, int ld, int B, int H, int W, int C, ayolo_stream s) {
@@ -1345,13 +1410,11 @@ extern "C" int ayolo_sppf_pool_bwd(int dtype, const unsigned char* argmax, void*
     const size_t lds = (size_t)H * W * ncg * 64;
     const long long plane = (long long)B * H * W * C;
     const unsigned grid = (unsigned)(B * (C / (8 * ncg)));
-    if (ncg == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_bwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sppf_bwd<2>, dim3(grid), dim3(256), lds, (hipStream_t)s, argmax, plane, (half_t*)dcat, ld, H, W, C);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sppf_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_sppf_bwd<1>, dim3(grid), dim3(256), lds, (hipStream_t)s, argmax, plane, (half_t*)dcat, ld, H, W, C);
-    }
+    const int nit = H * W * ncg;
+    if (ncg == 4) sppf_launch_bwd<4, 4, 512>(grid, lds, (hipStream_t)s, argmax, plane, (half_t*)dcat, ld, H, W, C);
+    else if (ncg == 2) sppf_launch_bwd<2, 4, 256>(grid, lds, (hipStream_t)s, argmax, plane, (half_t*)dcat, ld, H, W, C);
+    else if (nit <= 1024) sppf_launch_bwd<1, 4, 256>(grid, lds, (hipStream_t)s, argmax, plane, (half_t*)dcat, ld, H, W, C);
+    else sppf_launch_bwd<1, 8, 256>(grid, lds, (hipStream_t)s, argmax, plane, (half_t*)dcat, ld, H, W, C);
     AY_CHECK_LAUNCH("k_sppf_bwd");
     return AYOLO_OK;
 }

@@ -36,8 +36,8 @@ def main():
             continue
         seen.setdefault((c.in_channels, c.out_channels, xs[2]), [mod, 0])[1] += 1
     dt = torch.float16
-    print(f"{'cin':>5}{'cout':>5}{'H':>5} cnt | {'bn+act us':>9} {'conv us':>8} {'sum':>8} | {'on-load us':>10} | {'saved us':>8}  x cnt")
-    tot2 = tot1 = 0.0
+    print(f"{'cin':>5}{'cout':>5}{'H':>5} cnt | {'bn+act us':>9} {'conv us':>8} {'sum':>8} | {'on-load us':>10} {'+store-back':>11} | {'saved us':>8} {'(store-back)':>12}  x cnt")
+    tot2 = tot1 = tots = 0.0
     for (cin, cout, H), (mod, cnt) in sorted(seen.items(), key=lambda kv: -kv[0][2]):
         z = torch.randn((batch, cin, H, H), device=dev).to(dt).contiguous(memory_format=torch.channels_last)
         a = ops.new_act(batch, cin, H, H, dt, dev)
@@ -50,10 +50,12 @@ def main():
         t_a = timeit(lambda: ops.affine_act(z, a, scale, shift, 1), 10)
         t_c = timeit(lambda: ops.conv_fwd(d, a, w, y, 0, stats=stats), 10)
         t_x = timeit(lambda: ops.conv_fwd_xf(d, z, scale, shift, 1, w, y, 0, stats=stats), 10)
-        print(f"{cin:5d}{cout:5d}{H:5d} {cnt:3d} | {t_a:9.1f} {t_c:8.1f} {t_a + t_c:8.1f} | {t_x:10.1f} | {t_a + t_c - t_x:8.1f}")
+        t_s = timeit(lambda: ops.conv_fwd_xf(d, z, scale, shift, 1, w, y, 0, stats=stats, store=a), 10)
+        print(f"{cin:5d}{cout:5d}{H:5d} {cnt:3d} | {t_a:9.1f} {t_c:8.1f} {t_a + t_c:8.1f} | {t_x:10.1f} {t_s:11.1f} | {t_a + t_c - t_x:8.1f} {t_a + t_c - t_s:12.1f}")
         tot2 += (t_a + t_c) * cnt
         tot1 += t_x * cnt
-    print(f"all 1x1 layers of the model: two launches {tot2 / 1e3:.3f} ms, transform on load {tot1 / 1e3:.3f} ms")
+        tots += t_s * cnt
+    print(f"all 1x1 layers of the model: two launches {tot2 / 1e3:.3f} ms, transform on load {tot1 / 1e3:.3f} ms, with store-back {tots / 1e3:.3f} ms")
 
 
 if __name__ == "__main__":
