@@ -2556,37 +2556,34 @@ static int launch_pw(GConvP p, hipStream_t s) {
 
 template <typename T, int TM, int EM, bool BNR = false, bool XF = false>
 static int launch_gconv_em(const GConvP& p, hipStream_t s) {
-    // the streaming 1x1 kernel (k_pw): whole reductions of 32 .. 256 channels whose three stages fit the LDS
+    // the streaming 1x1 kernel (k_pw): whole reductions of 64 / 128 / 256 channels into 64- or 128-channel tiles -- forward, dgrad and
+    // the transform-on-load readers.  Same-box A/B of the routes (profiles/r06_ab_pw_v1..v4.txt, r06_ab_pw_nw8.txt): TM 128 with
+    // K = 128 / 256 -0.07 ms, + K = 64 and the 64-channel tiles -0.1 ... -0.2 ms, + the readers -0.23 ms in all; the 32-channel
+    // tiles (K = 32 / 64 on the 160 x 160 / 320 x 320 maps) were level with k_gconv and are not instantiated.
     if constexpr (sizeof(T) == 2 && XF && EM == 0) {
-        static const int pw_on = getenv("AYOLO_PW") ? atoi(getenv("AYOLO_PW")) : 11;
         // transform on load: the same tilings as the plain conv of the same shape (a layer's two routes share one kernel family, so
         // that they stay bit-identical: test_conv_transform_on_load_equals_materialised_route)
-        if ((pw_on & 8) && p.xf && p.C % BK == 0 && p.xs_split % 8 == 0) {
+        if (p.xf && p.C % BK == 0 && p.xs_split % 8 == 0) {
             const bool two = p.x2 != nullptr;
             if constexpr (TM == 128) {
-                if (p.C == 64 && (pw_on & 2)) return two ? launch_pw<TM, 4, EM, false, 2>(p, s) : launch_pw<TM, 4, EM, false, 1>(p, s);
+                if (p.C == 64) return two ? launch_pw<TM, 4, EM, false, 2>(p, s) : launch_pw<TM, 4, EM, false, 1>(p, s);
                 if (p.C == 128) return two ? launch_pw<TM, 8, EM, false, 2>(p, s) : launch_pw<TM, 8, EM, false, 1>(p, s);
                 if (p.C == 256) return two ? launch_pw<TM, 16, EM, false, 2>(p, s) : launch_pw<TM, 16, EM, false, 1>(p, s);
             } else if constexpr (TM == 64) {
-                if (p.C == 64 && (pw_on & 2)) return two ? launch_pw<TM, 4, EM, false, 2>(p, s) : launch_pw<TM, 4, EM, false, 1>(p, s);
-                if (p.C == 128 && (pw_on & 2)) return two ? launch_pw<TM, 8, EM, false, 2>(p, s) : launch_pw<TM, 8, EM, false, 1>(p, s);
+                if (p.C == 64) return two ? launch_pw<TM, 4, EM, false, 2>(p, s) : launch_pw<TM, 4, EM, false, 1>(p, s);
+                if (p.C == 128) return two ? launch_pw<TM, 8, EM, false, 2>(p, s) : launch_pw<TM, 8, EM, false, 1>(p, s);
             }
         }
     }
     if constexpr (sizeof(T) == 2 && !XF && EM != 3) {
-        static const int pw_on = getenv("AYOLO_PW") ? atoi(getenv("AYOLO_PW")) : 11;
-        static const long long pw_maxm = getenv("AYOLO_PW_MAXM") ? atoll(getenv("AYOLO_PW_MAXM")) : (1ll << 40);
-        if (pw_on && p.lin && p.Mtotal <= pw_maxm) {
+        if (p.lin) {
             if constexpr (TM == 128) {
-                if (p.C == 64 && (pw_on & 2)) return launch_pw<TM, 4, EM, BNR>(p, s);
+                if (p.C == 64) return launch_pw<TM, 4, EM, BNR>(p, s);
                 if (p.C == 128) return launch_pw<TM, 8, EM, BNR>(p, s);
                 if (p.C == 256) return launch_pw<TM, 16, EM, BNR>(p, s);
             } else if constexpr (TM == 64) {
-                if (p.C == 64 && (pw_on & 2)) return launch_pw<TM, 4, EM, BNR>(p, s);
-                if (p.C == 128 && (pw_on & 2)) return launch_pw<TM, 8, EM, BNR>(p, s);
-            } else {
-                if (p.C == 32 && (pw_on & 4)) return launch_pw<TM, 2, EM, BNR>(p, s);
-                if (p.C == 64 && (pw_on & 4)) return launch_pw<TM, 4, EM, BNR>(p, s);
+                if (p.C == 64) return launch_pw<TM, 4, EM, BNR>(p, s);
+                if (p.C == 128) return launch_pw<TM, 8, EM, BNR>(p, s);
             }
         }
     }
@@ -2617,11 +2614,12 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     // that rate.  Here every wavefront owns 32 channels x 64 pixels (32 accumulator registers), two workgroups per CU put four
     // wavefronts on every SIMD, and a workgroup walks two or more tiles so that the next tile's DMA runs under the epilogue.
     if constexpr (sizeof(T) == 2 && TM == 128 && (EM != 3 || XF)) {
-        static const int nw8 = getenv("AYOLO_GCONV_NW8") ? atoi(getenv("AYOLO_GCONV_NW8")) : 1;
-        static const long long nw8_maxm = getenv("AYOLO_GCONV_NW8_MAXM") ? atoll(getenv("AYOLO_GCONV_NW8_MAXM")) : 102400;
+        // (the layers k_pw does not take: 512-channel reductions, head levels; maps of <= 40 x 40 at batch 64.  Same-box A/B: -0.06 ms,
+        // profiles/r06_ab_nw8_v1.txt)
+        constexpr long long nw8_maxm = 102400;
         // (transform on load: only with whole 32-channel chunks, the 1x1 loader's condition, so that a layer's two routes -- reader
         // over z / conv over the materialised activation -- always share one tiling and stay bit-identical)
-        if (nw8 && (p.lin || (XF && p.C % BK == 0)) && !p.row3 && !p.s2f && p.Mtotal <= nw8_maxm) {
+        if ((p.lin || (XF && p.C % BK == 0)) && !p.row3 && !p.s2f && p.Mtotal <= nw8_maxm) {
             if constexpr (XF) return launch_gconv_tp<T, TM, EM, 128, BNR, true, false, 8>(p, s);
             else if constexpr (EM != 3) { if (p.lin) return launch_gconv_tp<T, TM, EM, 128, BNR, false, true, 8>(p, s); }
         }
@@ -2748,8 +2746,7 @@ static int dispatch_gconv(int dtype, GConvP p, hipStream_t s) {
     p.y_bytes = (unsigned)(y_img * p.B);
     p.w_bytes = (unsigned)w_bytes;
     p.dOW = make_fastdiv((unsigned)p.OW); p.dOH = make_fastdiv((unsigned)p.OH); p.dC = make_fastdiv((unsigned)(p.C > 0 ? p.C : 1));
-    static const int lin_on = getenv("AYOLO_GCONV_LIN") ? atoi(getenv("AYOLO_GCONV_LIN")) : 1;
-    p.lin = (lin_on && dtype == AYOLO_F16 && p.x_linear && p.ncls <= 1 && p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.wt[0] == 0 &&
+    p.lin = (dtype == AYOLO_F16 && p.x_linear && p.ncls <= 1 && p.ntaps == 1 && p.dh[0] == 0 && p.dw[0] == 0 && p.wt[0] == 0 &&
              p.C % BK == 0 && p.XH == p.OH && p.XW == p.OW && p.ish == 1 && p.isw == 1 && !p.xf) ? 1 : 0;
     if (p.ncls <= 0) {                       // ordinary launch: one class = all taps
         p.ncls = 1; p.ctap0[0] = 0; p.cnt[0] = p.ntaps; p.coah[0] = p.oah; p.coaw[0] = p.oaw;
@@ -4028,11 +4025,6 @@ static int stem_fwd_dispatch(const ayolo_conv_desc* d, const void* x, const void
 // ---------------------------------------------------------------------------------------------------
 // Weight gradients, host side: planning of a (grouped) launch, the C entries.
 // ---------------------------------------------------------------------------------------------------
-static int wgrad_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // geometry of one job (a layer, or one batch half of a layer whose tensors exceed the 2 GiB descriptor range)
 static int wgrad_fill(const ayolo_conv_desc* d, const void* x, const void* dy, WGradP& p) {
     p = WGradP{};
@@ -4169,8 +4161,7 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
     // (prologue + epilogue of a workgroup cost ~10 steps' worth of time; every extra split is one more N x K slot to store and add)
     const int bpc = g.dtype == AYOLO_F16 ? 3 : 1;
     const double slots = (double)num_cus() * bpc;
-    const double waves = (double)wgrad_env("AYOLO_WGRAD_WAVES", 3);
-    const double minq = (double)wgrad_env("AYOLO_WGRAD_MINQ", 24);
+    const double waves = 3.0, minq = 24.0;    // re-swept on round 5's final code (profiles/r05_ab_wgrad_retune.txt); switches retired in round 6
     double total = 0.0;
     for (const WGradP& p : g.jobs) total += (double)p.gx * p.gy * (double)((p.P + 31) / 32);
     double q = total / (slots * waves);
@@ -4182,9 +4173,8 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
         // (half a round of workgroups -- one per CU: every extra row range is one more slot to store and add and one more
         // epilogue; 3 / 2 / 1 / 0.5 rounds measured +0.12 / +0.07 / 0 / -0.05 ms against one, all inside +-0.06 ms of each other on
         // a second box: profiles/r05_ab_wgrad_groups_waves.txt, r05_ab_wgrad3_waves.txt)
-        const char* w3e = getenv("AYOLO_WGRAD3_WAVES");
-        const double waves3 = w3e ? atof(w3e) : 0.5;
-        const double minq3 = (double)wgrad_env("AYOLO_WGRAD3_MINQ", 6);
+        const double waves3 = 0.5;
+        const double minq3 = 6.0;
         double total3 = 0.0;
         for (const W3P& p : g.jobs3) total3 += (double)w3_tiles(p) * p.strips * (double)((p.NU + p.RPS - 1) / p.RPS) * w3_step_cost(p);
         const double t_item = total3 / (slots3 * waves3);
@@ -4303,7 +4293,7 @@ extern "C" int ayolo_wgrad_group_build(const ayolo_wgrad_job* jobs, int njobs, v
     unsigned char* t = (unsigned char*)table;
     memset(t, 0, (size_t)h.table_bytes);
     memcpy(t, &h, sizeof(h));
-    memcpy(t + h.off_jobs, g.jobs.data(), g.jobs.size() * sizeof(WGradP));
+    if (!g.jobs.empty()) memcpy(t + h.off_jobs, g.jobs.data(), g.jobs.size() * sizeof(WGradP));     // (a group of k_wgrad3 jobs only: no k_wgrad jobs)
     if (!g.jobs3.empty()) memcpy(t + h.off_jobs3, g.jobs3.data(), g.jobs3.size() * sizeof(W3P));
     for (int c = 0; c < 4; ++c)
         if (!g.items[c].empty()) memcpy(t + h.off_items[c], g.items[c].data(), g.items[c].size() * sizeof(WItem));
@@ -4349,15 +4339,14 @@ template <typename T, int TM, bool XFW>
 static int launch_wgrad_k(const WGradP& pv, const WGradP* jobs, const WItem* items, unsigned blocks, float* ws, const WOvr& ovr, hipStream_t s) {
     using W = WT<T, TM>;
     static bool attr_set[16] = {false};
-    // experiment (round 6, fork placement): grouped launches may ask for more LDS than they use, so that fewer of their workgroups
-    // fit a CU and the main stream's kernels always find a free slot
-    static const int lds_pad = getenv("AYOLO_WGRAD_LDS") ? atoi(getenv("AYOLO_WGRAD_LDS")) : 0;
-    const size_t lds = (items != nullptr && lds_pad > (int)W::LDS) ? (size_t)lds_pad : W::LDS;
+    // (a cap on a group's resident workgroups -- asking for more LDS than the kernel uses, so that the main stream's kernels always
+    // find a free slot -- was measured in round 6 and lost: 55 KB +0.05 ms, 82 KB +0.35 ms, profiles/r06_ab_fork_placement_1.txt)
+    const size_t lds = W::LDS;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad<T, TM, XFW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(lds_pad > (int)W::LDS ? lds_pad : W::LDS));
+                                  (int)W::LDS);
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_wgrad<T, TM, XFW>), dim3(blocks), dim3(256), lds, s, pv, jobs, items, ws, ovr);
@@ -4436,7 +4425,7 @@ static int wgrad_single_plan(const ayolo_conv_desc* d, const void* x, const void
     double total = 0.0;
     for (const WGradP& q : jobs) total += (double)q.gx * q.gy * (double)((q.P + 31) / 32);
     double q = total / ((double)num_cus() * bpc * 2.0);
-    const double minq = (double)wgrad_env("AYOLO_WGRAD_MINQ", 24);
+    const double minq = 24.0;
     if (q < minq) q = minq;
     unsigned S = 0;
     for (WGradP& j : jobs) { wgrad_split(j, q); j.ws_off = 0; j.zz0 = S; S += j.splits; }
@@ -4450,7 +4439,7 @@ static bool w3_single_plan(const ayolo_conv_desc* d, const void* x, const void* 
     const double steps = (double)p.strips * (double)((p.NU + p.RPS - 1) / p.RPS);
     const double want = (double)num_cus() * 2.0 * 2.0 / (double)w3_tiles(p);                    // row ranges per tile
     double q = steps / (want < 1.0 ? 1.0 : want);
-    const double minq = (double)wgrad_env("AYOLO_WGRAD3_MINQ", 6);
+    const double minq = 6.0;
     w3_split_job(p, q < minq ? minq : q);
     p.ws_off = 0; p.zz0 = 0;
     return true;

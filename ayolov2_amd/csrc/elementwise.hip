@@ -1280,10 +1280,9 @@ __global__ __launch_bounds__(NT) void k_sppf_fwd(half_t* cat, int ld, unsigned c
 static size_t sppf_lds_fwd(int H, int W, int ncg) { return (size_t)32 * ncg * ((size_t)H * (W + 4) + (size_t)(H + 4) * W); }
 static int sppf_ncg(int H, int W, int C) {
     if (H < 1 || W < 1 || H > 64 || W > 64) return 0;                  // 6-bit position fields
-    static const int force = getenv("AYOLO_SPPF_NCG") ? atoi(getenv("AYOLO_SPPF_NCG")) : 0;
     const long long hw = (long long)H * W;
-    if ((force == 0 || force == 4) && C % 32 == 0 && hw * 4 <= 2048 && sppf_lds_fwd(H, W, 4) <= 150 * 1024) return 4;
-    if ((force == 0 || force == 2) && C % 16 == 0 && hw * 2 <= 1024 && sppf_lds_fwd(H, W, 2) <= 64 * 1024) return 2;
+    if (C % 32 == 0 && hw * 4 <= 2048 && sppf_lds_fwd(H, W, 4) <= 150 * 1024) return 4;
+    if (C % 16 == 0 && hw * 2 <= 1024 && sppf_lds_fwd(H, W, 2) <= 64 * 1024) return 2;
     if (hw <= 2048 && sppf_lds_fwd(H, W, 1) <= 150 * 1024) return 1;
     return 0;
 }

@@ -432,25 +432,22 @@ size_t w3_lds_bytes(const W3P& p) {
 }
 
 int w3_fill(const ayolo_conv_desc* d, const void* x, const void* dy, W3P& p, bool any_route) {
-    // Routing (read at every planning call so that a test can switch it).  Alone on the chip the kernel beats the generic k_wgrad
-    // on the stride-1 3x3 layers of YOLOv5s at batch 64 except the smallest map (122 vs 154 us at 160 x 160, 62 vs 82 at 80 x 80,
-    // 67 vs 73 at 40 x 40, 82 vs 73 at 20 x 20: profiles/r05_wgrad3_layer_sweep.txt).  Inside the train step -- one more launch and
-    // tail per weight-gradient group, an 8-wavefront workgroup owning a CU while the main stream's kernels look for slots -- taking
-    // ALL of them made the step 0.04-0.25 ms slower in every same-box A/B of every version (profiles/r05_ab_wgrad3_*.txt); taking
-    // only the maps of >= 80 rows, where the layer is HBM-heavy and the gain per layer largest, is worth -0.06 ms
-    // (r05_ab_wgrad3_minhw.txt) and -0.11 ms with the final loader (r05_ab_wgrad3_v5d.txt: every stride-1 layer -0.05).  AYOLO_WGRAD3=0: generic kernel everywhere; AYOLO_WGRAD3_MINHW: the row threshold.
-    const int on = w3_env("AYOLO_WGRAD3", 1);
+    // Routing.  Alone on the chip the kernel beats the generic k_wgrad on the stride-1 3x3 layers of YOLOv5s at batch 64 except the
+    // smallest map (122 vs 154 us at 160 x 160, 62 vs 82 at 80 x 80, 67 vs 73 at 40 x 40, 82 vs 73 at 20 x 20:
+    // profiles/r05_wgrad3_layer_sweep.txt).  Inside the train step -- one more launch and tail per weight-gradient group, an
+    // 8-wavefront workgroup owning a CU while the main stream's kernels look for slots -- it never paid for itself: round 5's best
+    // routing (maps of >= 80 rows) measured -0.06 ... -0.11 ms on one box and level on the next, and on round 6's code on/off is
+    // 11.973 / 11.972 ms (profiles/r06_ab_sppf_v2_wgrad3.txt).  RETIRED from the default route in round 6:
+    // nothing is routed here unless AYOLO_WGRAD3 is set (1: every stride-1 3x3 layer; 2: the stride-2 layers too -- slower on every
+    // stride-2 layer of YOLOv5s, r05_wgrad3_layer_sweep.txt); the variable is read at every planning call so that the tests that
+    // keep the kernel honest can switch it.  The former tuning switches (_MINHW, _S2, _WAVES, _MINQ) are gone.
+    const int on = w3_env("AYOLO_WGRAD3", 0);
     if (!on && !any_route) return 1;
-    const int minhw = w3_env("AYOLO_WGRAD3_MINHW", 80);
-    if (d->Ho < minhw && !any_route) return 1;
     if (d->dtype != AYOLO_F16 || d->kh != 3 || d->kw != 3 || d->ph != 1 || d->pw != 1 || d->sh != d->sw || (d->sh != 1 && d->sh != 2)) return 1;
     if (d->Cin % 8 || d->Cout % 8 || d->ldx % 8 || d->ldy % 8 || d->Cin < 16 || d->Cout < 16) return 1;
     const int s = d->sh;
-    // stride 2: the window is four input pixels per output pixel -- more DMA bytes per MFMA than the generic kernel's widest
-    // tiles on the wide layers; slower on every stride-2 layer of YOLOv5s (profiles/r05_wgrad3_layer_sweep.txt, first versions):
-    // generic kernel unless AYOLO_WGRAD3_S2=1
-    const int s2on = w3_env("AYOLO_WGRAD3_S2", 0);
-    if (s == 2 && !s2on && !any_route) return 1;
+    // stride 2: the window is four input pixels per output pixel -- more DMA bytes per MFMA than the generic kernel's widest tiles
+    if (s == 2 && on < 2 && !any_route) return 1;
     if (d->Ho != (d->H + 2 - 3) / s + 1 || d->Wo != (d->W + 2 - 3) / s + 1) return 1;
     const long long xb = (long long)d->B * d->H * d->W * d->ldx * 2, yb = (long long)d->B * d->Ho * d->Wo * d->ldy * 2;
     if (xb >= (1ll << 30) || yb >= (1ll << 30)) return 1;

@@ -73,15 +73,15 @@ MAX_PLANS = int(_os.environ.get("AYOLO_MAX_PLANS", "4"))                 # cache
 MERGE_SIBLINGS = _os.environ.get("AYOLO_MERGE_SIBLINGS", "1") == "1"     # C3: cv1 | cv2 as one conv
 # the BatchNorm-backward apply passes of a merged cv1 | cv2 pair as ONE launch over whole rows of the shared z / dz buffers
 # (ayolo_bn_act_bwd_apply2) instead of two over half rows
-BN_APPLY_PAIR = _os.environ.get("AYOLO_BN_APPLY2", "1") == "1"
+BN_APPLY_PAIR = True          # (tests flip the attribute to pin the pair against two launches)
 # SPPF's three chained max-pools as one launch per direction on the LDS-resident map (ayolo_sppf_pool_fwd / _bwd; fp16 plans)
-SPPF_FUSED = _os.environ.get("AYOLO_SPPF_FUSED", "1") == "1"
+SPPF_FUSED = True
 # BatchNorm-backward sums (the first of the two backward passes of a Conv-BN-act block) computed in the epilogue of the
 # dgrad that produces the block's output gradient, instead of a pass of its own over da and z (ayolo_conv_dgrad_bn)
 BN_REDUCE_IN_DGRAD = _os.environ.get("AYOLO_BNR", "1") == "1"
 # Weight gradients run as a few GROUPED launches (ayolo_wgrad_group_run: one launch per tile class over the item list of all
 # layers of a group + one fixed-order reduction of the split-K partials) instead of one launch per layer.  The backward list is
-# cut into this many groups of similar work (the last one is halved AYOLO_WGRAD_TAIL more times: what the final group still has
+# cut into this many groups of similar work (the last one is halved WGRAD_TAIL more times: what the final group still has
 # to do when the main stream's backward ends is exposed).
 # Transform on load (ayolo_conv_fwd_xf): the BatchNorm + SiLU pass of a Conv block whose activation has exactly ONE reader, a
 # 1x1 / stride-1 conv, is not launched -- that conv (and its weight gradient) read the block's pre-activation z and form the
@@ -100,12 +100,11 @@ XF_WGRAD_ON_LOAD = False
 # route of round 4's A/B -- +0.67 ms, profiles/r04_ab_wgrad_groups.txt -- is gone).
 WGRAD_GROUPS = int(_os.environ.get("AYOLO_WGRAD_GROUPS", "-1"))
 WGRAD_GROUP_WORK = 0.36e6
-WGRAD_TAIL = int(_os.environ.get("AYOLO_WGRAD_TAIL", "2"))
-# Fork placement: group g may launch LATER than the slot where its last layer's dz is complete -- at the slot
-# of the weight-gradient job `k_g` jobs further down the backward list ("k0,k1,..."; every layer keeps its dz buffer until the end
-# of backward, so any later slot is valid).  Lets the small-map (issue-bound, cache-resident) groups run under the large-map
-# (HBM-bound) part of the main chain instead of under the small-map dgrads they stall.
-WGRAD_DEFER = [int(v) for v in _os.environ.get("AYOLO_WGRAD_DEFER", "").split(",") if v.strip()]
+WGRAD_TAIL = 2            # re-swept on round 5's final code (profiles/r05_ab_wgrad_retune.txt); environment switch retired in round 6
+# Fork placement, measured in round 6 and NOT kept: launching group g later than the slot where its last layer's dz
+# is complete -- so that the small-map groups run under the large-map part of the main chain -- cost +0.07 ... +0.17 ms in every
+# placement tried (26 / 26 + 8 / 19 + 7 jobs later), and the groups on the main stream +0.06 ms: the main-stream kernels behind a
+# fork wait for workgroup slots exactly as long as the group's work takes, wherever it is placed (profiles/r06_ab_fork_placement_1.txt).
 # (A cap on a group's resident workgroups per CU -- so that the kernels of backward's dependent chain forked behind it find free
 # slots at once -- was measured and lost: 13.58 ms uncapped, 14.45 with two workgroups per CU, 16.3 with one; the weight
 # gradients are latency-bound per workgroup and need every slot they can get, profiles/r04_ab_wgrad_cap.txt; code removed.)
@@ -332,9 +331,8 @@ class TrainPlan:
         job_pos = {id(j): k for k, j in enumerate(jobs)}
         taken = set()
         for g, (js, host, dev) in enumerate(built):
-            # the group launches where its LAST layer's dz is complete, or (WGRAD_DEFER) at a later layer's slot
-            k = job_pos[id(js[-1])] + (WGRAD_DEFER[g] if g < len(WGRAD_DEFER) else 0)
-            k = max(job_pos[id(js[-1])], min(k, len(jobs) - 1))
+            # the group launches where its LAST layer's dz is complete
+            k = job_pos[id(js[-1])]
             while jobs[k]["idx"] in taken and k + 1 < len(jobs):
                 k += 1
             while jobs[k]["idx"] in taken:

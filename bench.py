@@ -27,6 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FWD_BWD_GFLOP_PER_IMG = 49.30      # conv MACs of YOLOv5s @640, fwd 16.43 GFLOP x 3
+# ... and of the other widths at 640 x 640 (same convention); conv work scales with the image area
+FWD_BWD_GFLOP_640 = {"yolov5s": 49.30, "yolov5m": 146.6, "yolov5l": 327.0, "yolov5x": 616.3}
+
+
+def fwd_bwd_gflop_per_img(model: str, size: int):
+    """Conv GFLOP (forward + backward) per image of `model` at size x size, or None for a model SURVEY.md 8d has no figure for."""
+    g = FWD_BWD_GFLOP_640.get(model)
+    return None if g is None else g * (size / 640.0) ** 2
 MFMA_PEAK_TFLOPS = 2500.0          # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
@@ -81,17 +89,26 @@ def build_train_objects(model_name, device, world_size):
     return model, run_model, opt, loss_fn, scaler
 
 
-def pmc_traffic(families):
+def pmc_traffic(families, workload=()):
     """HBM bytes per step of a kernel family from the newest committed PMC summary (tools/profile_round.sh: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950).  The fallback of pmc_traffic_live (no
-    rocprofv3 on the box, a pass failed, AYOLO_BENCH_PMC=0): reported together with the file and commit it comes from."""
+    rocprofv3 on the box, a pass failed, AYOLO_BENCH_PMC=0): reported together with the file and commit it comes from -- and ONLY
+    for the workload the summary was measured on (its "_workload" entry; summaries without one are the default bench workload,
+    YOLOv5s 640 x 640 batch 64): another --model / --batch / --size reports traffic = None."""
     import glob
     import subprocess
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not files:
         return None, None
+    data = json.load(open(files[-1]))
+    wl = dict(zip(workload[0::2], workload[1::2]))
+    have = data.get("_workload", {"model": "yolov5s", "batch": 64, "size": 640})
+    if wl and (wl.get("--model"), int(wl.get("--batch", 0)), int(wl.get("--size", 0))) != (have["model"], int(have["batch"]), int(have["size"])):
+        return None, "no committed PMC summary for this workload (AYOLO_BENCH_PMC=1 measures it in the run)"
     tot = 0.0
-    for k, v in json.load(open(files[-1])).items():
+    for k, v in data.items():
+        if k == "_workload":
+            continue
         if any(f in k for f in families):
             tot += v["fetch_GB_per_step_corrected"] + v["write_GB_per_step"]
     src = os.path.relpath(files[-1], ROOT)
@@ -185,8 +202,8 @@ def in_situ_roofline(model, one_step, ms_per_step, batch, workload=()):
         tf = sum(fam[n][2] for n in names if n in fam) / 1e12
         return ms, gb, tf
     ms, gb, tf = view(("conv_fwd", "conv_dgrad"))
-    live = pmc_traffic_live(("k_gconv", "k_dgrad_s2"), workload)
-    traffic, src = pmc_traffic(("k_gconv", "k_dgrad_s2"))
+    live = pmc_traffic_live(("k_gconv", "k_dgrad_s2", "k_pw"), workload)
+    traffic, src = pmc_traffic(("k_gconv", "k_dgrad_s2", "k_pw"), workload)
     if live is not None:
         traffic, src = live["gb_per_step"], "measured in this run: " + live["how"]
     fams = {n: {"launches": v[3], "ms_per_step": round(v[0], 3), "algorithmic_gb": round(v[1] / 1e9, 3),
@@ -202,18 +219,21 @@ def in_situ_roofline(model, one_step, ms_per_step, batch, workload=()):
         conv_only_gb -= sum(2 * o.conv.B * o.conv.H * o.conv.W * sum(_seg_c(o)) for o in plan.bwd
                             if (o.kind & 0xff) == OP_CONV_DGRAD and o.i[1] > 0) / 1e9
     img_s = batch / (ms_per_step * 1e-3)
-    step_tf = img_s * FWD_BWD_GFLOP_PER_IMG / 1e3
-    return {"bound": "hbm", "kernel": "k_gconv / k_gconv3 / k_dgrad_s2 <f16>: every forward + dgrad conv launch of one train step, timed in situ",
+    wl = dict(zip(workload[0::2], workload[1::2]))
+    gflop_img = fwd_bwd_gflop_per_img(wl["--model"], int(wl["--size"])) if wl else FWD_BWD_GFLOP_PER_IMG
+    step_tf = img_s * gflop_img / 1e3 if gflop_img else None
+    return {"bound": "hbm", "kernel": "k_gconv / k_gconv3 / k_pw / k_dgrad_s2 <f16>: every forward + dgrad conv launch of one train step, timed in situ",
             "achieved": round(gb / ms * 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / ms * 1e3 / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_unit": "GB per train step over every k_gconv launch, PMC", "traffic_source": src,
+            "traffic": traffic, "traffic_unit": "GB per train step over every k_gconv / k_gconv3 / k_pw / k_dgrad_s2 launch, PMC", "traffic_source": src,
             "algorithmic_gb": round(gb, 3), "launch_ms_sum": round(ms, 3),
             "measured": f"HIP events around each op on its own stream inside {reps} real train steps (ayolo_run_ops_timed)",
             "mfma_view": {"achieved_tflops": round(tf / ms * 1e3, 1), "peak_tflops": MFMA_PEAK_TFLOPS,
                           "frac": round(tf / ms * 1e3 / MFMA_PEAK_TFLOPS, 4)},
             # SURVEY.md 8d's headline: (49.30 GFLOP x img/s) / dense fp16 MFMA peak, over the WHOLE step
-            "mfma": {"bound": "mfma", "achieved": round(step_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
-                     "basis": f"{FWD_BWD_GFLOP_PER_IMG} GFLOP per image (conv MACs fwd + bwd, SURVEY.md 8d) x {img_s:.0f} img/s, wall time of the step"},
+            "mfma": ({"bound": "mfma", "achieved": round(step_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(step_tf / MFMA_PEAK_TFLOPS, 4),
+                      "basis": f"{gflop_img:.2f} GFLOP per image (conv MACs fwd + bwd, SURVEY.md 8d) x {img_s:.0f} img/s, wall time of the step"}
+                     if step_tf else None),
             "bn_layers_folded_into_dgrad": plan.bn_in_dgrad,
             # round 4: BatchNorm + SiLU passes folded into their single 1x1 reader (transform on load), grouped weight-gradient launches
             "bn_act_passes_folded_into_reader": getattr(plan, "xf_layers", 0),
@@ -656,9 +676,11 @@ def main():
             "config": {"workload": f"{args.model} {args.size}x{args.size} per-GPU batch {args.batch}: forward + ComputeLoss "
                                    f"+ backward + SGD-nesterov step, fp16 autocast / fp32 master weights, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-            "step_conv_tflops": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / world, 2),
-            "step_frac_of_mfma_peak": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / world / MFMA_PEAK_TFLOPS, 4),
         }
+        gfl = fwd_bwd_gflop_per_img(args.model, args.size)        # SURVEY.md 8d's figure of THIS model (None: no figure, no number)
+        if gfl is not None:
+            out["step_conv_tflops"] = round(value * gfl / 1e3 / world, 2)
+            out["step_frac_of_mfma_peak"] = round(value * gfl / 1e3 / world / MFMA_PEAK_TFLOPS, 4)
         if not args.no_extras and world == 1:
             out["roofline"] = in_situ_roofline(model, step, ms, args.batch,
                                                ("--model", args.model, "--batch", str(args.batch), "--size", str(args.size)))

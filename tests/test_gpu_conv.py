@@ -1021,7 +1021,8 @@ W3_SHAPES = [  # (B, Cin, Cout, stride, H, W)
 
 @pytest.mark.parametrize("shape", W3_SHAPES)
 def test_wgrad3_patch_kernel_vs_torch_and_generic(shape, monkeypatch):
-    """k_wgrad3 (csrc/wgrad3.hip: the 3x3 weight gradient on a once-staged input patch; AYOLO_WGRAD3 / _MINHW / _S2 route layers to it) through
+    """k_wgrad3 (csrc/wgrad3.hip: the 3x3 weight gradient on a once-staged input patch -- retired from the default route in round 6,
+    AYOLO_WGRAD3 = 1 / 2 routes the stride-1 / all 3x3 layers to it) through
     the C ABI's ayolo_conv_wgrad: against plain PyTorch fp32 on the CPU (same fp16-rounded operands, fp32 accumulation on both
     sides), against the generic k_wgrad on the same device buffers, bit-reproducible from run to run, and accumulating into dw
     (alpha) like the generic entry."""
@@ -1040,10 +1041,8 @@ def test_wgrad3_patch_kernel_vs_torch_and_generic(shape, monkeypatch):
     dyg = dy.cuda().to(dt).contiguous(memory_format=torch.channels_last)
     d = geo.desc(dt, Cin, Cout)
     out = {}
-    for name, env in (("patch", "1"), ("generic", "0")):
+    for name, env in (("patch", "2"), ("generic", "0")):
         monkeypatch.setenv("AYOLO_WGRAD3", env)
-        monkeypatch.setenv("AYOLO_WGRAD3_S2", env)
-        monkeypatch.setenv("AYOLO_WGRAD3_MINHW", "0")
         if name == "patch":
             gq = (ctypes.c_int64 * 24)()
             _lib.check(_lib.lib().ayolo_wgrad3_geometry(d, gq, 24), "ayolo_wgrad3_geometry")

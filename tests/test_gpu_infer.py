@@ -384,19 +384,21 @@ def test_fp16_train_step_is_reproducible_and_routes_agree(monkeypatch):
         m.load_state_dict(sd)
         m.__dict__.pop("_plans", None)
         m.use_plan = kw.get("use_plan", True)
-        old, old_xf, old_xw = P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD, P.XF_WGRAD_ON_LOAD
+        old, old_xf, old_xw, old_pair, old_sppf = P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD, P.XF_WGRAD_ON_LOAD, P.BN_APPLY_PAIR, P.SPPF_FUSED
         P.BN_REDUCE_IN_DGRAD = kw.get("bnr", True)
         P.XF_ON_LOAD = kw.get("xf", True)
         P.XF_WGRAD_ON_LOAD = kw.get("xf_wgrad", False)
-        monkeypatch.setenv("AYOLO_WGRAD3", "1" if kw.get("wgrad3") else "0")      # read when the plan's group tables are built
-        monkeypatch.setenv("AYOLO_WGRAD3_MINHW", "0")                             # (every stride-1 3x3 layer, not only the large maps)
+        P.BN_APPLY_PAIR = kw.get("pair", True)
+        P.SPPF_FUSED = kw.get("sppf", True)
+        monkeypatch.setenv("AYOLO_WGRAD3", "1" if kw.get("wgrad3") else "0")      # read when the plan's group tables are built (1: every
+                                                                                  # stride-1 3x3 layer on the retired k_wgrad3)
         try:
             loss, _, g = _train_step(m, x, t, amp=True)
             if kw.get("use_plan", True):
                 pl = [v for v in m._plans.values() if v][0]
                 assert (pl.xf_layers >= 10) == kw.get("xf", True), pl.xf_layers
         finally:
-            P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD, P.XF_WGRAD_ON_LOAD = old, old_xf, old_xw
+            P.BN_REDUCE_IN_DGRAD, P.XF_ON_LOAD, P.XF_WGRAD_ON_LOAD, P.BN_APPLY_PAIR, P.SPPF_FUSED = old, old_xf, old_xw, old_pair, old_sppf
             m.use_plan = True
         last.append(g)
         return loss, _flat(g)
@@ -434,6 +436,20 @@ def test_fp16_train_step_is_reproducible_and_routes_agree(monkeypatch):
     assert _cos(g0, g6) >= 1.0 - 1e-9
     bad = [k for k in conv_w if float((last[0][k] - last[-1][k]).abs().max()) > 1e-5 * float(last[0][k].abs().max())]
     assert not bad, bad
+    # round 6: the BatchNorm-backward apply of a merged cv1 | cv2 pair as one launch (ayolo_bn_act_bwd_apply2) against two launches
+    # over half rows: the same arithmetic per element -- the loss and every conv weight gradient bit for bit, the rest as close as
+    # two runs of one route are (BatchNorm gradients come from fp64 sums accumulated by atomics: their last fp32 place may move)
+    l7, g7 = run(pair=False)
+    assert l7 == l0, (l7, l0)
+    not_equal = [k for k in conv_w if not torch.equal(last[0][k], last[-1][k])]
+    assert not not_equal, not_equal
+    assert _cos(g0, g7) >= 1.0 - 1e-9 and float((g0 - g7).abs().max()) <= 1e-5 * float(g0.abs().max())
+    # ... and SPPF's pool cascade in one launch per direction (ayolo_sppf_pool_fwd / _bwd) against three pool launches: values and
+    # window positions are the scan's, the backward sums are exact where the launches' sequential fp32 sums round -- bit-identical
+    # loss, gradients equal up to a stray last place of the pooled map's gradient
+    l8, g8 = run(sppf=False)
+    assert l8 == l0, (l8, l0)
+    assert _cos(g0, g8) >= 1.0 - 1e-9 and float((g0 - g8).abs().max()) <= 1e-4 * float(g0.abs().max())
     l2, g2 = run(bnr=False)
     l3, g3 = run(use_plan=False)
     print("fp16 step: same route twice cos %.9f; epilogue sums vs reduce pass cos %.9f; plan vs module path cos %.9f"
@@ -547,32 +563,40 @@ def test_full_size_fp16_step_vs_fp32_mode(name, batch, thr):
 
 def test_cfg3_model_yolov5l_fp16_train_step_vs_oracle():
     """BASELINE cfg 3's model and dtype on one GPU (the 8-GPU exchange itself is covered by the bucket tests and measured by
-    the driver): YOLOv5l, fp16 autocast with a scaled loss, one train step at 2 x 256^2 against the CPU oracle.
-    Measured logits error / range per level: 2.4 %, 4.3 %, 5.7-6.5 % (the stride-32 level normalises over 128 samples per
-    channel behind ~100 fp16 layers); the same figures with the 128-pixel tiles forced (AYOLO_GCONV_TP=128) and with sibling
-    merging off, and 1e-4 in the exact-fp32 mode of the same kernels -- i.e. storage rounding, not a kernel variant."""
+    the driver): YOLOv5l, fp16 autocast with a scaled loss, one train step at 4 x 320^2 against the CPU oracle, at a size and
+    with BatchNorm gains (0.3, see test_fp16_train_step_well_conditioned_vs_oracle) where the comparison is decided by the kernels:
+    the stride-32 level normalises over 400 samples per channel (until round 5 this test ran 2 x 256^2 at random initialisation
+    -- 128 samples behind ~100 fp16 layers -- and could only hold the logits to 10 % of their range and the gradient to cosine
+    0.80).  Logits within 0.5 % of the range per level (measured 0.05 %), loss within 2e-3, whole-gradient cosine >= 0.99 (measured
+    0.9972) against the oracle's Jacobian
+    at the fp16 logits (_oracle_grads_at_logits) and >= 0.98 against the oracle's own step."""
     from ayolov2_amd.losses import ComputeLoss
     m, r = _pair("l", seed=33)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.fill_(0.3)
+    r.load_state_dict(m.state_dict())
     for mod in (m, r):
         mod.hyp, mod.gr, mod.nc = dict(HYP), 1.0, 80
     m, r = m.cuda().train(), r.train()
-    x, t = torch.rand(2, 3, 256, 256), _targets(2, 34)     # 8 x 8 cells at stride 32: batch statistics over 128 samples
+    x, t = torch.rand(4, 3, 320, 320), _targets(4, 34)
     raws_r = r(x)
     loss_r, _ = ComputeLoss(r)(raws_r, t)
     loss_r.backward()
+    gr_direct = {k: p.grad.detach().clone() for k, p in r.named_parameters()}
     l16, raws16, g16 = _train_step(m, x.cuda(), t.cuda(), amp=True)
-    for a, b in zip(raws16, raws_r):
-        assert float((a.cpu() - b.detach()).abs().max()) <= 0.10 * float(b.max() - b.min())
-    print("yolov5l fp16 vs oracle: loss %.6f / %.6f" % (l16, float(loss_r.detach())))
-    assert abs(l16 - float(loss_r.detach())) <= 1e-2 * abs(float(loss_r.detach()))
-    gr = dict(r.named_parameters())
-    a_ = torch.cat([g16[k].cpu().flatten().double() for k in g16])
-    b_ = torch.cat([gr[k].grad.flatten().double() for k in g16])
-    cos = float((a_ @ b_) / (a_.norm() * b_.norm()))
-    print("yolov5l fp16 vs oracle: whole-gradient cosine %.5f" % cos)
-    # measured 0.905: at 2 images the stride-32 BatchNorms see 128 samples and the fp16 noise of ~100 layers is amplified;
-    # the well-conditioned check of this model's fp16 kernels is test_full_size_fp16_step_vs_fp32_mode[l-16]
-    assert cos >= 0.80, cos
+    worst = max(float((a.cpu() - b.detach()).abs().max()) / float(b.max() - b.min()) for a, b in zip(raws16, raws_r))
+    print("yolov5l fp16 vs oracle: loss %.6f / %.6f, logits within %.4f of the range" % (l16, float(loss_r.detach()), worst))
+    assert worst <= 0.005, worst
+    assert abs(l16 - float(loss_r.detach())) <= 2e-3 * abs(float(loss_r.detach()))
+    gr, cond = _oracle_grads_at_logits(r, x, t, raws16)
+    a_ = _flat({k: v.cpu() for k, v in g16.items()})
+    cos, direct = _cos(a_, _flat({k: gr[k] for k in g16})), _cos(a_, _flat({k: gr_direct[k] for k in g16}))
+    print("yolov5l fp16 vs oracle: whole-gradient cosine %.5f (oracle Jacobian at the fp16 logits), %.5f (oracle's own step), loss-gradient "
+          "cosine per level %s" % (cos, direct, [round(c, 5) for c in cond]))
+    assert cos >= 0.99, cos
+    assert direct >= 0.98, direct
 
 
 def test_decomposed_model_train_step_fp32():

@@ -206,9 +206,16 @@ def test_tucker_decomposed_model_eval():
     np.testing.assert_allclose(zg.cpu().numpy(), zr.numpy(), rtol=2e-4, atol=2e-3)
 
 
+# plan vs module path in the exact-fp32 mode: both routes are reproducible (fp64 statistics, fixed-order split-K sums -- no atomics in
+# any sum since round 4); they differ in how the work is cut (merged cv1 | cv2 convs, grouped weight-gradient items, one
+# statistics replica per workgroup slot), i.e. in the ORDER of fp32 partial sums.  Thresholds = measured on MI355X in round 6
+# (printed by the test) with a factor ~3 of room.
+LOGIT_TOL, GRAD_TOL = 2e-5, 2e-4       # measured: 3.6e-6 (logits), 4.8e-5 (worst parameter)
+
+
 def test_plan_equals_module_path():
-    """The static-plan executor and the per-module autograd path launch the same kernels: logits are identical and
-    gradients agree to atomics-order noise (fp32 mode)."""
+    """The static-plan executor and the per-module autograd path launch the same kernels over differently cut work: logits and
+    gradients agree to the rounding of re-ordered fp32 partial sums (fp32 mode; LOGIT_TOL / GRAD_TOL above)."""
     import copy
     m, r = _pair("n", seed=13)
     m2 = copy.deepcopy(m)
@@ -216,13 +223,16 @@ def test_plan_equals_module_path():
     m.train(); m2.train(); r.train()
     x = torch.rand(2, 3, 96, 128).cuda()
     ra, rb = m(x), m2(x)
+    worst_l = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(ra, rb))
     for a, b in zip(ra, rb):
-        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)   # atomics order
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=LOGIT_TOL, atol=LOGIT_TOL)
     sum(t.square().sum() for t in ra).backward()
     sum(t.square().sum() for t in rb).backward()
     pb = dict(m2.named_parameters())
+    worst_g = max(_rel(p.grad.float().cpu(), pb[k].grad.float().cpu()) for k, p in m.named_parameters())
+    print("plan vs module path (fp32): logits %.2e of the largest, gradients %.2e of each parameter's largest element" % (worst_l, worst_g))
     for k, p in m.named_parameters():
-        assert _rel(p.grad.float().cpu(), pb[k].grad.float().cpu()) < 2e-3, k   # split-K atomics order
+        assert _rel(p.grad.float().cpu(), pb[k].grad.float().cpu()) < GRAD_TOL, k
     # second step through the cached plan (buffers reused) still matches
     m.zero_grad(set_to_none=True); m2.zero_grad(set_to_none=True)
     x2 = torch.rand(2, 3, 96, 128).cuda()
@@ -290,6 +300,9 @@ def test_model_ema_fused_update():
             assert torch.equal(v.cpu(), ref[k])
 
 
+PERM_TOL, SCALE_TOL = 5e-3, 2e-6       # measured: 1.3e-3 (permutation), 2.1e-7 (loss scale 2: one fused multiply-add rounds differently)
+
+
 def test_full_size_step_properties():
     """BASELINE configuration (YOLOv5s, batch 64, 640x640) where the CPU oracle is too slow: the train step must be
     invariant to a permutation of the images of the batch (targets re-indexed) and linear in the loss scale -- every
@@ -332,6 +345,8 @@ def test_full_size_step_properties():
         worst_p = max(worst_p, float((g0[k] - g1[k]).abs().max()) / scale)
         worst_s = max(worst_s, float((2.0 * g0[k] - g2[k]).abs().max()) / (2 * scale))
     print("full-size fp32: permutation err %.2e, scale-linearity err %.2e" % (worst_p, worst_s))
-    # run-to-run noise of the worst (most cancelling) parameter is ~1e-2 even in fp32: atomics order in the statistics
-    assert worst_p < 3e-2, worst_p
-    assert worst_s < 3e-2, worst_s
+    # scale linearity: a power-of-two loss scale changes no rounding of a reproducible fp32 step (SCALE_TOL: last place).  Permutation: the
+    # images' rows move to other workgroups, so every fp32 partial sum (statistics replicas, split-K items) adds in another order;
+    # the worst (most cancelling) parameter carries that as PERM_TOL of its largest element (measured, printed above).
+    assert worst_s <= SCALE_TOL, worst_s
+    assert worst_p < PERM_TOL, worst_p

@@ -378,8 +378,8 @@ def test_wgrad_group_tables_cover_every_tile_once(monkeypatch):
     from ayolov2_amd._lib import WgradJob
     lib = _lib.lib()
     F16 = 0
-    monkeypatch.setenv("AYOLO_WGRAD3", "1")      # the patch-staged 3x3 kernel for every stride-1 3x3 layer (default: maps of >= 80 rows):
-    monkeypatch.setenv("AYOLO_WGRAD3_MINHW", "0")    # its planner is part of what is checked here
+    monkeypatch.setenv("AYOLO_WGRAD3", "1")      # the patch-staged 3x3 kernel for every stride-1 3x3 layer (retired from the default
+                                                 # route in round 6): its planner is part of what is checked here
     shapes = [  # (B, H, W, Cin, Cout, k, s)
         (8, 40, 40, 128, 128, 3, 1), (8, 40, 40, 256, 64, 1, 1), (8, 80, 80, 64, 32, 3, 2), (8, 20, 20, 512, 255 + 1, 1, 1),
         (192, 320, 320, 64, 64, 1, 1)]           # the last: x = dy = 2.5 GB -> two batch halves of 1.26 GB
@@ -398,7 +398,7 @@ def test_wgrad_group_tables_cover_every_tile_once(monkeypatch):
     _lib.check(lib.ayolo_wgrad_group_info(host, -1, out, 20), "info")
     njobs, n_items, n_red, ws_floats, njobs3 = out[0], [out[1], out[2], out[3], out[12]], out[4], out[5], out[13]
     # the fp16 3x3 / stride-1 layer is a k_wgrad3 job (item class 3, numbered behind k_wgrad's; stride 2 stays on the generic kernel
-    # unless AYOLO_WGRAD3_S2=1); the 320 x 320 layer became two halves
+    # unless AYOLO_WGRAD3=2); the 320 x 320 layer became two halves
     assert njobs == len(shapes) - 1 + 1 and njobs3 == 1 and ws_floats * 4 == wb.value
     jobs = []
     for j in range(njobs + njobs3):
