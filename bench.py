@@ -52,7 +52,7 @@ def synth_targets(batch, per_img, gen):
     return torch.cat((img[:, None], cls[:, None], xy, wh), 1)
 
 
-def build_train_objects(model_name, device, world_size):
+def build_train_objects(model_name, device, world_size, sync_bn=False):
     from ayolov2_amd import YOLOModel
     from ayolov2_amd.losses import ComputeLoss
     from torch import nn
@@ -84,7 +84,7 @@ def build_train_objects(model_name, device, world_size):
             run_model = nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
         else:
             from ayolov2_amd.trainer import FlatGradDDP      # one all-reduce of the plan's flat gradient arena per step
-            run_model = FlatGradDDP(model)
+            run_model = FlatGradDDP(model, sync_bn=sync_bn)     # sync_bn: train_config.yaml:17 (default false in the reference)
     scaler = torch.amp.GradScaler("cuda")
     return model, run_model, opt, loss_fn, scaler
 
@@ -594,6 +594,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / NMS legs")
+    ap.add_argument("--sync-bn", action="store_true", help="synchronised BatchNorm across the ranks (train_model_builder.py:135-136; off in the reference's config)")
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -622,7 +623,7 @@ def main():
         rccl_ranks = dist.get_world_size()
         assert rccl_ranks == world, (rccl_ranks, world)
 
-    model, run_model, opt, loss_fn, scaler = build_train_objects(args.model, device, 2 if force_ddp and world == 1 else world)
+    model, run_model, opt, loss_fn, scaler = build_train_objects(args.model, device, 2 if force_ddp and world == 1 else world, sync_bn=args.sync_bn)
     gen = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, args.size, args.size, generator=gen).to(device)       # resident in HBM
     targets_cpu = synth_targets(args.batch, 8, gen)              # labels arrive from the CPU loader (data_loader.py:905-908)
