@@ -2559,7 +2559,10 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     // the streaming 1x1 kernel (k_pw): whole reductions of 64 / 128 / 256 channels into 64- or 128-channel tiles -- forward, dgrad and
     // the transform-on-load readers.  Same-box A/B of the routes (profiles/r06_ab_pw_v1..v4.txt, r06_ab_pw_nw8.txt): TM 128 with
     // K = 128 / 256 -0.07 ms, + K = 64 and the 64-channel tiles -0.1 ... -0.2 ms, + the readers -0.23 ms in all; the 32-channel
-    // tiles (K = 32 / 64 on the 160 x 160 / 320 x 320 maps) were level with k_gconv and are not instantiated.
+    // tiles (K = 32 / 64 on the 160 x 160 / 320 x 320 maps) were level with k_gconv and are not instantiated.  K = 512 as two half-K
+    // sub-tiles per pixel tile (128 weight registers, one workgroup per CU) was built and measured in round 6: 512 -> 256 at 40 x 40
+    // 68.8 -> 53.7 us, but every 512-channel layer at 20 x 20 level or slower (three or four pixel tiles per workgroup do not amortise
+    // 256 KB of weight loads: 512 -> 256 35.6 -> 44.5 us) and the step +0.08 ms (profiles/r06_ab_pw_k512.txt); not kept.
     if constexpr (sizeof(T) == 2 && XF && EM == 0) {
         // transform on load: the same tilings as the plain conv of the same shape (a layer's two routes share one kernel family, so
         // that they stay bit-identical: test_conv_transform_on_load_equals_materialised_route)

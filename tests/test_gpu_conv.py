@@ -42,6 +42,12 @@ SHAPES = [
     (2, 256, 128, 1, 1, 0, 16, 16),
     (2, 128, 384, 1, 1, 0, 5, 5),
     (5, 128, 136, 1, 1, 0, 64, 65),
+    # ... K = 512 as two half-K sub-tiles per pixel tile (forward: Cin = 512; dgrad: Cout = 512): ragged tile, one / four channel tiles,
+    # several pixel tiles per workgroup
+    (2, 512, 256, 1, 1, 0, 9, 11),
+    (1, 512, 512, 1, 1, 0, 20, 20),
+    (3, 256, 512, 1, 1, 0, 7, 5),
+    (16, 512, 128, 1, 1, 0, 40, 40),
 ]
 
 
@@ -490,6 +496,8 @@ BNR_CASES = [
     ((2, 128, 128, 1, 1, 0, 13, 17), [(0, 128)]),              # k_pw (K = Cout = 128), ragged last tile
     ((3, 256, 256, 1, 1, 0, 9, 11), [(0, 128), (128, 128)]),   # k_pw (K = 256), two channel tiles, a segment each
     ((2, 256, 128, 1, 1, 0, 40, 40), [(0, 96), (96, 160)]),    # k_pw, segment boundary inside a channel tile (32-channel blocks)
+    ((2, 256, 512, 1, 1, 0, 10, 10), [(0, 256)]),              # k_pw with K = Cout = 512 (two sub-tiles per pixel tile), a wave without pixels
+    ((3, 512, 512, 1, 1, 0, 9, 11), [(0, 256), (256, 256)]),   # ... four channel tiles, a segment per pair
 ]
 
 
@@ -900,7 +908,8 @@ def test_conv_transform_on_load_equals_materialised_route(shape):
 
 
 @pytest.mark.parametrize("case", [(4, 64, 64, 128, 40, 40, (1, 1), (True, True)), (2, 32, 96, 64, 24, 20, (1, 0), (True, False)),
-                                  (3, 128, 128, 256, 10, 12, (0, 1), (False, True)), (2, 64, 32, 48, 33, 7, (1, 1), (True, True))])
+                                  (3, 128, 128, 256, 10, 12, (0, 1), (False, True)), (2, 64, 32, 48, 33, 7, (1, 1), (True, True)),
+                                  (3, 256, 256, 256, 10, 12, (1, 1), (True, True)), (2, 256, 256, 512, 9, 7, (1, 0), (True, False))])
 def test_conv_transform_on_load_two_segments(case):
     """C3's cv3 reads [last Bottleneck output | cv2 half]: two input segments from two buffers with their own channel strides,
     each virtual (the producer's z, transformed on load) or a plain activation.  Forward vs the conv over the materialised concat
