@@ -538,3 +538,19 @@ def test_weight_gradient_group_count_follows_the_work():
         n = Counter(o.kind & 0xff for o in pl.bwd)[P.OP_WGRAD_GROUP]
         assert lo <= n <= hi, (name, batch, n)
         assert sum(v[2] for v in pl.wgroup_costs.values()) >= len({j["off"] for j in pl._wjobs})
+
+
+def test_kernarg_touch_destinations_survive_until_the_wait():
+    """ScalarTouch (csrc/common.h) prefetches a kernel's argument block with inline-asm `s_load_dword` into SGPRs the compiler
+    believes are defined at once; tools/check_kernarg_touch.py compiles a source to gfx950 assembly and verifies that nothing
+    redefines those registers before the `s_waitcnt lgkmcnt(0)` of done().  Here on elementwise.hip (10 s; conv.hip
+    takes 90 s and is checked by tools/final_round.sh: profiles/r06_kernarg_touch_check.txt)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_kernarg_touch.py"),
+                          os.path.join(root, "ayolov2_amd", "csrc", "elementwise.hip")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " 0 hazards" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert int(out.stdout.split(" touch sequences")[0].split()[-1]) >= 20      # the parser still finds the inline asm

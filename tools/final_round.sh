@@ -6,6 +6,8 @@ tag=${1:-r05}
 out=gpurun_out; mkdir -p $out
 [ -z "$SKIP_TESTS" ] && timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $out/${tag}_gpu_tests_tail.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.txt 2>&1
+# inline-asm kernel-argument prefetch: its destination SGPRs must survive until the wait (tools/check_kernarg_touch.py, no GPU needed)
+timeout 600 python tools/check_kernarg_touch.py ayolov2_amd/csrc/conv.hip ayolov2_amd/csrc/elementwise.hip 2>&1 | tail -3 > $out/${tag}_kernarg_touch_check.txt
 # kernel stats + the two PMC passes first: bench.py's roofline.traffic then cites THIS tree's summary (copy it into profiles/)
 bash tools/profile_round.sh $tag > /dev/null 2>&1
 cp $out/${tag}_pmc_hbm_traffic.json profiles/ 2>/dev/null
