@@ -4160,7 +4160,7 @@ static int wgroup_plan(const ayolo_wgrad_job* jj, int njobs, WGroupPlan& g) {
         layers.push_back({j0, g.jobs.size(), a.dw, a.alpha, a.overwrite, (unsigned)(a.dw_ld > 0 ? a.dw_ld : kj), false});
     }
     // ---- item length.  All items of the group together should fill the chip's workgroup slots a few times over (so that the
-    // tail of the launch is short against its body) without cutting a layer finer than ~AYOLO_WGRAD_MINQ steps per item
+    // tail of the launch is short against its body) without cutting a layer finer than ~24 (minq) steps per item
     // (prologue + epilogue of a workgroup cost ~10 steps' worth of time; every extra split is one more N x K slot to store and add)
     const int bpc = g.dtype == AYOLO_F16 ? 3 : 1;
     const double slots = (double)num_cus() * bpc;

@@ -20,8 +20,8 @@ for k in (5, 7):
     t_f = timeit(lambda: ops.maxpool_fwd(x, k, y), 20)
     t_b = timeit(lambda: ops.maxpool_bwd(arg, g[:, C:2 * C], k, g[:, :C], accumulate=True), 20)
     print(f"k={k}: forward {t_f:6.1f} us   backward {t_b:6.1f} us")
-# the whole cascade in one launch per direction (ayolo_sppf_pool_fwd / _bwd; AYOLO_SPPF_NCG picks the channel groups per workgroup)
+# the whole cascade in one launch per direction (ayolo_sppf_pool_fwd / _bwd; four channel groups per workgroup on this shape)
 arg3 = ops.sppf_pool_fwd(cat, C)
 t_f = timeit(lambda: ops.sppf_pool_fwd(cat, C), 20)
 t_b = timeit(lambda: ops.sppf_pool_bwd(arg3, g, C), 20)
-print(f"cascade (three pools): forward {t_f:6.1f} us   backward {t_b:6.1f} us   [AYOLO_SPPF_NCG={os.environ.get('AYOLO_SPPF_NCG', 'auto')}]")
+print(f"cascade (three pools): forward {t_f:6.1f} us   backward {t_b:6.1f} us")
