@@ -1418,9 +1418,10 @@ extern "C" int ayolo_sppf_pool_bwd(int dtype, const unsigned char* argmax, void*
     return AYOLO_OK;
 }
 
-/* 1 when ayolo_sppf_pool_fwd / _bwd accept this map (it fits a workgroup's LDS), else 0 */
+/* > 0 when ayolo_sppf_pool_fwd / _bwd accept this map (it fits a workgroup's LDS): the channel groups a workgroup takes -- 4 / 2 / 1,
+ * i.e. 64- / 32- / 16-byte runs per pixel row; with 1 the cascade is slower than it could be (profiles/r06_sppf_geometry.txt) */
 extern "C" int ayolo_sppf_pool_supported(int dtype, int H, int W, int C) {
-    return dtype == AYOLO_F16 && C % 8 == 0 && sppf_ncg(H, W, C) > 0 ? 1 : 0;
+    return dtype == AYOLO_F16 && C % 8 == 0 ? sppf_ncg(H, W, C) : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ from . import _lib, ops
 from . import functional as F_
 from ._lib import EPI_AFFINE, EPI_AFFINE_RES, EPI_AFFINE_SILU, EPI_AFFINE_SILU_RES, EPI_HEAD, EPI_NONE
 from .modules import C3, SPPF, Bottleneck, Concat, Conv, UpSample, YOLOHead, _act_code, _pair
-from .plan import (OP_CAST_WEIGHT, OP_CAST_WEIGHTS, OP_CONV_FWD, OP_MAXPOOL_FWD, OP_PACK_INPUT, OP_UPSAMPLE_FWD, Act, Op,
+from .plan import (OP_CAST_WEIGHT, OP_CAST_WEIGHTS, OP_CONV_FWD, OP_MAXPOOL_FWD, OP_PACK_INPUT, OP_SPPF_FWD, OP_UPSAMPLE_FWD, Act, Op,
                    PlanUnsupported, _op)
 
 OP_HEAD_DECODE = 20
@@ -324,9 +324,14 @@ class InferPlan:
         self._block(m.cv1, x, cat.slice(0, h))
         k = m.pool.kernel_size
         code = ops.dtype_code(self.dt)
-        for j in range(3):
-            src, d = cat.slice(j * h, (j + 1) * h), cat.slice((j + 1) * h, (j + 2) * h)
-            self.fwd.append(_op(OP_MAXPOOL_FWD, i=(code, ops.nhwc_info(src.t)[4], ops.nhwc_info(d.t)[4], self.B, H, W, h, k), p=(src.t, d.t, None)))
+        # the three chained pools in one launch on the LDS-resident map where a workgroup gets runs of >= 32 bytes (the 20 x 20 maps of
+        # 640 x 640 inputs; at 40 x 40 only one channel group fits and three pool launches are faster)
+        if k == 5 and self.dt == torch.float16 and _lib.lib().ayolo_sppf_pool_supported(code, H, W, h) >= 2:
+            self.fwd.append(_op(OP_SPPF_FWD, i=(code, ops.nhwc_info(cat.t)[4], self.B, H, W, h), p=(cat.t, None)))
+        else:
+            for j in range(3):
+                src, d = cat.slice(j * h, (j + 1) * h), cat.slice((j + 1) * h, (j + 2) * h)
+                self.fwd.append(_op(OP_MAXPOOL_FWD, i=(code, ops.nhwc_info(src.t)[4], ops.nhwc_info(d.t)[4], self.B, H, W, h, k), p=(src.t, d.t, None)))
         return self._block(m.cv2, cat, dst)
 
     def _upsample(self, x: Act, dst: Optional[Act]) -> Act:

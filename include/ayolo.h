@@ -302,7 +302,8 @@ int ayolo_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, in
  * ayolo_maxpool_fwd's format (first maximum in row-major scan order, torch's NaN rule);  backward takes the gradient of the
  * concat buffer and leaves d(x) = d0 + pool_bwd(d1 + pool_bwd(d2 + pool_bwd(d3))) in slice 0 (intermediate sums rounded to fp16
  * as three ayolo_maxpool_bwd launches would store them; slices 1..3 are left as they were).  The map must fit a workgroup's
- * LDS: ayolo_sppf_pool_supported() == 1, else use the per-pool entry points. */
+ * LDS: ayolo_sppf_pool_supported() > 0 (its value: the 16-byte channel groups a workgroup takes, 4 / 2 / 1 -- the width of the
+ * runs it reads and writes per pixel row), else use the per-pool entry points. */
 int ayolo_sppf_pool_fwd(int dtype, void* cat, int ld, unsigned char* argmax, int B, int H, int W, int C, ayolo_stream s);
 int ayolo_sppf_pool_bwd(int dtype, const unsigned char* argmax, void* dcat, int ld, int B, int H, int W, int C, ayolo_stream s);
 int ayolo_sppf_pool_supported(int dtype, int H, int W, int C);
