@@ -34,5 +34,5 @@ for path in sys.argv[1:]:
             small += us; ns += 1; bytes_s += mb
         else:
             big += us; nb += 1; bytes_b += mb
-    print(f"{path}: <=40^2: {ns} ops {small / 1e3:.3f} ms {bytes_s / 1e3:.2f} GB ({bytes_s / max(small, 1e-9) * 1e-3:.2f} TB/s) | larger: {nb} ops {big / 1e3:.3f} ms "
-          f"{bytes_b / 1e3:.2f} GB ({bytes_b / max(big, 1e-9) * 1e-3:.2f} TB/s)")
+    print(f"{path}: <=40^2: {ns} ops {small / 1e3:.3f} ms {bytes_s / 1e3:.2f} GB ({bytes_s / max(small, 1e-9):.2f} TB/s) | larger: {nb} ops {big / 1e3:.3f} ms "
+          f"{bytes_b / 1e3:.2f} GB ({bytes_b / max(big, 1e-9):.2f} TB/s)")
