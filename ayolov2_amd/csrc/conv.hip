@@ -2105,7 +2105,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
 template <int TM, int KC>
 struct PW {
     static constexpr int NW = 8;
-    static constexpr int WM = TM / 32, WP = NW / WM, TP = 32 * WP;     // 128 channels: 64-pixel tiles; 64 channels: 128-pixel tiles
+    static constexpr int WM = TM / 32, WP = NW / WM, TP = 32 * WP;     // 256 channels: 32-pixel tiles; 128: 64-pixel tiles; 64: 128-pixel tiles
     static constexpr int K = KC * 16, RB = K * 2;                      // bytes per x row
     static constexpr int CPR = RB / 16;                                // 16-byte chunks per row: 16 / 32
     static constexpr int XT = TP * RB;                                 // bytes per stage
@@ -2569,6 +2569,13 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
         if (p.xf && p.C % BK == 0 && p.xs_split % 8 == 0) {
             const bool two = p.x2 != nullptr;
             if constexpr (TM == 128) {
+                // 256-channel tiles (eight wavefronts x 32 channels, 32-pixel tiles) where the output channels are a multiple of 256: every x
+                // tile is read -- and transformed -- once instead of once per 128-channel tile (256 -> 256 at 40 x 40: 59-62 -> 48-52 us,
+                // step -0.09 ms, profiles/r06_ab_pw_tm256.txt)
+                if (p.Nout % 256 == 0) {
+                    if (p.C == 128) return two ? launch_pw<256, 8, EM, false, 2>(p, s) : launch_pw<256, 8, EM, false, 1>(p, s);
+                    if (p.C == 256) return two ? launch_pw<256, 16, EM, false, 2>(p, s) : launch_pw<256, 16, EM, false, 1>(p, s);
+                }
                 if (p.C == 64) return two ? launch_pw<TM, 4, EM, false, 2>(p, s) : launch_pw<TM, 4, EM, false, 1>(p, s);
                 if (p.C == 128) return two ? launch_pw<TM, 8, EM, false, 2>(p, s) : launch_pw<TM, 8, EM, false, 1>(p, s);
                 if (p.C == 256) return two ? launch_pw<TM, 16, EM, false, 2>(p, s) : launch_pw<TM, 16, EM, false, 1>(p, s);
@@ -2581,6 +2588,10 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     if constexpr (sizeof(T) == 2 && !XF && EM != 3) {
         if (p.lin) {
             if constexpr (TM == 128) {
+                if (p.Nout % 256 == 0) {
+                    if (p.C == 128) return launch_pw<256, 8, EM, BNR>(p, s);
+                    if (p.C == 256) return launch_pw<256, 16, EM, BNR>(p, s);
+                }
                 if (p.C == 64) return launch_pw<TM, 4, EM, BNR>(p, s);
                 if (p.C == 128) return launch_pw<TM, 8, EM, BNR>(p, s);
                 if (p.C == 256) return launch_pw<TM, 16, EM, BNR>(p, s);
