@@ -2563,7 +2563,9 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
     // sub-tiles per pixel tile (128 weight registers, one workgroup per CU) was built and measured in round 6: 512 -> 256 at 40 x 40
     // 68.8 -> 53.7 us, but every 512-channel layer at 20 x 20 level or slower (three or four pixel tiles per workgroup do not amortise
     // 256 KB of weight loads: 512 -> 256 35.6 -> 44.5 us) and the step +0.08 ms (profiles/r06_ab_pw_k512.txt); not kept.
-    if constexpr (sizeof(T) == 2 && XF && EM == 0) {
+    // YOLOHead's epilogue (EM 3: fp32 logits + bias; 255 of 256 channels) on the same kernel: 128 -> 255 at 80 x 80 132 -> 119 us,
+    // 256 -> 255 at 40 x 40 65 -> 51 us, step -0.04 ms (profiles/r06_ab_pw_head.txt).
+    if constexpr (sizeof(T) == 2 && XF && (EM == 0 || EM == 3)) {
         // transform on load: the same tilings as the plain conv of the same shape (a layer's two routes share one kernel family, so
         // that they stay bit-identical: test_conv_transform_on_load_equals_materialised_route)
         if (p.xf && p.C % BK == 0 && p.xs_split % 8 == 0) {
@@ -2572,7 +2574,7 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
                 // 256-channel tiles (eight wavefronts x 32 channels, 32-pixel tiles) where the output channels are a multiple of 256: every x
                 // tile is read -- and transformed -- once instead of once per 128-channel tile (256 -> 256 at 40 x 40: 59-62 -> 48-52 us,
                 // step -0.09 ms, profiles/r06_ab_pw_tm256.txt)
-                if (p.Nout % 256 == 0) {
+                if (EM == 3 ? (p.Nout > 128 && p.Nout <= 256) : p.Nout % 256 == 0) {
                     if (p.C == 128) return two ? launch_pw<256, 8, EM, false, 2>(p, s) : launch_pw<256, 8, EM, false, 1>(p, s);
                     if (p.C == 256) return two ? launch_pw<256, 16, EM, false, 2>(p, s) : launch_pw<256, 16, EM, false, 1>(p, s);
                 }
@@ -2585,10 +2587,10 @@ static int launch_gconv_em(const GConvP& p, hipStream_t s) {
             }
         }
     }
-    if constexpr (sizeof(T) == 2 && !XF && EM != 3) {
+    if constexpr (sizeof(T) == 2 && !XF) {
         if (p.lin) {
             if constexpr (TM == 128) {
-                if (p.Nout % 256 == 0) {
+                if (EM == 3 ? (p.Nout > 128 && p.Nout <= 256) : p.Nout % 256 == 0) {
                     if (p.C == 128) return launch_pw<256, 8, EM, BNR>(p, s);
                     if (p.C == 256) return launch_pw<256, 16, EM, BNR>(p, s);
                 }
