@@ -2084,7 +2084,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_s2f(GConvP p) {
 // channels as a STREAMING kernel.
 //
 // Why: on the <= 40 x 40 maps k_gconv runs one 256-pixel tile per workgroup at 1-1.5 workgroups per CU.  A life of 18 k cycles
-// (128 -> 128 on 40 x 40, tools/gconv_probe.py, profiles/r06_probe_small_maps.txt) is 4.5 k of prologue, 4 k-steps of ~1.35 k (one
+// (128 -> 128 on 40 x 40, tools/gconv_probe.py, profiles/r06_probe_small_maps_full.txt) is 4.5 k of prologue, 4 k-steps of ~1.35 k (one
 // barrier + counted wait + fragment fetch + DMA issue per 32-deep step, 512 cycles of them matrix pipe) and 5.3 k of epilogue, all
 // at the issue rate of one or two wavefronts per SIMD.  Eight wavefronts on the same step structure bought nothing (v1 of this
 // round, profiles/r06_probe_nw8_v1.txt: a step costs ~800 cycles however few MFMAs it holds -- it is the barrier / wait / fetch
