@@ -502,7 +502,7 @@ class TrainPlan:
             dzv = dz.view(self.B, geo.Ho, geo.Wo, Ct).permute(0, 3, 1, 2) if dz is not None else None
             pair = (BN_APPLY_PAIR and len(per) == 2 and residual is None and not stem_fused and per[0][1] == per[1][1]
                     and Ct <= 2048 and all(e[5] % (8 if dt == torch.float16 else 4) == 0 for e in per))
-            pair_p, pair_i = [], []
+            pair_p, pair_i, pair_done = [], [], []
             for bn, act, a, zj, c0, co, sm_off, su_off, gg_off, gb_off in per:
                 da = a.grad()
                 if not a.is_init():
@@ -533,8 +533,11 @@ class TrainPlan:
                                         l=(npix,), f=(1.0,),
                                         p=(zj, da, dzv[:, c0:c0 + co], sm[0:co], sm[co:2 * co], bn.weight, bn.bias, su, dgam, dbet,
                                            dr if fold_res else None)))
-                self._wrote(gg_off, co)
-                self._wrote(gb_off, co)
+                if pair:
+                    pair_done += [(gg_off, co), (gb_off, co)]   # dgamma / dbeta leave with the pair's apply pass, appended below
+                else:
+                    self._wrote(gg_off, co)
+                    self._wrote(gb_off, co)
                 ridx = len(self.bwd) - (1 if pair else 2)       # this block's reduce op
                 self.bwd_sync.append((ridx, su))               # sync_bn: all-reduce of the sums between reduce and apply
                 self._bn_layers.append(dict(reduce=ridx, a=a, z=zj, ldz=Ct, sm=sm[0:2 * co], gamma=bn.weight,
@@ -549,6 +552,8 @@ class TrainPlan:
                 # both blocks' sums are complete (two reduce ops / dgrad epilogues above): one apply pass over whole rows
                 self.bwd.append(_op(OP_BN_BWD_APPLY2, i=(code, Ct, Ct, per[0][1], R, pair_i[0], pair_i[2], pair_i[1], pair_i[3]),
                                     l=(npix,), f=(1.0,), p=[z.t, dzv] + pair_p))
+                for off, n in pair_done:                        # gradient-arena ranges this op completes (bucket readiness, DDP)
+                    self._wrote(off, n)
             if stem_fused:
                 return
             # the weight gradient only needs dz: its slot comes BEFORE the layer's dgrad, so that a (grouped) launch forked

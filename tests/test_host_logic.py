@@ -343,6 +343,24 @@ def test_plan_gradient_buckets_cover_the_arena():
         assert ready >= idx and off + n <= next(hi for r, lo, hi in b if lo <= off < hi)
     covered = sum(n for _, _, n in pl.grad_done)
     assert covered >= sum(p.numel() for p in m.parameters())          # every parameter has a writer (slots are padded)
+    # ... and the recorded "complete after op idx" of a range is not EARLIER than an op that writes into it: every gradient-arena
+    # pointer a BatchNorm-backward op carries (dgamma / dbeta of the apply pass, of the paired apply pass of a merged cv1 | cv2, the
+    # stem's fused op incl. its dw) must lie in a range whose hand-over index is >= that op's index (round 6: the paired pass
+    # recorded its ranges two ops early -- a bucket's all-reduce could have started before the pass had written them)
+    base, end = pl.gradarena.buf.data_ptr(), pl.gradarena.buf.data_ptr() + 4 * pl.gradarena.total
+    slots = {8: (8, 9), 24: (7, 8, 14, 15), 22: (8, 9, 10)}           # op kind -> pointer slots that are gradient destinations
+    checked = 0
+    for k, o in enumerate(pl.bwd):
+        for sl in slots.get(o.kind & 0xff, ()):
+            ptr = o.p[sl]
+            if not ptr:
+                continue
+            assert base <= ptr < end, (k, sl)
+            off = (ptr - base) // 4
+            idxs = [idx for idx, eo, n in pl.grad_done if eo <= off < eo + n]
+            assert idxs and max(idxs) >= k, (k, o.kind & 0xff, sl, idxs)
+            checked += 1
+    assert checked >= 2 * 57 - 10
     # C3's cv1 | cv2 run as one conv: 8 fewer forward / dgrad / wgrad launches than the 60 convolutions of the model
     from collections import Counter
     kinds = Counter(o.kind & 0xff for o in pl.bwd)
