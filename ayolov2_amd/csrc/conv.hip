@@ -1308,6 +1308,15 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
 
     // block -> (channel tile, XCD band, slot): as k_gconv
     const unsigned Lb = blockIdx.x;
+#ifdef AYOLO_PROBE
+    __shared__ unsigned long long s_probe[AY_PROBE_N];   // tools/gconv_probe.py: [top | wait done | barrier passed | MFMAs issued] per sub-step
+    const bool probe_on = blockIdx.x < 512;
+    int probe_k = 2;
+    if (threadIdx.x < AY_PROBE_N) s_probe[threadIdx.x] = 0;
+    __syncthreads();
+    AY_PROBE(0);
+    if (threadIdx.x == 0) s_probe[AY_PROBE_N - 3] = __builtin_amdgcn_s_memrealtime();
+#endif
     const unsigned xcd = Lb & 7u, idx = Lb >> 3;
     const unsigned nt = idx % (unsigned)p.ntn;
     const unsigned slot = (idx / (unsigned)p.ntn) * 8u + xcd;
@@ -1442,6 +1451,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
     G3_XPART(0, 1, 0) G3_XPART(1, 1, 0) G3_XPART(2, 1, 0)
     G3_W(0, 0)
     G3_W(1, 0)
+    AY_PROBE(1);
 
     int c = 0;
     bool after_epi = false;
@@ -1467,10 +1477,13 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
                ~30 VGPRs (the forward variant then spills) */                                                            \
             _Pragma("unroll") for (int r = 0; r <= XR; ++r) asm volatile("" : "+v"(xoff[r]), "+v"(xh0[r]));  \
             asm volatile("" : "+v"(brow0));                                                                \
+            G3_PROBE();                                                                                    \
             if ((q_) == 0) { if (after_epi) wait_vm<WR + NSTK>(); else wait_vm<WR>(); }                    \
             else if (j_ == 0) wait_vm<WR>();                                                               \
             else wait_vm<WR + XP>();                                                                       \
+            G3_PROBE();                                                                                    \
             __builtin_amdgcn_s_barrier();                                                                  \
+            G3_PROBE();                                                                                    \
             const unsigned char* stW = sW + ((q_) % 3) * G3::WS + arow;                                    \
             const int jr = brow0 + (j_ - 1);                                                               \
             const int swzB = (jr >> 2) & (G::CPR - 1);                                                     \
@@ -1520,7 +1533,13 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
             }                                                                                              \
             _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi)                                           \
                 _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) mma_step(fa1[mi], fb1[ni], acc[mi * G::NI + ni]); \
+            G3_PROBE();                                                                                    \
         }
+#ifdef AYOLO_PROBE
+#define G3_PROBE() do { AY_PROBE(probe_k); ++probe_k; } while (0)
+#else
+#define G3_PROBE() do { } while (0)
+#endif
         G3_SUB(0) G3_SUB(1) G3_SUB(2) G3_SUB(3) G3_SUB(4) G3_SUB(5) G3_SUB(6) G3_SUB(7) G3_SUB(8)
         after_epi = false;
         if (c == nC - 1) {
@@ -1548,10 +1567,17 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
         c = cn;
     }
 #undef G3_SUB
+#undef G3_PROBE
 #undef G3_W
 #undef G3_XPART
 #undef G3_SETUP
     wait_vm<0>();                             // trailing DMAs must land before this LDS is released
+#ifdef AYOLO_PROBE
+    AY_PROBE(AY_PROBE_N - 1);
+    if (threadIdx.x == 0) s_probe[AY_PROBE_N - 2] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (probe_on && threadIdx.x < AY_PROBE_N) g_probe[blockIdx.x * AY_PROBE_N + threadIdx.x] = s_probe[threadIdx.x];
+#endif
     if constexpr (SREG) {
         if (any_stats) g_stats_flush<T, TM, G::MI, BNR>(p, reinterpret_cast<double*>(sStat), tid, lane, wm, n0, slot, rsum, rsq);
         return;
