@@ -1501,7 +1501,9 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
                 _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) fb1[ni] = *reinterpret_cast<const half8*>(stX + ni * 32 * G::ROWB + sb); \
             }                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                             \
-            /* ahead: part j_ of the x group two groups on, the W tile two sub-steps on */                  \
+            /* ahead: part j_ of the x group two groups on, the W tile two sub-steps on.  The ADDRESS work sits here, under the \
+               fragment-fetch latency; the DMA instructions themselves go one behind each of the first MFMAs (a piece costs ~60 \
+               issue cycles among bare MFMAs and 100-185 in a block of its own: round 3 did this for k_gconv, g_mma_k_issue) */ \
             if ((q_) == 3) {                                                                               \
                 if (c + 1 == nC) {                                                                         \
                     x_tile += lstride;                                                                     \
@@ -1509,17 +1511,43 @@ __global__ __launch_bounds__(256, 2) void k_gconv3(GConvP p) {
                     G3_SETUP(x_tile, x_valid)                                                              \
                 }                                                                                          \
             }                                                                                              \
-            if (g_ == 0) G3_XPART(j_, 2, c)                                                                \
-            else G3_XPART(j_, g_ - 1, cn)                                                                  \
-            if ((q_) + 2 < 9) G3_W(((q_) + 2) % 9, c)                                                      \
-            else G3_W(((q_) + 2) % 9, cn)                                                                  \
+            constexpr int gx_ = g_ == 0 ? 2 : g_ - 1;                      /* x stage the part goes to */  \
+            constexpr int qw_ = ((q_) + 2) % 9;                            /* tap of the W tile */         \
+            constexpr int NPX_ = j_ < 2 ? XP : 1;                          /* x pieces (the halo part: one, wave 0 only) */ \
+            const int cx_ = g_ == 0 ? c : cn, cw_ = (q_) + 2 < 9 ? c : cn;                                 \
+            unsigned pxo_[NPX_], pwo_[WR];                                                                 \
+            {                                                                                              \
+                const int cb_ = cx_ * (BK * G::ES), dh_ = gx_ - 1;                                         \
+                _Pragma("unroll") for (int k_ = 0; k_ < NPX_; ++k_) {                                      \
+                    const int r = j_ < 2 ? j_ * XP + k_ : XR;                                              \
+                    const bool ok = ((unsigned)(xh0[r] + dh_) < (unsigned)p.XH) & (cx_ * BK < cmax);       \
+                    pxo_[k_] = ok ? (unsigned)(xoff[r] + dh_ * dhstep + cb_) : G_OOB;                      \
+                }                                                                                          \
+                const unsigned col_ = (unsigned)(wtap[qw_] + cw_ * (BK * G::ES)) | (cw_ * BK < cmax ? 0u : G_OOB); \
+                _Pragma("unroll") for (int r = 0; r < WR; ++r) pwo_[r] = (woff[r] + col_) | (col_ & G_OOB); \
+            }                                                                                              \
+            /* piece k_ of this sub-step, in the order the counted waits assume: the x part, then the W tile */ \
+            auto g3_piece = [&](int k_) __attribute__((always_inline)) {                                   \
+                if (k_ < NPX_) {                                                                           \
+                    if (j_ < 2) glds16(rsX, lds_x + gx_ * G3::XS + ((j_ * XP + k_) * 4 + wave) * 1024, pxo_[k_ < NPX_ ? k_ : 0]); \
+                    else if (wave == 0) glds16(rsX, lds_x + gx_ * G3::XS + XR * 4 * 1024, pxo_[0]);        \
+                } else if (k_ < NPX_ + WR) {                                                               \
+                    const int r = k_ - NPX_;                                                               \
+                    glds16(rsW, lds_w + (qw_ % 3) * G3::WS + (r * 4 + wave) * 1024, pwo_[r < WR ? r : 0]); \
+                }                                                                                          \
+            };                                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                             \
             if (zmask) {                                                                                   \
                 _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni)                                       \
                     if ((zmask >> ni) & 1u) { _Pragma("unroll") for (int e = 0; e < 8; ++e) fb0[ni][e] = (_Float16)0.0f; } \
             }                                                                                              \
             _Pragma("unroll") for (int mi = 0; mi < G::MI; ++mi)                                           \
-                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) mma_step(fa0[mi], fb0[ni], acc[mi * G::NI + ni]); \
+                _Pragma("unroll") for (int ni = 0; ni < G::NI; ++ni) {                                     \
+                    mma_step(fa0[mi], fb0[ni], acc[mi * G::NI + ni]);                                      \
+                    if (mi * G::NI + ni < NPX_ + WR) { g3_piece(mi * G::NI + ni); __builtin_amdgcn_sched_barrier(0); } \
+                }                                                                                          \
+            /* tiles with fewer MFMAs in the first half than pieces: the rest of the pieces behind them */ \
+            _Pragma("unroll") for (int k_ = G::MI * G::NI; k_ < NPX_ + WR; ++k_) g3_piece(k_);             \
             if constexpr (G::NACC >= 8) {                                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
                 const int sa = ((1 * 2 + hi) ^ swzA) * 16, sb = ((1 * 2 + hi) ^ swzB) * 16;                \
